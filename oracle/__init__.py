@@ -1,0 +1,247 @@
+"""ctypes binding of the CPU oracle (oracle/usc_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline leg
+of bench.py as the checker.  Nothing under video_unscreen_amd/ may import this package.
+Parity status of the arithmetic behind it: see the header of usc_oracle.c ("parity unpinned" at
+the OpenCV boundary; the reference has no tests or fixtures).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libusc_oracle.so")
+_lib = None
+
+u8p = C.POINTER(C.c_uint8)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "usc_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_count_ge.restype = C.c_longlong
+        _lib.orc_count_ge.argtypes = [u8p, C.c_size_t, C.c_int]
+        _lib.orc_version.restype = C.c_char_p
+        _lib.orc_remove_invalid_objects.restype = C.c_int
+        _lib.orc_remove_invalid_objects.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                                    C.c_double, C.c_double, f64p, C.c_int]
+        _lib.orc_bgdiff_mask.argtypes = [u8p, u8p, u8p, u8p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, u8p, u8p]
+        _lib.orc_get_fg.argtypes = [u8p, u8p, u8p, C.c_int, C.c_size_t, u8p, u8p]
+        _lib.orc_get_bg.argtypes = [u8p, u8p, C.c_size_t, u8p]
+        _lib.orc_blend.argtypes = [u8p, u8p, C.c_int, u8p, C.c_size_t, u8p]
+        _lib.orc_score_map.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, f64p]
+        for name in ("orc_bgr2gray_u8", "orc_bgr2hsv_u8", "orc_hsv2bgr_u8"):
+            getattr(_lib, name).argtypes = [u8p, u8p, C.c_size_t]
+    return _lib
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(u8p)
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(f32p)
+
+
+def get_target_size(h, w, long_side, division=1):
+    th, tw = C.c_int(), C.c_int()
+    lib().orc_get_target_size(int(h), int(w), int(long_side), int(division), C.byref(th), C.byref(tw))
+    return th.value, tw.value
+
+
+def pad_resize_geometry(h, w, target_h, target_w):
+    a, b = C.c_int(), C.c_int()
+    lib().orc_pad_resize_geometry(int(h), int(w), int(target_h), int(target_w), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def resize_nearest(img, dh, dw):
+    img, p = _u8(img)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
+    lib().orc_resize_nearest_u8(p, img.shape[0], img.shape[1], cn, out.ctypes.data_as(u8p), dh, dw)
+    return out
+
+
+def resize_linear(img, dh, dw):
+    if img.dtype == np.uint8:
+        img, p = _u8(img)
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
+        lib().orc_resize_linear_u8(p, img.shape[0], img.shape[1], cn, out.ctypes.data_as(u8p), dh, dw)
+        return out
+    img, p = _f32(img)
+    out = np.empty((dh, dw), np.float32)
+    lib().orc_resize_linear_f32(p, img.shape[0], img.shape[1], img.shape[1], out.ctypes.data_as(f32p), dh, dw)
+    return out
+
+
+def pad_reflect(img, dh, dw):
+    img, p = _u8(img)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
+    lib().orc_pad_reflect_u8(p, img.shape[0], img.shape[1], cn, out.ctypes.data_as(u8p), dh, dw)
+    return out
+
+
+def morph(mask, ksize, iters, op):
+    """op: 'dilate' or 'erode' (maskprocess.py:7-34)."""
+    mask, p = _u8(mask)
+    out = np.empty_like(mask)
+    lib().orc_morph_u8(p, out.ctypes.data_as(u8p), mask.shape[0], mask.shape[1], int(ksize), int(iters),
+                       0 if op == "dilate" else 1)
+    return out
+
+
+def bgr2gray(img):
+    img, p = _u8(img)
+    out = np.empty(img.shape[:2], np.uint8)
+    lib().orc_bgr2gray_u8(p, out.ctypes.data_as(u8p), out.size)
+    return out
+
+
+def bgr2hsv(img):
+    img, p = _u8(img)
+    out = np.empty_like(img)
+    lib().orc_bgr2hsv_u8(p, out.ctypes.data_as(u8p), img.size // 3)
+    return out
+
+
+def hsv2bgr(img):
+    img, p = _u8(img)
+    out = np.empty_like(img)
+    lib().orc_hsv2bgr_u8(p, out.ctypes.data_as(u8p), img.size // 3)
+    return out
+
+
+def count_ge(mask, thr=128):
+    mask, p = _u8(mask)
+    return int(lib().orc_count_ge(p, mask.size, int(thr)))
+
+
+def exist_foreground(mask, fg_exist_thr):
+    """maskprocess.py:56-60."""
+    h, w = mask.shape
+    return count_ge(mask, 128) > fg_exist_thr * h * w
+
+
+def trimap(mask, long_side=960, ksize=3, iters=5):
+    mask, p = _u8(mask)
+    out = np.empty_like(mask)
+    lib().orc_trimap(p, mask.shape[0], mask.shape[1], int(long_side), int(ksize), int(iters), out.ctypes.data_as(u8p))
+    return out
+
+
+def bgdiff_mask(frame, bg_i, bg_always, seg, beta, thr):
+    frame, pf = _u8(frame)
+    bg_i, pi = _u8(bg_i)
+    bg_always, pa = _u8(bg_always)
+    seg, ps = _u8(seg)
+    H, W = frame.shape[:2]
+    out_bg = np.empty_like(frame)
+    out_alpha = np.empty((H, W), np.uint8)
+    lib().orc_bgdiff_mask(pf, pi, pa, ps, 3 if seg.ndim == 3 else 1, float(beta), int(thr), H, W,
+                          out_bg.ctypes.data_as(u8p), out_alpha.ctypes.data_as(u8p))
+    return out_bg, out_alpha
+
+
+def vmat_input_size(H, W, long_side=960, division=32):
+    """vmatting/agent.py:38-42 + :93."""
+    if long_side % division != 0:
+        long_side = (long_side // division + 1) * division
+    return get_target_size(H, W, long_side, division)
+
+
+def vmat_pre(frame, alpha_pre, trimap_, inH, inW, layout="nchw"):
+    frame, pf = _u8(frame)
+    alpha_pre, pa = _u8(alpha_pre)
+    trimap_, pt = _u8(trimap_)
+    H, W = frame.shape[:2]
+    out = np.empty((7, inH, inW) if layout == "nchw" else (inH, inW, 7), np.float32)
+    lib().orc_vmat_pre(pf, pa, pt, H, W, inH, inW, out.ctypes.data_as(f32p), 0 if layout == "nchw" else 1)
+    return out
+
+
+def vmat_post(pred, trimap_, want_float=False):
+    pred, pp = _f32(pred)
+    trimap_, pt = _u8(trimap_)
+    H, W = trimap_.shape
+    a8 = np.empty((H, W), np.uint8)
+    af = np.empty((H, W), np.float32) if want_float else None
+    lib().orc_vmat_post(pp, pred.shape[0], pred.shape[1], pt, H, W, a8.ctypes.data_as(u8p),
+                        af.ctypes.data_as(f32p) if want_float else None)
+    return (a8, af) if want_float else a8
+
+
+def get_fg(frame, alpha, bg, paste_thr=0):
+    """fgfuncs.py:84-110; paste_thr=1 additionally applies bg[alpha==0]=frame[alpha==0] first
+    (bg_offline.py:171), paste_thr=128 the green-mode variant (green.py:125).  Returns (fg, bg_pasted)."""
+    frame, pf = _u8(frame)
+    alpha, pa = _u8(alpha)
+    bg, pb = _u8(bg)
+    fg = np.empty_like(frame)
+    bgp = np.empty_like(frame)
+    lib().orc_get_fg(pf, pa, pb, int(paste_thr), alpha.size, fg.ctypes.data_as(u8p), bgp.ctypes.data_as(u8p))
+    return fg, bgp
+
+
+def get_bg(alpha, bg):
+    alpha, pa = _u8(alpha)
+    bg, pb = _u8(bg)
+    out = np.empty_like(bg)
+    lib().orc_get_bg(pa, pb, alpha.size, out.ctypes.data_as(u8p))
+    return out
+
+
+def blend(fg, mask, bg):
+    fg, pf = _u8(fg)
+    mask, pm = _u8(mask)
+    bg, pb = _u8(bg)
+    out = np.empty_like(fg)
+    lib().orc_blend(pf, pm, 3 if mask.ndim == 3 else 1, pb, fg.size // 3, out.ctypes.data_as(u8p))
+    return out
+
+
+def score_map(h, w, center):
+    out = np.empty((h, w), np.float64)
+    lib().orc_score_map(h, w, float(center[0]), float(center[1]), out.ctypes.data_as(f64p))
+    return out
+
+
+def remove_invalid_objects(cfg, alpha, segmask=None, return_stats=False):
+    """maskprocess.py:77-152 (+ build_score_map :181-189).  Mutates and returns `alpha` like the reference."""
+    assert alpha.dtype == np.uint8 and alpha.flags.c_contiguous
+    h, w = alpha.shape
+    centers = cfg["objectremoval"]["score_map_center"]
+    center = centers["landscape"] if w > h else centers["portrait"]
+    seg_p = None
+    if segmask is not None:
+        segmask, seg_p = _u8(segmask)
+    stats = np.zeros((4096, 4), np.float64)
+    n = lib().orc_remove_invalid_objects(alpha.ctypes.data_as(u8p), seg_p, h, w, float(center[0]), float(center[1]),
+                                         float(cfg["objectremoval"]["saliency_thr"]),
+                                         float(cfg["objectremoval"]["consensus_thr"]),
+                                         stats.ctypes.data_as(f64p), stats.shape[0])
+    if return_stats:
+        return alpha, stats[:min(n, stats.shape[0])]
+    return alpha
+
+
+def version():
+    return lib().orc_version().decode()

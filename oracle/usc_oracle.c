@@ -1,0 +1,785 @@
+/*
+ * usc_oracle.c - CPU restatement of the reference's per-frame unscreen path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under video_unscreen_amd/ may import, link or
+ * call this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do,
+ * and only as the checker.  Plain scalar C, one thread, no SIMD: it is the spec the HIP
+ * kernels are compared with bit for bit, not a fast CPU implementation.
+ *
+ * PARITY STATUS: the reference (AnyiRao/video_unscreen) has no tests, fixtures or golden
+ * vectors, and all of its non-CNN arithmetic is delegated to OpenCV (cv2), which is neither
+ * vendored nor pinned nor installed here.  The OpenCV primitives below (resize, morphology,
+ * cvtColor, copyMakeBorder, findContours/contourArea/drawContours) are therefore restated
+ * from the published algorithms of OpenCV 4.x's generic (non-SIMD, non-IPP) C++ paths:
+ * PARITY UNPINNED at that boundary.  What IS pinned: the order of operations, thresholds,
+ * dtype promotions and truncations of the reference's own Python, cited per function as
+ * reference file:line (paths relative to the reference repo root).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: every float op rounds once, as the
+ * NumPy / torch-CPU elementwise ops of the reference do).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+static inline int orc_round_i(double v) { return (int)lrint(v); }          /* cvRound: half-to-even */
+static inline int orc_floor_i(double v) { int i = (int)v; return i - (i > v); }
+static inline int orc_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline uint8_t orc_sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+static inline short orc_sat_s16(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+/* ------------------------------------------------------------------------------------------
+ * geometry helpers
+ * ---------------------------------------------------------------------------------------- */
+
+/* unscreen/utils/imgprocess.py:164-192 get_target_size.  Python floats are doubles; int() truncates. */
+ORC_API void orc_get_target_size(int h, int w, int long_side, int division, int* th, int* tw)
+{
+    if (h > w) {
+        *th = long_side;
+        int t = (int)((double)long_side * w / h);
+        if (t % division != 0) t = (t / division + 1) * division;
+        *tw = t;
+    } else {
+        *tw = long_side;
+        int t = (int)((double)long_side * h / w);
+        if (t % division != 0) t = (t / division + 1) * division;
+        *th = t;
+    }
+}
+
+/* unscreen/utils/imgprocess.py:67-97 pad_resize: size of the aspect-preserving resize inside
+ * a (target_h, target_w) canvas; the remainder is reflect-padded at the bottom / right. */
+ORC_API void orc_pad_resize_geometry(int h, int w, int target_h, int target_w, int* new_h, int* new_w)
+{
+    if ((double)h / w > (double)target_h / target_w) {
+        *new_h = target_h;
+        *new_w = (int)((double)target_h * w / h);
+    } else {
+        *new_w = target_w;
+        *new_h = (int)((double)target_w * h / w);
+    }
+}
+
+/* unscreen/utils/imgprocess.py:100-132 inv_pad_resize: the un-padded region of an (h, w) canvas
+ * for an original of (ori_h, ori_w). */
+ORC_API void orc_inv_pad_geometry(int h, int w, int ori_h, int ori_w, int* resized_h, int* resized_w)
+{
+    if ((double)ori_h / ori_w > (double)h / w) {
+        *resized_h = h;
+        *resized_w = (int)((double)h * ori_w / ori_h);
+    } else {
+        *resized_w = w;
+        *resized_h = (int)((double)w * ori_h / ori_w);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * cv2.resize
+ * ---------------------------------------------------------------------------------------- */
+
+/* cv2.resize(..., interpolation=cv2.INTER_NEAREST)  (call site: unscreen/trimap/agent.py:52-53).
+ * OpenCV resizeNN: sx = min(floor(x * (1/fx)), sw-1) with fx = dw/sw as double. */
+ORC_API void orc_resize_nearest_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw)
+{
+    double fx = (double)dw / sw, fy = (double)dh / sh;
+    double ifx = 1. / fx, ify = 1. / fy;
+    for (int y = 0; y < dh; y++) {
+        int sy = orc_floor_i(y * ify);
+        if (sy > sh - 1) sy = sh - 1;
+        for (int x = 0; x < dw; x++) {
+            int sx = orc_floor_i(x * ifx);
+            if (sx > sw - 1) sx = sw - 1;
+            for (int c = 0; c < cn; c++)
+                dst[((size_t)y * dw + x) * cn + c] = src[((size_t)sy * sw + sx) * cn + c];
+        }
+    }
+}
+
+typedef struct { int ofs; short a0, a1; float f0, f1; } orc_tap;
+
+/* Source tap + weights of one destination coordinate for INTER_LINEAR (OpenCV resize():
+ * f = (d + 0.5) * scale - 0.5 computed in double, cast to float; s = floor(f); f -= s;
+ * left edge: s < 0 -> s = 0, f = 0; right edge: s + 1 >= n -> s = n - 1, f = 0.
+ * 8-bit images use 11-bit fixed point weights (INTER_RESIZE_COEF_SCALE = 2048). */
+static void orc_linear_taps(int dn, int sn, orc_tap* t, int clamp_edges)
+{
+    double inv_scale = (double)dn / sn;
+    double scale = 1. / inv_scale;
+    for (int d = 0; d < dn; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = orc_floor_i(f);
+        f -= s;
+        if (clamp_edges) {
+            if (s < 0) { s = 0; f = 0.f; }
+            if (s + 1 >= sn) { s = sn - 1; f = 0.f; }
+        }
+        t[d].ofs = s;
+        t[d].f0 = 1.f - f;
+        t[d].f1 = f;
+        t[d].a0 = orc_sat_s16(orc_round_i((1.f - f) * 2048.f));
+        t[d].a1 = orc_sat_s16(orc_round_i(f * 2048.f));
+    }
+}
+
+static int orc_is_area_fast_2x(int sh, int sw, int dh, int dw)
+{
+    double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    int ix = orc_round_i(scale_x), iy = orc_round_i(scale_y);
+    return fabs(scale_x - ix) < 2.220446049250313e-16 && fabs(scale_y - iy) < 2.220446049250313e-16 && ix == 2 && iy == 2;
+}
+
+/* cv2.resize(img, (dw, dh)) with the default INTER_LINEAR on uint8 data
+ * (call sites: unscreen/utils/imgprocess.py:95 pad_resize, :36 adaptive_resize;
+ * unscreen/trimap/agent.py:59 where the flag lands in `dst` so the default applies).
+ * - exact 2x decimation is rerouted by OpenCV to the 2x2 INTER_AREA box average (s+2)>>2;
+ * - otherwise horizontal pass keeps S0*a0 + S1*a1 (int), vertical pass is
+ *   (((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2; rows are clamped, columns zero-weighted. */
+ORC_API void orc_resize_linear_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw)
+{
+    if (sh == dh && sw == dw) { memcpy(dst, src, (size_t)sh * sw * cn); return; }
+    if (orc_is_area_fast_2x(sh, sw, dh, dw)) {
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++)
+                for (int c = 0; c < cn; c++) {
+                    const uint8_t* p = src + ((size_t)(2 * y) * sw + 2 * x) * cn + c;
+                    int s = p[0] + p[cn] + p[(size_t)sw * cn] + p[(size_t)sw * cn + cn];
+                    dst[((size_t)y * dw + x) * cn + c] = (uint8_t)((s + 2) >> 2);
+                }
+        return;
+    }
+    orc_tap* tx = (orc_tap*)malloc(sizeof(orc_tap) * dw);
+    orc_tap* ty = (orc_tap*)malloc(sizeof(orc_tap) * dh);
+    orc_linear_taps(dw, sw, tx, 1);
+    orc_linear_taps(dh, sh, ty, 0);
+    for (int y = 0; y < dh; y++) {
+        int y0 = orc_clampi(ty[y].ofs, 0, sh - 1), y1 = orc_clampi(ty[y].ofs + 1, 0, sh - 1);
+        int b0 = ty[y].a0, b1 = ty[y].a1;
+        for (int x = 0; x < dw; x++) {
+            int x0 = tx[x].ofs, x1 = x0 + 1 < sw ? x0 + 1 : x0;
+            int a0 = tx[x].a0, a1 = tx[x].a1;
+            for (int c = 0; c < cn; c++) {
+                int r0 = src[((size_t)y0 * sw + x0) * cn + c] * a0 + src[((size_t)y0 * sw + x1) * cn + c] * a1;
+                int r1 = src[((size_t)y1 * sw + x0) * cn + c] * a0 + src[((size_t)y1 * sw + x1) * cn + c] * a1;
+                int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                dst[((size_t)y * dw + x) * cn + c] = (uint8_t)v;
+            }
+        }
+    }
+    free(tx); free(ty);
+}
+
+/* cv2.resize on a float32 single-channel image (unscreen/utils/imgprocess.py:131 inv_pad_resize on
+ * the network's alpha, reached from unscreen/vmatting/agent.py:127).  Float weights, two passes:
+ * row = S[x0]*a0 + S[x1]*a1, then out = row0*b0 + row1*b1, each product and sum rounded to f32. */
+ORC_API void orc_resize_linear_f32(const float* src, int sh, int sw, int sstride, float* dst, int dh, int dw)
+{
+    orc_tap* tx = (orc_tap*)malloc(sizeof(orc_tap) * dw);
+    orc_tap* ty = (orc_tap*)malloc(sizeof(orc_tap) * dh);
+    orc_linear_taps(dw, sw, tx, 1);
+    orc_linear_taps(dh, sh, ty, 0);
+    for (int y = 0; y < dh; y++) {
+        int y0 = orc_clampi(ty[y].ofs, 0, sh - 1), y1 = orc_clampi(ty[y].ofs + 1, 0, sh - 1);
+        float b0 = ty[y].f0, b1 = ty[y].f1;
+        for (int x = 0; x < dw; x++) {
+            int x0 = tx[x].ofs, x1 = x0 + 1 < sw ? x0 + 1 : x0;
+            float a0 = tx[x].f0, a1 = tx[x].f1;
+            float r0 = src[(size_t)y0 * sstride + x0] * a0 + src[(size_t)y0 * sstride + x1] * a1;
+            float r1 = src[(size_t)y1 * sstride + x0] * a0 + src[(size_t)y1 * sstride + x1] * a1;
+            dst[(size_t)y * dw + x] = r0 * b0 + r1 * b1;
+        }
+    }
+    free(tx); free(ty);
+}
+
+/* cv2.copyMakeBorder(img, 0, pad_h, 0, pad_w, cv2.BORDER_REFLECT)  (unscreen/utils/imgprocess.py:96):
+ * fedcba|abcdefgh|hgfedcb - the edge sample is repeated. */
+ORC_API void orc_pad_reflect_u8(const uint8_t* src, int h, int w, int cn, uint8_t* dst, int dh, int dw)
+{
+    for (int y = 0; y < dh; y++) {
+        int sy = y < h ? y : 2 * h - 1 - y;
+        for (int x = 0; x < dw; x++) {
+            int sx = x < w ? x : 2 * w - 1 - x;
+            memcpy(dst + ((size_t)y * dw + x) * cn, src + ((size_t)sy * w + sx) * cn, cn);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * morphology
+ * ---------------------------------------------------------------------------------------- */
+
+/* cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (k, k)): row i spans [c-dx, c+dx] with
+ * dx = round(c * sqrt((r^2 - dy^2) / r^2)), r = c = k/2.  k=3 -> plus; k=4 -> 0010/1111/1111/1111. */
+static void orc_ellipse(int k, uint8_t* se)
+{
+    int r = k / 2, c = k / 2;
+    double inv_r2 = r ? 1. / ((double)r * r) : 0;
+    memset(se, 0, (size_t)k * k);
+    for (int i = 0; i < k; i++) {
+        int dy = i - r, j1 = 0, j2 = 0;
+        if (abs(dy) <= r) {
+            int dx = orc_round_i(c * sqrt((r * r - dy * dy) * inv_r2));
+            j1 = c - dx > 0 ? c - dx : 0;
+            j2 = c + dx + 1 < k ? c + dx + 1 : k;
+        }
+        for (int j = j1; j < j2; j++) se[i * k + j] = 1;
+    }
+}
+
+/* unscreen/utils/maskprocess.py:7-34 dilate_mask / erode_mask: cv2.dilate / cv2.erode with the
+ * ellipse element, anchor at (k/2, k/2), `iters` successive passes, and the default border that
+ * never wins (out-of-image taps are ignored).  op: 0 = dilate (max), 1 = erode (min). */
+ORC_API void orc_morph_u8(const uint8_t* src, uint8_t* dst, int h, int w, int ksize, int iters, int op)
+{
+    uint8_t se[64 * 64];
+    if (ksize > 64) ksize = 64;
+    orc_ellipse(ksize, se);
+    int a = ksize / 2;
+    uint8_t* cur = (uint8_t*)malloc((size_t)h * w);
+    uint8_t* nxt = (uint8_t*)malloc((size_t)h * w);
+    memcpy(cur, src, (size_t)h * w);
+    for (int it = 0; it < iters; it++) {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int best = op ? 255 : 0;
+                for (int i = 0; i < ksize; i++) {
+                    int yy = y + i - a;
+                    if (yy < 0 || yy >= h) continue;
+                    for (int j = 0; j < ksize; j++) {
+                        if (!se[i * ksize + j]) continue;
+                        int xx = x + j - a;
+                        if (xx < 0 || xx >= w) continue;
+                        int v = cur[(size_t)yy * w + xx];
+                        if (op ? v < best : v > best) best = v;
+                    }
+                }
+                nxt[(size_t)y * w + x] = (uint8_t)best;
+            }
+        uint8_t* t = cur; cur = nxt; nxt = t;
+    }
+    memcpy(dst, cur, (size_t)h * w);
+    free(cur); free(nxt);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * cv2.cvtColor (8-bit)
+ * ---------------------------------------------------------------------------------------- */
+
+/* COLOR_BGR2GRAY, 8-bit: 15-bit fixed point (OpenCV 4.x: B 3735, G 19235, R 9798, +16384 >> 15). */
+static inline uint8_t orc_gray(int b, int g, int r) { return (uint8_t)((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15); }
+
+ORC_API void orc_bgr2gray_u8(const uint8_t* src, uint8_t* dst, size_t n)
+{
+    for (size_t i = 0; i < n; i++) dst[i] = orc_gray(src[3 * i], src[3 * i + 1], src[3 * i + 2]);
+}
+
+static int orc_sdiv[256], orc_hdiv[256], orc_tabs_ready = 0;
+static void orc_hsv_tables(void)
+{
+    if (orc_tabs_ready) return;
+    orc_sdiv[0] = orc_hdiv[0] = 0;
+    for (int i = 1; i < 256; i++) {
+        orc_sdiv[i] = orc_round_i((255 << 12) / (1. * i));
+        orc_hdiv[i] = orc_round_i((180 << 12) / (6. * i));
+    }
+    orc_tabs_ready = 1;
+}
+
+/* COLOR_BGR2HSV, 8-bit, H in [0,180): OpenCV RGB2HSV_b integer path with hsv_shift = 12 tables. */
+static inline void orc_bgr2hsv_px(int b, int g, int r, uint8_t* out)
+{
+    int v = b, vmin = b;
+    if (g > v) v = g;
+    if (r > v) v = r;
+    if (g < vmin) vmin = g;
+    if (r < vmin) vmin = r;
+    int diff = v - vmin;
+    int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+    int s = (diff * orc_sdiv[v] + (1 << 11)) >> 12;
+    int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    hh = (hh * orc_hdiv[diff] + (1 << 11)) >> 12;
+    hh += hh < 0 ? 180 : 0;
+    out[0] = orc_sat_u8(hh); out[1] = (uint8_t)s; out[2] = (uint8_t)v;
+}
+
+ORC_API void orc_bgr2hsv_u8(const uint8_t* src, uint8_t* dst, size_t n)
+{
+    orc_hsv_tables();
+    for (size_t i = 0; i < n; i++) orc_bgr2hsv_px(src[3 * i], src[3 * i + 1], src[3 * i + 2], dst + 3 * i);
+}
+
+/* COLOR_HSV2BGR, 8-bit: h, s/255, v/255 as float, the six-sector float formula, *255 and
+ * round-to-nearest-even with saturation (OpenCV HSV2RGB_b scalar path, hscale = 6/180). */
+static inline void orc_hsv2bgr_px(const uint8_t* in, uint8_t* out)
+{
+    static const int sector_data[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    float h = in[0], s = in[1] * (1.f / 255.f), v = in[2] * (1.f / 255.f);
+    float b, g, r;
+    if (s == 0) b = g = r = v;
+    else {
+        float tab[4];
+        h *= (6.f / 180.f);
+        if (h < 0) do h += 6; while (h < 0);
+        else if (h >= 6) do h -= 6; while (h >= 6);
+        int sector = orc_floor_i(h);
+        h -= sector;
+        if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
+        tab[0] = v;
+        tab[1] = v * (1.f - s);
+        tab[2] = v * (1.f - s * h);
+        tab[3] = v * (1.f - s * (1.f - h));
+        b = tab[sector_data[sector][0]];
+        g = tab[sector_data[sector][1]];
+        r = tab[sector_data[sector][2]];
+    }
+    out[0] = orc_sat_u8((int)lrintf(b * 255.f));
+    out[1] = orc_sat_u8((int)lrintf(g * 255.f));
+    out[2] = orc_sat_u8((int)lrintf(r * 255.f));
+}
+
+ORC_API void orc_hsv2bgr_u8(const uint8_t* src, uint8_t* dst, size_t n)
+{
+    for (size_t i = 0; i < n; i++) orc_hsv2bgr_px(src + 3 * i, dst + 3 * i);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * stage restatements
+ * ---------------------------------------------------------------------------------------- */
+
+/* unscreen/utils/maskprocess.py:56-60 exist_foreground: number of pixels >= 128 (the caller compares
+ * it with fg_exist_thr * h * w in double). */
+ORC_API long long orc_count_ge(const uint8_t* mask, size_t n, int thr)
+{
+    long long c = 0;
+    for (size_t i = 0; i < n; i++) c += mask[i] >= thr;
+    return c;
+}
+
+/* unscreen/trimap/agent.py:35-61 TrimapAgent.generate_trimap:
+ *  :50-53 NEAREST resize to get_target_size(h, w, long_side);  :55-56 dilate / erode (k, iters);
+ *  :54,57-58 trimap = 128, [eroded > 127] = 255, [dilated < 128] = 0 (in that order);
+ *  :59 resize back with the DEFAULT bilinear (the INTER_NEAREST constant is passed as `dst`);
+ *  :60 every value strictly between 0 and 255 becomes 128. */
+ORC_API void orc_trimap(const uint8_t* mask, int H, int W, int long_side, int ksize, int iters, uint8_t* out)
+{
+    int h, w;
+    orc_get_target_size(H, W, long_side, 1, &h, &w);
+    size_t n = (size_t)h * w;
+    uint8_t* small = (uint8_t*)malloc(n);
+    uint8_t* dil = (uint8_t*)malloc(n);
+    uint8_t* ero = (uint8_t*)malloc(n);
+    uint8_t* tri = (uint8_t*)malloc(n);
+    orc_resize_nearest_u8(mask, H, W, 1, small, h, w);
+    orc_morph_u8(small, dil, h, w, ksize, iters, 0);
+    orc_morph_u8(small, ero, h, w, ksize, iters, 1);
+    for (size_t i = 0; i < n; i++) {
+        uint8_t t = 128;
+        if (ero[i] > 127) t = 255;
+        if (dil[i] < 128) t = 0;
+        tri[i] = t;
+    }
+    orc_resize_linear_u8(tri, h, w, 1, out, H, W);
+    for (size_t i = 0; i < (size_t)H * W; i++)
+        if (out[i] > 0 && out[i] < 255) out[i] = 128;
+    free(small); free(dil); free(ero); free(tri);
+}
+
+/* tools/unscreen/bg_offline.py:150-160 (the same arithmetic as tools/unscreen/bg.py:85-92):
+ *  :150-151 bg = uint8(f32(bg_i) * beta + (1 - beta) * f32(bg_always))   (f32 products, f32 sum, truncation;
+ *           `1 - beta` is evaluated in double first, then used as an f32 scalar)
+ *  :152     alpha = BGR2GRAY(segmask, 3 channels)
+ *  :154     d = uint8(|f32(frame) - f32(bg)|)
+ *  :155-157 g = BGR2GRAY(d); g[g > thr] = 255
+ *  :158     dilate_mask(g, 4, 2)
+ *  :160     alpha = alpha * (g // 255)    (uint8 product with 0 / 1)
+ * seg_cn is 3 (the reference reads the mask JPEGs as 3-channel) or 1 (already grey). */
+ORC_API void orc_bgdiff_mask(const uint8_t* frame, const uint8_t* bg_i, const uint8_t* bg_always,
+                             const uint8_t* seg, int seg_cn, double beta, int thr, int H, int W,
+                             uint8_t* out_bg, uint8_t* out_alpha)
+{
+    size_t n = (size_t)H * W;
+    float fb = (float)beta, fb1 = (float)(1 - beta);
+    uint8_t* g = (uint8_t*)malloc(n);
+    uint8_t* gd = (uint8_t*)malloc(n);
+    for (size_t i = 0; i < n; i++) {
+        int d[3];
+        for (int c = 0; c < 3; c++) {
+            float p0 = (float)bg_i[3 * i + c] * fb;
+            float p1 = fb1 * (float)bg_always[3 * i + c];
+            float f = p0 + p1;
+            uint8_t b = (uint8_t)f;
+            out_bg[3 * i + c] = b;
+            float df = fabsf((float)frame[3 * i + c] - (float)b);
+            d[c] = (uint8_t)df;
+        }
+        uint8_t gv = orc_gray(d[0], d[1], d[2]);
+        g[i] = gv > thr ? 255 : gv;
+    }
+    orc_morph_u8(g, gd, H, W, 4, 2, 0);
+    for (size_t i = 0; i < n; i++) {
+        uint8_t a = seg_cn == 3 ? orc_gray(seg[3 * i], seg[3 * i + 1], seg[3 * i + 2]) : seg[i];
+        out_alpha[i] = (uint8_t)(a * (gd[i] / 255));
+    }
+    free(g); free(gd);
+}
+
+/* unscreen/vmatting/agent.py:76-106 preprocess + :44-74 to_tensor + unscreen/utils/imgprocess.py:135-161
+ * imnormalize, producing the network's 7-channel input in NCHW order (model.py:564 torch.cat):
+ *  ch0-2  RGB (the BGR frame is swapped, imgprocess.py:157): (f32(u8) / 255) - f32(mean) then * f32(1/std)
+ *         (cv2.subtract / cv2.multiply with float64 scalars run in f32 on an f32 image)
+ *  ch3    alpha_pre / 255 evaluated in double, rounded to f32 (agent.py:100 + .float())
+ *  ch4-6  one-hot of the bilinearly resized trimap: 0 -> ch4, strictly between -> ch5, 255 -> ch6
+ * Each u8 input is resized with pad_resize (bilinear + bottom/right BORDER_REFLECT).
+ * layout: 0 = NCHW planes, 1 = NHWC (7 floats per pixel). */
+ORC_API void orc_vmat_pre(const uint8_t* frame, const uint8_t* alpha_pre, const uint8_t* trimap, int H, int W,
+                          int inH, int inW, float* out, int layout)
+{
+    static const double mean[3] = {0.485, 0.456, 0.406}, std[3] = {0.229, 0.224, 0.225};
+    int nh, nw;
+    orc_pad_resize_geometry(H, W, inH, inW, &nh, &nw);
+    size_t n = (size_t)inH * inW;
+    uint8_t* img_r = (uint8_t*)malloc((size_t)nh * nw * 3);
+    uint8_t* img_p = (uint8_t*)malloc(n * 3);
+    uint8_t* tmp_r = (uint8_t*)malloc((size_t)nh * nw);
+    uint8_t* tri_p = (uint8_t*)malloc(n);
+    uint8_t* ap_p = (uint8_t*)malloc(n);
+    orc_resize_linear_u8(frame, H, W, 3, img_r, nh, nw);
+    orc_pad_reflect_u8(img_r, nh, nw, 3, img_p, inH, inW);
+    orc_resize_linear_u8(trimap, H, W, 1, tmp_r, nh, nw);
+    orc_pad_reflect_u8(tmp_r, nh, nw, 1, tri_p, inH, inW);
+    orc_resize_linear_u8(alpha_pre, H, W, 1, tmp_r, nh, nw);
+    orc_pad_reflect_u8(tmp_r, nh, nw, 1, ap_p, inH, inW);
+    float meanf[3], stdinvf[3];
+    for (int c = 0; c < 3; c++) { meanf[c] = (float)mean[c]; stdinvf[c] = (float)(1 / std[c]); }
+    for (size_t i = 0; i < n; i++) {
+        float v[7];
+        for (int c = 0; c < 3; c++) {
+            float x = (float)img_p[3 * i + (2 - c)] / 255.f;
+            x = x - meanf[c];
+            v[c] = x * stdinvf[c];
+        }
+        v[3] = (float)((double)ap_p[i] / 255.);
+        uint8_t t = tri_p[i];
+        v[4] = t == 0 ? 1.f : 0.f;
+        v[5] = (t > 0 && t < 255) ? 1.f : 0.f;
+        v[6] = t == 255 ? 1.f : 0.f;
+        for (int c = 0; c < 7; c++) {
+            if (layout == 0) out[(size_t)c * n + i] = v[c];
+            else out[i * 7 + c] = v[c];
+        }
+    }
+    free(img_r); free(img_p); free(tmp_r); free(tri_p); free(ap_p);
+}
+
+/* unscreen/vmatting/agent.py:108-132 postprocess: inv_pad_resize (crop the pad, float bilinear back to H x W),
+ * pred[trimap == 0] = 0, pred[trimap == 255] = 1, (pred * 255).astype(uint8) (f32 product, truncation).
+ * alpha_f32 (optional) receives the clamped float alpha before the *255 truncation. */
+ORC_API void orc_vmat_post(const float* pred, int inH, int inW, const uint8_t* trimap, int H, int W,
+                           uint8_t* alpha_u8, float* alpha_f32)
+{
+    int rh, rw;
+    orc_inv_pad_geometry(inH, inW, H, W, &rh, &rw);
+    float* up = (float*)malloc(sizeof(float) * (size_t)H * W);
+    orc_resize_linear_f32(pred, rh, rw, inW, up, H, W);
+    for (size_t i = 0; i < (size_t)H * W; i++) {
+        float a = up[i];
+        if (trimap[i] == 0) a = 0.f;
+        if (trimap[i] == 255) a = 1.f;
+        if (alpha_f32) alpha_f32[i] = a;
+        float s = a * 255.f;
+        alpha_u8[i] = (uint8_t)s;
+    }
+    free(up);
+}
+
+/* tools/unscreen/bg_offline.py:171 paste + unscreen/utils/fgfuncs.py:84-110 get_fg:
+ *  bg[alpha == 0] = frame[alpha == 0]   (paste != 0; bg_offline.py:171, bg.py:99, green.py:125 uses alpha < 128)
+ *  both to 8-bit HSV; a = f32(alpha) / 255; fg = img_hsv - (1 - a) * bg_hsv on all three channels,
+ *  clamp to [0, 255], truncate to uint8, HSV -> BGR.  Every float op rounds to f32 (torch CPU). */
+ORC_API void orc_get_fg(const uint8_t* frame, const uint8_t* alpha, const uint8_t* bg, int paste_thr, size_t n,
+                        uint8_t* out_fg, uint8_t* out_bg_pasted)
+{
+    orc_hsv_tables();
+    for (size_t i = 0; i < n; i++) {
+        uint8_t bpx[3], ih[3], bh[3], fh[3];
+        /* paste_thr: 0 -> no paste; 1 -> alpha == 0 (alpha < 1); 128 -> alpha < 128 */
+        int paste = alpha[i] < paste_thr;
+        for (int c = 0; c < 3; c++) bpx[c] = paste ? frame[3 * i + c] : bg[3 * i + c];
+        if (out_bg_pasted) memcpy(out_bg_pasted + 3 * i, bpx, 3);
+        orc_bgr2hsv_px(frame[3 * i], frame[3 * i + 1], frame[3 * i + 2], ih);
+        orc_bgr2hsv_px(bpx[0], bpx[1], bpx[2], bh);
+        float a = (float)alpha[i] / 255.f;
+        float w = 1.f - a;
+        for (int c = 0; c < 3; c++) {
+            float t = w * (float)bh[c];
+            float f = (float)ih[c] - t;
+            f = f < 0.f ? 0.f : (f > 255.f ? 255.f : f);
+            fh[c] = (uint8_t)f;
+        }
+        orc_hsv2bgr_px(fh, out_fg + 3 * i);
+    }
+}
+
+/* unscreen/utils/fgfuncs.py:113-137 get_bg: (1 - a) * bg_hsv, clamp, truncate, HSV -> BGR. */
+ORC_API void orc_get_bg(const uint8_t* alpha, const uint8_t* bg, size_t n, uint8_t* out)
+{
+    orc_hsv_tables();
+    for (size_t i = 0; i < n; i++) {
+        uint8_t bh[3], fh[3];
+        orc_bgr2hsv_px(bg[3 * i], bg[3 * i + 1], bg[3 * i + 2], bh);
+        float a = (float)alpha[i] / 255.f;
+        float w = 1.f - a;
+        for (int c = 0; c < 3; c++) {
+            float f = w * (float)bh[c];
+            f = f < 0.f ? 0.f : (f > 255.f ? 255.f : f);
+            fh[c] = (uint8_t)f;
+        }
+        orc_hsv2bgr_px(fh, out + 3 * i);
+    }
+}
+
+/* tools/replace/replace.py:74-76: res = fg * m + bg * (1 - m) in float64 with m = mask / 255 per channel,
+ * truncated to uint8.  mask_cn: 1 or 3. */
+ORC_API void orc_blend(const uint8_t* fg, const uint8_t* mask, int mask_cn, const uint8_t* bg, size_t n, uint8_t* out)
+{
+    for (size_t i = 0; i < n; i++)
+        for (int c = 0; c < 3; c++) {
+            double m = (double)(mask_cn == 3 ? mask[3 * i + c] : mask[i]) / 255.;
+            double r = (double)fg[3 * i + c] * m + (double)bg[3 * i + c] * (1 - m);
+            out[3 * i + c] = (uint8_t)r;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * remove_invalid_objects (unscreen/utils/maskprocess.py:77-189)
+ * ---------------------------------------------------------------------------------------- */
+
+/* numpy.linspace(start, stop, n)[i]: i * ((stop - start) / (n - 1)) + start, last element = stop. */
+static double orc_linspace(double start, double stop, int n, int i)
+{
+    if (n == 1) return start;
+    if (i == n - 1) return stop;
+    double step = (stop - start) / (double)(n - 1);
+    return (double)i * step + start;
+}
+
+/* unscreen/utils/maskprocess.py:155-178 get_score_map, float64:
+ * s = sqrt(colterm(x)^2 + rowterm(y)^2) with linspace ramps around (y, x) = (int(h*cy), int(w*cx));
+ * score = (max(s) - s) / max(s). */
+ORC_API void orc_score_map(int h, int w, double cy, double cx, double* out)
+{
+    int y0 = (int)(h * cy), x0 = (int)(w * cx);
+    double* col = (double*)malloc(sizeof(double) * w);
+    double* row = (double*)malloc(sizeof(double) * h);
+    for (int x = 0; x < w; x++) {
+        double v = x >= x0 ? orc_linspace(0, 1, w - x0, x - x0) : orc_linspace(1, 0, x0, x);
+        col[x] = v * v;
+    }
+    for (int y = 0; y < h; y++) {
+        double v = y >= y0 ? orc_linspace(0, 1, h - y0, y - y0) : orc_linspace(1, 0, y0, y);
+        row[y] = v * v;
+    }
+    double mx = -1;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            double s = sqrt(col[x] + row[y]);
+            out[(size_t)y * w + x] = s;
+            if (s > mx) mx = s;
+        }
+    for (size_t i = 0; i < (size_t)h * w; i++) out[i] = (mx - out[i]) / mx;
+    free(col); free(row);
+}
+
+/* numpy's pairwise summation of a contiguous float64 vector (what ndarray.sum() does on the
+ * boolean-indexed score values, maskprocess.py:134). */
+static double orc_pairwise_sum(const double* a, size_t n)
+{
+    if (n < 8) {
+        double r = 0.;
+        for (size_t i = 0; i < n; i++) r += a[i];
+        return r;
+    } else if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        size_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        size_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return orc_pairwise_sum(a, n2) + orc_pairwise_sum(a + n2, n - n2);
+    }
+}
+
+typedef struct { int x, y; } orc_pt;
+typedef struct { orc_pt* p; size_t n, cap; } orc_chain;
+
+static void orc_chain_push(orc_chain* c, int x, int y)
+{
+    if (c->n == c->cap) { c->cap = c->cap ? c->cap * 2 : 256; c->p = (orc_pt*)realloc(c->p, c->cap * sizeof(orc_pt)); }
+    c->p[c->n].x = x; c->p[c->n].y = y; c->n++;
+}
+
+/* Border following of cv2.findContours(RETR_LIST) (Suzuki-Abe as implemented by OpenCV's
+ * icvFetchContour): directions 0..7 = E, NE, N, NW, W, SW, S, SE; border pixels are re-labelled
+ * 2, or -126 when the pixel to the east was examined and is zero.  Every visited pixel is pushed
+ * (CHAIN_APPROX_SIMPLE only drops collinear ones, which changes neither area nor fill). */
+static void orc_follow(int8_t* img, int step, int x, int y, int is_hole, orc_chain* ch)
+{
+    static const int dxs[8] = {1, 1, 0, -1, -1, -1, 0, 1}, dys[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    int delta[16];
+    for (int k = 0; k < 8; k++) delta[k] = delta[k + 8] = dys[k] * step + dxs[k];
+    int8_t* i0 = img + (size_t)y * step + x;
+    int8_t *i1, *i3, *i4 = 0;
+    int s_end, s;
+    s_end = s = is_hole ? 0 : 4;
+    do {
+        s = (s - 1) & 7;
+        i1 = i0 + delta[s];
+    } while (*i1 == 0 && s != s_end);
+    ch->n = 0;
+    if (s == s_end) {                      /* isolated pixel */
+        *i0 = (int8_t)(2 | -128);
+        orc_chain_push(ch, x, y);
+        return;
+    }
+    i3 = i0;
+    int px = x, py = y;
+    for (;;) {
+        s_end = s;
+        for (;;) {
+            i4 = i3 + delta[++s];
+            if (*i4 != 0) break;
+        }
+        s &= 7;
+        if ((unsigned)(s - 1) < (unsigned)s_end) *i3 = (int8_t)(2 | -128);
+        else if (*i3 == 1) *i3 = 2;
+        orc_chain_push(ch, px, py);
+        px += dxs[s]; py += dys[s];
+        if (i4 == i0 && i3 == i1) break;
+        i3 = i4;
+        s = (s + 4) & 7;
+    }
+}
+
+/* cv2.contourArea: |sum(x_prev * y - y_prev * x)| / 2 over the closed polygon. */
+static double orc_chain_area(const orc_chain* c)
+{
+    double a = 0;
+    if (c->n == 0) return 0;
+    orc_pt prev = c->p[c->n - 1];
+    for (size_t i = 0; i < c->n; i++) {
+        a += (double)prev.x * c->p[i].y - (double)prev.y * c->p[i].x;
+        prev = c->p[i];
+    }
+    return fabs(a * 0.5);
+}
+
+/* cv2.drawContours(zeros, contours, i, 255, cv2.FILLED): the polygon's own pixels plus every pixel
+ * whose centre is inside it by the even-odd rule (edges are horizontal, vertical or 45 degrees, so
+ * scanline intersections are integers).  obj is H x W, set to 1 inside. */
+static void orc_fill(const orc_chain* c, int H, int W, uint8_t* obj)
+{
+    uint8_t* par = (uint8_t*)calloc((size_t)H * W, 1);
+    for (size_t i = 0; i < c->n; i++) {
+        orc_pt a = c->p[i], b = c->p[(i + 1) % c->n];
+        obj[(size_t)a.y * W + a.x] = 1;
+        if (a.y != b.y) {                  /* half-open in y: toggle on the upper row of the move */
+            orc_pt top = a.y < b.y ? a : b;
+            par[(size_t)top.y * W + top.x] ^= 1;
+        }
+    }
+    for (int y = 0; y < H; y++) {
+        int inside = 0;
+        for (int x = 0; x < W; x++) {
+            if (par[(size_t)y * W + x]) inside ^= 1;
+            if (inside) obj[(size_t)y * W + x] = 1;
+        }
+    }
+    free(par);
+}
+
+/* unscreen/utils/maskprocess.py:77-152 remove_invalid_objects, with build_score_map (:181-189) choosing the
+ * centre by orientation before the call.  alpha is modified in place (and is what the caller gets back).
+ *  :123-124 findContours(alpha, RETR_LIST, CHAIN_APPROX_SIMPLE): non-zero = object; outer AND hole borders
+ *  :130-132 skip contourArea < 100
+ *  :134-135 saliency = sum(score_map[filled]) / (h*w)
+ *  :137-138 consensus = mean(segmask[filled]) / 255   (segmask defaults to alpha itself, :115-116)
+ *  :142-146 keep if (sal > sal_thr and cons > cons_thr) or sal > 10 * sal_thr
+ *  :151     alpha[valid == 0] = 0
+ * Returns the number of contours found; stats (optional, 4 doubles per contour, up to max_stats):
+ * area, saliency, consensus, kept. */
+ORC_API int orc_remove_invalid_objects(uint8_t* alpha, const uint8_t* segmask, int H, int W, double cy, double cx,
+                                       double sal_thr, double cons_thr, double* stats, int max_stats)
+{
+    size_t n = (size_t)H * W;
+    const uint8_t* seg = segmask ? segmask : alpha;
+    uint8_t* seg_copy = NULL;
+    if (!segmask) { seg_copy = (uint8_t*)malloc(n); memcpy(seg_copy, alpha, n); seg = seg_copy; }
+    double* score = (double*)malloc(sizeof(double) * n);
+    orc_score_map(H, W, cy, cx, score);
+    int step = W + 2;
+    int8_t* img = (int8_t*)calloc((size_t)(H + 2) * step, 1);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) img[(size_t)(y + 1) * step + x + 1] = alpha[(size_t)y * W + x] != 0;
+    uint8_t* valid = (uint8_t*)calloc(n, 1);
+    uint8_t* obj = (uint8_t*)malloc(n);
+    double* vals = (double*)malloc(sizeof(double) * n);
+    orc_chain ch = {0, 0, 0};
+    int count = 0;
+    /* OpenCV scans rows 1..H and columns 1..W of the zero-padded image (the last padded column is
+     * never a scan position, so an object touching the right edge cannot open a "hole"). */
+    for (int y = 1; y <= H; y++) {
+        int prev = 0;
+        for (int x = 1; x <= W; x++) {
+            int p = img[(size_t)y * step + x];
+            if (p != prev) {
+                int is_hole = 0, start = 0;
+                if (prev == 0 && p == 1) start = 1;
+                else if (p == 0 && prev >= 1) { is_hole = 1; start = 1; }
+                if (start) {
+                    orc_follow(img, step, x - is_hole, y, is_hole, &ch);
+                    for (size_t i = 0; i < ch.n; i++) { ch.p[i].x -= 1; ch.p[i].y -= 1; }
+                    double area = orc_chain_area(&ch);
+                    double sal = 0, cons = 0; int kept = 0;
+                    if (area >= 100) {
+                        memset(obj, 0, n);
+                        orc_fill(&ch, H, W, obj);
+                        size_t m = 0; double ssum = 0;
+                        for (size_t i = 0; i < n; i++)
+                            if (obj[i]) { vals[m++] = score[i]; ssum += seg[i]; }
+                        sal = orc_pairwise_sum(vals, m) / (double)(H * W);
+                        cons = (ssum / (double)m) / 255.;
+                        if ((sal > sal_thr && cons > cons_thr) || (sal > sal_thr * 10)) {
+                            kept = 1;
+                            for (size_t i = 0; i < n; i++) if (obj[i]) valid[i] = 255;
+                        }
+                    }
+                    if (stats && count < max_stats) {
+                        stats[4 * count] = area; stats[4 * count + 1] = sal;
+                        stats[4 * count + 2] = cons; stats[4 * count + 3] = kept;
+                    }
+                    count++;
+                    p = img[(size_t)y * step + x];
+                }
+            }
+            prev = p;
+        }
+    }
+    for (size_t i = 0; i < n; i++) if (!valid[i]) alpha[i] = 0;
+    free(ch.p); free(vals); free(obj); free(valid); free(img); free(score); free(seg_copy);
+    return count;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * one bg_step stage-3 frame, pixel stages only (tools/unscreen/bg_offline.py:145-176); the
+ * matting network runs between pre and post and is supplied by the caller.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API const char* orc_version(void) { return "usc-oracle 1 (OpenCV-4.x generic-path restatement, parity unpinned)"; }
