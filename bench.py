@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py - frames/sec of the bg_step (stage 3) unscreen loop on synthetic 1080p, one process per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--height 1080 --width 1920] [--no-cpu-baseline]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame through the whole per-frame path (difference mask -> host object filter -> trimap ->
+matting pre / network / post -> foreground), inputs already resident in HBM.  With N ranks the clip is sharded
+into contiguous frame ranges (no data-path collective: frames only couple through alpha_pre inside a shard,
+exactly like the reference's --range runs); weights and the overall background are broadcast from rank 0 over
+RCCL before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured-achievable
+MFMA_F32_PEAK_TFLOPS = 157.3     # f32-input MFMA dense peak (no xf32 on gfx950)
+UNET_GFLOP_544x960 = 132.75      # SURVEY.md section 6, torch flop counter on the reference module
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--dtype", default="float32", choices=["float32", "float16", "bfloat16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--sync-loop", action="store_true", help="use the synchronous step() instead of the pipelined run()")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    return ap.parse_args()
+
+
+def time_kernel(fn, iters=30, warm=5):
+    """Average launch duration in seconds, HIP events on torch's current stream (= the stream the C ABI launches on)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def kernel_table(pipe, sample, H, W):
+    """Per-stage achieved GB/s against the algorithmic byte counts of SURVEY.md section 8d."""
+    from video_unscreen_amd import _native as nv
+    frame, seg, bg_i, bg_always = sample
+    N = H * W
+    n_lo = int(np.prod(nv.get_target_size(H, W, pipe.long_side, 1)))
+    n_in = pipe.in_h * pipe.in_w
+    seg_b = seg.numel()
+    slot = pipe.slots[0]
+    out = pipe.step(frame, seg, bg_i, bg_always)
+    alpha, tri = out["alpha"].clone(), out["trimap"].clone()
+    gate = slot.gate.clone()
+    pred = out["pred"].clone().view(pipe.in_h, pipe.in_w)
+    rows = []
+
+    def add(name, fn, nbytes):
+        t = time_kernel(fn)
+        rows.append({"kernel": name, "us": round(t * 1e6, 2), "alg_bytes": int(nbytes),
+                     "GBps": round(nbytes / t / 1e9, 1), "frac_hbm_peak": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4)})
+
+    add("bgdiff_mask (point + gate)", lambda: nv.bgdiff_mask(frame, bg_i, bg_always, seg, pipe.beta, pipe.thr,
+                                                             out_bg=slot.bg, out_alpha=slot.gate, ws=pipe.ws_bgdiff),
+        9 * N + seg_b + 3 * N + N)
+    add("trimap (small + up)", lambda: nv.trimap(gate, pipe.long_side, pipe.ksize, pipe.iters, out=slot.trimap, ws=pipe.ws_trimap),
+        N + n_lo)
+    add("vmat_pre", lambda: nv.vmat_pre(frame, alpha, tri, pipe.in_h, pipe.in_w, layout=nv.NHWC, out=pipe.x7), 5 * N + 28 * n_in)
+    add("vmat_post", lambda: nv.vmat_post(pred, tri, out_u8=alpha), 2 * N + 4 * n_in)
+    add("get_fg", lambda: nv.get_fg(frame, alpha, slot.bg, paste_thr=1, out_fg=out["fg"]), 10 * N)
+    cnt = torch.empty(1, dtype=torch.int64, device=frame.device)
+    add("count_ge", lambda: nv.count_ge(alpha, 128, out=cnt), N)
+    t_net = time_kernel(lambda: pipe.net(pipe.x7), iters=20, warm=3)
+    return rows, t_net
+
+
+def cpu_baseline(cfg, pipe, clip_cpu_frames, bg_always, nframes):
+    """The CPU oracle (C restatement, 1 thread) + the same network on torch-CPU, on a bounded sample."""
+    import __graft_entry__ as ge
+    import oracle
+    oracle.build()
+    alpha_pre = None
+    t0 = time.time()
+    for f in clip_cpu_frames[:nframes]:
+        o = ge.oracle_frame(oracle, cfg, pipe, f["frame"], f["seg"], f["bg"], bg_always, alpha_pre)
+        alpha_pre = o["alpha"]
+    dt = time.time() - t0
+    return nframes / dt, dt
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build_native()
+    if world > 1:
+        dist.barrier()
+    from video_unscreen_amd import _native as nv
+    from video_unscreen_amd.dist import broadcast_state, shard_range
+    from video_unscreen_amd.pipeline import BgStepPipeline, default_config
+    from video_unscreen_amd.synth import SyntheticClip
+    from video_unscreen_amd.vmatting.net import synthetic_state_dict
+
+    H, W, K, Wm = args.height, args.width, args.steps, args.warmup
+    cfg = default_config()
+    dtype = getattr(torch, args.dtype)
+
+    # weights + overall background: rank 0 owns them, everyone else receives them over RCCL / xGMI
+    clip = SyntheticClip(H, W, (K + Wm) * world, config_id=2, device=dev)
+    sd = synthetic_state_dict(0) if rank == 0 else None
+    sd, bg_always = broadcast_state(sd, clip.bg_always if rank == 0 else torch.empty_like(clip.bg_always), dev, world)
+    pipe = BgStepPipeline(cfg, H, W, device=dev, dtype=dtype, state_dict=sd)
+
+    # this rank's contiguous frame range, generated straight into HBM (not timed)
+    lo, hi = shard_range((K + Wm) * world, rank, world)
+    clip.gen.manual_seed(20260002 + 7919 * rank)
+    frames = []
+    for t in range(lo, hi):
+        f = clip.frame(t)
+        frames.append((f["frame"], f["seg"], f["bg"], bg_always))
+    torch.cuda.synchronize()
+
+    def run(inputs):
+        if args.sync_loop:
+            for i in inputs:
+                pipe.step(*i)
+        else:
+            pipe.run(iter(inputs))
+
+    pipe.reset()
+    run(frames[:Wm])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(frames[Wm:Wm + K])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    result = None
+    if rank == 0:
+        fps = world * K / dt
+        result = {
+            "metric": "frames/sec end-to-end unscreen (bg_step, 1080p)" if (H, W) == (1080, 1920) else f"frames/sec end-to-end unscreen (bg_step, {W}x{H})",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": {"float32": "f32", "float16": "f16", "bfloat16": "bf16"}[args.dtype],
+            "data": "synthetic",
+            "config": {"workload": f"bg_step stage-3 loop (bgdiff mask + object filter + trimap + matting UNet-18 + get_fg), "
+                                   f"{W}x{H}, {K} frames/GPU, frame-sharded x{world}",
+                       "net_input": [pipe.in_h, pipe.in_w], "loop": "sync" if args.sync_loop else "pipelined",
+                       "weights": "keyed-deterministic synthetic (no checkpoint offline)"},
+        }
+        if not args.no_kernel_table:
+            rows, t_net = kernel_table(pipe, frames[Wm], H, W)
+            dom = max(rows, key=lambda r: r["us"])
+            result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": dom["frac_hbm_peak"], "traffic": None,
+                                  "alg_bytes_per_launch": dom["alg_bytes"], "us_per_launch": dom["us"]}
+            result["kernels"] = rows
+            scale = (pipe.in_h * pipe.in_w) / (544 * 960)
+            tf = UNET_GFLOP_544x960 * scale / t_net / 1e3
+            result["net"] = {"bound": "mfma", "what": "matting UNet-18 via PyTorch-ROCm (MIOpen)", "ms": round(t_net * 1e3, 3),
+                             "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+        if not args.no_cpu_baseline:
+            clip_cpu = SyntheticClip(H, W, args.cpu_frames, config_id=2, device="cpu")
+            cf = []
+            for t in range(args.cpu_frames):
+                f = clip_cpu.frame(t)
+                cf.append({k: f[k].numpy() for k in ("frame", "seg", "bg")})
+            cpu_fps, cpu_dt = cpu_baseline(cfg, pipe, cf, clip_cpu.bg_always.numpy(), args.cpu_frames)
+            result["cpu_baseline"] = {"value": round(cpu_fps, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
+                                      "kind": "port",
+                                      "sample": f"{args.cpu_frames} frames {W}x{H}: C oracle (1 thread) for the pixel stages + the same "
+                                                f"network on torch-CPU ({torch.get_num_threads()} threads), {cpu_dt:.1f} s",
+                                      "host_cpus": os.cpu_count()}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+/*
+ * unscreen_hip.h - C ABI of libunscreen_hip.so: the MI355X (gfx950) pixel stages of the
+ * per-frame video-unscreen path.
+ *
+ * The reference (AnyiRao/video_unscreen) is pure Python; the interface this library sits behind is
+ * its agent API (unscreen/<stage>/agent.py classes and unscreen/utils functions).  Each entry point
+ * names the reference code it replaces as file:line (paths relative to the reference repo root).
+ * The Python side binds these with ctypes (video_unscreen_amd/_native.py); INTEGRATION.md shows the
+ * stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; images are uint8, HWC, BGR, densely packed; masks uint8 HW;
+ *  - every pointer not marked "host" is a DEVICE pointer (e.g. torch.Tensor.data_ptr());
+ *  - every call enqueues work on `stream` (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream)
+ *    and returns without synchronising; no allocation, no global mutable state, re-entrant;
+ *  - the caller owns every buffer, including the scratch `ws` whose size the matching
+ *    *_ws_bytes() function reports;
+ *  - return value: 0 = ok, < 0 = error (USC_E_*); usc_last_error() gives the thread-local message.
+ */
+#ifndef UNSCREEN_HIP_H
+#define UNSCREEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* usc_stream_t;               /* hipStream_t */
+
+#define USC_OK            0
+#define USC_E_ARG        -1               /* bad argument (null pointer, non-positive size, ...) */
+#define USC_E_UNSUPPORTED -2              /* parameter combination outside the kernels' limits */
+#define USC_E_WORKSPACE  -3               /* workspace too small */
+#define USC_E_LAUNCH     -4               /* HIP reported a launch error */
+
+#define USC_MORPH_DILATE 0
+#define USC_MORPH_ERODE  1
+#define USC_LAYOUT_NCHW  0
+#define USC_LAYOUT_NHWC  1
+
+int         usc_abi_version(void);
+const char* usc_last_error(void);
+
+/* Geometry helpers (host, pure): unscreen/utils/imgprocess.py:164-192 get_target_size,
+ * :67-97 pad_resize (size of the resized image inside the padded canvas),
+ * :100-132 inv_pad_resize (size of the un-padded region). */
+void usc_get_target_size(int h, int w, int long_side, int division, int* target_h, int* target_w);
+void usc_pad_resize_geometry(int h, int w, int target_h, int target_w, int* new_h, int* new_w);
+void usc_inv_pad_geometry(int h, int w, int ori_h, int ori_w, int* resized_h, int* resized_w);
+
+/* unscreen/utils/maskprocess.py:7-34 dilate_mask / erode_mask: grey-level max / min filter with
+ * cv2.getStructuringElement(MORPH_ELLIPSE, (ksize, ksize)), `iters` passes, out-of-image taps ignored.
+ * src and dst may not alias. */
+size_t usc_morph_ws_bytes(int H, int W, int ksize, int iters);
+int usc_morph_u8(const uint8_t* src, uint8_t* dst, int H, int W, int ksize, int iters, int op,
+                 void* ws, size_t ws_bytes, usc_stream_t stream);
+
+/* unscreen/trimap/agent.py:35-61 TrimapAgent.generate_trimap: NEAREST down to
+ * get_target_size(H, W, long_side), dilate + erode (ksize, iters), {0,128,255}, bilinear back to H x W,
+ * intermediate values -> 128. */
+size_t usc_trimap_ws_bytes(int H, int W, int long_side);
+int usc_trimap_u8(const uint8_t* mask, int H, int W, int long_side, int ksize, int iters, uint8_t* out,
+                  void* ws, size_t ws_bytes, usc_stream_t stream);
+
+/* tools/unscreen/bg_offline.py:150-160 (same arithmetic: tools/unscreen/bg.py:85-92): background fusion
+ * bg = u8(bg_i*beta + (1-beta)*bg_always) and the background-difference gate
+ * alpha = gray(seg) * (dilate4x4x2(gray(|frame - bg|) > thr) // 255).
+ * bg_always may be NULL with beta = 1 (bg.py: a single background image).  seg_cn is 1 or 3. */
+size_t usc_bgdiff_ws_bytes(int H, int W);
+int usc_bgdiff_mask_u8(const uint8_t* frame, const uint8_t* bg_i, const uint8_t* bg_always,
+                       const uint8_t* seg, int seg_cn, double beta, int thr, int H, int W,
+                       uint8_t* out_bg, uint8_t* out_alpha, void* ws, size_t ws_bytes, usc_stream_t stream);
+
+/* unscreen/vmatting/agent.py:76-106 preprocess (+ :44-74 to_tensor, unscreen/utils/imgprocess.py:135-161
+ * imnormalize, model.py:564 torch.cat): frame, previous alpha and trimap -> the network's packed
+ * 7-channel float input of size inH x inW (bilinear pad_resize + BORDER_REFLECT, ImageNet normalise in RGB
+ * order, alpha/255, one-hot trimap). */
+int usc_vmat_pre(const uint8_t* frame, const uint8_t* alpha_pre, const uint8_t* trimap, int H, int W,
+                 int inH, int inW, float* out7, int layout, usc_stream_t stream);
+
+/* unscreen/vmatting/agent.py:108-132 postprocess: crop the pad, float bilinear back to H x W, force known
+ * trimap regions, (a * 255) truncated to uint8.  alpha_f32 (optional, may be NULL) gets the float alpha. */
+int usc_vmat_post(const float* pred, int inH, int inW, const uint8_t* trimap, int H, int W,
+                  uint8_t* alpha_u8, float* alpha_f32, usc_stream_t stream);
+
+/* unscreen/utils/fgfuncs.py:84-110 get_fg, optionally preceded by the caller's paste
+ * bg[alpha < paste_thr] = frame[alpha < paste_thr] (tools/unscreen/bg_offline.py:171 and bg.py:99 use
+ * alpha == 0 -> paste_thr 1; green.py:125 uses alpha < 128; 0 = no paste).
+ * out_bg (optional, may be NULL) receives the pasted background. */
+int usc_get_fg_u8(const uint8_t* frame, const uint8_t* alpha, const uint8_t* bg, int paste_thr, int H, int W,
+                  uint8_t* out_fg, uint8_t* out_bg, usc_stream_t stream);
+
+/* unscreen/utils/fgfuncs.py:113-137 get_bg. */
+int usc_get_bg_u8(const uint8_t* alpha, const uint8_t* bg, int H, int W, uint8_t* out, usc_stream_t stream);
+
+/* tools/replace/replace.py:74-76 composite: u8(fg*m + bg*(1-m)), m = mask/255 in float64; mask_cn 1 or 3. */
+int usc_blend_u8(const uint8_t* fg, const uint8_t* mask, int mask_cn, const uint8_t* bg, int H, int W,
+                 uint8_t* out, usc_stream_t stream);
+
+/* unscreen/utils/maskprocess.py:56-60 exist_foreground: *out_count (device, 8 bytes) = #(mask >= thr). */
+int usc_count_ge_u8(const uint8_t* mask, size_t n, int thr, unsigned long long* out_count, usc_stream_t stream);
+
+/* unscreen/utils/maskprocess.py:77-189 remove_invalid_objects (+ get_score_map / build_score_map).
+ * HOST function on HOST pointers: contour tracing is sequential, so this stage runs on the CPU between
+ * two device stages exactly where the reference runs it.  alpha (H*W) is modified in place; seg may be NULL
+ * (then alpha itself is the consensus mask).  score_cache is optional caller-owned host scratch of
+ * H*W doubles reused across calls of the same geometry (NULL = rebuilt per call like the reference). */
+int usc_remove_invalid_objects_host(uint8_t* alpha, const uint8_t* seg, int H, int W,
+                                    double center_y, double center_x, double saliency_thr, double consensus_thr,
+                                    double* score_cache, int* score_cache_valid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

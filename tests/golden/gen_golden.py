@@ -1,0 +1,104 @@
+"""Generates the committed golden fixtures from the REFERENCE's own code (run in the build container only;
+/root/reference never travels).  Fixtures are data: inputs + expected outputs.
+
+  unet_64x96.npz        reference unscreen/vmatting/model.py UNet (loaded by file path; torch-only module) with
+                        the keyed-deterministic checkpoint of video_unscreen_amd.vmatting.net.synthetic_state_dict
+  target_size.npz       reference unscreen/utils/imgprocess.py get_target_size over a grid (function extracted
+                        with ast; the module itself needs cv2)
+  score_map.npz         reference unscreen/utils/maskprocess.py get_score_map / build_score_map / exist_foreground
+                        (extracted with ast; np.float aliased to float for NumPy >= 1.24)
+
+Usage: python tests/golden/gen_golden.py
+"""
+import ast
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def extract(path, names, extra_globals=None):
+    """exec only the named top-level functions of a reference file."""
+    src = open(path).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    mod = ast.Module(body=keep, type_ignores=[])
+    ns = {"np": np}
+    ns.update(extra_globals or {})
+    exec(compile(mod, path, "exec"), ns)
+    return ns
+
+
+def unet_input(h, w, seed):
+    """Deterministic, realistic 7-channel input: normalised image, alpha in [0,1], one-hot trimap."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(1, 3, h, w, generator=g)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    img = (img - mean) / std
+    alpha = torch.rand(1, 1, h, w, generator=g)
+    tri = torch.randint(0, 3, (h, w), generator=g)
+    onehot = torch.nn.functional.one_hot(tri, 3).permute(2, 0, 1).float()[None]
+    return torch.cat([img, alpha, onehot], 1)
+
+
+def main():
+    from video_unscreen_amd.vmatting.net import synthetic_state_dict
+
+    # ---- 1. UNet
+    spec = importlib.util.spec_from_file_location("ref_vmat_model", os.path.join(REF, "unscreen/vmatting/model.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ref = mod.UNet().eval()
+    ref.load_state_dict(synthetic_state_dict(0))
+    x = unet_input(64, 96, 1234)
+    with torch.no_grad():
+        y = ref(x[:, :3], x[:, 3:4], x[:, 4:])
+        x2 = unet_input(96, 160, 99)
+        y2 = ref(x2[:, :3], x2[:, 3:4], x2[:, 4:])
+    np.savez_compressed(os.path.join(HERE, "unet_64x96.npz"), y=y.numpy(), seed=1234,
+                        y2_sub=y2.numpy()[:, :, ::4, ::4], seed2=99)
+    print("unet", y.shape, float(y.min()), float(y.max()), float(y.std()))
+
+    # ---- 2. get_target_size
+    ns = extract(os.path.join(REF, "unscreen/utils/imgprocess.py"), {"get_target_size"})
+    rows = []
+    sizes = [(1080, 1920), (2160, 3840), (256, 256), (720, 1280), (1920, 1080), (480, 640), (481, 641), (333, 1000),
+             (1000, 333), (17, 31), (31, 17), (540, 960), (1079, 1919), (600, 600), (1, 5), (7, 7)]
+    for (h, w) in sizes:
+        for L in (960, 962, 912, 800, 473, 513, 64, 48):
+            for d in (1, 32, 8):
+                th, tw = ns["get_target_size"](h, w, L, d)
+                rows.append((h, w, L, d, th, tw))
+    np.savez_compressed(os.path.join(HERE, "target_size.npz"), table=np.array(rows, np.int64))
+    print("target_size rows", len(rows))
+
+    # ---- 3. score map + exist_foreground
+    np.float = float  # removed alias used by the reference
+    ns = extract(os.path.join(REF, "unscreen/utils/maskprocess.py"), {"get_score_map", "build_score_map", "exist_foreground"})
+    cfg = {"objectremoval": {"score_map_center": {"landscape": [0.5, 0.5], "portrait": [0.6, 0.5]}}}
+    out = {}
+    for (h, w) in [(54, 96), (96, 54), (33, 47), (64, 64), (2, 3)]:
+        out[f"score_{h}x{w}"] = ns["build_score_map"](h, w, cfg)
+    out["score_c_40x60"] = ns["get_score_map"]((40, 60), (0.3, 0.8))
+    rng = np.random.default_rng(7)
+    masks = rng.integers(0, 256, (6, 20, 30), dtype=np.uint8)
+    masks[0] = 0
+    masks[1] = 127
+    masks[2] = 128
+    out["ef_masks"] = masks
+    out["ef_thr"] = np.array([0.001, 0.5, 0.25, 0.999])
+    out["ef_expected"] = np.array([[ns["exist_foreground"](m, t) for t in out["ef_thr"]] for m in masks])
+    np.savez_compressed(os.path.join(HERE, "score_map.npz"), **out)
+    print("score_map keys", list(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,233 @@
+"""GPU parity tests (-m gpu): every HIP stage, called through the C ABI (video_unscreen_amd._native -> ctypes ->
+libunscreen_hip.so), against the CPU oracle on the same seeded inputs.  Integer / byte stages must be bit-exact;
+the float alpha must be within 1e-3 (BASELINE.json north_star) - tolerances are stated at each assert."""
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ALPHA_TOL = 1e-3          # north_star: alpha / foreground within 1e-3 L-inf of the reference CPU path
+
+
+@pytest.fixture(scope="module")
+def nv():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from video_unscreen_amd import _native
+    _native.load()                     # raises if the HIP extension is missing: no fallback
+    return _native
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def blob_mask(H, W, seed, q=0.6, sigma=None):
+    rng = np.random.default_rng(seed)
+    sigma = sigma if sigma is not None else max(2, min(H, W) // 40)
+    x = ndi.gaussian_filter(rng.random((H, W)), sigma)
+    return (x > np.quantile(x, q)).astype(np.uint8) * 255
+
+
+def rand_img(H, W, seed, smooth=True):
+    rng = np.random.default_rng(seed)
+    if not smooth:
+        return rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    base = ndi.gaussian_filter(rng.random((H, W, 3)) * 255, (3, 3, 0))
+    img = (base - base.min()) / (base.max() - base.min() + 1e-9) * 255 + rng.normal(0, 2, (H, W, 3))
+    return np.clip(np.round(img), 0, 255).astype(np.uint8)
+
+
+SIZES = [(1080, 1920), (2160, 3840), (256, 256), (270, 480), (135, 241), (64, 96), (1920, 1080), (33, 47), (1, 7), (5, 1)]
+
+
+@pytest.mark.parametrize("H,W", SIZES)
+def test_trimap_bit_exact(nv, oracle_lib, H, W):
+    for seed, (L, k, it) in enumerate([(960, 3, 5), (960, 3, 5), (64, 4, 2), (100, 5, 3)]):
+        if seed >= 2 and H * W > 600000:
+            continue
+        m = blob_mask(H, W, 10 + seed)
+        if seed == 1:                                   # grey masks: thresholds 127 / 128 matter
+            m = np.random.default_rng(seed).integers(0, 256, (H, W), dtype=np.uint8)
+        want = oracle_lib.trimap(m, L, k, it)
+        got = host(nv.trimap(dev(m), L, k, it))
+        assert np.array_equal(got, want), f"{(H, W, L, k, it)}: {(got != want).sum()} pixels differ"   # bit-exact
+    for m in (np.zeros((H, W), np.uint8), np.full((H, W), 255, np.uint8)):
+        assert np.array_equal(host(nv.trimap(dev(m))), oracle_lib.trimap(m))
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920), (270, 480), (65, 130), (33, 47), (3, 200)])
+@pytest.mark.parametrize("k,it", [(3, 5), (4, 2), (5, 10), (3, 2), (7, 3), (1, 3), (3, 0)])
+def test_morph_bit_exact(nv, oracle_lib, H, W, k, it):
+    if H * W > 600000 and (k, it) not in ((3, 5), (4, 2)):
+        pytest.skip("large size covered for the reference's own parameter pairs")
+    g = np.random.default_rng(k * 100 + it).integers(0, 256, (H, W), dtype=np.uint8)
+    for op, name in ((nv.DILATE, "dilate"), (nv.ERODE, "erode")):
+        assert np.array_equal(host(nv.morph(dev(g), k, it, op)), oracle_lib.morph(g, k, it, name))   # bit-exact
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920), (2160, 3840), (270, 480), (135, 241), (33, 47), (2, 3)])
+def test_bgdiff_mask_bit_exact(nv, oracle_lib, H, W):
+    frame = rand_img(H, W, 1)
+    bg_always = rand_img(H, W, 2)
+    bg_i = np.clip(bg_always.astype(int) + np.random.default_rng(3).integers(-3, 4, bg_always.shape), 0, 255).astype(np.uint8)
+    fgm = blob_mask(H, W, 4)
+    frame = np.where(fgm[..., None] > 0, frame, np.clip(bg_always.astype(int) + np.random.default_rng(5).integers(-20, 21, frame.shape), 0, 255)).astype(np.uint8)
+    seg1 = blob_mask(H, W, 6)
+    seg3 = np.stack([seg1, np.roll(seg1, 1, 1), np.roll(seg1, 1, 0)], -1)
+    for seg in (seg3, seg1):
+        for beta, thr in ((0.1, 25), (0.37, 3)):
+            wb, wa = oracle_lib.bgdiff_mask(frame, bg_i, bg_always, seg, beta, thr)
+            gb, ga = nv.bgdiff_mask(dev(frame), dev(bg_i), dev(bg_always), dev(seg), beta, thr)
+            assert np.array_equal(host(gb), wb)            # fused background: bit-exact (f32 blend, truncation)
+            assert np.array_equal(host(ga), wa)            # gated alpha: bit-exact
+
+
+@pytest.mark.parametrize("H,W,L", [(1080, 1920, 960), (2160, 3840, 960), (256, 256, 960), (270, 480, 960),
+                                   (135, 241, 64), (64, 128, 64), (1920, 1080, 960), (50, 70, 70), (33, 47, 96)])
+def test_vmat_pre_bit_exact(nv, oracle_lib, H, W, L):
+    frame = rand_img(H, W, 11, smooth=False)
+    ap = np.random.default_rng(12).integers(0, 256, (H, W), dtype=np.uint8)
+    tri = np.random.default_rng(13).choice(np.array([0, 128, 255], np.uint8), (H, W))
+    tri = ndi.median_filter(tri, 5)
+    in_h, in_w = oracle_lib.vmat_input_size(H, W, L)
+    want_nchw = oracle_lib.vmat_pre(frame, ap, tri, in_h, in_w, "nchw")
+    got_nhwc = nv.vmat_pre(dev(frame), dev(ap), dev(tri), in_h, in_w, layout=nv.NHWC)
+    assert got_nhwc.shape == (1, 7, in_h, in_w)
+    assert np.array_equal(host(got_nhwc)[0], want_nchw)    # float32, bit-exact (same op order, no contraction)
+    got_nchw = nv.vmat_pre(dev(frame), dev(ap), dev(tri), in_h, in_w, layout=nv.NCHW)
+    assert np.array_equal(host(got_nchw)[0], want_nchw)
+
+
+@pytest.mark.parametrize("H,W,L", [(1080, 1920, 960), (2160, 3840, 960), (256, 256, 960), (135, 241, 64), (64, 128, 64),
+                                   (1920, 1080, 960), (33, 47, 96), (544, 960, 960)])
+def test_vmat_post_bit_exact(nv, oracle_lib, H, W, L):
+    in_h, in_w = oracle_lib.vmat_input_size(H, W, L)
+    rng = np.random.default_rng(21)
+    pred = ndi.gaussian_filter(rng.random((in_h, in_w)), 2).astype(np.float32)
+    pred = ((pred - pred.min()) / (pred.max() - pred.min())).astype(np.float32)
+    pred[0, 0] = 1.0
+    tri = ndi.median_filter(rng.choice(np.array([0, 128, 255], np.uint8), (H, W)), 5)
+    w8, wf = oracle_lib.vmat_post(pred, tri, want_float=True)
+    g8, gf = nv.vmat_post(dev(pred), dev(tri), want_float=True)
+    assert np.array_equal(host(gf), wf)                    # float alpha: bit-exact
+    assert np.array_equal(host(g8), w8)                    # uint8 alpha (truncation): bit-exact
+    assert np.array_equal(host(nv.vmat_post(dev(pred), dev(tri))), w8)
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920), (2160, 3840), (270, 480), (33, 47), (1, 3), (7, 1)])
+def test_get_fg_get_bg_blend_bit_exact(nv, oracle_lib, H, W):
+    frame = rand_img(H, W, 31, smooth=False)
+    bg = rand_img(H, W, 32, smooth=False)
+    alpha = np.random.default_rng(33).integers(0, 256, (H, W), dtype=np.uint8)
+    alpha[np.random.default_rng(34).random((H, W)) < 0.3] = 0
+    alpha[np.random.default_rng(35).random((H, W)) < 0.2] = 255
+    for paste in (0, 1, 128):
+        wf, wb = oracle_lib.get_fg(frame, alpha, bg, paste)
+        gf, gb = nv.get_fg(dev(frame), dev(alpha), dev(bg), paste, want_bg=True)
+        assert np.array_equal(host(gf), wf), f"paste {paste}: {(host(gf) != wf).sum()} bytes differ"   # bit-exact
+        assert np.array_equal(host(gb), wb)
+    assert np.array_equal(host(nv.get_bg(dev(alpha), dev(bg))), oracle_lib.get_bg(alpha, bg))           # bit-exact
+    m3 = np.stack([alpha, np.roll(alpha, 1, 0), np.roll(alpha, 1, 1)], -1)
+    for m in (alpha, m3):
+        assert np.array_equal(host(nv.blend(dev(frame), dev(m), dev(bg))), oracle_lib.blend(frame, m, bg))   # bit-exact
+
+
+def test_get_fg_exhaustive_hsv_colours(nv, oracle_lib):
+    """All 2^24 BGR colours once as frame (alpha 255 -> pure HSV round trip) and once as background."""
+    v = np.arange(256, dtype=np.uint8)
+    for chunk in range(0, 256, 64):
+        b, g, r = np.meshgrid(v[chunk:chunk + 64], v, v, indexing="ij")
+        img = np.stack([b, g, r], -1).reshape(64 * 256, 256, 3)
+        other = np.roll(img, 17, axis=1)[::-1].copy()
+        alpha = ((np.arange(img.shape[0])[:, None] * 7 + np.arange(256)[None, :] * 13) % 256).astype(np.uint8)
+        for (f, bgd) in ((img, other), (other, img)):
+            wf, _ = oracle_lib.get_fg(f, alpha, bgd, 0)
+            assert np.array_equal(host(nv.get_fg(dev(f), dev(alpha), dev(bgd), 0)), wf)       # bit-exact
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 2073600, 8294400])
+def test_count_ge_exact(nv, oracle_lib, n):
+    m = np.random.default_rng(n).integers(0, 256, n, dtype=np.uint8)
+    for thr in (128, 1, 255):
+        assert int(nv.count_ge(dev(m), thr).item()) == oracle_lib.count_ge(m, thr)
+    assert int(nv.count_ge(dev(np.zeros(n, np.uint8)), 128).item()) == 0
+
+
+def test_agents_numpy_api(nv, oracle_lib, cfg):
+    """The reference-shaped NumPy API (drop-in agents / utils) gives the oracle's answers."""
+    from video_unscreen_amd.trimap import TrimapAgent
+    from video_unscreen_amd.utils import dilate_mask, erode_mask, exist_foreground, get_bg, get_fg
+    H, W = 120, 200
+    m = blob_mask(H, W, 41)
+    agent = TrimapAgent(**cfg["trimap"])
+    assert np.array_equal(agent.forward(m.copy()), oracle_lib.trimap(m, 960, 3, 5))
+    assert np.array_equal(dilate_mask(m, 4, 2), oracle_lib.morph(m, 4, 2, "dilate"))
+    assert np.array_equal(erode_mask(m, 3, 2), oracle_lib.morph(m, 3, 2, "erode"))
+    assert exist_foreground(m, 0.001) == oracle_lib.exist_foreground(m, 0.001)
+    assert exist_foreground(np.zeros_like(m), 0.001) is False
+    frame, bg = rand_img(H, W, 42), rand_img(H, W, 43)
+    assert np.array_equal(get_fg(frame, m, bg), oracle_lib.get_fg(frame, m, bg, 0)[0])
+    assert np.array_equal(get_bg(m, bg), oracle_lib.get_bg(m, bg))
+
+
+@pytest.mark.parametrize("H,W", [(270, 480), (1080, 1920)])
+def test_matting_agent_and_pipeline_vs_oracle(nv, oracle_lib, cfg, H, W):
+    """Whole frames: the device-resident loop against the oracle loop (bg_offline.py:145-176).  Index masks
+    bit-exact; float alpha within ALPHA_TOL of the CPU path; uint8 alpha within 1 LSB (a truncation can flip)."""
+    import __graft_entry__ as ge
+    from video_unscreen_amd.pipeline import BgStepPipeline
+    from video_unscreen_amd.synth import SyntheticClip
+    nframes = 3 if H < 1000 else 2
+    clip = SyntheticClip(H, W, nframes, config_id=2, device="cpu")
+    pipe = BgStepPipeline(cfg, H, W, device="cuda:0")
+    bg_always = clip.bg_always
+    alpha_pre = None
+    for t in range(nframes):
+        f = clip.frame(t)
+        out = pipe.step(f["frame"].cuda(), f["seg"].cuda(), f["bg"].cuda(), bg_always.cuda(), want_float=True)
+        want = ge.oracle_frame(oracle_lib, cfg, pipe, f["frame"].numpy(), f["seg"].numpy(), f["bg"].numpy(),
+                               bg_always.numpy(), alpha_pre)
+        assert np.array_equal(host(out["bg"]), want["bg"])                      # bit-exact
+        assert np.array_equal(host(out["gate"]), want["alpha_gate"])            # bit-exact
+        assert np.array_equal(host(out["alphaor"]), want["alphaor"])            # bit-exact
+        assert np.array_equal(host(out["trimap"]), want["trimap"])              # bit-exact
+        dpred = np.abs(host(out["pred"])[0, 0] - want["pred"]).max()
+        assert dpred < ALPHA_TOL, f"network output differs from the CPU path by {dpred}"
+        da = np.abs(host(out["alpha_f32"]) - want["alpha_f32"]).max()
+        assert da < ALPHA_TOL, f"float alpha differs by {da}"
+        d8 = np.abs(host(out["alpha"]).astype(int) - want["alpha"].astype(int)).max()
+        assert d8 <= 1
+        # foreground: given the SAME alpha the HIP composite is bit-exact
+        fg_same, _ = oracle_lib.get_fg(f["frame"].numpy(), host(out["alpha"]), want["bg"], paste_thr=1)
+        assert np.array_equal(host(out["fg"]), fg_same)
+        alpha_pre = host(out["alpha"])          # keep both chains on the same previous alpha
+        pipe.alpha_pre = out["alpha"]
+
+
+def test_pipelined_run_equals_step(nv, cfg):
+    """run() (two streams + host worker) must produce exactly what the synchronous step() produces."""
+    from video_unscreen_amd.pipeline import BgStepPipeline
+    from video_unscreen_amd.synth import SyntheticClip
+    H, W, n = 270, 480, 6
+    clip = SyntheticClip(H, W, n, config_id=2, device="cpu")
+    frames = [clip.frame(t) for t in range(n)]
+    bga = clip.bg_always.cuda()
+    ins = [(f["frame"].cuda(), f["seg"].cuda(), f["bg"].cuda(), bga) for f in frames]
+    p1 = BgStepPipeline(cfg, H, W)
+    ref = []
+    for i in ins:
+        o = p1.step(*i)
+        ref.append((o["alpha"].clone(), o["fg"].clone(), o["trimap"].clone()))
+    p2 = BgStepPipeline(cfg, H, W)
+    got = []
+    p2.run(iter(ins), on_result=lambda k, o: got.append((o["alpha"].clone(), o["fg"].clone(), o["trimap"].clone())))
+    torch.cuda.synchronize()
+    assert len(got) == n
+    for (a, f, t), (a2, f2, t2) in zip(ref, got):
+        assert torch.equal(t, t2) and torch.equal(a, a2) and torch.equal(f, f2)

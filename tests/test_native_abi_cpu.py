@@ -1,0 +1,91 @@
+"""CPU tests of the product side that need no GPU: the C-ABI library loads and exports every symbol the header
+declares, its pure host functions agree with the oracle / the reference table, and the host object filter is
+bit-identical to the oracle's independent restatement."""
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def nv():
+    import __graft_entry__ as g
+    g.build_native()
+    from video_unscreen_amd import _native
+    _native.load()
+    return _native
+
+
+def test_library_exports_every_declared_symbol(nv):
+    header = open(os.path.join(ROOT, "include", "unscreen_hip.h")).read()
+    declared = set(re.findall(r"\b(usc_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = nv.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/unscreen_hip.h but not exported"
+    assert declared == set(nv.EXPORTS), declared ^ set(nv.EXPORTS)
+    assert lib.usc_abi_version() == 1
+
+
+def test_host_geometry_matches_reference_table(nv, oracle_lib):
+    table = np.load(os.path.join(GOLD, "target_size.npz"))["table"]
+    for h, w, L, d, th, tw in table:
+        assert nv.get_target_size(h, w, L, d) == (th, tw)
+    assert nv.get_target_size(1080, 1920, 960, 32) == (544, 960)
+    assert nv.pad_resize_geometry(1080, 1920, 544, 960) == (540, 960) == oracle_lib.pad_resize_geometry(1080, 1920, 544, 960)
+    assert nv.inv_pad_geometry(544, 960, 1080, 1920) == (540, 960)
+    assert nv.pad_resize_geometry(256, 256, 960, 960) == (960, 960)
+    assert nv.pad_resize_geometry(1920, 1080, 960, 544) == (960, 540)
+
+
+def test_device_entry_points_reject_host_arrays(nv):
+    import torch
+    with pytest.raises(nv.NativeError):
+        nv.trimap(torch.zeros(8, 8, dtype=torch.uint8))          # CPU tensor: no silent fallback
+
+
+def test_argument_errors_are_reported(nv):
+    lib = nv.load()
+    rc = lib.usc_trimap_u8(None, 0, 0, 960, 3, 5, None, None, 0, None)
+    assert rc == -1 and b"usc_trimap_u8" in lib.usc_last_error()
+    rc = lib.usc_morph_u8(1, 2, 8, 8, 99, 1, 0, None, 0, None)
+    assert rc == -2
+
+
+def _random_mask(H, W, seed, q, sigma):
+    rng = np.random.default_rng(seed)
+    x = ndi.gaussian_filter(rng.random((H, W)), sigma)
+    return (x > np.quantile(x, q)).astype(np.uint8) * 255
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_host_object_filter_equals_oracle(nv, oracle_lib, cfg, seed):
+    H, W = [(64, 96), (120, 80), (200, 300), (33, 47)][seed % 4]
+    m = _random_mask(H, W, seed, [0.5, 0.7, 0.3, 0.9][seed % 4], [1, 2, 3, 5][(seed // 4) % 4])
+    if seed % 3 == 0:                                             # grey alpha values (anything non-zero is object)
+        m = ((m > 0) * np.random.default_rng(seed).integers(1, 256, m.shape)).astype(np.uint8)
+    seg = None if seed % 2 == 0 else _random_mask(H, W, seed + 1000, 0.5, 3)
+    want = oracle_lib.remove_invalid_objects(cfg, m.copy(), seg)
+    from video_unscreen_amd.utils import remove_invalid_objects
+    got = remove_invalid_objects(cfg, m.copy(), seg)
+    assert np.array_equal(got, want)
+
+
+def test_host_object_filter_edge_cases(nv, oracle_lib, cfg):
+    from video_unscreen_amd.utils import remove_invalid_objects
+    for m in (np.zeros((40, 50), np.uint8), np.full((40, 50), 255, np.uint8)):
+        assert np.array_equal(remove_invalid_objects(cfg, m.copy()), oracle_lib.remove_invalid_objects(cfg, m.copy()))
+    m = np.zeros((60, 60), np.uint8)
+    m[0:30, 40:60] = 255            # touches top and right image edges
+    m[59, 0] = 255                  # single pixel in a corner
+    m[20:50, 5:35] = 255
+    m[30:40, 15:25] = 0             # hole
+    m[33:37, 18:22] = 255           # island inside the hole
+    assert np.array_equal(remove_invalid_objects(cfg, m.copy()), oracle_lib.remove_invalid_objects(cfg, m.copy()))
+    a = m.copy()
+    assert remove_invalid_objects(cfg, a) is a                   # in place, like the reference

@@ -1,0 +1,170 @@
+"""CPU tests: the oracle against the golden fixtures generated from the reference's own code
+(tests/golden/gen_golden.py) and against independent restatements (scipy / colorsys) of the primitives."""
+import colorsys
+import os
+
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_target_size_matches_reference_table(oracle_lib):
+    table = np.load(os.path.join(GOLD, "target_size.npz"))["table"]
+    for h, w, L, d, th, tw in table:
+        assert oracle_lib.get_target_size(h, w, L, d) == (th, tw), (h, w, L, d)
+
+
+def test_score_map_matches_reference(oracle_lib):
+    z = np.load(os.path.join(GOLD, "score_map.npz"))
+    for key in z.files:
+        if not key.startswith("score_") or key.startswith("score_c_"):
+            continue
+        h, w = map(int, key[len("score_"):].split("x"))
+        center = [0.5, 0.5] if w > h else [0.6, 0.5]
+        got = oracle_lib.score_map(h, w, center)
+        assert np.array_equal(got, z[key]), key            # float64, bit for bit
+    assert np.array_equal(oracle_lib.score_map(40, 60, (0.3, 0.8)), z["score_c_40x60"])
+
+
+def test_exist_foreground_matches_reference(oracle_lib):
+    z = np.load(os.path.join(GOLD, "score_map.npz"))
+    for m, row in zip(z["ef_masks"], z["ef_expected"]):
+        for t, e in zip(z["ef_thr"], row):
+            assert oracle_lib.exist_foreground(m, float(t)) == bool(e)
+
+
+def test_morphology_against_scipy(oracle_lib):
+    rng = np.random.default_rng(3)
+    m = (ndi.gaussian_filter(rng.random((70, 90)), 2) > 0.5).astype(np.uint8) * 255
+    cross = ndi.generate_binary_structure(2, 1)
+    for it in (1, 2, 5):
+        d = ndi.binary_dilation(m > 0, cross, iterations=it)
+        e = ndi.binary_erosion(m > 0, cross, iterations=it, border_value=1)
+        assert np.array_equal(oracle_lib.morph(m, 3, it, "dilate") > 0, d)
+        assert np.array_equal(oracle_lib.morph(m, 3, it, "erode") > 0, e)
+    # 4x4 ellipse: rows 0010 / 1111 / 1111 / 1111 around anchor (2, 2); grey-level max
+    g = rng.integers(0, 256, (40, 50), dtype=np.uint8)
+    fp = np.zeros((5, 5), bool)       # scipy needs an odd, centred footprint: embed the 4x4 element
+    se = np.array([[0, 0, 1, 0], [1, 1, 1, 1], [1, 1, 1, 1], [1, 1, 1, 1]], bool)
+    fp[0:4, 0:4] = se                 # anchor (2,2) of the 4x4 == centre (2,2) of the 5x5
+    # cv2.dilate does NOT reflect the element: dst(p) = max src(p + k - anchor) == scipy's maximum_filter
+    ref = ndi.maximum_filter(g, footprint=fp, mode="constant", cval=0)
+    assert np.array_equal(oracle_lib.morph(g, 4, 1, "dilate"), ref)
+    ref2 = ndi.maximum_filter(ref, footprint=fp, mode="constant", cval=0)
+    assert np.array_equal(oracle_lib.morph(g, 4, 2, "dilate"), ref2)
+
+
+def test_hsv_against_colorsys(oracle_lib):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)
+    img[0, 0] = (0, 0, 0)
+    img[0, 1] = (255, 255, 255)
+    img[0, 2] = (10, 10, 10)
+    hsv = oracle_lib.bgr2hsv(img)
+    for y in range(32):
+        for x in range(32):
+            b, g, r = (int(v) for v in img[y, x])
+            h, s, v = colorsys.rgb_to_hsv(r / 255., g / 255., b / 255.)
+            H, S, V = (int(c) for c in hsv[y, x])
+            assert V == max(b, g, r)
+            assert abs(S - s * 255) <= 1
+            dh = abs(H - h * 180) % 180
+            assert min(dh, 180 - dh) <= 1.01, (b, g, r, H, h * 180)
+    back = oracle_lib.hsv2bgr(hsv)
+    assert np.abs(back.astype(int) - img.astype(int)).max() <= 6      # 8-bit HSV is lossy, not wrong
+
+
+def test_gray_identity_on_equal_channels(oracle_lib):
+    v = np.arange(256, dtype=np.uint8)
+    img = np.stack([v, v, v], -1)[None]
+    assert np.array_equal(oracle_lib.bgr2gray(img)[0], v)
+
+
+def test_resize_properties(oracle_lib):
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (40, 64), dtype=np.uint8)
+    assert np.array_equal(oracle_lib.resize_linear(img, 40, 64), img)
+    half = oracle_lib.resize_linear(img, 20, 32)            # exact 2x: box average, round half up
+    box = (img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(half, box)
+    const = np.full((13, 17), 200, np.uint8)
+    for dh, dw in ((26, 34), (5, 9), (40, 11)):
+        assert np.all(oracle_lib.resize_linear(const, dh, dw) == 200)
+        assert np.all(oracle_lib.resize_nearest(const, dh, dw) == 200)
+    up = oracle_lib.resize_nearest(img, 80, 128)
+    assert np.array_equal(up[::2, ::2], img) and np.array_equal(up[1::2, 1::2], img)
+    f = rng.random((12, 20)).astype(np.float32)
+    fu = oracle_lib.resize_linear(f, 24, 40)
+    assert fu.min() >= f.min() - 1e-6 and fu.max() <= f.max() + 1e-6
+    # 2x float upsample: interior samples are the 0.75/0.25 blends
+    exp = (f[3, 5] * np.float32(0.75) + f[3, 6] * np.float32(0.25)) * np.float32(0.75) + \
+          (f[4, 5] * np.float32(0.75) + f[4, 6] * np.float32(0.25)) * np.float32(0.25)
+    assert fu[7, 11] == np.float32(exp)
+
+
+def test_trimap_structure(oracle_lib):
+    yy, xx = np.mgrid[0:120, 0:200]
+    m = ((((yy - 60) / 40.) ** 2 + ((xx - 100) / 50.) ** 2) < 1).astype(np.uint8) * 255
+    tri = oracle_lib.trimap(m, long_side=100, ksize=3, iters=5)
+    assert set(np.unique(tri)) == {0, 128, 255}
+    assert np.all(tri[m == 0][ndi.binary_erosion(m == 0, iterations=14)[m == 0]] == 0)
+    assert tri[60, 100] == 255 and tri[0, 0] == 0
+    band = tri == 128
+    assert band.sum() > 0 and np.all(ndi.binary_dilation(m > 0, iterations=16)[band])
+    assert np.all(oracle_lib.trimap(np.zeros((50, 60), np.uint8), 60) == 0)
+    assert np.all(oracle_lib.trimap(np.full((50, 60), 255, np.uint8), 60) == 255)
+
+
+def test_contours_count_and_fill_against_scipy(oracle_lib, cfg):
+    """Independent check of the border follower: #contours = #8-connected objects + #4-connected holes, and
+    objects kept/removed as whole filled regions."""
+    rng = np.random.default_rng(11)
+    for trial in range(12):
+        H, W = [(60, 80), (90, 50), (128, 128)][trial % 3]
+        x = ndi.gaussian_filter(rng.random((H, W)), [1, 2, 3][trial % 3])
+        m = (x > np.quantile(x, [0.4, 0.6, 0.8][trial % 3])).astype(np.uint8) * 255
+        _, stats = oracle_lib.remove_invalid_objects(cfg, m.copy(), return_stats=True)
+        _, n_obj = ndi.label(m > 0, structure=np.ones((3, 3)))
+        lab_bg, n_bg = ndi.label(np.pad(m == 0, 1, constant_values=True))       # 4-connected background
+        n_holes = n_bg - 1                                                      # minus the outside
+        assert len(stats) == n_obj + n_holes
+
+
+def test_remove_invalid_objects_semantics(oracle_lib, cfg):
+    H, W = 200, 300
+    a = np.zeros((H, W), np.uint8)
+    a[80:130, 120:180] = 255          # big central object: kept
+    a[5:9, 5:9] = 255                 # polygon area 9 < 100: dropped
+    a[100:110, 140:150] = 0           # hole inside the kept object: stays a hole
+    out = oracle_lib.remove_invalid_objects(cfg, a.copy())
+    assert out[100, 130] == 255 and out[6, 6] == 0 and out[105, 145] == 0
+    assert np.array_equal(out[80:130, 120:180], a[80:130, 120:180])
+    # consensus: object absent from the segmentation mask and of modest saliency is dropped
+    seg = np.zeros_like(a)
+    b = np.zeros((H, W), np.uint8)
+    b[10:22, 10:22] = 255             # area 121, near the corner: saliency between thr and 10*thr?
+    out2, st = oracle_lib.remove_invalid_objects(cfg, b.copy(), seg, return_stats=True)
+    area, sal, cons, kept = st[0]
+    assert area == 121 and cons == 0
+    assert kept == float(sal > 1e-4)
+    # in-place contract (reference maskprocess.py:151-152)
+    c = a.copy()
+    r = oracle_lib.remove_invalid_objects(cfg, c)
+    assert r is c
+
+
+def test_unet_restatement_matches_reference_golden():
+    """The folded conv plan (product module, run on CPU as the network's oracle) against the reference UNet."""
+    import sys
+    import torch
+    sys.path.insert(0, GOLD)
+    from gen_golden import unet_input
+    from video_unscreen_amd.vmatting.net import MattingNet, synthetic_state_dict
+    z = np.load(os.path.join(GOLD, "unet_64x96.npz"))
+    net = MattingNet(synthetic_state_dict(0), device="cpu")
+    y = net(unet_input(64, 96, int(z["seed"]))).numpy()
+    assert np.abs(y - z["y"]).max() < 1e-5
+    y2 = net(unet_input(96, 160, int(z["seed2"]))).numpy()[:, :, ::4, ::4]
+    assert np.abs(y2 - z["y2_sub"]).max() < 1e-5

@@ -1,0 +1,243 @@
+"""ctypes binding of libunscreen_hip.so (C ABI: include/unscreen_hip.h).
+
+There is NO CPU fallback: if the shared library is missing, or a device function is handed a
+non-CUDA tensor, this module raises.  Build the library with ``python -c "import __graft_entry__ as g;
+g.build()"`` or ``make -C video_unscreen_amd/csrc``.
+
+Device functions take ``torch`` CUDA tensors only to borrow ``data_ptr()`` and the current HIP stream;
+no torch types cross the ABI.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunscreen_hip.so")
+
+DILATE, ERODE = 0, 1
+NCHW, NHWC = 0, 1
+
+_vp = C.c_void_p
+_SIGNATURES = {
+    "usc_abi_version": (C.c_int, []),
+    "usc_last_error": (C.c_char_p, []),
+    "usc_get_target_size": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "usc_pad_resize_geometry": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "usc_inv_pad_geometry": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "usc_morph_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "usc_morph_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
+    "usc_trimap_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "usc_trimap_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    "usc_bgdiff_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "usc_bgdiff_mask_u8": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                                     _vp, _vp, _vp, C.c_size_t, _vp]),
+    "usc_vmat_pre": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
+    "usc_vmat_post": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "usc_get_fg_u8": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "usc_get_bg_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "usc_blend_u8": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "usc_count_ge_u8": (C.c_int, [_vp, C.c_size_t, C.c_int, _vp, _vp]),
+    "usc_remove_invalid_objects_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                                  C.c_double, _vp, C.POINTER(C.c_int)]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `make -C video_unscreen_amd/csrc`). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise NativeError(f"{what} failed ({rc}): {load().usc_last_error().decode()}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev_u8(t, name, shape=None):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise NativeError(f"{name}: expected a CUDA tensor (the HIP path has no CPU fallback)")
+    if t.dtype != torch.uint8 or not t.is_contiguous():
+        raise NativeError(f"{name}: expected a contiguous uint8 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise NativeError(f"{name}: shape {tuple(t.shape)} != {tuple(shape)}")
+    return t.data_ptr()
+
+
+# ---------------------------------------------------------------- geometry (host)
+def get_target_size(h, w, long_side, division=1):
+    a, b = C.c_int(), C.c_int()
+    load().usc_get_target_size(int(h), int(w), int(long_side), int(division), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def pad_resize_geometry(h, w, th, tw):
+    a, b = C.c_int(), C.c_int()
+    load().usc_pad_resize_geometry(int(h), int(w), int(th), int(tw), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def inv_pad_geometry(h, w, ori_h, ori_w):
+    a, b = C.c_int(), C.c_int()
+    load().usc_inv_pad_geometry(int(h), int(w), int(ori_h), int(ori_w), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+# ---------------------------------------------------------------- device stages
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def morph(src, ksize, iters, op, out=None):
+    H, W = src.shape
+    ps = _dev_u8(src, "morph.src")
+    out = torch.empty_like(src) if out is None else out
+    po = _dev_u8(out, "morph.out", (H, W))
+    _check(load().usc_morph_u8(ps, po, H, W, int(ksize), int(iters), int(op), None, 0, _stream()), "usc_morph_u8")
+    return out
+
+
+def trimap(mask, long_side=960, ksize=3, iters=5, out=None, ws=None):
+    H, W = mask.shape
+    pm = _dev_u8(mask, "trimap.mask")
+    out = torch.empty_like(mask) if out is None else out
+    po = _dev_u8(out, "trimap.out", (H, W))
+    need = load().usc_trimap_ws_bytes(H, W, int(long_side))
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, mask.device)
+    _check(load().usc_trimap_u8(pm, H, W, int(long_side), int(ksize), int(iters), po, ws.data_ptr(), ws.numel(), _stream()),
+           "usc_trimap_u8")
+    return out
+
+
+def bgdiff_mask(frame, bg_i, bg_always, seg, beta, thr, out_bg=None, out_alpha=None, ws=None):
+    H, W, _ = frame.shape
+    pf = _dev_u8(frame, "bgdiff.frame", (H, W, 3))
+    pi = _dev_u8(bg_i, "bgdiff.bg_i", (H, W, 3))
+    pa = _dev_u8(bg_always, "bgdiff.bg_always", (H, W, 3)) if bg_always is not None else None
+    seg_cn = 3 if seg.dim() == 3 else 1
+    ps = _dev_u8(seg, "bgdiff.seg", (H, W, 3) if seg_cn == 3 else (H, W))
+    out_bg = torch.empty_like(frame) if out_bg is None else out_bg
+    out_alpha = torch.empty((H, W), dtype=torch.uint8, device=frame.device) if out_alpha is None else out_alpha
+    need = load().usc_bgdiff_ws_bytes(H, W)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, frame.device)
+    _check(load().usc_bgdiff_mask_u8(pf, pi, pa, ps, seg_cn, float(beta), int(thr), H, W,
+                                     _dev_u8(out_bg, "bgdiff.out_bg", (H, W, 3)), _dev_u8(out_alpha, "bgdiff.out_alpha", (H, W)),
+                                     ws.data_ptr(), ws.numel(), _stream()), "usc_bgdiff_mask_u8")
+    return out_bg, out_alpha
+
+
+def vmat_pre(frame, alpha_pre, trimap_, inH, inW, layout=NHWC, out=None):
+    """Returns a (1, 7, inH, inW) float32 tensor (channels-last memory if layout == NHWC)."""
+    H, W, _ = frame.shape
+    pf = _dev_u8(frame, "vmat_pre.frame", (H, W, 3))
+    pa = _dev_u8(alpha_pre, "vmat_pre.alpha_pre", (H, W))
+    pt = _dev_u8(trimap_, "vmat_pre.trimap", (H, W))
+    if out is None:
+        out = torch.empty((1, 7, inH, inW), dtype=torch.float32, device=frame.device,
+                          memory_format=torch.channels_last if layout == NHWC else torch.contiguous_format)
+    _check(load().usc_vmat_pre(pf, pa, pt, H, W, int(inH), int(inW), out.data_ptr(), int(layout), _stream()), "usc_vmat_pre")
+    return out
+
+
+def vmat_post(pred, trimap_, out_u8=None, out_f32=None, want_float=False):
+    H, W = trimap_.shape
+    if not (pred.is_cuda and pred.dtype == torch.float32 and pred.is_contiguous()):
+        raise NativeError("vmat_post.pred: expected a contiguous float32 CUDA tensor")
+    inH, inW = pred.shape[-2], pred.shape[-1]
+    pt = _dev_u8(trimap_, "vmat_post.trimap")
+    out_u8 = torch.empty((H, W), dtype=torch.uint8, device=pred.device) if out_u8 is None else out_u8
+    if want_float and out_f32 is None:
+        out_f32 = torch.empty((H, W), dtype=torch.float32, device=pred.device)
+    _check(load().usc_vmat_post(pred.data_ptr(), inH, inW, pt, H, W, _dev_u8(out_u8, "vmat_post.out", (H, W)),
+                                out_f32.data_ptr() if out_f32 is not None else None, _stream()), "usc_vmat_post")
+    return (out_u8, out_f32) if want_float else out_u8
+
+
+def get_fg(frame, alpha, bg, paste_thr=0, out_fg=None, out_bg=None, want_bg=False):
+    H, W, _ = frame.shape
+    pf = _dev_u8(frame, "get_fg.frame", (H, W, 3))
+    pa = _dev_u8(alpha, "get_fg.alpha", (H, W))
+    pb = _dev_u8(bg, "get_fg.bg", (H, W, 3))
+    out_fg = torch.empty_like(frame) if out_fg is None else out_fg
+    if want_bg and out_bg is None:
+        out_bg = torch.empty_like(frame)
+    _check(load().usc_get_fg_u8(pf, pa, pb, int(paste_thr), H, W, _dev_u8(out_fg, "get_fg.out", (H, W, 3)),
+                                _dev_u8(out_bg, "get_fg.out_bg", (H, W, 3)) if out_bg is not None else None, _stream()),
+           "usc_get_fg_u8")
+    return (out_fg, out_bg) if (want_bg or out_bg is not None) else out_fg
+
+
+def get_bg(alpha, bg, out=None):
+    H, W, _ = bg.shape
+    out = torch.empty_like(bg) if out is None else out
+    _check(load().usc_get_bg_u8(_dev_u8(alpha, "get_bg.alpha", (H, W)), _dev_u8(bg, "get_bg.bg", (H, W, 3)), H, W,
+                                _dev_u8(out, "get_bg.out", (H, W, 3)), _stream()), "usc_get_bg_u8")
+    return out
+
+
+def blend(fg, mask, bg, out=None):
+    H, W, _ = fg.shape
+    mask_cn = 3 if mask.dim() == 3 else 1
+    out = torch.empty_like(fg) if out is None else out
+    _check(load().usc_blend_u8(_dev_u8(fg, "blend.fg", (H, W, 3)), _dev_u8(mask, "blend.mask"), mask_cn,
+                               _dev_u8(bg, "blend.bg", (H, W, 3)), H, W, _dev_u8(out, "blend.out", (H, W, 3)), _stream()),
+           "usc_blend_u8")
+    return out
+
+
+def count_ge(mask, thr=128, out=None):
+    """Asynchronous: returns a 1-element int64 CUDA tensor holding #(mask >= thr)."""
+    pm = _dev_u8(mask, "count_ge.mask")
+    out = torch.empty(1, dtype=torch.int64, device=mask.device) if out is None else out
+    _check(load().usc_count_ge_u8(pm, mask.numel(), int(thr), out.data_ptr(), _stream()), "usc_count_ge_u8")
+    return out
+
+
+# ---------------------------------------------------------------- host stage
+class ObjectFilter:
+    """remove_invalid_objects on host memory with a per-geometry cached score map."""
+
+    def __init__(self):
+        self._score = {}
+
+    def __call__(self, alpha, seg, center, saliency_thr, consensus_thr):
+        if not (isinstance(alpha, np.ndarray) and alpha.dtype == np.uint8 and alpha.flags.c_contiguous and alpha.ndim == 2):
+            raise NativeError("remove_invalid_objects: alpha must be a contiguous 2-D uint8 ndarray")
+        H, W = alpha.shape
+        key = (H, W, float(center[0]), float(center[1]))
+        if key not in self._score:
+            self._score[key] = [np.empty((H, W), np.float64), C.c_int(0)]
+        score, flag = self._score[key]
+        seg_p = None
+        if seg is not None:
+            seg = np.ascontiguousarray(seg, dtype=np.uint8)
+            seg_p = seg.ctypes.data
+        _check(load().usc_remove_invalid_objects_host(alpha.ctypes.data, seg_p, H, W, float(center[0]), float(center[1]),
+                                                      float(saliency_thr), float(consensus_thr), score.ctypes.data,
+                                                      C.byref(flag)), "usc_remove_invalid_objects_host")
+        return alpha

@@ -1,0 +1,684 @@
+// usc_pixel.hip - hand-written gfx950 kernels + the C ABI of libunscreen_hip.so (include/unscreen_hip.h).
+//
+// All of these stages are HBM-bound byte work (1-28 B per pixel, O(10-100) integer ops per byte), so the
+// design rules are the memory ones: flat 4-pixel (12/4-byte) coalesced accesses, LDS only where a stencil
+// needs neighbours (morphology tiles with halo), LDS-resident lookup tables for the 8-bit HSV conversion,
+// grids of >> 256 workgroups, no host synchronisation, everything on the caller's stream.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/unscreen_hip.h"
+#include "usc_device.h"
+
+using namespace usc;
+
+// --------------------------------------------------------------------------------------------
+// error plumbing
+// --------------------------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(USC_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return USC_OK;
+}
+extern "C" const char* usc_last_error(void) { return g_err; }
+extern "C" int usc_abi_version(void) { return 1; }
+
+// --------------------------------------------------------------------------------------------
+// host geometry (pure functions)
+// --------------------------------------------------------------------------------------------
+extern "C" void usc_get_target_size(int h, int w, int long_side, int division, int* th, int* tw) {
+    // int(float(L) * short / long), rounded UP to a multiple of `division`; square goes to the width branch.
+    if (h > w) {
+        int t = (int)((double)long_side * w / h);
+        if (t % division) t = (t / division + 1) * division;
+        *th = long_side; *tw = t;
+    } else {
+        int t = (int)((double)long_side * h / w);
+        if (t % division) t = (t / division + 1) * division;
+        *tw = long_side; *th = t;
+    }
+}
+extern "C" void usc_pad_resize_geometry(int h, int w, int target_h, int target_w, int* new_h, int* new_w) {
+    if ((double)h / w > (double)target_h / target_w) { *new_h = target_h; *new_w = (int)((double)target_h * w / h); }
+    else { *new_w = target_w; *new_h = (int)((double)target_w * h / w); }
+}
+extern "C" void usc_inv_pad_geometry(int h, int w, int ori_h, int ori_w, int* rh, int* rw) {
+    if ((double)ori_h / ori_w > (double)h / w) { *rh = h; *rw = (int)((double)h * ori_w / ori_h); }
+    else { *rw = w; *rh = (int)((double)w * ori_h / ori_w); }
+}
+
+// How cv::resize(INTER_LINEAR, 8-bit) treats a (src -> dst) size pair.
+enum ResizeMode { RS_COPY = 0, RS_AREA2 = 1, RS_LINEAR = 2 };
+struct ResizeGeom { int mode; double scale_x, scale_y; };
+static ResizeGeom resize_geom(int sh, int sw, int dh, int dw) {
+    ResizeGeom g;
+    g.scale_x = 1. / ((double)dw / sw);
+    g.scale_y = 1. / ((double)dh / sh);
+    g.mode = RS_LINEAR;
+    if (sh == dh && sw == dw) g.mode = RS_COPY;
+    else {
+        int ix = (int)lrint(g.scale_x), iy = (int)lrint(g.scale_y);
+        if (fabs(g.scale_x - ix) < 2.220446049250313e-16 && fabs(g.scale_y - iy) < 2.220446049250313e-16 && ix == 2 && iy == 2)
+            g.mode = RS_AREA2;        // OpenCV reroutes exact 2x bilinear decimation to the 2x2 box average
+    }
+    return g;
+}
+
+// --------------------------------------------------------------------------------------------
+// structuring element (cv::getStructuringElement(MORPH_ELLIPSE, (k,k)), anchor (k/2, k/2))
+// --------------------------------------------------------------------------------------------
+constexpr int kMaxK = 9;
+struct StructElem {
+    int n, ksize, anchor;
+    int8_t dy[kMaxK * kMaxK];
+    int8_t dx[kMaxK * kMaxK];
+};
+static StructElem make_ellipse(int k) {
+    StructElem se;
+    memset(&se, 0, sizeof(se));
+    se.ksize = k; se.anchor = k / 2;
+    int r = k / 2, c = k / 2;
+    double inv_r2 = r ? 1. / ((double)r * r) : 0;
+    for (int i = 0; i < k; i++) {
+        int dy = i - r, j1 = 0, j2 = 0;
+        if (abs(dy) <= r) {
+            int dx = (int)lrint(c * sqrt((r * r - dy * dy) * inv_r2));
+            j1 = c - dx > 0 ? c - dx : 0;
+            j2 = c + dx + 1 < k ? c + dx + 1 : k;
+        }
+        for (int j = j1; j < j2; j++) { se.dy[se.n] = (int8_t)(i - se.anchor); se.dx[se.n] = (int8_t)(j - se.anchor); se.n++; }
+    }
+    return se;
+}
+
+// --------------------------------------------------------------------------------------------
+// LDS tile morphology
+// --------------------------------------------------------------------------------------------
+constexpr int kTileH = 16, kTileW = 64, kMorphThreads = 256;
+
+struct TileGeom {             // extended (core + halo) tile of one workgroup
+    int eh, ew, pitch;        // rows, cols, LDS row pitch (bytes)
+    int top, left;            // halo before the core
+};
+static TileGeom tile_geom(const StructElem& se, int iters) {
+    TileGeom t;
+    int before = iters * se.anchor, after = iters * (se.ksize - 1 - se.anchor);
+    t.top = before; t.left = before;
+    t.eh = kTileH + before + after;
+    t.ew = kTileW + before + after;
+    t.pitch = (t.ew + 3) & ~3;
+    return t;
+}
+
+// `iters` passes of the SE over an LDS tile, ping-ponging a <-> b.  Positions outside the image hold the
+// identity (0 for max, 255 for min) in every pass - that is cv2's "border never wins" rule per iteration.
+// Taps that fall outside the extended tile are skipped; the error this causes stays inside the halo.
+// Returns the buffer holding the result.
+template <bool ERODE>
+__device__ uint8_t* morph_passes(uint8_t* a, uint8_t* b, const TileGeom& tg, int gy0, int gx0, int H, int W,
+                                 const StructElem& se, int iters) {
+    const int total = tg.eh * tg.ew;
+    for (int it = 0; it < iters; it++) {
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            int ty = i / tg.ew, tx = i - ty * tg.ew;
+            int gy = gy0 + ty, gx = gx0 + tx;
+            int best = ERODE ? 255 : 0;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                for (int k = 0; k < se.n; k++) {
+                    int yy = ty + se.dy[k], xx = tx + se.dx[k];
+                    if (yy < 0 || yy >= tg.eh || xx < 0 || xx >= tg.ew) continue;
+                    int v = a[yy * tg.pitch + xx];
+                    best = ERODE ? min(best, v) : max(best, v);
+                }
+            }
+            b[ty * tg.pitch + tx] = (uint8_t)best;
+        }
+        __syncthreads();
+        uint8_t* t = a; a = b; b = t;
+    }
+    return a;
+}
+
+// Plain morphology: dst = morph(src).  MODE_GATE additionally applies the bg_offline.py:160 gate
+// alpha = gray(seg) * (dilated // 255) in the epilogue.
+enum { MODE_PLAIN = 0, MODE_GATE = 1 };
+template <int MODE>
+__global__ __launch_bounds__(kMorphThreads) void morph_tile_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                   int H, int W, StructElem se, TileGeom tg, int iters, int op,
+                                                                   const uint8_t* __restrict__ seg, int seg_cn) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t* a = lds;
+    uint8_t* b = lds + tg.eh * tg.pitch;
+    const int y0 = blockIdx.y * kTileH, x0 = blockIdx.x * kTileW;
+    const int gy0 = y0 - tg.top, gx0 = x0 - tg.left;
+    const uint8_t ident = op == USC_MORPH_ERODE ? 255 : 0;
+    for (int i = threadIdx.x; i < tg.eh * tg.ew; i += blockDim.x) {
+        int ty = i / tg.ew, tx = i - ty * tg.ew;
+        int gy = gy0 + ty, gx = gx0 + tx;
+        uint8_t v = ident;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = src[(size_t)gy * W + gx];
+        a[ty * tg.pitch + tx] = v;
+    }
+    __syncthreads();
+    uint8_t* r = op == USC_MORPH_ERODE ? morph_passes<true>(a, b, tg, gy0, gx0, H, W, se, iters)
+                                       : morph_passes<false>(a, b, tg, gy0, gx0, H, W, se, iters);
+    for (int i = threadIdx.x; i < kTileH * kTileW; i += blockDim.x) {
+        int ty = i / kTileW, tx = i - ty * kTileW;
+        int gy = y0 + ty, gx = x0 + tx;
+        if (gy >= H || gx >= W) continue;
+        int v = r[(ty + tg.top) * tg.pitch + tx + tg.left];
+        size_t o = (size_t)gy * W + gx;
+        if (MODE == MODE_GATE) {
+            int s = seg_cn == 3 ? gray_u8(seg[3 * o], seg[3 * o + 1], seg[3 * o + 2]) : seg[o];
+            v = (s * (v / 255)) & 0xff;
+        }
+        dst[o] = (uint8_t)v;
+    }
+}
+
+static int launch_morph(int mode, const uint8_t* src, uint8_t* dst, int H, int W, int ksize, int iters, int op,
+                        const uint8_t* seg, int seg_cn, hipStream_t st) {
+    if (ksize < 1 || ksize > kMaxK) return fail(USC_E_UNSUPPORTED, "morph: ksize %d outside [1,%d]", ksize, kMaxK);
+    if (iters < 0) return fail(USC_E_ARG, "morph: iters %d < 0", iters);
+    StructElem se = make_ellipse(ksize);
+    TileGeom tg = tile_geom(se, iters);
+    size_t lds = 2 * (size_t)tg.eh * tg.pitch;
+    if (lds > 60 * 1024) return fail(USC_E_UNSUPPORTED, "morph: ksize %d x iters %d needs %zu B of LDS", ksize, iters, lds);
+    dim3 grid((W + kTileW - 1) / kTileW, (H + kTileH - 1) / kTileH);
+    if (mode == MODE_GATE)
+        hipLaunchKernelGGL(morph_tile_kernel<MODE_GATE>, grid, dim3(kMorphThreads), lds, st, src, dst, H, W, se, tg, iters, op, seg, seg_cn);
+    else
+        hipLaunchKernelGGL(morph_tile_kernel<MODE_PLAIN>, grid, dim3(kMorphThreads), lds, st, src, dst, H, W, se, tg, iters, op, seg, seg_cn);
+    return check_launch("morph_tile_kernel");
+}
+
+extern "C" size_t usc_morph_ws_bytes(int, int, int, int) { return 0; }
+
+extern "C" int usc_morph_u8(const uint8_t* src, uint8_t* dst, int H, int W, int ksize, int iters, int op,
+                            void*, size_t, usc_stream_t stream) {
+    if (!src || !dst || H <= 0 || W <= 0) return fail(USC_E_ARG, "usc_morph_u8: null pointer or empty image");
+    if (src == dst) return fail(USC_E_ARG, "usc_morph_u8: src and dst alias");
+    if (op != USC_MORPH_DILATE && op != USC_MORPH_ERODE) return fail(USC_E_ARG, "usc_morph_u8: op %d", op);
+    return launch_morph(MODE_PLAIN, src, dst, H, W, ksize, iters, op, nullptr, 1, (hipStream_t)stream);
+}
+
+// --------------------------------------------------------------------------------------------
+// trimap
+// --------------------------------------------------------------------------------------------
+
+// Stage 1: NEAREST decimation + dilate + erode + classify, one low-res tile per workgroup.
+__global__ __launch_bounds__(kMorphThreads) void trimap_small_kernel(const uint8_t* __restrict__ mask, int H, int W,
+                                                                     uint8_t* __restrict__ tri, int h, int w,
+                                                                     double ify, double ifx, StructElem se, TileGeom tg, int iters) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int plane = tg.eh * tg.pitch;
+    uint8_t *da = lds, *db = lds + plane, *ea = lds + 2 * plane, *eb = lds + 3 * plane;
+    const int y0 = blockIdx.y * kTileH, x0 = blockIdx.x * kTileW;
+    const int gy0 = y0 - tg.top, gx0 = x0 - tg.left;
+    for (int i = threadIdx.x; i < tg.eh * tg.ew; i += blockDim.x) {
+        int ty = i / tg.ew, tx = i - ty * tg.ew;
+        int ly = gy0 + ty, lx = gx0 + tx;
+        uint8_t vd = 0, ve = 255;
+        if (ly >= 0 && ly < h && lx >= 0 && lx < w) {
+            int sy = min((int)floor(ly * ify), H - 1);       // cv::resizeNN
+            int sx = min((int)floor(lx * ifx), W - 1);
+            vd = ve = mask[(size_t)sy * W + sx];
+        }
+        da[ty * tg.pitch + tx] = vd;
+        ea[ty * tg.pitch + tx] = ve;
+    }
+    __syncthreads();
+    uint8_t* rd = morph_passes<false>(da, db, tg, gy0, gx0, h, w, se, iters);
+    uint8_t* re = morph_passes<true>(ea, eb, tg, gy0, gx0, h, w, se, iters);
+    for (int i = threadIdx.x; i < kTileH * kTileW; i += blockDim.x) {
+        int ty = i / kTileW, tx = i - ty * kTileW;
+        int ly = y0 + ty, lx = x0 + tx;
+        if (ly >= h || lx >= w) continue;
+        int o = (ty + tg.top) * tg.pitch + tx + tg.left;
+        uint8_t t = 128;
+        if (re[o] > 127) t = 255;
+        if (rd[o] < 128) t = 0;
+        tri[(size_t)ly * w + lx] = t;
+    }
+}
+
+// 8-bit cv::resize(INTER_LINEAR) of a single-channel image, one value.
+__device__ __forceinline__ int resize_u8_c1(const uint8_t* __restrict__ s, int sh, int sw, int y, int x,
+                                            int mode, double scale_y, double scale_x) {
+    if (mode == RS_COPY) return s[(size_t)y * sw + x];
+    if (mode == RS_AREA2) {
+        const uint8_t* p = s + (size_t)(2 * y) * sw + 2 * x;
+        return (p[0] + p[1] + p[sw] + p[sw + 1] + 2) >> 2;
+    }
+    Tap tx = linear_tap_x(x, scale_x, sw), ty = linear_tap(y, scale_y);
+    int x0 = tx.s, x1 = min(x0 + 1, sw - 1);
+    int y0 = clampi(ty.s, 0, sh - 1), y1 = clampi(ty.s + 1, 0, sh - 1);
+    int a0 = coef11(1.f - tx.f), a1 = coef11(tx.f), b0 = coef11(1.f - ty.f), b1 = coef11(ty.f);
+    return bilinear_u8(s[(size_t)y0 * sw + x0], s[(size_t)y0 * sw + x1], s[(size_t)y1 * sw + x0], s[(size_t)y1 * sw + x1],
+                       a0, a1, b0, b1);
+}
+
+// Stage 2: bilinear back to H x W (trimap/agent.py:59) and collapse the blur to 128 (:60). 4 pixels per lane.
+__global__ __launch_bounds__(256) void trimap_up_kernel(const uint8_t* __restrict__ tri, int h, int w,
+                                                        uint8_t* __restrict__ out, int H, int W,
+                                                        int mode, double scale_y, double scale_x) {
+    const size_t n = (size_t)H * W;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += (size_t)gridDim.x * blockDim.x) {
+        size_t i0 = q * 4;
+        uint32_t packed = 0;
+        int cnt = (int)min((size_t)4, n - i0);
+        for (int k = 0; k < cnt; k++) {
+            size_t i = i0 + k;
+            int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+            int v = resize_u8_c1(tri, h, w, y, x, mode, scale_y, scale_x);
+            if (v > 0 && v < 255) v = 128;
+            packed |= (uint32_t)v << (8 * k);
+        }
+        if (cnt == 4) *reinterpret_cast<uint32_t*>(out + i0) = packed;
+        else for (int k = 0; k < cnt; k++) out[i0 + k] = (packed >> (8 * k)) & 0xff;
+    }
+}
+
+extern "C" size_t usc_trimap_ws_bytes(int H, int W, int long_side) {
+    int h, w;
+    usc_get_target_size(H, W, long_side, 1, &h, &w);
+    return ((size_t)h * w + 255) & ~(size_t)255;
+}
+
+static int grid_for(size_t work_items, int threads) {
+    size_t blocks = (work_items + threads - 1) / threads;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;       // 16 workgroups per CU, grid-stride beyond that
+    return (int)blocks;
+}
+
+extern "C" int usc_trimap_u8(const uint8_t* mask, int H, int W, int long_side, int ksize, int iters, uint8_t* out,
+                             void* ws, size_t ws_bytes, usc_stream_t stream) {
+    if (!mask || !out || H <= 0 || W <= 0 || long_side <= 0) return fail(USC_E_ARG, "usc_trimap_u8: bad argument");
+    if (ksize < 1 || ksize > kMaxK) return fail(USC_E_UNSUPPORTED, "usc_trimap_u8: ksize %d outside [1,%d]", ksize, kMaxK);
+    if (iters < 0) return fail(USC_E_ARG, "usc_trimap_u8: iters < 0");
+    int h, w;
+    usc_get_target_size(H, W, long_side, 1, &h, &w);
+    if (h <= 0 || w <= 0) return fail(USC_E_ARG, "usc_trimap_u8: degenerate low-res size %dx%d", h, w);
+    if (!ws || ws_bytes < (size_t)h * w) return fail(USC_E_WORKSPACE, "usc_trimap_u8: workspace %zu < %zu", ws_bytes, (size_t)h * w);
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* tri = (uint8_t*)ws;
+    StructElem se = make_ellipse(ksize);
+    TileGeom tg = tile_geom(se, iters);
+    size_t lds = 4 * (size_t)tg.eh * tg.pitch;
+    if (lds > 60 * 1024) return fail(USC_E_UNSUPPORTED, "usc_trimap_u8: ksize %d x iters %d needs %zu B of LDS", ksize, iters, lds);
+    double ifx = 1. / ((double)w / W), ify = 1. / ((double)h / H);
+    dim3 grid((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH);
+    hipLaunchKernelGGL(trimap_small_kernel, grid, dim3(kMorphThreads), lds, st, mask, H, W, tri, h, w, ify, ifx, se, tg, iters);
+    int rc = check_launch("trimap_small_kernel");
+    if (rc) return rc;
+    ResizeGeom rg = resize_geom(h, w, H, W);
+    size_t quads = ((size_t)H * W + 3) / 4;
+    hipLaunchKernelGGL(trimap_up_kernel, dim3(grid_for(quads, 256)), dim3(256), 0, st, tri, h, w, out, H, W, rg.mode, rg.scale_y, rg.scale_x);
+    return check_launch("trimap_up_kernel");
+}
+
+// --------------------------------------------------------------------------------------------
+// background fusion + difference mask
+// --------------------------------------------------------------------------------------------
+
+// Pointwise half: fused background and the thresholded grey difference, 4 pixels per lane.
+__global__ __launch_bounds__(256) void bgdiff_point_kernel(const uint8_t* __restrict__ frame, const uint8_t* __restrict__ bg_i,
+                                                           const uint8_t* __restrict__ bg_always, float beta, float beta1, int thr,
+                                                           size_t n, uint8_t* __restrict__ out_bg, uint8_t* __restrict__ diff) {
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += (size_t)gridDim.x * blockDim.x) {
+        size_t i0 = q * 4;
+        if (i0 + 4 <= n) {
+            int f[12], bi[12], ba[12], o[12];
+            unpack12(*reinterpret_cast<const Px4*>(frame + 3 * i0), f);
+            unpack12(*reinterpret_cast<const Px4*>(bg_i + 3 * i0), bi);
+            if (bg_always) unpack12(*reinterpret_cast<const Px4*>(bg_always + 3 * i0), ba);
+            uint32_t m = 0;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                int d[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    int k = 3 * p + c;
+                    int b;
+                    if (bg_always) {
+                        float p0 = (float)bi[k] * beta;
+                        float p1 = beta1 * (float)ba[k];
+                        b = (int)(p0 + p1);
+                    } else b = bi[k];
+                    o[k] = b;
+                    d[c] = abs(f[k] - b);
+                }
+                int g = gray_u8(d[0], d[1], d[2]);
+                if (g > thr) g = 255;
+                m |= (uint32_t)g << (8 * p);
+            }
+            *reinterpret_cast<Px4*>(out_bg + 3 * i0) = pack12(o);
+            *reinterpret_cast<uint32_t*>(diff + i0) = m;
+        } else {
+            for (size_t i = i0; i < n; i++) {
+                int d[3];
+                for (int c = 0; c < 3; c++) {
+                    int b;
+                    if (bg_always) {
+                        float p0 = (float)bg_i[3 * i + c] * beta;
+                        float p1 = beta1 * (float)bg_always[3 * i + c];
+                        b = (int)(p0 + p1);
+                    } else b = bg_i[3 * i + c];
+                    out_bg[3 * i + c] = (uint8_t)b;
+                    d[c] = abs((int)frame[3 * i + c] - b);
+                }
+                int g = gray_u8(d[0], d[1], d[2]);
+                diff[i] = (uint8_t)(g > thr ? 255 : g);
+            }
+        }
+    }
+}
+
+extern "C" size_t usc_bgdiff_ws_bytes(int H, int W) { return (((size_t)H * W) + 255) & ~(size_t)255; }
+
+extern "C" int usc_bgdiff_mask_u8(const uint8_t* frame, const uint8_t* bg_i, const uint8_t* bg_always,
+                                  const uint8_t* seg, int seg_cn, double beta, int thr, int H, int W,
+                                  uint8_t* out_bg, uint8_t* out_alpha, void* ws, size_t ws_bytes, usc_stream_t stream) {
+    if (!frame || !bg_i || !seg || !out_bg || !out_alpha || H <= 0 || W <= 0) return fail(USC_E_ARG, "usc_bgdiff_mask_u8: bad argument");
+    if (seg_cn != 1 && seg_cn != 3) return fail(USC_E_ARG, "usc_bgdiff_mask_u8: seg_cn %d", seg_cn);
+    size_t n = (size_t)H * W;
+    if (!ws || ws_bytes < n) return fail(USC_E_WORKSPACE, "usc_bgdiff_mask_u8: workspace %zu < %zu", ws_bytes, n);
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* diff = (uint8_t*)ws;
+    // `1 - beta` is formed in double by the reference and only then meets the float32 image.
+    hipLaunchKernelGGL(bgdiff_point_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, st,
+                       frame, bg_i, bg_always, (float)beta, (float)(1 - beta), thr, n, out_bg, diff);
+    int rc = check_launch("bgdiff_point_kernel");
+    if (rc) return rc;
+    return launch_morph(MODE_GATE, diff, out_alpha, H, W, 4, 2, USC_MORPH_DILATE, seg, seg_cn, st);
+}
+
+// --------------------------------------------------------------------------------------------
+// matting pre / post processing
+// --------------------------------------------------------------------------------------------
+
+// One work-item per network-input pixel: reflect-pad index -> resized image -> taps in the full-res sources.
+__global__ __launch_bounds__(256) void vmat_pre_kernel(const uint8_t* __restrict__ frame, const uint8_t* __restrict__ alpha_pre,
+                                                       const uint8_t* __restrict__ trimap, int H, int W, int nh, int nw,
+                                                       int inH, int inW, int mode, double scale_y, double scale_x,
+                                                       float* __restrict__ out, int layout,
+                                                       float m0, float m1, float m2, float s0, float s1, float s2) {
+    const size_t n = (size_t)inH * inW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int py = (int)(i / inW), px = (int)(i - (size_t)py * inW);
+        int y = py < nh ? py : 2 * nh - 1 - py;        // BORDER_REFLECT: the edge sample repeats
+        int x = px < nw ? px : 2 * nw - 1 - px;
+        int bgr[3], tri, ap;
+        if (mode == RS_COPY) {
+            size_t o = (size_t)y * W + x;
+            bgr[0] = frame[3 * o]; bgr[1] = frame[3 * o + 1]; bgr[2] = frame[3 * o + 2];
+            tri = trimap[o]; ap = alpha_pre[o];
+        } else if (mode == RS_AREA2) {
+            size_t o = (size_t)(2 * y) * W + 2 * x;
+            const uint8_t* f0 = frame + 3 * o;
+            const uint8_t* f1 = f0 + 3 * (size_t)W;
+#pragma unroll
+            for (int c = 0; c < 3; c++) bgr[c] = (f0[c] + f0[3 + c] + f1[c] + f1[3 + c] + 2) >> 2;
+            tri = (trimap[o] + trimap[o + 1] + trimap[o + W] + trimap[o + W + 1] + 2) >> 2;
+            ap = (alpha_pre[o] + alpha_pre[o + 1] + alpha_pre[o + W] + alpha_pre[o + W + 1] + 2) >> 2;
+        } else {
+            Tap tx = linear_tap_x(x, scale_x, W), ty = linear_tap(y, scale_y);
+            int x0 = tx.s, x1 = min(x0 + 1, W - 1);
+            int y0 = clampi(ty.s, 0, H - 1), y1 = clampi(ty.s + 1, 0, H - 1);
+            int a0 = coef11(1.f - tx.f), a1 = coef11(tx.f), b0 = coef11(1.f - ty.f), b1 = coef11(ty.f);
+            size_t o00 = (size_t)y0 * W + x0, o01 = (size_t)y0 * W + x1, o10 = (size_t)y1 * W + x0, o11 = (size_t)y1 * W + x1;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                bgr[c] = bilinear_u8(frame[3 * o00 + c], frame[3 * o01 + c], frame[3 * o10 + c], frame[3 * o11 + c], a0, a1, b0, b1);
+            tri = bilinear_u8(trimap[o00], trimap[o01], trimap[o10], trimap[o11], a0, a1, b0, b1);
+            ap = bilinear_u8(alpha_pre[o00], alpha_pre[o01], alpha_pre[o10], alpha_pre[o11], a0, a1, b0, b1);
+        }
+        float v[7];
+        v[0] = ((float)bgr[2] / 255.f - m0) * s0;       // R
+        v[1] = ((float)bgr[1] / 255.f - m1) * s1;       // G
+        v[2] = ((float)bgr[0] / 255.f - m2) * s2;       // B
+        v[3] = (float)((double)ap / 255.);
+        v[4] = tri == 0 ? 1.f : 0.f;
+        v[5] = (tri > 0 && tri < 255) ? 1.f : 0.f;
+        v[6] = tri == 255 ? 1.f : 0.f;
+        if (layout == USC_LAYOUT_NCHW) {
+#pragma unroll
+            for (int c = 0; c < 7; c++) out[(size_t)c * n + i] = v[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 7; c++) out[i * 7 + c] = v[c];
+        }
+    }
+}
+
+extern "C" int usc_vmat_pre(const uint8_t* frame, const uint8_t* alpha_pre, const uint8_t* trimap, int H, int W,
+                            int inH, int inW, float* out7, int layout, usc_stream_t stream) {
+    if (!frame || !alpha_pre || !trimap || !out7 || H <= 0 || W <= 0 || inH <= 0 || inW <= 0) return fail(USC_E_ARG, "usc_vmat_pre: bad argument");
+    if (layout != USC_LAYOUT_NCHW && layout != USC_LAYOUT_NHWC) return fail(USC_E_ARG, "usc_vmat_pre: layout %d", layout);
+    int nh, nw;
+    usc_pad_resize_geometry(H, W, inH, inW, &nh, &nw);
+    if (nh <= 0 || nw <= 0 || nh > inH || nw > inW) return fail(USC_E_ARG, "usc_vmat_pre: resized size %dx%d does not fit %dx%d", nh, nw, inH, inW);
+    if (inH - nh > nh || inW - nw > nw) return fail(USC_E_UNSUPPORTED, "usc_vmat_pre: reflect pad larger than the image");
+    ResizeGeom rg = resize_geom(H, W, nh, nw);
+    static const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+    size_t n = (size_t)inH * inW;
+    hipLaunchKernelGGL(vmat_pre_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, frame, alpha_pre, trimap,
+                       H, W, nh, nw, inH, inW, rg.mode, rg.scale_y, rg.scale_x, out7, layout,
+                       (float)mean[0], (float)mean[1], (float)mean[2],
+                       (float)(1 / stdv[0]), (float)(1 / stdv[1]), (float)(1 / stdv[2]));
+    return check_launch("vmat_pre_kernel");
+}
+
+// Float bilinear back to full resolution + known-region clamp + *255 truncation; 4 pixels per lane.
+__global__ __launch_bounds__(256) void vmat_post_kernel(const float* __restrict__ pred, int rh, int rw, int pitch,
+                                                        const uint8_t* __restrict__ trimap, int H, int W,
+                                                        double scale_y, double scale_x, int copy,
+                                                        uint8_t* __restrict__ alpha_u8, float* __restrict__ alpha_f32) {
+    const size_t n = (size_t)H * W;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += (size_t)gridDim.x * blockDim.x) {
+        size_t i0 = q * 4;
+        int cnt = (int)min((size_t)4, n - i0);
+        uint32_t packed = 0;
+        for (int k = 0; k < cnt; k++) {
+            size_t i = i0 + k;
+            int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+            float a;
+            if (copy) a = pred[(size_t)y * pitch + x];
+            else {
+                Tap tx = linear_tap_x(x, scale_x, rw), ty = linear_tap(y, scale_y);
+                int x0 = tx.s, x1 = min(x0 + 1, rw - 1);
+                int y0 = clampi(ty.s, 0, rh - 1), y1 = clampi(ty.s + 1, 0, rh - 1);
+                float a0 = 1.f - tx.f, a1 = tx.f, b0 = 1.f - ty.f, b1 = ty.f;
+                float r0 = pred[(size_t)y0 * pitch + x0] * a0 + pred[(size_t)y0 * pitch + x1] * a1;
+                float r1 = pred[(size_t)y1 * pitch + x0] * a0 + pred[(size_t)y1 * pitch + x1] * a1;
+                a = r0 * b0 + r1 * b1;
+            }
+            int t = trimap[i];
+            if (t == 0) a = 0.f;
+            if (t == 255) a = 1.f;
+            if (alpha_f32) alpha_f32[i] = a;
+            float s = a * 255.f;
+            int u = (int)s;                         // astype(uint8) of a value in [0, 255]: truncation
+            packed |= (uint32_t)(u & 0xff) << (8 * k);
+        }
+        if (cnt == 4) *reinterpret_cast<uint32_t*>(alpha_u8 + i0) = packed;
+        else for (int k = 0; k < cnt; k++) alpha_u8[i0 + k] = (packed >> (8 * k)) & 0xff;
+    }
+}
+
+extern "C" int usc_vmat_post(const float* pred, int inH, int inW, const uint8_t* trimap, int H, int W,
+                             uint8_t* alpha_u8, float* alpha_f32, usc_stream_t stream) {
+    if (!pred || !trimap || !alpha_u8 || H <= 0 || W <= 0 || inH <= 0 || inW <= 0) return fail(USC_E_ARG, "usc_vmat_post: bad argument");
+    int rh, rw;
+    usc_inv_pad_geometry(inH, inW, H, W, &rh, &rw);
+    if (rh <= 0 || rw <= 0 || rh > inH || rw > inW) return fail(USC_E_ARG, "usc_vmat_post: un-padded size %dx%d", rh, rw);
+    double scale_x = 1. / ((double)W / rw), scale_y = 1. / ((double)H / rh);
+    int copy = (rh == H && rw == W);
+    size_t quads = ((size_t)H * W + 3) / 4;
+    hipLaunchKernelGGL(vmat_post_kernel, dim3(grid_for(quads, 256)), dim3(256), 0, (hipStream_t)stream, pred, rh, rw, inW, trimap,
+                       H, W, scale_y, scale_x, copy, alpha_u8, alpha_f32);
+    return check_launch("vmat_post_kernel");
+}
+
+// --------------------------------------------------------------------------------------------
+// foreground / background extraction in HSV, composite
+// --------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void fg_pixel(int fb, int fg_, int fr, int bb, int bg_, int br, int alpha,
+                                         const int* s_sdiv, const int* s_hdiv, int* out /*3*/) {
+    int ih[3], bh[3], oh[3];
+    bgr2hsv_u8(fb, fg_, fr, s_sdiv, s_hdiv, ih[0], ih[1], ih[2]);
+    bgr2hsv_u8(bb, bg_, br, s_sdiv, s_hdiv, bh[0], bh[1], bh[2]);
+    float a = (float)alpha / 255.f;
+    float w = 1.f - a;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float t = w * (float)bh[c];
+        float f = (float)ih[c] - t;
+        f = fminf(fmaxf(f, 0.f), 255.f);
+        oh[c] = (int)f;
+    }
+    hsv2bgr_u8(oh[0], oh[1], oh[2], out[0], out[1], out[2]);
+}
+
+__global__ __launch_bounds__(256) void get_fg_kernel(const uint8_t* __restrict__ frame, const uint8_t* __restrict__ alpha,
+                                                     const uint8_t* __restrict__ bg, int paste_thr, size_t n,
+                                                     uint8_t* __restrict__ out_fg, uint8_t* __restrict__ out_bg) {
+    __shared__ int s_sdiv[256], s_hdiv[256];
+    load_hsv_tables(s_sdiv, s_hdiv);
+    __syncthreads();
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += (size_t)gridDim.x * blockDim.x) {
+        size_t i0 = q * 4;
+        if (i0 + 4 <= n) {
+            int f[12], b[12], o[12];
+            unpack12(*reinterpret_cast<const Px4*>(frame + 3 * i0), f);
+            unpack12(*reinterpret_cast<const Px4*>(bg + 3 * i0), b);
+            uint32_t a4 = *reinterpret_cast<const uint32_t*>(alpha + i0);
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                int a = (a4 >> (8 * p)) & 0xff;
+                if (a < paste_thr) { b[3 * p] = f[3 * p]; b[3 * p + 1] = f[3 * p + 1]; b[3 * p + 2] = f[3 * p + 2]; }
+                fg_pixel(f[3 * p], f[3 * p + 1], f[3 * p + 2], b[3 * p], b[3 * p + 1], b[3 * p + 2], a, s_sdiv, s_hdiv, o + 3 * p);
+            }
+            *reinterpret_cast<Px4*>(out_fg + 3 * i0) = pack12(o);
+            if (out_bg) *reinterpret_cast<Px4*>(out_bg + 3 * i0) = pack12(b);
+        } else {
+            for (size_t i = i0; i < n; i++) {
+                int a = alpha[i], o[3], b[3];
+                for (int c = 0; c < 3; c++) b[c] = a < paste_thr ? frame[3 * i + c] : bg[3 * i + c];
+                fg_pixel(frame[3 * i], frame[3 * i + 1], frame[3 * i + 2], b[0], b[1], b[2], a, s_sdiv, s_hdiv, o);
+                for (int c = 0; c < 3; c++) { out_fg[3 * i + c] = (uint8_t)o[c]; if (out_bg) out_bg[3 * i + c] = (uint8_t)b[c]; }
+            }
+        }
+    }
+}
+
+extern "C" int usc_get_fg_u8(const uint8_t* frame, const uint8_t* alpha, const uint8_t* bg, int paste_thr, int H, int W,
+                             uint8_t* out_fg, uint8_t* out_bg, usc_stream_t stream) {
+    if (!frame || !alpha || !bg || !out_fg || H <= 0 || W <= 0) return fail(USC_E_ARG, "usc_get_fg_u8: bad argument");
+    size_t n = (size_t)H * W;
+    hipLaunchKernelGGL(get_fg_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, frame, alpha, bg, paste_thr, n, out_fg, out_bg);
+    return check_launch("get_fg_kernel");
+}
+
+__global__ __launch_bounds__(256) void get_bg_kernel(const uint8_t* __restrict__ alpha, const uint8_t* __restrict__ bg, size_t n,
+                                                     uint8_t* __restrict__ out) {
+    __shared__ int s_sdiv[256], s_hdiv[256];
+    load_hsv_tables(s_sdiv, s_hdiv);
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int bh[3], oh[3], o[3];
+        bgr2hsv_u8(bg[3 * i], bg[3 * i + 1], bg[3 * i + 2], s_sdiv, s_hdiv, bh[0], bh[1], bh[2]);
+        float a = (float)alpha[i] / 255.f;
+        float w = 1.f - a;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float f = w * (float)bh[c];
+            f = fminf(fmaxf(f, 0.f), 255.f);
+            oh[c] = (int)f;
+        }
+        hsv2bgr_u8(oh[0], oh[1], oh[2], o[0], o[1], o[2]);
+        out[3 * i] = (uint8_t)o[0]; out[3 * i + 1] = (uint8_t)o[1]; out[3 * i + 2] = (uint8_t)o[2];
+    }
+}
+
+extern "C" int usc_get_bg_u8(const uint8_t* alpha, const uint8_t* bg, int H, int W, uint8_t* out, usc_stream_t stream) {
+    if (!alpha || !bg || !out || H <= 0 || W <= 0) return fail(USC_E_ARG, "usc_get_bg_u8: bad argument");
+    size_t n = (size_t)H * W;
+    hipLaunchKernelGGL(get_bg_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, alpha, bg, n, out);
+    return check_launch("get_bg_kernel");
+}
+
+__global__ __launch_bounds__(256) void blend_kernel(const uint8_t* __restrict__ fg, const uint8_t* __restrict__ mask, int mask_cn,
+                                                    const uint8_t* __restrict__ bg, size_t n, uint8_t* __restrict__ out) {
+    __shared__ double s_m[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_m[i] = (double)i / 255.;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double m = s_m[mask_cn == 3 ? mask[3 * i + c] : mask[i]];
+            double r = (double)fg[3 * i + c] * m + (double)bg[3 * i + c] * (1 - m);
+            out[3 * i + c] = (uint8_t)(int)r;
+        }
+    }
+}
+
+extern "C" int usc_blend_u8(const uint8_t* fg, const uint8_t* mask, int mask_cn, const uint8_t* bg, int H, int W,
+                            uint8_t* out, usc_stream_t stream) {
+    if (!fg || !mask || !bg || !out || H <= 0 || W <= 0) return fail(USC_E_ARG, "usc_blend_u8: bad argument");
+    if (mask_cn != 1 && mask_cn != 3) return fail(USC_E_ARG, "usc_blend_u8: mask_cn %d", mask_cn);
+    size_t n = (size_t)H * W;
+    hipLaunchKernelGGL(blend_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, fg, mask, mask_cn, bg, n, out);
+    return check_launch("blend_kernel");
+}
+
+// --------------------------------------------------------------------------------------------
+// exist_foreground reduction
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void count_ge_kernel(const uint8_t* __restrict__ mask, size_t n, int thr, unsigned long long* out) {
+    unsigned int local = 0;
+    const size_t nvec = n / 16;
+    const uint4* v = reinterpret_cast<const uint4*>(mask);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        uint4 q = v[i];
+        uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) local += (int)((w[k] >> (8 * b)) & 0xff) >= thr;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = nvec * 16 + threadIdx.x; i < n; i += blockDim.x) local += mask[i] >= thr;
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) local += __shfl_down(local, off, kWave);
+    __shared__ unsigned int s_part[256 / kWave];
+    if ((threadIdx.x & (kWave - 1)) == 0) s_part[threadIdx.x / kWave] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < 256 / kWave; i++) t += s_part[i];
+        if (t) atomicAdd(out, t);
+    }
+}
+
+extern "C" int usc_count_ge_u8(const uint8_t* mask, size_t n, int thr, unsigned long long* out_count, usc_stream_t stream) {
+    if (!mask || !out_count || n == 0) return fail(USC_E_ARG, "usc_count_ge_u8: bad argument");
+    if (((uintptr_t)mask & 15) != 0) return fail(USC_E_ARG, "usc_count_ge_u8: mask must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out_count, 0, sizeof(unsigned long long), st) != hipSuccess) return fail(USC_E_LAUNCH, "usc_count_ge_u8: memset failed");
+    hipLaunchKernelGGL(count_ge_kernel, dim3(grid_for((n + 15) / 16, 256)), dim3(256), 0, st, mask, n, thr, out_count);
+    return check_launch("count_ge_kernel");
+}

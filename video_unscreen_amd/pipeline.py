@@ -1,0 +1,191 @@
+"""Device-resident bg_step (stage 3) frame loop: tools/unscreen/bg_offline.py:145-176 of the reference.
+
+Per frame, with every image staying in HBM between stages:
+
+    bg, gate   = usc_bgdiff_mask_u8(frame, bg_i, bg_always, seg)        bg_offline.py:150-160
+    alpha_pre  = gate on the first frame                                 :162-163
+    alphaor    = remove_invalid_objects(gate)      (host stage)          :165
+    trimap     = usc_trimap_u8(alphaor)                                  :166
+    alpha      = usc_vmat_pre -> matting net -> usc_vmat_post            :167
+    fg         = usc_get_fg_u8(frame, alpha, bg pasted where alpha == 0) :171-172
+    alpha_pre  = alpha                                                   :176
+
+`step()` is the plain synchronous form.  `run()` software-pipelines it: the front half of frame t+1 (difference
+mask, the 1 byte/pixel round trip through the host object filter, trimap) runs on its own HIP stream and a
+worker thread while the back half of frame t (network + foreground) runs on the main stream - legal because the
+only cross-frame dependency is alpha_pre -> network input.
+"""
+import copy
+import queue
+import threading
+
+import numpy as np
+import torch
+
+from . import _native as nv
+from .vmatting.net import MattingNet, synthetic_state_dict
+
+_DEFAULT_CFG = {
+    "fg_exist_thr": 0.001,
+    "bg_mask": {"thr": 25, "fusion_weight": 0.1},
+    "objectremoval": {"score_map_center": {"landscape": [0.5, 0.5], "portrait": [0.6, 0.5]},
+                      "saliency_thr": 0.00001, "consensus_thr": 0.5},
+    "trimap": {"input_long_side": 960, "kernelsize": 3, "iters": 5, "color_winsize": [10, 100, 180]},
+    "vmatting": {"model_path": "synthetic", "input_long_side": 960},
+}
+
+
+def default_config():
+    """The bg_step subset of the reference's configs/bg.json."""
+    return copy.deepcopy(_DEFAULT_CFG)
+
+
+class _Slot:
+    """Per-frame device buffers of the front half (double-buffered by run())."""
+
+    def __init__(self, H, W, dev):
+        u8 = dict(dtype=torch.uint8, device=dev)
+        self.bg = torch.empty((H, W, 3), **u8)
+        self.gate = torch.empty((H, W), **u8)
+        self.alphaor = torch.empty((H, W), **u8)
+        self.trimap = torch.empty((H, W), **u8)
+        self.host = torch.empty((H, W), dtype=torch.uint8).pin_memory()
+        self.ready = torch.cuda.Event()
+        self.copied = torch.cuda.Event()
+        self.frame = None
+
+
+class BgStepPipeline:
+    def __init__(self, cfg, H, W, device="cuda:0", dtype=torch.float32, state_dict=None):
+        self.cfg = cfg
+        self.H, self.W = H, W
+        self.device = torch.device(device)
+        nv.load()
+        self._sd = state_dict if state_dict is not None else synthetic_state_dict(0)
+        self.net = MattingNet(self._sd, device=self.device, dtype=dtype)
+        self._cpu_net = None
+        self.beta = cfg["bg_mask"]["fusion_weight"]
+        self.thr = cfg["bg_mask"]["thr"]
+        tcfg = cfg["trimap"]
+        self.long_side, self.ksize, self.iters = tcfg["input_long_side"], tcfg["kernelsize"], tcfg["iters"]
+        L = cfg["vmatting"]["input_long_side"]
+        if L % 32 != 0:
+            L = (L // 32 + 1) * 32
+        self.in_h, self.in_w = nv.get_target_size(H, W, L, 32)
+        centers = cfg["objectremoval"]["score_map_center"]
+        self.center = centers["landscape"] if W > H else centers["portrait"]
+        self.sal_thr = cfg["objectremoval"]["saliency_thr"]
+        self.cons_thr = cfg["objectremoval"]["consensus_thr"]
+        self.filter = nv.ObjectFilter()
+        dev = self.device
+        self.ws_bgdiff = torch.empty(nv.load().usc_bgdiff_ws_bytes(H, W), dtype=torch.uint8, device=dev)
+        self.ws_trimap = torch.empty(nv.load().usc_trimap_ws_bytes(H, W, self.long_side), dtype=torch.uint8, device=dev)
+        self.x7 = torch.empty((1, 7, self.in_h, self.in_w), dtype=torch.float32, device=dev,
+                              memory_format=torch.channels_last)
+        self.slots = [_Slot(H, W, dev) for _ in range(3)]
+        self.alpha_pre = None
+
+    def cpu_net(self):
+        """The same folded plan on the CPU in float32 (used by tests / smoke as the network's oracle)."""
+        if self._cpu_net is None:
+            self._cpu_net = MattingNet(self._sd, device="cpu", dtype=torch.float32)
+        return self._cpu_net
+
+    def reset(self):
+        self.alpha_pre = None
+
+    # ------------------------------------------------------------------ stages
+    def _front_device(self, slot, frame, seg, bg_i, bg_always):
+        nv.bgdiff_mask(frame, bg_i, bg_always, seg, self.beta, self.thr, out_bg=slot.bg, out_alpha=slot.gate,
+                       ws=self.ws_bgdiff)
+        slot.host.copy_(slot.gate, non_blocking=True)
+        slot.copied.record()
+
+    def _front_host(self, slot):
+        slot.copied.synchronize()
+        self.filter(slot.host.numpy(), None, self.center, self.sal_thr, self.cons_thr)
+        slot.alphaor.copy_(slot.host, non_blocking=True)
+        nv.trimap(slot.alphaor, self.long_side, self.ksize, self.iters, out=slot.trimap, ws=self.ws_trimap)
+        slot.ready.record()
+
+    def _back(self, slot, frame, want_float=False):
+        alpha_pre = self.alpha_pre if self.alpha_pre is not None else slot.gate       # bg_offline.py:162-163
+        nv.vmat_pre(frame, alpha_pre, slot.trimap, self.in_h, self.in_w, layout=nv.NHWC, out=self.x7)
+        pred = self.net(self.x7)
+        res = nv.vmat_post(pred.view(self.in_h, self.in_w), slot.trimap, want_float=want_float)
+        alpha, alpha_f = (res if want_float else (res, None))
+        fg = nv.get_fg(frame, alpha, slot.bg, paste_thr=1)
+        self.alpha_pre = alpha
+        return {"alpha": alpha, "alpha_f32": alpha_f, "fg": fg, "trimap": slot.trimap, "bg": slot.bg,
+                "gate": slot.gate, "alphaor": slot.alphaor, "pred": pred}
+
+    # ------------------------------------------------------------------ synchronous form
+    def step(self, frame, seg, bg_i, bg_always, want_float=False):
+        """One frame, all stages in order on the current stream (one host sync for the object filter)."""
+        slot = self.slots[0]
+        self._front_device(slot, frame, seg, bg_i, bg_always)
+        self._front_host(slot)
+        return self._back(slot, frame, want_float=want_float)
+
+    # ------------------------------------------------------------------ pipelined form
+    def run(self, inputs, on_result=None):
+        """inputs: iterable of (frame, seg, bg_i, bg_always) CUDA tensors.  Calls on_result(index, dict) per frame
+        (the dict's tensors are only valid until two more frames have been submitted).  Returns the frame count."""
+        main = torch.cuda.current_stream(self.device)
+        front = torch.cuda.Stream(self.device)
+        work = queue.Queue()
+        done = queue.Queue()
+        err = []
+
+        def worker():
+            torch.cuda.set_device(self.device)
+            with torch.cuda.stream(front):
+                while True:
+                    slot = work.get()
+                    if slot is None:
+                        return
+                    try:
+                        self._front_host(slot)
+                    except Exception as e:      # surfaced to the main thread
+                        err.append(e)
+                    done.put(slot)
+
+        th = threading.Thread(target=worker, daemon=True)
+        th.start()
+        n = 0
+        pending = []
+        submitted = 0
+        try:
+            it = iter(inputs)
+            exhausted = False
+            while True:
+                while not exhausted and len(pending) < 2:
+                    try:
+                        frame, seg, bg_i, bg_always = next(it)
+                    except StopIteration:
+                        exhausted = True
+                        break
+                    slot = self.slots[submitted % len(self.slots)]
+                    slot.frame = frame
+                    front.wait_stream(main)                 # inputs produced on the main stream
+                    with torch.cuda.stream(front):
+                        self._front_device(slot, frame, seg, bg_i, bg_always)
+                    work.put(slot)
+                    pending.append(slot)
+                    submitted += 1
+                if not pending:
+                    break
+                slot = done.get()
+                if err:
+                    raise err[0]
+                assert slot is pending[0]
+                pending.pop(0)
+                main.wait_event(slot.ready)
+                out = self._back(slot, slot.frame)
+                if on_result is not None:
+                    on_result(n, out)
+                n += 1
+        finally:
+            work.put(None)
+            th.join()
+        return n

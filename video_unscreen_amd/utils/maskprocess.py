@@ -1,0 +1,47 @@
+"""Mask helpers with the reference's names and NumPy calling convention
+(reference unscreen/utils/maskprocess.py); the arithmetic runs in libunscreen_hip.so."""
+import numpy as np
+
+from .. import _native as nv
+from ._dev import to_dev, to_host
+
+_object_filter = nv.ObjectFilter()
+
+
+def dilate_mask(mask, kernelsize=5, iters=10):
+    """cv2.dilate with an ellipse element (reference maskprocess.py:7-19)."""
+    return to_host(nv.morph(to_dev(mask), kernelsize, iters, nv.DILATE))
+
+
+def erode_mask(mask, kernelsize=5, iters=10):
+    """cv2.erode with an ellipse element (reference maskprocess.py:22-34)."""
+    return to_host(nv.morph(to_dev(mask), kernelsize, iters, nv.ERODE))
+
+
+def exist_foreground(mask, fg_exist_thr):
+    """count(mask >= 128) > thr*h*w (reference maskprocess.py:56-60)."""
+    h, w = mask.shape
+    return int(nv.count_ge(to_dev(mask), 128).item()) > fg_exist_thr * h * w
+
+
+def get_outer_boundary(mask, kernelsize=7, iters=10):
+    """reference maskprocess.py:63-74 (uint8 wrap-around subtraction, then clip)."""
+    dilated = dilate_mask(mask, kernelsize, iters)
+    return np.clip(dilated - mask, 0, 255)
+
+
+def score_map_center(h, w, config):
+    centers = config['objectremoval']['score_map_center']
+    return centers['landscape'] if w > h else centers['portrait']
+
+
+def remove_invalid_objects(cfg, alpha, segmask=None, saliency_thr=0.001, consensus_thr=0.5,
+                           score_map=None, score_map_center=(3. / 5, 1. / 2)):
+    """Contour-based object filter (reference maskprocess.py:77-152).  Like the reference, the thresholds come
+    from cfg (the keyword values are ignored, :113-114), the centre from build_score_map (:119, :181-189), and
+    `alpha` is modified in place and returned.  Host stage: see csrc/usc_host_objects.cpp."""
+    h, w = alpha.shape
+    centers = cfg['objectremoval']['score_map_center']
+    center = centers['landscape'] if w > h else centers['portrait']
+    return _object_filter(alpha, segmask, center, cfg['objectremoval']['saliency_thr'],
+                          cfg['objectremoval']['consensus_thr'])
