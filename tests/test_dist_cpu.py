@@ -1,0 +1,83 @@
+"""world_size-2 gloo tests of the multi-GPU plumbing (frame sharding + set-up broadcasts), on the CPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from video_unscreen_amd.dist import broadcast_state, gather_stats, shard_range
+
+
+def test_shard_range_partitions_every_frame_once():
+    for F in (0, 1, 7, 300, 301, 2400):
+        for G in (1, 2, 3, 8):
+            seen = []
+            for r in range(G):
+                lo, hi = shard_range(F, r, G)
+                assert 0 <= lo <= hi <= F
+                seen += list(range(lo, hi))
+            assert seen == list(range(F))                               # contiguous, ordered, complete
+            sizes = [shard_range(F, r, G)[1] - shard_range(F, r, G)[0] for r in range(G)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from video_unscreen_amd.vmatting.net import MattingNet, synthetic_state_dict
+    torch.manual_seed(0)
+    sd = synthetic_state_dict(0) if rank == 0 else None
+    bg = torch.arange(4 * 6 * 3, dtype=torch.uint8).view(4, 6, 3) if rank == 0 else torch.zeros(4, 6, 3, dtype=torch.uint8)
+    sd2, bg2 = broadcast_state(sd, bg, torch.device("cpu"), world)
+    # every rank must now hold rank 0's checkpoint, bit for bit, in the reference key order
+    ref = synthetic_state_dict(0)
+    same = list(sd2.keys()) == list(ref.keys()) and all(torch.equal(sd2[k], ref[k]) for k in ref)
+    same = same and torch.equal(bg2, torch.arange(4 * 6 * 3, dtype=torch.uint8).view(4, 6, 3))
+    # and the network built from it computes the same thing on each rank's own frame range
+    net = MattingNet(sd2, device="cpu")
+    lo, hi = shard_range(5, rank, world)
+    outs = []
+    for t in range(lo, hi):
+        g = torch.Generator().manual_seed(100 + t)
+        outs.append(float(net(torch.rand(1, 7, 32, 32, generator=g)).sum()))
+    table = gather_stats([float(rank), float(hi - lo), float(same)], torch.device("cpu"))
+    q.put((rank, same, lo, hi, outs, table.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_shards_world2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+    assert [(r[2], r[3]) for r in res] == [(0, 3), (3, 5)]
+    # the sharded run equals a single-process run over the same frames
+    from video_unscreen_amd.vmatting.net import MattingNet, synthetic_state_dict
+    net = MattingNet(synthetic_state_dict(0), device="cpu")
+    single = []
+    for t in range(5):
+        g = torch.Generator().manual_seed(100 + t)
+        single.append(float(net(torch.rand(1, 7, 32, 32, generator=g)).sum()))
+    assert res[0][4] + res[1][4] == single
+    assert res[0][5] == [[0.0, 3.0, 1.0], [1.0, 2.0, 1.0]]

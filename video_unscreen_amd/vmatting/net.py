@@ -106,7 +106,17 @@ def checkpoint_layout():
     return keys
 
 
+_SYNTH_CACHE: Dict[int, Dict[str, torch.Tensor]] = {}
+
+
 def synthetic_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Keyed-deterministic weights in the reference checkpoint format (cached per seed; returns clones)."""
+    if seed not in _SYNTH_CACHE:
+        _SYNTH_CACHE[seed] = _synthetic_state_dict(seed)
+    return {k: v.clone() for k, v in _SYNTH_CACHE[seed].items()}
+
+
+def _synthetic_state_dict(seed: int) -> Dict[str, torch.Tensor]:
     """Keyed-deterministic weights in the reference checkpoint format.
 
     No trained checkpoint exists offline, so tests, the bench and
