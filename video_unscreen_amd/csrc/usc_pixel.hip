@@ -217,39 +217,190 @@ extern "C" int usc_morph_u8(const uint8_t* src, uint8_t* dst, int H, int W, int 
 // trimap
 // --------------------------------------------------------------------------------------------
 
-// Stage 1: NEAREST decimation + dilate + erode + classify, one low-res tile per workgroup.
-__global__ __launch_bounds__(kMorphThreads) void trimap_small_kernel(const uint8_t* __restrict__ mask, int H, int W,
-                                                                     uint8_t* __restrict__ tri, int h, int w,
-                                                                     double ify, double ifx, StructElem se, TileGeom tg, int iters) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int plane = tg.eh * tg.pitch;
-    uint8_t *da = lds, *db = lds + plane, *ea = lds + 2 * plane, *eb = lds + 3 * plane;
-    const int y0 = blockIdx.y * kTileH, x0 = blockIdx.x * kTileW;
-    const int gy0 = y0 - tg.top, gx0 = x0 - tg.left;
-    for (int i = threadIdx.x; i < tg.eh * tg.ew; i += blockDim.x) {
-        int ty = i / tg.ew, tx = i - ty * tg.ew;
-        int ly = gy0 + ty, lx = gx0 + tx;
-        uint8_t vd = 0, ve = 255;
-        if (ly >= 0 && ly < h && lx >= 0 && lx < w) {
-            int sy = min((int)floor(ly * ify), H - 1);       // cv::resizeNN
-            int sx = min((int)floor(lx * ifx), W - 1);
-            vd = ve = mask[(size_t)sy * W + sx];
+// ---- bit-packed binary morphology ---------------------------------------------------------------
+// Both hot uses of morphology are binary in disguise: the trimap thresholds the grey dilation / erosion at
+// 127/128 (min / max filters commute with a threshold), and the difference gate only asks whether the dilated
+// value reaches 255.  One uint32 holds 32 horizontal pixels (bit i <-> x0 + i), a workgroup owns a tile of
+// kBitH rows x kBitWW words plus halo rows and one halo word (32 px) per side, and one SE pass is a handful of
+// shifts / ORs per word instead of k*k byte compares per pixel.
+constexpr int kBitH = 16, kBitWW = 4, kBitEWW = kBitWW + 2, kBitThreads = 256;
+
+struct BitSE {                // per SE row: contiguous run [lo, hi] of dx (lo > hi: empty row)
+    int nrows, anchor, top, bottom;
+    int8_t lo[kMaxK], hi[kMaxK];
+};
+static BitSE make_bit_se(int ksize, int iters) {
+    StructElem se = make_ellipse(ksize);
+    BitSE b;
+    memset(&b, 0, sizeof(b));
+    b.nrows = ksize; b.anchor = se.anchor;
+    for (int i = 0; i < ksize; i++) { b.lo[i] = 1; b.hi[i] = 0; }
+    for (int k = 0; k < se.n; k++) {
+        int i = se.dy[k] + se.anchor;
+        if (b.lo[i] > b.hi[i]) { b.lo[i] = se.dx[k]; b.hi[i] = se.dx[k]; }
+        else { if (se.dx[k] < b.lo[i]) b.lo[i] = se.dx[k]; if (se.dx[k] > b.hi[i]) b.hi[i] = se.dx[k]; }
+    }
+    b.top = iters * se.anchor;
+    b.bottom = iters * (ksize - 1 - se.anchor);
+    return b;
+}
+// the horizontal halo is one word: iters * max(|dx|) must fit in 32 bits
+static bool bit_se_fits(int ksize, int iters) { return iters * (ksize / 2) <= 32 && iters * (ksize - 1 - ksize / 2) <= 32; }
+
+// `iters` passes over the LDS bit tile.  D accumulates OR (dilation, outside = 0), E accumulates AND (erosion,
+// outside = 1); positions outside the image are forced back to the identity after every pass.
+template <bool WITH_ERODE>
+__device__ void bit_morph_passes(uint32_t*& d, uint32_t*& d2, uint32_t*& e, uint32_t*& e2, const uint32_t* inimg,
+                                 int ER, const BitSE& se, int iters) {
+    for (int it = 0; it < iters; it++) {
+        for (int idx = threadIdx.x; idx < ER * kBitEWW; idx += blockDim.x) {
+            const int r = idx / kBitEWW, w = idx - r * kBitEWW;
+            uint32_t accD = 0, accE = 0xffffffffu;
+            for (int i = 0; i < se.nrows; i++) {
+                const int lo = se.lo[i], hi = se.hi[i];
+                const int rr = r + i - se.anchor;
+                if (lo > hi || rr < 0 || rr >= ER) continue;
+                const int base = rr * kBitEWW + w;
+                const uint32_t dc = d[base], dl = w > 0 ? d[base - 1] : 0u, dr = w < kBitEWW - 1 ? d[base + 1] : 0u;
+                uint32_t ec = 0, el = 0, er = 0;
+                if (WITH_ERODE) {
+                    ec = e[base]; el = w > 0 ? e[base - 1] : 0xffffffffu; er = w < kBitEWW - 1 ? e[base + 1] : 0xffffffffu;
+                }
+                for (int dx = lo; dx <= hi; dx++) {
+                    if (dx == 0) { accD |= dc; if (WITH_ERODE) accE &= ec; }
+                    else if (dx > 0) {
+                        accD |= (dc >> dx) | (dr << (32 - dx));
+                        if (WITH_ERODE) accE &= (ec >> dx) | (er << (32 - dx));
+                    } else {
+                        accD |= (dc << (-dx)) | (dl >> (32 + dx));
+                        if (WITH_ERODE) accE &= (ec << (-dx)) | (el >> (32 + dx));
+                    }
+                }
+            }
+            const uint32_t in = inimg[idx];
+            d2[idx] = accD & in;
+            if (WITH_ERODE) e2[idx] = accE | ~in;
         }
-        da[ty * tg.pitch + tx] = vd;
-        ea[ty * tg.pitch + tx] = ve;
+        __syncthreads();
+        uint32_t* t = d; d = d2; d2 = t;
+        if (WITH_ERODE) { t = e; e = e2; e2 = t; }
+    }
+}
+
+// Stage 1: NEAREST decimation + threshold to bits + dilate + erode + classify, one low-res tile per workgroup.
+__global__ __launch_bounds__(kBitThreads) void trimap_small_kernel(const uint8_t* __restrict__ mask, int H, int W,
+                                                                   uint8_t* __restrict__ tri, int h, int w,
+                                                                   double ify, double ifx, BitSE se, int iters) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const int ER = kBitH + se.top + se.bottom;
+    const int plane = ER * kBitEWW;
+    uint32_t* lds = reinterpret_cast<uint32_t*>(lds_raw);
+    uint32_t *d = lds, *d2 = lds + plane, *e = lds + 2 * plane, *e2 = lds + 3 * plane, *inimg = lds + 4 * plane;
+    const int y0 = blockIdx.y * kBitH, x0 = blockIdx.x * (kBitWW * 32);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
+    const int chunks_per_row = kBitEWW / 2;                      // 64 pixels = 2 words per wave-instruction
+    for (int c = wave; c < ER * chunks_per_row; c += nwaves) {
+        const int r = c / chunks_per_row, cx = c - r * chunks_per_row;
+        const int ly = y0 - se.top + r, lx = x0 - 32 + cx * 64 + lane;
+        const bool in = ly >= 0 && ly < h && lx >= 0 && lx < w;
+        bool b = false;
+        if (in) {
+            const int sy = min((int)floor(ly * ify), H - 1);     // cv::resizeNN
+            const int sx = min((int)floor(lx * ifx), W - 1);
+            b = mask[(size_t)sy * W + sx] > 127;
+        }
+        const unsigned long long bal = __ballot(b), inb = __ballot(in);
+        if (lane == 0) {
+            const int o = r * kBitEWW + 2 * cx;
+            d[o] = (uint32_t)bal; d[o + 1] = (uint32_t)(bal >> 32);
+            e[o] = (uint32_t)(bal | ~inb); e[o + 1] = (uint32_t)((bal | ~inb) >> 32);
+            inimg[o] = (uint32_t)inb; inimg[o + 1] = (uint32_t)(inb >> 32);
+        }
     }
     __syncthreads();
-    uint8_t* rd = morph_passes<false>(da, db, tg, gy0, gx0, h, w, se, iters);
-    uint8_t* re = morph_passes<true>(ea, eb, tg, gy0, gx0, h, w, se, iters);
-    for (int i = threadIdx.x; i < kTileH * kTileW; i += blockDim.x) {
-        int ty = i / kTileW, tx = i - ty * kTileW;
-        int ly = y0 + ty, lx = x0 + tx;
+    bit_morph_passes<true>(d, d2, e, e2, inimg, ER, se, iters);
+    // epilogue: 8 pixels per lane.  trimap = 128; [eroded > 127] = 255; [dilated < 128] = 0  (agent.py:54,57-58)
+    for (int idx = threadIdx.x; idx < kBitH * kBitWW * 4; idx += blockDim.x) {
+        const int row = idx / (kBitWW * 4), seg = idx - row * (kBitWW * 4);
+        const int ly = y0 + row, lx = x0 + seg * 8;
         if (ly >= h || lx >= w) continue;
-        int o = (ty + tg.top) * tg.pitch + tx + tg.left;
-        uint8_t t = 128;
-        if (re[o] > 127) t = 255;
-        if (rd[o] < 128) t = 0;
-        tri[(size_t)ly * w + lx] = t;
+        const int o = (row + se.top) * kBitEWW + 1 + (seg >> 2), sh = (seg & 3) * 8;
+        const uint32_t db = (d[o] >> sh) & 0xff, eb = (e[o] >> sh) & 0xff;
+        uint32_t out[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) out[k] = ((db >> k) & 1) ? (((eb >> k) & 1) ? 255u : 128u) : 0u;
+        uint8_t* dst = tri + (size_t)ly * w + lx;
+        if (lx + 8 <= w && (((size_t)ly * w + lx) & 7) == 0) {
+            uint2 v;
+            v.x = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+            v.y = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
+            *reinterpret_cast<uint2*>(dst) = v;
+        } else for (int k = 0; k < 8 && lx + k < w; k++) dst[k] = (uint8_t)out[k];
+    }
+}
+
+// Difference gate (bg_offline.py:158-160): binary dilation of (diff == 255) by the 4x4 ellipse x2, then
+// alpha = gray(seg) where the dilation reached, else 0.
+__global__ __launch_bounds__(kBitThreads) void gate_kernel(const uint8_t* __restrict__ diff, int H, int W,
+                                                           const uint8_t* __restrict__ seg, int seg_cn,
+                                                           uint8_t* __restrict__ alpha, BitSE se, int iters) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const int ER = kBitH + se.top + se.bottom;
+    const int plane = ER * kBitEWW;
+    uint32_t* lds = reinterpret_cast<uint32_t*>(lds_raw);
+    uint32_t *d = lds, *d2 = lds + plane, *inimg = lds + 2 * plane, *unused = nullptr, *unused2 = nullptr;
+    const int y0 = blockIdx.y * kBitH, x0 = blockIdx.x * (kBitWW * 32);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
+    const int chunks_per_row = kBitEWW / 2;
+    for (int c = wave; c < ER * chunks_per_row; c += nwaves) {
+        const int r = c / chunks_per_row, cx = c - r * chunks_per_row;
+        const int gy = y0 - se.top + r, gx = x0 - 32 + cx * 64 + lane;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const bool b = in && diff[(size_t)gy * W + gx] == 255;
+        const unsigned long long bal = __ballot(b), inb = __ballot(in);
+        if (lane == 0) {
+            const int o = r * kBitEWW + 2 * cx;
+            d[o] = (uint32_t)bal; d[o + 1] = (uint32_t)(bal >> 32);
+            inimg[o] = (uint32_t)inb; inimg[o + 1] = (uint32_t)(inb >> 32);
+        }
+    }
+    __syncthreads();
+    bit_morph_passes<false>(d, d2, unused, unused2, inimg, ER, se, iters);
+    for (int idx = threadIdx.x; idx < kBitH * kBitWW * 4; idx += blockDim.x) {
+        const int row = idx / (kBitWW * 4), sg = idx - row * (kBitWW * 4);
+        const int gy = y0 + row, gx = x0 + sg * 8;
+        if (gy >= H || gx >= W) continue;
+        const int o = (row + se.top) * kBitEWW + 1 + (sg >> 2), sh = (sg & 3) * 8;
+        const uint32_t db = (d[o] >> sh) & 0xff;
+        const size_t p = (size_t)gy * W + gx;
+        uint32_t out[8];
+        if (gx + 8 <= W && (p & 3) == 0) {
+            if (seg_cn == 3) {
+                int c0[12], c1[12];
+                unpack12(*reinterpret_cast<const Px4*>(seg + 3 * p), c0);
+                unpack12(*reinterpret_cast<const Px4*>(seg + 3 * p + 12), c1);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    out[k] = ((db >> k) & 1) ? (uint32_t)gray_u8(c0[3 * k], c0[3 * k + 1], c0[3 * k + 2]) : 0u;
+                    out[4 + k] = ((db >> (4 + k)) & 1) ? (uint32_t)gray_u8(c1[3 * k], c1[3 * k + 1], c1[3 * k + 2]) : 0u;
+                }
+            } else {
+                const uint32_t s0 = *reinterpret_cast<const uint32_t*>(seg + p), s1 = *reinterpret_cast<const uint32_t*>(seg + p + 4);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    out[k] = ((db >> k) & 1) ? ((s0 >> (8 * k)) & 0xffu) : 0u;
+                    out[4 + k] = ((db >> (4 + k)) & 1) ? ((s1 >> (8 * k)) & 0xffu) : 0u;
+                }
+            }
+            *reinterpret_cast<uint32_t*>(alpha + p) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+            *reinterpret_cast<uint32_t*>(alpha + p + 4) = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
+        } else {
+            for (int k = 0; k < 8 && gx + k < W; k++) {
+                const size_t q = p + k;
+                const int sv = seg_cn == 3 ? gray_u8(seg[3 * q], seg[3 * q + 1], seg[3 * q + 2]) : seg[q];
+                alpha[q] = ((db >> k) & 1) ? (uint8_t)sv : 0;
+            }
+        }
     }
 }
 
@@ -273,17 +424,17 @@ __device__ __forceinline__ int resize_u8_c1(const uint8_t* __restrict__ s, int s
 __global__ __launch_bounds__(256) void trimap_up_kernel(const uint8_t* __restrict__ tri, int h, int w,
                                                         uint8_t* __restrict__ out, int H, int W,
                                                         int mode, double scale_y, double scale_x) {
-    const size_t n = (size_t)H * W;
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += (size_t)gridDim.x * blockDim.x) {
-        size_t i0 = q * 4;
+    const uint32_t n = (uint32_t)H * (uint32_t)W;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += gridDim.x * blockDim.x) {
+        const uint32_t i0 = q * 4;
+        uint32_t y = i0 / (uint32_t)W, x = i0 - y * (uint32_t)W;      // one 32-bit division per 4 pixels
+        const int cnt = (int)min(4u, n - i0);
         uint32_t packed = 0;
-        int cnt = (int)min((size_t)4, n - i0);
         for (int k = 0; k < cnt; k++) {
-            size_t i = i0 + k;
-            int y = (int)(i / W), x = (int)(i - (size_t)y * W);
-            int v = resize_u8_c1(tri, h, w, y, x, mode, scale_y, scale_x);
+            int v = resize_u8_c1(tri, h, w, (int)y, (int)x, mode, scale_y, scale_x);
             if (v > 0 && v < 255) v = 128;
             packed |= (uint32_t)v << (8 * k);
+            if (++x == (uint32_t)W) { x = 0; y++; }
         }
         if (cnt == 4) *reinterpret_cast<uint32_t*>(out + i0) = packed;
         else for (int k = 0; k < cnt; k++) out[i0 + k] = (packed >> (8 * k)) & 0xff;
@@ -295,6 +446,8 @@ extern "C" size_t usc_trimap_ws_bytes(int H, int W, int long_side) {
     usc_get_target_size(H, W, long_side, 1, &h, &w);
     return ((size_t)h * w + 255) & ~(size_t)255;
 }
+
+static bool too_big(int H, int W) { return (long long)H * W >= (1ll << 31); }   // kernels index pixels with 32 bits
 
 static int grid_for(size_t work_items, int threads) {
     size_t blocks = (work_items + threads - 1) / threads;
@@ -308,19 +461,20 @@ extern "C" int usc_trimap_u8(const uint8_t* mask, int H, int W, int long_side, i
     if (!mask || !out || H <= 0 || W <= 0 || long_side <= 0) return fail(USC_E_ARG, "usc_trimap_u8: bad argument");
     if (ksize < 1 || ksize > kMaxK) return fail(USC_E_UNSUPPORTED, "usc_trimap_u8: ksize %d outside [1,%d]", ksize, kMaxK);
     if (iters < 0) return fail(USC_E_ARG, "usc_trimap_u8: iters < 0");
+    if (too_big(H, W)) return fail(USC_E_UNSUPPORTED, "usc_trimap_u8: image of %dx%d pixels", H, W);
     int h, w;
     usc_get_target_size(H, W, long_side, 1, &h, &w);
     if (h <= 0 || w <= 0) return fail(USC_E_ARG, "usc_trimap_u8: degenerate low-res size %dx%d", h, w);
     if (!ws || ws_bytes < (size_t)h * w) return fail(USC_E_WORKSPACE, "usc_trimap_u8: workspace %zu < %zu", ws_bytes, (size_t)h * w);
     hipStream_t st = (hipStream_t)stream;
     uint8_t* tri = (uint8_t*)ws;
-    StructElem se = make_ellipse(ksize);
-    TileGeom tg = tile_geom(se, iters);
-    size_t lds = 4 * (size_t)tg.eh * tg.pitch;
+    if (!bit_se_fits(ksize, iters)) return fail(USC_E_UNSUPPORTED, "usc_trimap_u8: ksize %d x iters %d exceeds the 32-pixel halo", ksize, iters);
+    BitSE se = make_bit_se(ksize, iters);
+    size_t lds = 5 * (size_t)(kBitH + se.top + se.bottom) * kBitEWW * sizeof(uint32_t);
     if (lds > 60 * 1024) return fail(USC_E_UNSUPPORTED, "usc_trimap_u8: ksize %d x iters %d needs %zu B of LDS", ksize, iters, lds);
     double ifx = 1. / ((double)w / W), ify = 1. / ((double)h / H);
-    dim3 grid((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH);
-    hipLaunchKernelGGL(trimap_small_kernel, grid, dim3(kMorphThreads), lds, st, mask, H, W, tri, h, w, ify, ifx, se, tg, iters);
+    dim3 grid((w + kBitWW * 32 - 1) / (kBitWW * 32), (h + kBitH - 1) / kBitH);
+    hipLaunchKernelGGL(trimap_small_kernel, grid, dim3(kBitThreads), lds, st, mask, H, W, tri, h, w, ify, ifx, se, iters);
     int rc = check_launch("trimap_small_kernel");
     if (rc) return rc;
     ResizeGeom rg = resize_geom(h, w, H, W);
@@ -402,7 +556,11 @@ extern "C" int usc_bgdiff_mask_u8(const uint8_t* frame, const uint8_t* bg_i, con
                        frame, bg_i, bg_always, (float)beta, (float)(1 - beta), thr, n, out_bg, diff);
     int rc = check_launch("bgdiff_point_kernel");
     if (rc) return rc;
-    return launch_morph(MODE_GATE, diff, out_alpha, H, W, 4, 2, USC_MORPH_DILATE, seg, seg_cn, st);
+    BitSE se = make_bit_se(4, 2);
+    size_t lds = 3 * (size_t)(kBitH + se.top + se.bottom) * kBitEWW * sizeof(uint32_t);
+    dim3 grid((W + kBitWW * 32 - 1) / (kBitWW * 32), (H + kBitH - 1) / kBitH);
+    hipLaunchKernelGGL(gate_kernel, grid, dim3(kBitThreads), lds, st, diff, H, W, seg, seg_cn, out_alpha, se, 2);
+    return check_launch("gate_kernel");
 }
 
 // --------------------------------------------------------------------------------------------
@@ -415,9 +573,9 @@ __global__ __launch_bounds__(256) void vmat_pre_kernel(const uint8_t* __restrict
                                                        int inH, int inW, int mode, double scale_y, double scale_x,
                                                        float* __restrict__ out, int layout,
                                                        float m0, float m1, float m2, float s0, float s1, float s2) {
-    const size_t n = (size_t)inH * inW;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        int py = (int)(i / inW), px = (int)(i - (size_t)py * inW);
+    const uint32_t n = (uint32_t)inH * (uint32_t)inW;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int py = (int)(i / (uint32_t)inW), px = (int)(i - (uint32_t)py * (uint32_t)inW);
         int y = py < nh ? py : 2 * nh - 1 - py;        // BORDER_REFLECT: the edge sample repeats
         int x = px < nw ? px : 2 * nw - 1 - px;
         int bgr[3], tri, ap;
@@ -458,7 +616,7 @@ __global__ __launch_bounds__(256) void vmat_pre_kernel(const uint8_t* __restrict
             for (int c = 0; c < 7; c++) out[(size_t)c * n + i] = v[c];
         } else {
 #pragma unroll
-            for (int c = 0; c < 7; c++) out[i * 7 + c] = v[c];
+            for (int c = 0; c < 7; c++) out[(size_t)i * 7 + c] = v[c];
         }
     }
 }
@@ -467,6 +625,7 @@ extern "C" int usc_vmat_pre(const uint8_t* frame, const uint8_t* alpha_pre, cons
                             int inH, int inW, float* out7, int layout, usc_stream_t stream) {
     if (!frame || !alpha_pre || !trimap || !out7 || H <= 0 || W <= 0 || inH <= 0 || inW <= 0) return fail(USC_E_ARG, "usc_vmat_pre: bad argument");
     if (layout != USC_LAYOUT_NCHW && layout != USC_LAYOUT_NHWC) return fail(USC_E_ARG, "usc_vmat_pre: layout %d", layout);
+    if (too_big(H, W) || too_big(inH, inW)) return fail(USC_E_UNSUPPORTED, "usc_vmat_pre: image too large");
     int nh, nw;
     usc_pad_resize_geometry(H, W, inH, inW, &nh, &nw);
     if (nh <= 0 || nw <= 0 || nh > inH || nw > inW) return fail(USC_E_ARG, "usc_vmat_pre: resized size %dx%d does not fit %dx%d", nh, nw, inH, inW);
@@ -486,14 +645,16 @@ __global__ __launch_bounds__(256) void vmat_post_kernel(const float* __restrict_
                                                         const uint8_t* __restrict__ trimap, int H, int W,
                                                         double scale_y, double scale_x, int copy,
                                                         uint8_t* __restrict__ alpha_u8, float* __restrict__ alpha_f32) {
-    const size_t n = (size_t)H * W;
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += (size_t)gridDim.x * blockDim.x) {
-        size_t i0 = q * 4;
-        int cnt = (int)min((size_t)4, n - i0);
+    const uint32_t n = (uint32_t)H * (uint32_t)W;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += gridDim.x * blockDim.x) {
+        const uint32_t i0 = q * 4;
+        const int cnt = (int)min(4u, n - i0);
         uint32_t packed = 0;
+        uint32_t yy = i0 / (uint32_t)W, xx = i0 - yy * (uint32_t)W;
         for (int k = 0; k < cnt; k++) {
-            size_t i = i0 + k;
-            int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+            const uint32_t i = i0 + k;
+            const int y = (int)yy, x = (int)xx;
+            if (++xx == (uint32_t)W) { xx = 0; yy++; }
             float a;
             if (copy) a = pred[(size_t)y * pitch + x];
             else {
@@ -521,6 +682,7 @@ __global__ __launch_bounds__(256) void vmat_post_kernel(const float* __restrict_
 extern "C" int usc_vmat_post(const float* pred, int inH, int inW, const uint8_t* trimap, int H, int W,
                              uint8_t* alpha_u8, float* alpha_f32, usc_stream_t stream) {
     if (!pred || !trimap || !alpha_u8 || H <= 0 || W <= 0 || inH <= 0 || inW <= 0) return fail(USC_E_ARG, "usc_vmat_post: bad argument");
+    if (too_big(H, W) || too_big(inH, inW)) return fail(USC_E_UNSUPPORTED, "usc_vmat_post: image too large");
     int rh, rw;
     usc_inv_pad_geometry(inH, inW, H, W, &rh, &rw);
     if (rh <= 0 || rw <= 0 || rh > inH || rw > inW) return fail(USC_E_ARG, "usc_vmat_post: un-padded size %dx%d", rh, rw);
