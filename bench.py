@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--sync-loop", action="store_true", help="use the synchronous step() instead of the pipelined run()")
     ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--net", default="hip", choices=["hip", "miopen"],
+                    help="conv stack: hand-written f32-MFMA kernels (default) or PyTorch-ROCm / MIOpen")
     return ap.parse_args()
 
 
@@ -85,7 +87,8 @@ def kernel_table(pipe, sample, H, W):
         9 * N + seg_b + 3 * N + N)
     add("trimap (small + up)", lambda: nv.trimap(gate, pipe.long_side, pipe.ksize, pipe.iters, out=slot.trimap, ws=pipe.ws_trimap),
         N + n_lo)
-    add("vmat_pre", lambda: nv.vmat_pre(frame, alpha, tri, pipe.in_h, pipe.in_w, layout=nv.NHWC, out=pipe.x7), 5 * N + 28 * n_in)
+    add("vmat_pre", lambda: nv.vmat_pre(frame, alpha, tri, pipe.in_h, pipe.in_w, layout=pipe._layout, out=pipe.x7),
+        5 * N + (32 if pipe._layout == nv.NHWC8 else 28) * n_in)
     add("vmat_post", lambda: nv.vmat_post(pred, tri, out_u8=alpha), 2 * N + 4 * n_in)
     add("get_fg", lambda: nv.get_fg(frame, alpha, slot.bg, paste_thr=1, out_fg=out["fg"]), 10 * N)
     cnt = torch.empty(1, dtype=torch.int64, device=frame.device)
@@ -141,7 +144,7 @@ def main():
     clip = SyntheticClip(H, W, (K + Wm) * world, config_id=2, device=dev)
     sd = synthetic_state_dict(0) if rank == 0 else None
     sd, bg_always = broadcast_state(sd, clip.bg_always if rank == 0 else torch.empty_like(clip.bg_always), dev, world)
-    pipe = BgStepPipeline(cfg, H, W, device=dev, dtype=dtype, state_dict=sd)
+    pipe = BgStepPipeline(cfg, H, W, device=dev, dtype=dtype, state_dict=sd, net_backend=args.net)
 
     # this rank's contiguous frame range, generated straight into HBM (not timed)
     lo, hi = shard_range((K + Wm) * world, rank, world)
@@ -188,7 +191,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"bg_step stage-3 loop (bgdiff mask + object filter + trimap + matting UNet-18 + get_fg), "
                                    f"{W}x{H}, {K} frames/GPU, frame-sharded x{world}",
-                       "net_input": [pipe.in_h, pipe.in_w], "loop": "sync" if args.sync_loop else "pipelined",
+                       "net_input": [pipe.in_h, pipe.in_w], "loop": "sync" if args.sync_loop else "pipelined", "convs": args.net,
                        "weights": "keyed-deterministic synthetic (no checkpoint offline)"},
         }
         if not args.no_kernel_table:
@@ -200,7 +203,9 @@ def main():
             result["kernels"] = rows
             scale = (pipe.in_h * pipe.in_w) / (544 * 960)
             tf = UNET_GFLOP_544x960 * scale / t_net / 1e3
-            result["net"] = {"bound": "mfma", "what": "matting UNet-18 via PyTorch-ROCm (MIOpen)", "ms": round(t_net * 1e3, 3),
+            what = ("matting UNet-18, hand-written f32 MFMA implicit-GEMM convs (usc_conv.hip), %d fused launches" % pipe.net.num_layers
+                    if args.net == "hip" else "matting UNet-18 via PyTorch-ROCm (MIOpen)")
+            result["net"] = {"bound": "mfma", "what": what, "ms": round(t_net * 1e3, 3),
                              "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
         if not args.no_cpu_baseline:

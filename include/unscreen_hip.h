@@ -39,6 +39,7 @@ typedef void* usc_stream_t;               /* hipStream_t */
 #define USC_MORPH_ERODE  1
 #define USC_LAYOUT_NCHW  0
 #define USC_LAYOUT_NHWC  1
+#define USC_LAYOUT_NHWC8 2                /* 7 channels + one zero channel per pixel (32-byte pixels for the HIP convs) */
 
 int         usc_abi_version(void);
 const char* usc_last_error(void);
@@ -110,6 +111,56 @@ int usc_count_ge_u8(const uint8_t* mask, size_t n, int thr, unsigned long long* 
 int usc_remove_invalid_objects_host(uint8_t* alpha, const uint8_t* seg, int H, int W,
                                     double center_y, double center_x, double saliency_thr, double consensus_thr,
                                     double* score_cache, int* score_cache_valid);
+
+/* ---------------------------------------------------------------------------------------------
+ * Matting network convolutions (reference unscreen/vmatting/model.py:435-568: every nn.Conv2d /
+ * nn.ConvTranspose2d of ResShortCut + ResShortCut_Dec with its BatchNorm / activation / residual).
+ * One descriptor = one fused layer on NHWC float32 tensors:
+ *   out[Y, X, n] = post( act( sum_{t, ci} in[oy*in_stride + dy[t], ox*in_stride + dx[t], ci] * W[t, ci, n]
+ *                             + bias[n] + res1[Y >> res1_shift, X >> res1_shift, n] ) ) + res2[Y, X, n]
+ *   (Y, X) = (oy*out_stride + out_py, ox*out_stride + out_px),  post(v) = v*scale[n] + shift[n]
+ * for (oy, ox) in [0, OH) x [0, OW); out-of-image taps contribute zero.  Optional pointers may be NULL.
+ * wpk is W padded to a multiple of 32 rows of k = t*Cin + ci and packed [k/4][Cout][4]
+ * (kind USC_CONV_HEAD: plain [k], Cout = 1, and the (tanh(.)+1)/2 of model.py:566 is applied).
+ * Cin must be a multiple of 4, Cout a multiple of 32 (or 1 for the head), ntaps <= 16. */
+#define USC_ACT_NONE  0
+#define USC_ACT_RELU  1
+#define USC_ACT_LEAKY 2            /* LeakyReLU(0.2) */
+#define USC_CONV_MFMA 0
+#define USC_CONV_HEAD 1
+
+typedef struct usc_conv_desc {
+    const float* in;
+    float*       out;
+    const float* wpk;
+    const float* bias;
+    const float* res1;
+    const float* scale;
+    const float* shift;
+    const float* res2;
+    int IH, IW, Cin;
+    int OH, OW;                    /* logical output grid of this launch */
+    int OHf, OWf, Cout;            /* dimensions of the tensor `out` points to */
+    int in_stride;
+    int out_stride, out_py, out_px;
+    int res1_shift;
+    int act;
+    int ntaps;                     /* taps per phase */
+    int kind;
+    signed char dy[16], dx[16];    /* nphase * ntaps entries */
+    int nphase;                    /* 1, or 4 = the (py, px) output phases of ConvTranspose2d(k4, s2, p1) in one launch:
+                                      phase p uses taps [p*ntaps, (p+1)*ntaps), weights wpk + p*wphase_stride and
+                                      writes (2*oy + (p >> 1), 2*ox + (p & 1)); out_py / out_px are then ignored */
+    int wphase_stride;             /* floats between the packed weights of consecutive phases */
+    int ksplit;                    /* set by the library */
+    int reserved;
+    float* slab;                   /* optional scratch for split-K partial sums (small-M layers), may be NULL */
+    size_t slab_bytes;
+} usc_conv_desc;
+
+/* Enqueue `n` layers in order on `stream` (one kernel launch each, no host synchronisation). */
+int usc_conv_sequence_f32(const usc_conv_desc* descs, int n, usc_stream_t stream);
+const char* usc_conv_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,178 @@
+"""GPU tests of the hand-written f32-MFMA convolution (csrc/usc_conv.hip) through the C ABI.
+
+Float kernels: compared with a plain PyTorch float32 reference of the same op (torch on the CPU, float64
+accumulate where noted); tolerance 2e-5 relative to the output scale for single layers (f32 accumulation in a
+different order), 1e-4 absolute on alpha for the whole network (north_star bound: 1e-3)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def hipnet():
+    assert torch.cuda.is_available()
+    from video_unscreen_amd import _native
+    _native.load()
+    from video_unscreen_amd.vmatting import net_hip
+    return net_hip
+
+
+class _Layer:
+    """One usc_conv_desc built by hand for a test."""
+
+    def __init__(self, hipnet):
+        self.m = hipnet
+        self.keep = []
+
+    def run(self, descs):
+        from video_unscreen_amd import _native as nv
+        arr = (self.m.ConvDesc * len(descs))(*descs)
+        rc = nv.load().usc_conv_sequence_f32(arr, len(descs), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, nv.load().usc_conv_last_error()
+        torch.cuda.synchronize()
+
+    def desc(self, x, out, taps, wk, bias, IH, IW, Cin, OH, OW, Cout, in_stride=1, out_stride=1, py=0, px=0,
+             res1=None, res1_shift=0, act=0, scale=None, shift=None, res2=None):
+        d = self.m.ConvDesc()
+        wp = self.m.pack_k_major(wk.float()).cuda()
+        self.keep += [wp]
+        d.inp, d.out, d.wpk = x.data_ptr(), out.data_ptr(), wp.data_ptr()
+        for name, t in (("bias", bias), ("res1", res1), ("scale", scale), ("shift", shift), ("res2", res2)):
+            if t is not None:
+                t = t.cuda().float().contiguous()
+                self.keep.append(t)
+                setattr(d, name, t.data_ptr())
+        d.IH, d.IW, d.Cin, d.OH, d.OW = IH, IW, Cin, OH, OW
+        d.OHf, d.OWf, d.Cout = OH * out_stride, OW * out_stride, Cout
+        d.in_stride, d.out_stride, d.out_py, d.out_px = in_stride, out_stride, py, px
+        d.res1_shift, d.act, d.ntaps, d.kind = res1_shift, act, len(taps), 0
+        for i, (dy, dx) in enumerate(taps):
+            d.dy[i], d.dx[i] = dy, dx
+        return d
+
+
+def nhwc(t):       # (1, C, H, W) -> (H, W, C) contiguous
+    return t[0].permute(1, 2, 0).contiguous()
+
+
+def rel_err(got, want):
+    return float((got - want).abs().max() / (want.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride,k", [
+    (8, 32, 20, 36, 1, 3), (32, 32, 17, 23, 1, 3), (32, 64, 16, 24, 2, 3), (64, 64, 9, 130, 1, 3),
+    (64, 128, 12, 20, 2, 3), (128, 128, 7, 11, 1, 3), (256, 512, 6, 10, 2, 3), (512, 256, 5, 6, 1, 1),
+    (64, 32, 8, 16, 1, 1), (32, 32, 1, 1, 1, 3), (32, 32, 3, 200, 1, 3)])
+def test_conv_layer_matches_torch(hipnet, cin, cout, h, w, stride, k):
+    g = torch.Generator().manual_seed(cin * 1000 + cout + h)
+    x = torch.randn(1, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    pad = k // 2
+    want = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=pad).float()
+    oh, ow = want.shape[2], want.shape[3]
+    L = _Layer(hipnet)
+    taps, wk = hipnet.conv_taps(wt, pad)
+    xin = nhwc(x).cuda()
+    out = torch.full((oh, ow, cout), float("nan"), device="cuda")
+    L.run([L.desc(xin, out, taps, wk, b, h, w, cin, oh, ow, cout, in_stride=stride)])
+    assert rel_err(out.cpu(), nhwc(want)) < 2e-5
+
+
+def test_conv_epilogue_fusions(hipnet):
+    """bias + residual (full and half resolution) + ReLU / LeakyReLU + affine + second residual."""
+    g = torch.Generator().manual_seed(7)
+    cin, cout, h, w = 32, 64, 10, 14
+    x = torch.randn(1, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / 17.
+    b = torch.randn(cout, generator=g)
+    r1 = torch.randn(1, cout, h, w, generator=g)
+    r1h = torch.randn(1, cout, h // 2, w // 2, generator=g)
+    r2 = torch.randn(1, cout, h, w, generator=g)
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    base = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    taps, wk = hipnet.conv_taps(wt, 1)
+    xin = nhwc(x).cuda()
+    cases = [
+        (dict(res1=nhwc(r1), act=1), F.relu(base + r1)),
+        (dict(res1=nhwc(r1h), res1_shift=1, act=2), F.leaky_relu(base + F.interpolate(r1h.double(), scale_factor=2, mode="nearest"), 0.2)),
+        (dict(act=1, scale=sc, shift=sh), F.relu(base) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)),
+        (dict(res1=nhwc(r1), act=2, res2=nhwc(r2)), F.leaky_relu(base + r1, 0.2) + r2),
+        (dict(), base),
+    ]
+    for kw, want in cases:
+        L = _Layer(hipnet)
+        out = torch.full((h, w, cout), float("nan"), device="cuda")
+        L.run([L.desc(xin, out, taps, wk, b, h, w, cin, h, w, cout, **kw)])
+        assert rel_err(out.cpu(), nhwc(want.float())) < 2e-5, kw.keys()
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(32, 32, 9, 13), (64, 64, 6, 10), (512, 512, 3, 5), (128, 128, 17, 30)])
+def test_conv_transpose_phases_match_torch(hipnet, cin, cout, h, w):
+    g = torch.Generator().manual_seed(cin + h)
+    x = torch.randn(1, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5
+    b = torch.randn(cout, generator=g)
+    want = F.leaky_relu(F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=2, padding=1), 0.2).float()
+    L = _Layer(hipnet)
+    xin = nhwc(x).cuda()
+    out = torch.full((2 * h, 2 * w, cout), float("nan"), device="cuda")
+    descs = []
+    for py in (0, 1):
+        for px in (0, 1):
+            taps, wk = hipnet.convt_phase_taps(wt, py, px)
+            descs.append(L.desc(xin, out, taps, wk, b, h, w, cin, h, w, cout, out_stride=2, py=py, px=px, act=2))
+    L.run(descs)
+    assert rel_err(out.cpu(), nhwc(want)) < 2e-5
+
+
+def test_avgpool_1x1_as_one_conv(hipnet):
+    g = torch.Generator().manual_seed(3)
+    cin, cout, h, w = 64, 128, 12, 20
+    x = torch.randn(1, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / 8.
+    b = torch.randn(cout, generator=g)
+    want = F.conv2d(F.avg_pool2d(x.double(), 2, 2), wt.double(), b.double()).float()
+    L = _Layer(hipnet)
+    wd = wt[:, :, 0, 0].t() * 0.25
+    out = torch.full((h // 2, w // 2, cout), float("nan"), device="cuda")
+    L.run([L.desc(nhwc(x).cuda(), out, [(0, 0), (0, 1), (1, 0), (1, 1)], torch.cat([wd] * 4, 0), b, h, w, cin,
+                  h // 2, w // 2, cout, in_stride=2)])
+    assert rel_err(out.cpu(), nhwc(want)) < 2e-5
+
+
+@pytest.mark.parametrize("H,W", [(64, 96), (96, 160), (544, 960)])
+def test_full_network_matches_torch_plan_and_golden(hipnet, H, W):
+    """Whole UNet on the HIP convs vs the folded plan on torch-CPU float32 (itself pinned to the reference UNet by
+    tests/golden/unet_64x96.npz).  Tolerance 1e-4 absolute on alpha in [0,1]; north_star allows 1e-3."""
+    sys.path.insert(0, GOLD)
+    from gen_golden import unet_input
+    from video_unscreen_amd.vmatting.net import MattingNet, synthetic_state_dict
+    sd = synthetic_state_dict(0)
+    seed = {(64, 96): 1234, (96, 160): 99}.get((H, W), 5)
+    x = unet_input(H, W, seed)
+    net = hipnet.HipMattingNet(sd, H, W)
+    x8 = torch.cat([x, torch.zeros(1, 1, H, W)], 1)[0].permute(1, 2, 0).contiguous().cuda()
+    got = net(x8).cpu()
+    torch.cuda.synchronize()
+    if (H, W) == (544, 960):
+        want = MattingNet(sd, device="cuda").forward(x.cuda()).cpu()        # full size: MIOpen f32 as the comparator
+    else:
+        want = MattingNet(sd, device="cpu")(x)
+    d = float((got - want).abs().max())
+    assert d < 1e-4, d
+    z = np.load(os.path.join(GOLD, "unet_64x96.npz"))
+    if (H, W) == (64, 96):
+        assert np.abs(got.numpy() - z["y"]).max() < 1e-4                    # the reference module's own output
+    if (H, W) == (96, 160):
+        assert np.abs(got.numpy()[:, :, ::4, ::4] - z["y2_sub"]).max() < 1e-4
+    # deterministic: same input twice -> bit-identical (no atomics in the accumulation)
+    again = net(x8).cpu()
+    assert torch.equal(again, got)

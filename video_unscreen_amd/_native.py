@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunscreen_hip.so")
 
 DILATE, ERODE = 0, 1
-NCHW, NHWC = 0, 1
+NCHW, NHWC, NHWC8 = 0, 1, 2
 
 _vp = C.c_void_p
 _SIGNATURES = {
@@ -41,6 +41,8 @@ _SIGNATURES = {
     "usc_count_ge_u8": (C.c_int, [_vp, C.c_size_t, C.c_int, _vp, _vp]),
     "usc_remove_invalid_objects_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                   C.c_double, _vp, C.POINTER(C.c_int)]),
+    "usc_conv_sequence_f32": (C.c_int, [_vp, C.c_int, _vp]),
+    "usc_conv_last_error": (C.c_char_p, []),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -158,8 +160,11 @@ def vmat_pre(frame, alpha_pre, trimap_, inH, inW, layout=NHWC, out=None):
     pa = _dev_u8(alpha_pre, "vmat_pre.alpha_pre", (H, W))
     pt = _dev_u8(trimap_, "vmat_pre.trimap", (H, W))
     if out is None:
-        out = torch.empty((1, 7, inH, inW), dtype=torch.float32, device=frame.device,
-                          memory_format=torch.channels_last if layout == NHWC else torch.contiguous_format)
+        if layout == NHWC8:
+            out = torch.empty((inH, inW, 8), dtype=torch.float32, device=frame.device)
+        else:
+            out = torch.empty((1, 7, inH, inW), dtype=torch.float32, device=frame.device,
+                              memory_format=torch.channels_last if layout == NHWC else torch.contiguous_format)
     _check(load().usc_vmat_pre(pf, pa, pt, H, W, int(inH), int(inW), out.data_ptr(), int(layout), _stream()), "usc_vmat_pre")
     return out
 

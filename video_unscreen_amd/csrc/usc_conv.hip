@@ -1,0 +1,366 @@
+// usc_conv.hip - fused NHWC float32 convolution on the f32-input matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// The matting network (reference unscreen/vmatting/model.py:435-568) is ~50 small convolutions on a
+// 544 x 960 frame: dense contractions with M = output pixels (510 ... 522,240), N = Cout (32 ... 512),
+// K = taps * Cin (72 ... 4608).  One implicit-GEMM kernel serves every shape:
+//   * taps are a list of (dy, dx) offsets with an input stride, so 3x3 s1/s2, 1x1, the 2x2-s2 form of
+//     avg-pool + 1x1, and the four 2x2 output phases of ConvTranspose2d(k4, s2, p1) are the same code;
+//   * a workgroup of 4 waves owns 128 output pixels x (32 | 64) channels; every K step stages a
+//     [128 px][32 k] slice of the im2col matrix and a [32 k][N] slice of the packed weights in LDS
+//     (double buffered, one barrier per step) and each wave issues 16 x NT back-to-back MFMAs on its 32 rows;
+//   * LDS images are padded / packed so every ds_read_b128 of a fragment is conflict-free
+//     (A: 36-float row pitch; B: [k/4][n][4] so consecutive lanes read consecutive 16-byte words);
+//   * the epilogue fuses bias, residual (optionally from a half-resolution tensor = nearest x2 upsample),
+//     ReLU / LeakyReLU(0.2), a per-channel affine (the shortcut branches' BN-after-ReLU) and a second residual,
+//     so no elementwise pass ever touches HBM again.
+// f32 MFMA is an exact k-ordered fmaf chain; accumulation order is fixed, so results are run-to-run identical
+// (the MIOpen kernels this replaces accumulate with atomics).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/unscreen_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BM = 128;        // output pixels per workgroup
+constexpr int KC = 32;         // K slice per step
+constexpr int APITCH = 36;     // floats per A row in LDS (32 + 4 pad: b128 reads hit 64 distinct banks)
+constexpr int THREADS = 256;
+
+template <int NT>
+__global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
+    __shared__ __attribute__((aligned(16))) float As[2][BM * APITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[2][8 * 32 * NT * 4];
+    __shared__ int s_dy[16], s_dx[16], s_toff[16];
+    __shared__ int s_outpix[BM], s_res1pix[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = d.OH * d.OW;
+    const int m0 = blockIdx.x * BM;
+    const int nb0 = blockIdx.y * (32 * NT);
+    const int Ktot = d.ntaps * d.Cin;
+    // blockIdx.z = phase * ksplit + k-slice.  Phases: the four (py, px) outputs of a transposed conv, each with
+    // its own tap table and weight block.  K slices: contiguous chunk ranges whose partial sums go to a slab.
+    const int S = d.ksplit;
+    const int ph = blockIdx.z / S, ks = blockIdx.z - ph * S;
+    const int nch_all = (Ktot + KC - 1) / KC;
+    const int c_begin = (int)((long long)ks * nch_all / S), c_end = (int)((long long)(ks + 1) * nch_all / S);
+    const float* __restrict__ wpk = d.wpk + (size_t)ph * d.wphase_stride;
+    const int out_py = d.nphase > 1 ? (ph >> 1) : d.out_py, out_px = d.nphase > 1 ? (ph & 1) : d.out_px;
+
+    // per-tap byte offset of the tap relative to the (0,0) tap, for the staging threads
+    if (tid < 16) {
+        const int t = tid < d.ntaps ? ph * d.ntaps + tid : 0;
+        s_dy[tid] = d.dy[t & 15];
+        s_dx[tid] = d.dx[t & 15];
+        s_toff[tid] = (d.dy[t & 15] * d.IW + d.dx[t & 15]) * d.Cin * 4;
+    }
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int op = -1, rp = -1;
+        if (m < M) {
+            const int oy = m / d.OW, ox = m - oy * d.OW;
+            const int Y = oy * d.out_stride + out_py, X = ox * d.out_stride + out_px;
+            op = Y * d.OWf + X;
+            rp = (Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (X >> d.res1_shift);
+        }
+        s_outpix[tid] = op;
+        s_res1pix[tid] = rp;
+    }
+    __syncthreads();
+
+    // ---- staging assignment: thread -> (4 pixels, one float4 of the 32-wide K slice).
+    // Everything that does not change from K step to K step is computed once: the byte offset of each pixel's
+    // (0,0) tap and a 16-bit mask of the taps that fall inside the image.  Per step a load then costs one add
+    // and one select; out-of-image taps get an offset beyond the buffer and the hardware range check of the
+    // buffer load returns zeros (no branch, no zero-fill code).
+    const int q = tid & 7;
+    const int log2cin = 31 - __builtin_clz(d.Cin);           // Cin is a power of two (checked by the host)
+    int vbase[4];
+    unsigned vmask[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int m = m0 + (tid >> 3) + 32 * j;
+        vbase[j] = 0; vmask[j] = 0;
+        if (m < M) {
+            const int oy = m / d.OW, ox = m - oy * d.OW;
+            const int iy0 = oy * d.in_stride, ix0 = ox * d.in_stride;
+            vbase[j] = (iy0 * d.IW + ix0) * d.Cin * 4;
+            for (int t = 0; t < d.ntaps; t++) {
+                const int iy = iy0 + s_dy[t], ix = ix0 + s_dx[t];
+                if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) vmask[j] |= 1u << t;
+            }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(d.in), 0, d.IH * d.IW * d.Cin * 4, 0x00020000);
+    const int wbytes = nch_all * 8 * d.Cout * 16;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpk), 0, wbytes, 0x00020000);
+    const int bkq = tid >> 5, bn = tid & 31;
+    const int wbase = (bkq * d.Cout + nb0 + bn) * 16;          // bytes; + 32*16 per extra N tile, + 8*Cout*16 per chunk
+    const int wstep = 8 * d.Cout * 16;
+
+    // Two register sets: chunk c+2 is requested while chunk c is multiplied, so a global load has two MFMA
+    // phases (~2 x 1024 cycles) to land before its ds_write.
+    float4 ra0[4], rb0[NT], ra1[4], rb1[NT];
+    // Loads are unconditional: a chunk index past this block's K range (c >= c_end) gets out-of-range offsets and
+    // comes back as zeros, so the main loop has no branches and hipcc can count vmcnt exactly.
+    auto load_chunk = [&](int c, float4 (&ra)[4], float4 (&rb)[NT]) {
+        const bool live = c < c_end;
+        const int k0 = c * KC + 4 * q;
+        const int tap = k0 >> log2cin;                          // >= ntaps in the zero-padded K tail: mask bit is 0
+        const int koff = ((d.reserved & 1) ? 0 : s_toff[tap & 15]) + ((k0 & (d.Cin - 1)) << 2);   // reserved&1: debug probe
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool ok = live && ((vmask[j] >> tap) & 1u);
+            const int off = ok ? vbase[j] + koff : 0x7ffffff0;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
+            ra[j] = *reinterpret_cast<const float4*>(&v);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, live ? wbase + c * wstep + j * 512 : 0x7ffffff0, 0, 0);
+            rb[j] = *reinterpret_cast<const float4*>(&v);
+        }
+    };
+    auto store_chunk = [&](int buf, const float4 (&ra)[4], const float4 (&rb)[NT]) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * j) * APITCH + 4 * q]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+            *reinterpret_cast<float4*>(&Bs[buf][(bkq * (32 * NT) + bn + 32 * j) * 4]) = rb[j];
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+    const int arow = (32 * wave + (lane & 31)) * APITCH + 4 * (lane >> 5);
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 a = *reinterpret_cast<const float4*>(&As[buf][arow + g * 8]);
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const float4 b = *reinterpret_cast<const float4*>(&Bs[buf][((g * 2 + (lane >> 5)) * (32 * NT) + j * 32 + (lane & 31)) * 4]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[j], 0, 0, 0);
+            }
+        }
+    };
+
+    load_chunk(c_begin, ra0, rb0);
+    load_chunk(c_begin + 1, ra1, rb1);
+    store_chunk(0, ra0, rb0);
+    __syncthreads();
+    int c = c_begin;
+    for (; c + 1 < c_end; c += 2) {
+        load_chunk(c + 2, ra0, rb0);
+        compute(0);
+        store_chunk(1, ra1, rb1);
+        __syncthreads();
+        load_chunk(c + 3, ra1, rb1);
+        compute(1);
+        store_chunk(0, ra0, rb0);
+        __syncthreads();
+    }
+    if (c < c_end) compute(0);          // odd chunk count: the last chunk is already staged in buffer 0
+
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    int ops[16], rps[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int p = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        ops[r] = s_outpix[p];
+        rps[r] = s_res1pix[p];
+    }
+    if (S > 1) {                 // partial sums only; usc_splitk_reduce_kernel finishes the layer
+        float* __restrict__ slab = d.slab + (size_t)ks * d.OHf * d.OWf * d.Cout;
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int n = nb0 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (ops[r] >= 0) slab[(size_t)ops[r] * d.Cout + n] = acc[j][r];
+        }
+        return;
+    }
+    // All residual loads of a tile are issued before the first use so they overlap (one wait, not sixteen).
+    const bool has_r1 = d.res1 != nullptr, has_r2 = d.res2 != nullptr, has_aff = d.scale != nullptr;
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        const int n = nb0 + j * 32 + (lane & 31);
+        const float bias = d.bias ? d.bias[n] : 0.f;
+        const float sc = has_aff ? d.scale[n] : 1.f;
+        const float sh = has_aff ? d.shift[n] : 0.f;
+        float r1v[16], r2v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            r1v[r] = (has_r1 && ops[r] >= 0) ? d.res1[(size_t)rps[r] * d.Cout + n] : 0.f;
+            r2v[r] = (has_r2 && ops[r] >= 0) ? d.res2[(size_t)ops[r] * d.Cout + n] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = acc[j][r] + bias;
+            if (has_r1) v += r1v[r];
+            if (d.act == USC_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (d.act == USC_ACT_LEAKY) v = v > 0.f ? v : v * 0.2f;
+            if (has_aff) v = v * sc + sh;
+            if (has_r2) v += r2v[r];
+            if (ops[r] >= 0) d.out[(size_t)ops[r] * d.Cout + n] = v;
+        }
+    }
+}
+
+// Second half of a split-K layer: sum the K slices in a fixed order (deterministic), then the fused epilogue.
+// One lane per (output pixel, 4 channels).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(usc_conv_desc d) {
+    const int npix = d.OHf * d.OWf, c4 = d.Cout / 4;
+    const size_t plane = (size_t)npix * d.Cout;
+    const bool has_r1 = d.res1 != nullptr, has_r2 = d.res2 != nullptr, has_aff = d.scale != nullptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix * c4; i += gridDim.x * blockDim.x) {
+        const int op = i / c4, n = (i - op * c4) * 4;
+        const size_t o = (size_t)op * d.Cout + n;
+        float4 v = *reinterpret_cast<const float4*>(d.slab + o);
+        for (int s = 1; s < d.ksplit; s++) {
+            const float4 t = *reinterpret_cast<const float4*>(d.slab + s * plane + o);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        float a[4] = {v.x, v.y, v.z, v.w};
+        const int Y = op / d.OWf, X = op - Y * d.OWf;
+        const size_t ro = ((size_t)(Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (X >> d.res1_shift)) * d.Cout + n;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float x = a[k] + (d.bias ? d.bias[n + k] : 0.f);
+            if (has_r1) x += d.res1[ro + k];
+            if (d.act == USC_ACT_RELU) x = fmaxf(x, 0.f);
+            else if (d.act == USC_ACT_LEAKY) x = x > 0.f ? x : x * 0.2f;
+            if (has_aff) x = x * d.scale[n + k] + d.shift[n + k];
+            if (has_r2) x += d.res2[o + k];
+            a[k] = x;
+        }
+        *reinterpret_cast<float4*>(d.out + o) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+}
+
+// Output head: Conv2d(32 -> 1, 3x3, pad 1, bias) followed by (tanh(x) + 1) / 2  (model.py:389, 566).
+// N = 1 is no matrix product: memory-bound.  A workgroup stages an (8+2) x (32+2) pixel patch of the 32-channel
+// input in LDS with coalesced 16-byte loads (pixel pitch 36 floats -> conflict-free b128 reads), then each lane
+// owns one output pixel: 9 taps x 8 float4 reads against the 288 weights held in LDS.
+constexpr int HT_H = 8, HT_W = 32, HPITCH = 36;
+__global__ __launch_bounds__(256) void head_conv_kernel(usc_conv_desc d) {
+    __shared__ __attribute__((aligned(16))) float patch[(HT_H + 2) * (HT_W + 2) * HPITCH];
+    __shared__ __attribute__((aligned(16))) float w[9 * 32];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 9 * 32; i += 256) w[i] = d.wpk[i];
+    const int y0 = blockIdx.y * HT_H, x0 = blockIdx.x * HT_W;
+    // (10 x 34) pixels x 8 float4 each
+    for (int i = tid; i < (HT_H + 2) * (HT_W + 2) * 8; i += 256) {
+        const int px = i >> 3, q = i & 7;
+        const int py = px / (HT_W + 2), pxx = px - py * (HT_W + 2);
+        const int gy = y0 - 1 + py, gx = x0 - 1 + pxx;
+        const bool ok = gy >= 0 && gy < d.IH && gx >= 0 && gx < d.IW;
+        const int cy = min(max(gy, 0), d.IH - 1), cx = min(max(gx, 0), d.IW - 1);
+        float4 v = *reinterpret_cast<const float4*>(d.in + ((size_t)(cy * d.IW + cx) * 32 + 4 * q));
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&patch[px * HPITCH + 4 * q]) = v;
+    }
+    __syncthreads();
+    const int ty = tid >> 5, tx = tid & 31;
+    const int gy = y0 + ty, gx = x0 + tx;
+    float acc = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < 9; t++) {
+        const int ky = t / 3, kx = t - ky * 3;
+        const float* src = &patch[((ty + ky) * (HT_W + 2) + tx + kx) * HPITCH];
+        const float* wt = &w[t * 32];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+            const float4 ww = *reinterpret_cast<const float4*>(wt + 4 * q);
+            acc += v.x * ww.x;
+            acc += v.y * ww.y;
+            acc += v.z * ww.z;
+            acc += v.w * ww.w;
+        }
+    }
+    if (gy < d.OH && gx < d.OW) {
+        acc += d.bias ? d.bias[0] : 0.f;
+        d.out[(size_t)gy * d.OW + gx] = (tanhf(acc) + 1.0f) / 2.0f;
+    }
+}
+
+thread_local char g_conv_err[256] = "";
+
+}  // namespace
+
+extern "C" const char* usc_conv_last_error(void) { return g_conv_err; }
+
+static int conv_fail(int code, const char* msg) {
+    snprintf(g_conv_err, sizeof(g_conv_err), "%s", msg);
+    return code;
+}
+
+extern "C" int usc_conv_sequence_f32(const usc_conv_desc* descs, int n, usc_stream_t stream) {
+    if (!descs || n < 0) return conv_fail(USC_E_ARG, "usc_conv_sequence_f32: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < n; i++) {
+        const usc_conv_desc& d = descs[i];
+        if (!d.in || !d.out || !d.wpk || d.Cin <= 0 || d.Cin % 4 || d.ntaps < 1 || d.ntaps > 16 || d.OH <= 0 || d.OW <= 0)
+            return conv_fail(USC_E_ARG, "usc_conv_sequence_f32: malformed layer descriptor");
+        const long long M = (long long)d.OH * d.OW;
+        if (d.kind == USC_CONV_HEAD) {
+            if (d.Cout != 1 || d.Cin != 32 || d.ntaps != 9 || d.in_stride != 1 || d.IH != d.OH || d.IW != d.OW)
+                return conv_fail(USC_E_UNSUPPORTED, "usc_conv_sequence_f32: the head kernel is Conv2d(32, 1, 3, padding=1)");
+            hipLaunchKernelGGL(head_conv_kernel, dim3((d.OW + HT_W - 1) / HT_W, (d.OH + HT_H - 1) / HT_H), dim3(256), 0, st, d);
+        } else {
+            if (d.Cout % 32) return conv_fail(USC_E_UNSUPPORTED, "usc_conv_sequence_f32: Cout must be a multiple of 32");
+            if (d.Cin & (d.Cin - 1)) return conv_fail(USC_E_UNSUPPORTED, "usc_conv_sequence_f32: Cin must be a power of two");
+            if ((long long)d.IH * d.IW * d.Cin * 4 >= 0x7ffffff0ll) return conv_fail(USC_E_UNSUPPORTED, "usc_conv_sequence_f32: input tensor >= 2 GiB");
+            const int nphase = d.nphase > 1 ? d.nphase : 1;
+            if (nphase != 1 && nphase != 4) return conv_fail(USC_E_ARG, "usc_conv_sequence_f32: nphase must be 1 or 4");
+            if (nphase * d.ntaps > 16) return conv_fail(USC_E_ARG, "usc_conv_sequence_f32: more than 16 taps");
+            const int mblocks = (int)((M + BM - 1) / BM);
+            // two 32-column tiles per workgroup only while that still leaves >= 2 workgroups per CU
+            const bool nt2 = (d.Cout % 64 == 0) && ((long long)mblocks * (d.Cout / 64) * nphase >= 512);
+            const int nblocks = nt2 ? d.Cout / 64 : d.Cout / 32;
+            // split K when the grid would leave most CUs idle (M = 510 ... 2040 layers)
+            const long long blocks = (long long)mblocks * nblocks * nphase;
+            const int nch = (d.ntaps * d.Cin + KC - 1) / KC;
+            int S = 1;
+            if (d.slab && blocks < 384) {
+                S = (int)((768 + blocks - 1) / blocks);
+                if (S > nch) S = nch;
+                if (S > 16) S = 16;
+                const size_t need = (size_t)S * d.OHf * d.OWf * d.Cout * sizeof(float);
+                if (need > d.slab_bytes) S = (int)(d.slab_bytes / ((size_t)d.OHf * d.OWf * d.Cout * sizeof(float)));
+                if (S < 1) S = 1;
+            }
+            usc_conv_desc dd = d;
+            dd.ksplit = S;
+            dd.nphase = nphase;
+            dim3 grid(mblocks, nblocks, nphase * S);
+            if (nt2) hipLaunchKernelGGL(conv_mfma_kernel<2>, grid, dim3(THREADS), 0, st, dd);
+            else hipLaunchKernelGGL(conv_mfma_kernel<1>, grid, dim3(THREADS), 0, st, dd);
+            if (S > 1) {
+                const long long items = (long long)d.OHf * d.OWf * (d.Cout / 4);
+                int rb = (int)((items + 255) / 256);
+                if (rb > 2048) rb = 2048;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, st, dd);
+            }
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return conv_fail(USC_E_LAUNCH, hipGetErrorString(e));
+    }
+    return USC_OK;
+}

@@ -614,6 +614,10 @@ __global__ __launch_bounds__(256) void vmat_pre_kernel(const uint8_t* __restrict
         if (layout == USC_LAYOUT_NCHW) {
 #pragma unroll
             for (int c = 0; c < 7; c++) out[(size_t)c * n + i] = v[c];
+        } else if (layout == USC_LAYOUT_NHWC8) {
+            float4* o = reinterpret_cast<float4*>(out + (size_t)i * 8);
+            o[0] = make_float4(v[0], v[1], v[2], v[3]);
+            o[1] = make_float4(v[4], v[5], v[6], 0.f);
         } else {
 #pragma unroll
             for (int c = 0; c < 7; c++) out[(size_t)i * 7 + c] = v[c];
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(256) void vmat_pre_kernel(const uint8_t* __restrict
 extern "C" int usc_vmat_pre(const uint8_t* frame, const uint8_t* alpha_pre, const uint8_t* trimap, int H, int W,
                             int inH, int inW, float* out7, int layout, usc_stream_t stream) {
     if (!frame || !alpha_pre || !trimap || !out7 || H <= 0 || W <= 0 || inH <= 0 || inW <= 0) return fail(USC_E_ARG, "usc_vmat_pre: bad argument");
-    if (layout != USC_LAYOUT_NCHW && layout != USC_LAYOUT_NHWC) return fail(USC_E_ARG, "usc_vmat_pre: layout %d", layout);
+    if (layout != USC_LAYOUT_NCHW && layout != USC_LAYOUT_NHWC && layout != USC_LAYOUT_NHWC8) return fail(USC_E_ARG, "usc_vmat_pre: layout %d", layout);
     if (too_big(H, W) || too_big(inH, inW)) return fail(USC_E_UNSUPPORTED, "usc_vmat_pre: image too large");
     int nh, nw;
     usc_pad_resize_geometry(H, W, inH, inW, &nh, &nw);

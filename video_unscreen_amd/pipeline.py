@@ -56,13 +56,13 @@ class _Slot:
 
 
 class BgStepPipeline:
-    def __init__(self, cfg, H, W, device="cuda:0", dtype=torch.float32, state_dict=None):
+    def __init__(self, cfg, H, W, device="cuda:0", dtype=torch.float32, state_dict=None, net_backend="hip"):
         self.cfg = cfg
         self.H, self.W = H, W
         self.device = torch.device(device)
         nv.load()
         self._sd = state_dict if state_dict is not None else synthetic_state_dict(0)
-        self.net = MattingNet(self._sd, device=self.device, dtype=dtype)
+        self.net_backend = net_backend
         self._cpu_net = None
         self.beta = cfg["bg_mask"]["fusion_weight"]
         self.thr = cfg["bg_mask"]["thr"]
@@ -80,8 +80,20 @@ class BgStepPipeline:
         dev = self.device
         self.ws_bgdiff = torch.empty(nv.load().usc_bgdiff_ws_bytes(H, W), dtype=torch.uint8, device=dev)
         self.ws_trimap = torch.empty(nv.load().usc_trimap_ws_bytes(H, W, self.long_side), dtype=torch.uint8, device=dev)
-        self.x7 = torch.empty((1, 7, self.in_h, self.in_w), dtype=torch.float32, device=dev,
-                              memory_format=torch.channels_last)
+        if net_backend == "hip":          # hand-written f32-MFMA convs, one C call per forward (vmatting/net_hip.py)
+            if dtype != torch.float32:
+                raise ValueError("the HIP conv path computes in float32")
+            from .vmatting.net_hip import HipMattingNet
+            self.net = HipMattingNet(self._sd, self.in_h, self.in_w, device=dev)
+            self.x7 = self.net.x8
+            self._layout = nv.NHWC8
+        elif net_backend == "miopen":     # the same plan through PyTorch-ROCm / MIOpen
+            self.net = MattingNet(self._sd, device=dev, dtype=dtype)
+            self.x7 = torch.empty((1, 7, self.in_h, self.in_w), dtype=torch.float32, device=dev,
+                                  memory_format=torch.channels_last)
+            self._layout = nv.NHWC
+        else:
+            raise ValueError(f"unknown net_backend {net_backend!r}")
         self.slots = [_Slot(H, W, dev) for _ in range(3)]
         self.alpha_pre = None
 
@@ -110,7 +122,7 @@ class BgStepPipeline:
 
     def _back(self, slot, frame, want_float=False):
         alpha_pre = self.alpha_pre if self.alpha_pre is not None else slot.gate       # bg_offline.py:162-163
-        nv.vmat_pre(frame, alpha_pre, slot.trimap, self.in_h, self.in_w, layout=nv.NHWC, out=self.x7)
+        nv.vmat_pre(frame, alpha_pre, slot.trimap, self.in_h, self.in_w, layout=self._layout, out=self.x7)
         pred = self.net(self.x7)
         res = nv.vmat_post(pred.view(self.in_h, self.in_w), slot.trimap, want_float=want_float)
         alpha, alpha_f = (res if want_float else (res, None))

@@ -1,0 +1,202 @@
+"""The matting network on the hand-written f32-MFMA convolution kernel (csrc/usc_conv.hip).
+
+Same folded plan as net.py (reference unscreen/vmatting/model.py:435-568, spectral norm and conv->BN folded at
+load), but instead of ~230 PyTorch / MIOpen kernel launches per frame the whole forward is ONE C call that
+enqueues 65 fused layers: every bias, residual add, ReLU / LeakyReLU, shortcut BN and nearest-x2 upsample lives
+in a conv epilogue, ConvTranspose2d(k4, s2, p1) runs as its four 2x2 output phases, AvgPool2d(2)+1x1 as one
+2x2-stride-2 conv.  All tensors are NHWC float32 buffers allocated once per frame size.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from .. import _native as nv
+from .net import fold_state_dict
+
+ACT = {"none": 0, "relu": 1, "leaky": 2}
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("wpk", C.c_void_p), ("bias", C.c_void_p),
+                ("res1", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("res2", C.c_void_p),
+                ("IH", C.c_int), ("IW", C.c_int), ("Cin", C.c_int),
+                ("OH", C.c_int), ("OW", C.c_int),
+                ("OHf", C.c_int), ("OWf", C.c_int), ("Cout", C.c_int),
+                ("in_stride", C.c_int),
+                ("out_stride", C.c_int), ("out_py", C.c_int), ("out_px", C.c_int),
+                ("res1_shift", C.c_int), ("act", C.c_int), ("ntaps", C.c_int), ("kind", C.c_int),
+                ("dy", C.c_byte * 16), ("dx", C.c_byte * 16),
+                ("nphase", C.c_int), ("wphase_stride", C.c_int), ("ksplit", C.c_int), ("reserved", C.c_int),
+                ("slab", C.c_void_p), ("slab_bytes", C.c_size_t)]
+
+
+def pack_k_major(wk):
+    """(K, Cout) rows k = tap*Cin + ci  ->  [Kpad/4][Cout][4] with K padded to a multiple of 32."""
+    K, N = wk.shape
+    Kp = (K + 31) // 32 * 32
+    if Kp != K:
+        wk = torch.cat([wk, wk.new_zeros(Kp - K, N)], 0)
+    return wk.view(Kp // 4, 4, N).permute(0, 2, 1).contiguous()
+
+
+def conv_taps(w, pad):
+    """Conv2d weight (Cout, Cin, kh, kw) -> (taps [(dy, dx)], (K, Cout) matrix)."""
+    co, ci, kh, kw = w.shape
+    taps = [(ky - pad, kx - pad) for ky in range(kh) for kx in range(kw)]
+    return taps, w.permute(2, 3, 1, 0).reshape(kh * kw * ci, co)
+
+
+def convt_phase_taps(w, py, px):
+    """ConvTranspose2d(k=4, s=2, p=1) weight (Cin, Cout, 4, 4), output phase (py, px):
+    out[2y+py, 2x+px] = sum over the two (dy, ky) pairs per axis of in[y+dy, x+dx] * w[:, :, ky, kx]."""
+    pairs = {0: [(0, 1), (-1, 3)], 1: [(1, 0), (0, 2)]}
+    taps, mats = [], []
+    for dy, ky in pairs[py]:
+        for dx, kx in pairs[px]:
+            taps.append((dy, dx))
+            mats.append(w[:, :, ky, kx])                     # (Cin, Cout)
+    return taps, torch.cat(mats, 0)
+
+
+class HipMattingNet:
+    def __init__(self, state_dict, in_h, in_w, device="cuda:0"):
+        if in_h % 32 or in_w % 32:
+            raise ValueError("HipMattingNet: input size must be a multiple of 32 (vmatting/agent.py:38-42 guarantees it)")
+        self.device = torch.device(device)
+        self.H, self.W = in_h, in_w
+        nv.load()
+        self._keep = []               # every tensor a descriptor points to
+        self._descs = []
+        self.slab = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=self.device)   # split-K partial sums (64 MiB)
+        self._build(fold_state_dict(state_dict))
+        self._arr = (ConvDesc * len(self._descs))(*self._descs)
+
+    # ------------------------------------------------------------------ helpers
+    def _dev(self, t):
+        t = t.detach().to(self.device, torch.float32).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _buf(self, h, w, c):
+        t = torch.empty((h, w, c), dtype=torch.float32, device=self.device)
+        self._keep.append(t)
+        return t
+
+    def _add(self, x, out, taps, wk, bias, IH, IW, Cin, OH, OW, Cout, in_stride=1, out_stride=1, py=0, px=0,
+             res1=None, res1_shift=0, act="none", scale=None, shift=None, res2=None, kind=0, OHf=None, OWf=None,
+             phases=None):
+        """phases: optional list of 4 (taps, wk) pairs (transposed conv); then `taps` / `wk` are ignored."""
+        d = ConvDesc()
+        d.inp, d.out = x.data_ptr(), out.data_ptr()
+        if phases is not None:
+            packed = [pack_k_major(w.float()) for _, w in phases]
+            wp = self._dev(torch.stack(packed, 0))
+            d.nphase, d.wphase_stride = len(phases), packed[0].numel()
+            taps_all = [t for tp, _ in phases for t in tp]
+            taps = phases[0][0]
+        else:
+            wp = self._dev(pack_k_major(wk.float()) if kind == 0 else wk.float().reshape(-1))
+            d.nphase, d.wphase_stride = 1, 0
+            taps_all = taps
+        d.wpk = wp.data_ptr()
+        d.slab, d.slab_bytes = self.slab.data_ptr(), self.slab.numel() * 4
+        d.bias = self._dev(bias).data_ptr() if bias is not None else None
+        d.res1 = res1.data_ptr() if res1 is not None else None
+        d.scale = self._dev(scale.reshape(-1)).data_ptr() if scale is not None else None
+        d.shift = self._dev(shift.reshape(-1)).data_ptr() if shift is not None else None
+        d.res2 = res2.data_ptr() if res2 is not None else None
+        d.IH, d.IW, d.Cin = IH, IW, Cin
+        d.OH, d.OW = OH, OW
+        d.OHf, d.OWf, d.Cout = (OHf or OH * out_stride), (OWf or OW * out_stride), Cout
+        d.in_stride, d.out_stride, d.out_py, d.out_px = in_stride, out_stride, py, px
+        d.res1_shift, d.act, d.ntaps, d.kind = res1_shift, ACT[act], len(taps), kind
+        for i, (dy, dx) in enumerate(taps_all):
+            d.dy[i], d.dx[i] = dy, dx
+        self._descs.append(d)
+
+    def _conv(self, c, x, IH, IW, out=None, **kw):
+        """Plain Conv2d from the folded plan (net.Conv): 3x3 s1/s2 pad 1 or 1x1."""
+        w = c.w
+        co, ci, kh, _ = w.shape
+        if ci % 4:                                             # the 7-channel input is stored with 8 channels
+            w = F.pad(w, (0, 0, 0, 0, 0, 4 - ci % 4))
+            ci = w.shape[1]
+        taps, wk = conv_taps(w, c.pad)
+        OH, OW = IH // c.stride, IW // c.stride
+        out = out if out is not None else self._buf(OH, OW, co)
+        self._add(x, out, taps, wk, c.b, IH, IW, ci, OH, OW, co, in_stride=c.stride, act=kw.pop("act", c.act), **kw)
+        return out
+
+    def _convt(self, c, x, IH, IW, res2=None):
+        """ConvTranspose2d(k4, s2, p1) as four phase convolutions writing one (2 IH, 2 IW) tensor."""
+        ci, co = c.w.shape[0], c.w.shape[1]
+        out = self._buf(2 * IH, 2 * IW, co)
+        phases = [convt_phase_taps(c.w, py, px) for py in (0, 1) for px in (0, 1)]       # phase index = 2*py + px
+        self._add(x, out, None, None, c.b, IH, IW, ci, IH, IW, co, out_stride=2, act=c.act, res2=res2, phases=phases)
+        return out
+
+    # ------------------------------------------------------------------ graph
+    def _build(self, p):
+        H, W = self.H, self.W
+        self.x8 = self._buf(H, W, 8)
+        x = self.x8
+        # stem (model.py:460-469)
+        t = self._conv(p["stem"][0], x, H, W)
+        x1 = self._conv(p["stem"][1], t, H // 2, W // 2)
+        t = self._conv(p["stem"][2], x1, H // 2, W // 2)
+        h, w = H // 4, W // 4
+        feats = []
+        for blocks in p["enc"]:                                 # BasicBlock x2 per stage (model.py:119-157)
+            for blk in blocks:
+                s = blk["conv1"].stride
+                if blk["down"] is not None:                     # AvgPool2d(2, 2) + 1x1 conv + BN as one 2x2/s2 conv
+                    wd = blk["down"].w[:, :, 0, 0].t() * 0.25   # (Cin, Cout)
+                    taps = [(0, 0), (0, 1), (1, 0), (1, 1)]
+                    idt = self._buf(h // 2, w // 2, wd.shape[1])
+                    self._add(t, idt, taps, torch.cat([wd] * 4, 0), blk["down"].b, h, w, wd.shape[0], h // 2, w // 2,
+                              wd.shape[1], in_stride=2)
+                else:
+                    idt = t
+                y = self._conv(blk["conv1"], t, h, w)
+                h, w = h // s, w // s
+                t = self._conv(blk["conv2"], y, h, w, res1=idt, act="relu")
+            feats.append((t, h, w))
+        (x2, h2, w2), (x3, h3, w3), (x4, h4, w4), (out, h5, w5) = feats
+        # shortcut branches: conv -> ReLU -> BN twice (model.py:452-456)
+        fea = []
+        for s, (z, zh, zw) in zip(p["shortcut"], ((x, H, W), (x1, H // 2, W // 2), (x2, h2, w2), (x3, h3, w3), (x4, h4, w4))):
+            y = self._conv(s["c1"], z, zh, zw, scale=s["s1"], shift=s["t1"])
+            fea.append(self._conv(s["c2"], y, zh, zw, scale=s["s2"], shift=s["t2"]))
+        # decoder (model.py:274-324, 505-515)
+        t, h, w = out, h5, w5
+        for blocks, skip in zip(p["dec"], (fea[4], fea[3], fea[2], fea[1])):
+            b0, b1 = blocks
+            up = self._conv(b0["up"], t, h, w)                  # 1x1 at low resolution; nearest x2 happens in the read
+            y = self._convt(b0["conv1"], t, h, w)
+            h, w = 2 * h, 2 * w
+            t = self._conv(b0["conv2"], y, h, w, res1=up, res1_shift=1, act="leaky")
+            y = self._conv(b1["conv1"], t, h, w)
+            t = self._conv(b1["conv2"], y, h, w, res1=t, act="leaky", res2=skip)
+        t = self._convt(p["head_up"], t, h, w, res2=fea[0])
+        self.pred = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
+        hw = p["head"].w                                         # (1, 32, 3, 3)
+        taps, wk = conv_taps(hw, 1)
+        self._add(t, self.pred, taps, wk, p["head"].b, H, W, hw.shape[1], H, W, 1, kind=1)
+
+    # ------------------------------------------------------------------ run
+    @property
+    def num_layers(self):
+        return len(self._descs)
+
+    def forward(self, x8=None):
+        """x8: (H, W, 8) float32 NHWC (channel 7 zero) - or None when the caller wrote self.x8 directly.
+        Returns self.pred, (1, 1, H, W)."""
+        if x8 is not None and x8.data_ptr() != self.x8.data_ptr():
+            self.x8.copy_(x8.view(self.H, self.W, 8))
+        rc = nv.load().usc_conv_sequence_f32(self._arr, len(self._descs), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise nv.NativeError(f"usc_conv_sequence_f32 failed ({rc}): {nv.load().usc_conv_last_error().decode()}")
+        return self.pred
+
+    __call__ = forward
