@@ -36,8 +36,8 @@ template <int NT>
 __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
     __shared__ __attribute__((aligned(16))) float As[2][BM * APITCH];
     __shared__ __attribute__((aligned(16))) float Bs[2][8 * 32 * NT * 4];
-    __shared__ int s_dy[16], s_dx[16], s_toff[16];
-    __shared__ int s_outpix[BM], s_res1pix[BM];
+    __shared__ int s_toff[16];
+    __shared__ int s_outpix[BM], s_res1pix[BM], s_vbase[BM], s_vmask[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = d.OH * d.OW;
@@ -53,49 +53,65 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
     const float* __restrict__ wpk = d.wpk + (size_t)ph * d.wphase_stride;
     const int out_py = d.nphase > 1 ? (ph >> 1) : d.out_py, out_px = d.nphase > 1 ? (ph & 1) : d.out_px;
 
-    // per-tap byte offset of the tap relative to the (0,0) tap, for the staging threads
+    if (d.reserved & 8) return;                                  // debug probe: launch cost only
+
+    // ---- per-tile tables, one output pixel per thread (tid < 128), everything that does not change from K step
+    // to K step: byte offset of the pixel's row in the output / residual tensors, byte offset of its (0,0) tap in
+    // the input, and a 16-bit mask of the taps that fall inside the image.  Tap offsets are read from the kernel
+    // arguments (scalar registers), so the only long-latency operation here is one integer division.
+    // Invalid rows / taps get offsets beyond their buffer: buffer loads then return 0 and buffer stores are dropped
+    // by the hardware range check - no branches anywhere downstream.
+    constexpr int INVALID = 0x7fff0000;
+    uint32_t dyw[4], dxw[4];
+    __builtin_memcpy(dyw, d.dy, 16);
+    __builtin_memcpy(dxw, d.dx, 16);
+    if (d.nphase > 1) {                                          // 4 phases x 4 taps: phase p owns bytes [4p, 4p+4)
+        dyw[0] = ph == 0 ? dyw[0] : ph == 1 ? dyw[1] : ph == 2 ? dyw[2] : dyw[3];
+        dxw[0] = ph == 0 ? dxw[0] : ph == 1 ? dxw[1] : ph == 2 ? dxw[2] : dxw[3];
+    }
     if (tid < 16) {
-        const int t = tid < d.ntaps ? ph * d.ntaps + tid : 0;
-        s_dy[tid] = d.dy[t & 15];
-        s_dx[tid] = d.dx[t & 15];
-        s_toff[tid] = (d.dy[t & 15] * d.IW + d.dx[t & 15]) * d.Cin * 4;
+        int dy = 0, dx = 0;
+#pragma unroll
+        for (int t = 0; t < 16; t++)
+            if (t == tid) { dy = (int)(int8_t)(dyw[t >> 2] >> (8 * (t & 3))); dx = (int)(int8_t)(dxw[t >> 2] >> (8 * (t & 3))); }
+        s_toff[tid] = (dy * d.IW + dx) * d.Cin * 4;
     }
     if (tid < BM) {
         const int m = m0 + tid;
-        int op = -1, rp = -1;
+        int opb = INVALID, rpb = INVALID, vb = 0;
+        unsigned mk = 0;
         if (m < M) {
             const int oy = m / d.OW, ox = m - oy * d.OW;
             const int Y = oy * d.out_stride + out_py, X = ox * d.out_stride + out_px;
-            op = Y * d.OWf + X;
-            rp = (Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (X >> d.res1_shift);
+            opb = (Y * d.OWf + X) * d.Cout * 4;
+            rpb = ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (X >> d.res1_shift)) * d.Cout * 4;
+            const int iy0 = oy * d.in_stride, ix0 = ox * d.in_stride;
+            vb = (iy0 * d.IW + ix0) * d.Cin * 4;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                if (t < d.ntaps) {
+                    const int iy = iy0 + (int)(int8_t)(dyw[t >> 2] >> (8 * (t & 3)));
+                    const int ix = ix0 + (int)(int8_t)(dxw[t >> 2] >> (8 * (t & 3)));
+                    mk |= (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) ? (1u << t) : 0u;
+                }
+            }
         }
-        s_outpix[tid] = op;
-        s_res1pix[tid] = rp;
+        s_outpix[tid] = opb;
+        s_res1pix[tid] = rpb;
+        s_vbase[tid] = vb;
+        s_vmask[tid] = (int)mk;
     }
     __syncthreads();
 
-    // ---- staging assignment: thread -> (4 pixels, one float4 of the 32-wide K slice).
-    // Everything that does not change from K step to K step is computed once: the byte offset of each pixel's
-    // (0,0) tap and a 16-bit mask of the taps that fall inside the image.  Per step a load then costs one add
-    // and one select; out-of-image taps get an offset beyond the buffer and the hardware range check of the
-    // buffer load returns zeros (no branch, no zero-fill code).
+    // ---- staging assignment: thread -> (4 pixels 32 apart, one float4 of the 32-wide K slice)
     const int q = tid & 7;
     const int log2cin = 31 - __builtin_clz(d.Cin);           // Cin is a power of two (checked by the host)
     int vbase[4];
     unsigned vmask[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int m = m0 + (tid >> 3) + 32 * j;
-        vbase[j] = 0; vmask[j] = 0;
-        if (m < M) {
-            const int oy = m / d.OW, ox = m - oy * d.OW;
-            const int iy0 = oy * d.in_stride, ix0 = ox * d.in_stride;
-            vbase[j] = (iy0 * d.IW + ix0) * d.Cin * 4;
-            for (int t = 0; t < d.ntaps; t++) {
-                const int iy = iy0 + s_dy[t], ix = ix0 + s_dx[t];
-                if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) vmask[j] |= 1u << t;
-            }
-        }
+        vbase[j] = s_vbase[(tid >> 3) + 32 * j];
+        vmask[j] = (unsigned)s_vmask[(tid >> 3) + 32 * j];
     }
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(d.in), 0, d.IH * d.IW * d.Cin * 4, 0x00020000);
@@ -159,6 +175,7 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
         }
     };
 
+    if (d.reserved & 4) return;                                  // debug probe: prologue only
     load_chunk(c_begin, ra0, rb0);
     load_chunk(c_begin + 1, ra1, rb1);
     store_chunk(0, ra0, rb0);
@@ -175,8 +192,11 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
         __syncthreads();
     }
     if (c < c_end) compute(0);          // odd chunk count: the last chunk is already staged in buffer 0
+    if (d.reserved & 2) { if (acc[0][0] == 123.456f) d.out[0] = 1.f; return; }   // debug probe: no epilogue
 
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    // 32-bit byte offsets + buffer instructions: rows past the end of the image carry an out-of-range offset and
+    // are dropped (stores) or read as zero (residuals) by the range check.
     int ops[16], rps[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -184,40 +204,51 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
         ops[r] = s_outpix[p];
         rps[r] = s_res1pix[p];
     }
-    if (S > 1) {                 // partial sums only; usc_splitk_reduce_kernel finishes the layer
-        float* __restrict__ slab = d.slab + (size_t)ks * d.OHf * d.OWf * d.Cout;
+    const int out_bytes = d.OHf * d.OWf * d.Cout * 4;
+    if (S > 1) {                 // partial sums only; splitk_reduce_kernel finishes the layer
+        const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            d.slab + (size_t)ks * d.OHf * d.OWf * d.Cout, 0, out_bytes, 0x00020000);
 #pragma unroll
         for (int j = 0; j < NT; j++) {
-            const int n = nb0 + j * 32 + (lane & 31);
+            const int nb4 = (nb0 + j * 32 + (lane & 31)) * 4;
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                if (ops[r] >= 0) slab[(size_t)ops[r] * d.Cout + n] = acc[j][r];
+            for (int r = 0; r < 16; r++) {
+                const float a = acc[j][r];          // (bit_cast straight from the vector element miscompiles: all 16 stores got element 0)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a), slab_rsrc, ops[r] + nb4, 0, 0);
+            }
         }
         return;
     }
-    // All residual loads of a tile are issued before the first use so they overlap (one wait, not sixteen).
     const bool has_r1 = d.res1 != nullptr, has_r2 = d.res2 != nullptr, has_aff = d.scale != nullptr;
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(d.res1), 0, has_r1 ? (d.OHf >> d.res1_shift) * (d.OWf >> d.res1_shift) * d.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(d.res2), 0, has_r2 ? out_bytes : 0, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NT; j++) {
         const int n = nb0 + j * 32 + (lane & 31);
+        const int nb4 = n * 4;
         const float bias = d.bias ? d.bias[n] : 0.f;
         const float sc = has_aff ? d.scale[n] : 1.f;
         const float sh = has_aff ? d.shift[n] : 0.f;
+        // all residual loads of a tile are issued before their first use so they overlap (one wait, not sixteen);
+        // a zero-sized descriptor (no residual) turns them into zeros without touching memory
         float r1v[16], r2v[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            r1v[r] = (has_r1 && ops[r] >= 0) ? d.res1[(size_t)rps[r] * d.Cout + n] : 0.f;
-            r2v[r] = (has_r2 && ops[r] >= 0) ? d.res2[(size_t)ops[r] * d.Cout + n] : 0.f;
+            r1v[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1_rsrc, rps[r] + nb4, 0, 0));
+            r2v[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2_rsrc, ops[r] + nb4, 0, 0));
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             float v = acc[j][r] + bias;
-            if (has_r1) v += r1v[r];
+            v += r1v[r];
             if (d.act == USC_ACT_RELU) v = fmaxf(v, 0.f);
             else if (d.act == USC_ACT_LEAKY) v = v > 0.f ? v : v * 0.2f;
             if (has_aff) v = v * sc + sh;
-            if (has_r2) v += r2v[r];
-            if (ops[r] >= 0) d.out[(size_t)ops[r] * d.Cout + n] = v;
+            v += r2v[r];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), out_rsrc, ops[r] + nb4, 0, 0);
         }
     }
 }
@@ -326,7 +357,8 @@ extern "C" int usc_conv_sequence_f32(const usc_conv_desc* descs, int n, usc_stre
         } else {
             if (d.Cout % 32) return conv_fail(USC_E_UNSUPPORTED, "usc_conv_sequence_f32: Cout must be a multiple of 32");
             if (d.Cin & (d.Cin - 1)) return conv_fail(USC_E_UNSUPPORTED, "usc_conv_sequence_f32: Cin must be a power of two");
-            if ((long long)d.IH * d.IW * d.Cin * 4 >= 0x7ffffff0ll) return conv_fail(USC_E_UNSUPPORTED, "usc_conv_sequence_f32: input tensor >= 2 GiB");
+            if ((long long)d.IH * d.IW * d.Cin * 4 >= 0x7fff0000ll || (long long)d.OHf * d.OWf * d.Cout * 4 >= 0x7fff0000ll)
+                return conv_fail(USC_E_UNSUPPORTED, "usc_conv_sequence_f32: tensor >= 2 GiB");
             const int nphase = d.nphase > 1 ? d.nphase : 1;
             if (nphase != 1 && nphase != 4) return conv_fail(USC_E_ARG, "usc_conv_sequence_f32: nphase must be 1 or 4");
             if (nphase * d.ntaps > 16) return conv_fail(USC_E_ARG, "usc_conv_sequence_f32: more than 16 taps");
