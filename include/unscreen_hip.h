@@ -162,6 +162,13 @@ typedef struct usc_conv_desc {
 int usc_conv_sequence_f32(const usc_conv_desc* descs, int n, usc_stream_t stream);
 const char* usc_conv_last_error(void);
 
+/* The same layer list as a pre-instantiated hipGraph (one node per launch; edges follow the buffers each layer
+ * reads, so independent branches run concurrently).  The descriptors are copied; the buffers they point to must
+ * stay valid until usc_conv_graph_destroy.  One handle may be in flight on one stream at a time. */
+int  usc_conv_graph_create(const usc_conv_desc* descs, int n, void** handle);
+int  usc_conv_graph_launch(void* handle, usc_stream_t stream);
+void usc_conv_graph_destroy(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,10 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
 
 #include "../../include/unscreen_hip.h"
 
@@ -342,57 +346,152 @@ static int conv_fail(int code, const char* msg) {
     return code;
 }
 
+// One layer = one main launch (+ one reduce launch when K is split).
+struct LayerPlan {
+    usc_conv_desc d;
+    void* fn;
+    dim3 grid, block;
+    bool reduce;
+    dim3 rgrid;
+};
+
+static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
+    if (!d.in || !d.out || !d.wpk || d.Cin <= 0 || d.Cin % 4 || d.ntaps < 1 || d.ntaps > 16 || d.OH <= 0 || d.OW <= 0)
+        return conv_fail(USC_E_ARG, "usc_conv: malformed layer descriptor");
+    const long long M = (long long)d.OH * d.OW;
+    p.d = d;
+    p.reduce = false;
+    p.block = dim3(THREADS);
+    if (d.kind == USC_CONV_HEAD) {
+        if (d.Cout != 1 || d.Cin != 32 || d.ntaps != 9 || d.in_stride != 1 || d.IH != d.OH || d.IW != d.OW)
+            return conv_fail(USC_E_UNSUPPORTED, "usc_conv: the head kernel is Conv2d(32, 1, 3, padding=1)");
+        p.fn = (void*)head_conv_kernel;
+        p.grid = dim3((d.OW + HT_W - 1) / HT_W, (d.OH + HT_H - 1) / HT_H);
+        return USC_OK;
+    }
+    if (d.Cout % 32) return conv_fail(USC_E_UNSUPPORTED, "usc_conv: Cout must be a multiple of 32");
+    if (d.Cin & (d.Cin - 1)) return conv_fail(USC_E_UNSUPPORTED, "usc_conv: Cin must be a power of two");
+    if ((long long)d.IH * d.IW * d.Cin * 4 >= 0x7fff0000ll || (long long)d.OHf * d.OWf * d.Cout * 4 >= 0x7fff0000ll)
+        return conv_fail(USC_E_UNSUPPORTED, "usc_conv: tensor >= 2 GiB");
+    const int nphase = d.nphase > 1 ? d.nphase : 1;
+    if (nphase != 1 && nphase != 4) return conv_fail(USC_E_ARG, "usc_conv: nphase must be 1 or 4");
+    if (nphase * d.ntaps > 16) return conv_fail(USC_E_ARG, "usc_conv: more than 16 taps");
+    const int mblocks = (int)((M + BM - 1) / BM);
+    // two 32-column tiles per workgroup only while that still leaves >= 2 workgroups per CU
+    const bool nt2 = (d.Cout % 64 == 0) && ((long long)mblocks * (d.Cout / 64) * nphase >= 512);
+    const int nblocks = nt2 ? d.Cout / 64 : d.Cout / 32;
+    // split K when the grid would leave most CUs idle (M = 510 ... 2040 layers)
+    const long long blocks = (long long)mblocks * nblocks * nphase;
+    const int nch = (d.ntaps * d.Cin + KC - 1) / KC;
+    int S = 1;
+    if (d.slab && blocks < 384) {
+        S = (int)((768 + blocks - 1) / blocks);
+        if (S > nch) S = nch;
+        if (S > 16) S = 16;
+        const size_t need = (size_t)S * d.OHf * d.OWf * d.Cout * sizeof(float);
+        if (need > d.slab_bytes) S = (int)(d.slab_bytes / ((size_t)d.OHf * d.OWf * d.Cout * sizeof(float)));
+        if (S < 1) S = 1;
+    }
+    p.d.ksplit = S;
+    p.d.nphase = nphase;
+    p.grid = dim3(mblocks, nblocks, nphase * S);
+    p.fn = nt2 ? (void*)conv_mfma_kernel<2> : (void*)conv_mfma_kernel<1>;
+    if (S > 1) {
+        const long long items = (long long)d.OHf * d.OWf * (d.Cout / 4);
+        int rb = (int)((items + 255) / 256);
+        if (rb > 2048) rb = 2048;
+        p.reduce = true;
+        p.rgrid = dim3(rb);
+    }
+    return USC_OK;
+}
+
 extern "C" int usc_conv_sequence_f32(const usc_conv_desc* descs, int n, usc_stream_t stream) {
     if (!descs || n < 0) return conv_fail(USC_E_ARG, "usc_conv_sequence_f32: bad argument");
     hipStream_t st = (hipStream_t)stream;
     for (int i = 0; i < n; i++) {
-        const usc_conv_desc& d = descs[i];
-        if (!d.in || !d.out || !d.wpk || d.Cin <= 0 || d.Cin % 4 || d.ntaps < 1 || d.ntaps > 16 || d.OH <= 0 || d.OW <= 0)
-            return conv_fail(USC_E_ARG, "usc_conv_sequence_f32: malformed layer descriptor");
-        const long long M = (long long)d.OH * d.OW;
-        if (d.kind == USC_CONV_HEAD) {
-            if (d.Cout != 1 || d.Cin != 32 || d.ntaps != 9 || d.in_stride != 1 || d.IH != d.OH || d.IW != d.OW)
-                return conv_fail(USC_E_UNSUPPORTED, "usc_conv_sequence_f32: the head kernel is Conv2d(32, 1, 3, padding=1)");
-            hipLaunchKernelGGL(head_conv_kernel, dim3((d.OW + HT_W - 1) / HT_W, (d.OH + HT_H - 1) / HT_H), dim3(256), 0, st, d);
-        } else {
-            if (d.Cout % 32) return conv_fail(USC_E_UNSUPPORTED, "usc_conv_sequence_f32: Cout must be a multiple of 32");
-            if (d.Cin & (d.Cin - 1)) return conv_fail(USC_E_UNSUPPORTED, "usc_conv_sequence_f32: Cin must be a power of two");
-            if ((long long)d.IH * d.IW * d.Cin * 4 >= 0x7fff0000ll || (long long)d.OHf * d.OWf * d.Cout * 4 >= 0x7fff0000ll)
-                return conv_fail(USC_E_UNSUPPORTED, "usc_conv_sequence_f32: tensor >= 2 GiB");
-            const int nphase = d.nphase > 1 ? d.nphase : 1;
-            if (nphase != 1 && nphase != 4) return conv_fail(USC_E_ARG, "usc_conv_sequence_f32: nphase must be 1 or 4");
-            if (nphase * d.ntaps > 16) return conv_fail(USC_E_ARG, "usc_conv_sequence_f32: more than 16 taps");
-            const int mblocks = (int)((M + BM - 1) / BM);
-            // two 32-column tiles per workgroup only while that still leaves >= 2 workgroups per CU
-            const bool nt2 = (d.Cout % 64 == 0) && ((long long)mblocks * (d.Cout / 64) * nphase >= 512);
-            const int nblocks = nt2 ? d.Cout / 64 : d.Cout / 32;
-            // split K when the grid would leave most CUs idle (M = 510 ... 2040 layers)
-            const long long blocks = (long long)mblocks * nblocks * nphase;
-            const int nch = (d.ntaps * d.Cin + KC - 1) / KC;
-            int S = 1;
-            if (d.slab && blocks < 384) {
-                S = (int)((768 + blocks - 1) / blocks);
-                if (S > nch) S = nch;
-                if (S > 16) S = 16;
-                const size_t need = (size_t)S * d.OHf * d.OWf * d.Cout * sizeof(float);
-                if (need > d.slab_bytes) S = (int)(d.slab_bytes / ((size_t)d.OHf * d.OWf * d.Cout * sizeof(float)));
-                if (S < 1) S = 1;
-            }
-            usc_conv_desc dd = d;
-            dd.ksplit = S;
-            dd.nphase = nphase;
-            dim3 grid(mblocks, nblocks, nphase * S);
-            if (nt2) hipLaunchKernelGGL(conv_mfma_kernel<2>, grid, dim3(THREADS), 0, st, dd);
-            else hipLaunchKernelGGL(conv_mfma_kernel<1>, grid, dim3(THREADS), 0, st, dd);
-            if (S > 1) {
-                const long long items = (long long)d.OHf * d.OWf * (d.Cout / 4);
-                int rb = (int)((items + 255) / 256);
-                if (rb > 2048) rb = 2048;
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, st, dd);
-            }
-        }
-        hipError_t e = hipGetLastError();
+        LayerPlan p;
+        int rc = plan_layer(descs[i], p);
+        if (rc) return rc;
+        void* args[] = {&p.d};
+        hipError_t e = hipLaunchKernel(p.fn, p.grid, p.block, args, 0, st);
+        if (e == hipSuccess && p.reduce) e = hipLaunchKernel((void*)splitk_reduce_kernel, p.rgrid, dim3(256), args, 0, st);
         if (e != hipSuccess) return conv_fail(USC_E_LAUNCH, hipGetErrorString(e));
     }
     return USC_OK;
+}
+
+// ---- the same layers as a hipGraph: one node per launch, edges from the producers of in / res1 / res2 (and from the
+// previous user of a shared split-K slab), so independent branches (shortcut convs, the 1x1 up-branch) overlap the
+// ramp / tail of the main chain, and one hipGraphLaunch replaces ~85 kernel launches per frame.
+struct ConvGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<LayerPlan> plans;          // kernel arguments must outlive the graph
+};
+
+extern "C" int usc_conv_graph_create(const usc_conv_desc* descs, int n, void** handle) {
+    if (!descs || n <= 0 || !handle) return conv_fail(USC_E_ARG, "usc_conv_graph_create: bad argument");
+    ConvGraph* g = new ConvGraph();
+    g->plans.resize(n);
+    for (int i = 0; i < n; i++) {
+        int rc = plan_layer(descs[i], g->plans[i]);
+        if (rc) { delete g; return rc; }
+    }
+    if (hipGraphCreate(&g->graph, 0) != hipSuccess) { delete g; return conv_fail(USC_E_LAUNCH, "hipGraphCreate failed"); }
+    std::vector<hipGraphNode_t> last(n);                     // node that completes layer i
+    std::vector<void*> kargs(n);
+    for (int i = 0; i < n; i++) {
+        LayerPlan& p = g->plans[i];
+        std::vector<hipGraphNode_t> deps;
+        for (int j = i - 1; j >= 0; j--) {
+            const usc_conv_desc& q = g->plans[j].d;
+            const bool raw = q.out == p.d.in || q.out == p.d.res1 || q.out == p.d.res2;
+            const bool waw = q.out == p.d.out;                                   // phases / reuse of an output buffer
+            const bool slab = p.reduce && g->plans[j].reduce && q.slab == p.d.slab;
+            if (raw || waw || slab) deps.push_back(last[j]);
+        }
+        kargs[i] = &p.d;
+        hipKernelNodeParams kp;
+        memset(&kp, 0, sizeof(kp));
+        kp.func = p.fn; kp.gridDim = p.grid; kp.blockDim = p.block; kp.sharedMemBytes = 0;
+        kp.kernelParams = &kargs[i]; kp.extra = nullptr;
+        hipGraphNode_t node;
+        if (hipGraphAddKernelNode(&node, g->graph, deps.data(), deps.size(), &kp) != hipSuccess) {
+            (void)hipGraphDestroy(g->graph); delete g;
+            return conv_fail(USC_E_LAUNCH, "hipGraphAddKernelNode failed");
+        }
+        last[i] = node;
+        if (p.reduce) {
+            kp.func = (void*)splitk_reduce_kernel; kp.gridDim = p.rgrid; kp.blockDim = dim3(256);
+            hipGraphNode_t rnode;
+            if (hipGraphAddKernelNode(&rnode, g->graph, &node, 1, &kp) != hipSuccess) {
+                (void)hipGraphDestroy(g->graph); delete g;
+                return conv_fail(USC_E_LAUNCH, "hipGraphAddKernelNode (reduce) failed");
+            }
+            last[i] = rnode;
+        }
+    }
+    if (hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGraphDestroy(g->graph); delete g;
+        return conv_fail(USC_E_LAUNCH, "hipGraphInstantiate failed");
+    }
+    *handle = g;
+    return USC_OK;
+}
+
+extern "C" int usc_conv_graph_launch(void* handle, usc_stream_t stream) {
+    if (!handle) return conv_fail(USC_E_ARG, "usc_conv_graph_launch: null handle");
+    ConvGraph* g = (ConvGraph*)handle;
+    hipError_t e = hipGraphLaunch(g->exec, (hipStream_t)stream);
+    if (e != hipSuccess) return conv_fail(USC_E_LAUNCH, hipGetErrorString(e));
+    return USC_OK;
+}
+
+extern "C" void usc_conv_graph_destroy(void* handle) {
+    if (!handle) return;
+    ConvGraph* g = (ConvGraph*)handle;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
 }

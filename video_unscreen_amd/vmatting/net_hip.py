@@ -31,6 +31,10 @@ class ConvDesc(C.Structure):
                 ("slab", C.c_void_p), ("slab_bytes", C.c_size_t)]
 
 
+def d_out_elems(OH, OW, out_stride, OHf, OWf, Cout):
+    return (OHf or OH * out_stride) * (OWf or OW * out_stride) * Cout
+
+
 def pack_k_major(wk):
     """(K, Cout) rows k = tap*Cin + ci  ->  [Kpad/4][Cout][4] with K padded to a multiple of 32."""
     K, N = wk.shape
@@ -60,7 +64,7 @@ def convt_phase_taps(w, py, px):
 
 
 class HipMattingNet:
-    def __init__(self, state_dict, in_h, in_w, device="cuda:0"):
+    def __init__(self, state_dict, in_h, in_w, device="cuda:0", use_graph=True):
         if in_h % 32 or in_w % 32:
             raise ValueError("HipMattingNet: input size must be a multiple of 32 (vmatting/agent.py:38-42 guarantees it)")
         self.device = torch.device(device)
@@ -68,9 +72,23 @@ class HipMattingNet:
         nv.load()
         self._keep = []               # every tensor a descriptor points to
         self._descs = []
-        self.slab = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=self.device)   # split-K partial sums (64 MiB)
+        self.slab = torch.empty(96 * 1024 * 1024, dtype=torch.float32, device=self.device)   # split-K partial sums (384 MiB)
+        self._slab_used = 0
         self._build(fold_state_dict(state_dict))
         self._arr = (ConvDesc * len(self._descs))(*self._descs)
+        self._graph = C.c_void_p()
+        if use_graph:
+            rc = nv.load().usc_conv_graph_create(self._arr, len(self._descs), C.byref(self._graph))
+            if rc != 0:
+                raise nv.NativeError(f"usc_conv_graph_create failed ({rc}): {nv.load().usc_conv_last_error().decode()}")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_graph", None) is not None and self._graph:
+                nv.load().usc_conv_graph_destroy(self._graph)
+                self._graph = C.c_void_p()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ helpers
     def _dev(self, t):
@@ -100,7 +118,12 @@ class HipMattingNet:
             d.nphase, d.wphase_stride = 1, 0
             taps_all = taps
         d.wpk = wp.data_ptr()
-        d.slab, d.slab_bytes = self.slab.data_ptr(), self.slab.numel() * 4
+        # every layer gets its own 16-slice region of the split-K scratch, so layers on different graph branches
+        # never share partial-sum memory
+        need = 16 * d_out_elems(OH, OW, out_stride, OHf, OWf, Cout) * 4
+        if kind == 0 and self._slab_used + need <= self.slab.numel() * 4 and need <= 32 * 1024 * 1024:
+            d.slab, d.slab_bytes = self.slab.data_ptr() + self._slab_used, need
+            self._slab_used += need
         d.bias = self._dev(bias).data_ptr() if bias is not None else None
         d.res1 = res1.data_ptr() if res1 is not None else None
         d.scale = self._dev(scale.reshape(-1)).data_ptr() if scale is not None else None
@@ -194,9 +217,13 @@ class HipMattingNet:
         Returns self.pred, (1, 1, H, W)."""
         if x8 is not None and x8.data_ptr() != self.x8.data_ptr():
             self.x8.copy_(x8.view(self.H, self.W, 8))
-        rc = nv.load().usc_conv_sequence_f32(self._arr, len(self._descs), torch.cuda.current_stream().cuda_stream)
+        st = torch.cuda.current_stream().cuda_stream
+        if self._graph:
+            rc = nv.load().usc_conv_graph_launch(self._graph, st)
+        else:
+            rc = nv.load().usc_conv_sequence_f32(self._arr, len(self._descs), st)
         if rc != 0:
-            raise nv.NativeError(f"usc_conv_sequence_f32 failed ({rc}): {nv.load().usc_conv_last_error().decode()}")
+            raise nv.NativeError(f"conv launch failed ({rc}): {nv.load().usc_conv_last_error().decode()}")
         return self.pred
 
     __call__ = forward
