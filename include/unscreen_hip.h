@@ -65,6 +65,19 @@ size_t usc_trimap_ws_bytes(int H, int W, int long_side);
 int usc_trimap_u8(const uint8_t* mask, int H, int W, int long_side, int ksize, int iters, uint8_t* out,
                   void* ws, size_t ws_bytes, usc_stream_t stream);
 
+/* unscreen/utils/fgfuncs.py:9-65 is_pixel_inrange (long_side_input <= 0): out[i] = 1 when every 8-bit HSV channel of
+ * img lies within clip(bg -/+ winsize//2, 10, 255).  Exactly one of bg_img (device, H*W*3) and bg_color_host
+ * (HOST pointer to 3 bytes BGR) must be given; winsize is a HOST pointer to 3 ints (h, s, v). */
+int usc_inrange_hsv_u8(const uint8_t* img, const uint8_t* bg_img, const uint8_t* bg_color_host, const int* winsize,
+                       int H, int W, uint8_t* out, usc_stream_t stream);
+
+/* unscreen/trimap/agent.py:63-101 TrimapAgent.generate_trimap_withbg, entirely on the device (the
+ * fuzzy / mask ratio test of :94 is evaluated by the kernels from device-side counters, no host sync). */
+size_t usc_trimap_withbg_ws_bytes(int H, int W, int long_side);
+int usc_trimap_withbg_u8(const uint8_t* mask, const uint8_t* img, const uint8_t* bg_img, const uint8_t* bg_color_host,
+                         const int* winsize, int H, int W, int long_side, int ksize, int iters, uint8_t* out,
+                         void* ws, size_t ws_bytes, usc_stream_t stream);
+
 /* tools/unscreen/bg_offline.py:150-160 (same arithmetic: tools/unscreen/bg.py:85-92): background fusion
  * bg = u8(bg_i*beta + (1-beta)*bg_always) and the background-difference gate
  * alpha = gray(seg) * (dilate4x4x2(gray(|frame - bg|) > thr) // 255).

@@ -44,6 +44,9 @@ def lib():
         _lib.orc_get_bg.argtypes = [u8p, u8p, C.c_size_t, u8p]
         _lib.orc_blend.argtypes = [u8p, u8p, C.c_int, u8p, C.c_size_t, u8p]
         _lib.orc_score_map.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, f64p]
+        _lib.orc_inrange_hsv.argtypes = [u8p, u8p, C.c_int, C.POINTER(C.c_int), C.c_size_t, u8p]
+        _lib.orc_trimap_withbg.argtypes = [u8p, u8p, u8p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, u8p]
         for name in ("orc_bgr2gray_u8", "orc_bgr2hsv_u8", "orc_hsv2bgr_u8"):
             getattr(_lib, name).argtypes = [u8p, u8p, C.c_size_t]
     return _lib
@@ -215,6 +218,28 @@ def blend(fg, mask, bg):
     bg, pb = _u8(bg)
     out = np.empty_like(fg)
     lib().orc_blend(pf, pm, 3 if mask.ndim == 3 else 1, pb, fg.size // 3, out.ctypes.data_as(u8p))
+    return out
+
+
+def is_pixel_inrange(img, bg, winsize=(20, 20, 120)):
+    """fgfuncs.py:9-65 with long_side_input <= 0.  bg: (3,) colour or (h, w, 3) image.  Returns a bool mask."""
+    img, pi = _u8(img)
+    bg, pb = _u8(bg)
+    win = (C.c_int * 3)(*[int(v) for v in winsize])
+    out = np.empty(img.shape[:2], np.uint8)
+    lib().orc_inrange_hsv(pi, pb, 1 if bg.ndim == 3 else 0, win, out.size, out.ctypes.data_as(u8p))
+    return out > 0
+
+
+def trimap_withbg(mask, img, bg, winsize=(10, 100, 180), long_side=960, ksize=3, iters=5):
+    """trimap/agent.py:63-101."""
+    mask, pm = _u8(mask)
+    img, pi = _u8(img)
+    bg, pb = _u8(bg)
+    win = (C.c_int * 3)(*[int(v) for v in winsize])
+    out = np.empty_like(mask)
+    lib().orc_trimap_withbg(pm, pi, pb, 1 if bg.ndim == 3 else 0, win, mask.shape[0], mask.shape[1], int(long_side),
+                            int(ksize), int(iters), out.ctypes.data_as(u8p))
     return out
 
 

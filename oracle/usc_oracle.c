@@ -554,6 +554,55 @@ ORC_API void orc_blend(const uint8_t* fg, const uint8_t* mask, int mask_cn, cons
         }
 }
 
+/* unscreen/utils/fgfuncs.py:9-65 is_pixel_inrange with long_side_input <= 0: the pixel is "background coloured" when
+ * every HSV channel lies in [clip(bg - win//2, 10, 255), clip(bg + win//2, 10, 255)] (both ends inclusive:
+ * cv2.inRange for a colour, the torch ge/ge pair for a background image).  bg_is_image: bg is H*W*3, else 3 bytes.
+ * out: 1 where in range, else 0. */
+ORC_API void orc_inrange_hsv(const uint8_t* img, const uint8_t* bg, int bg_is_image, const int* winsize, size_t n, uint8_t* out)
+{
+    orc_hsv_tables();
+    int half[3] = {winsize[0] / 2, winsize[1] / 2, winsize[2] / 2};
+    uint8_t bh[3];
+    if (!bg_is_image) orc_bgr2hsv_px(bg[0], bg[1], bg[2], bh);
+    for (size_t i = 0; i < n; i++) {
+        uint8_t ih[3];
+        orc_bgr2hsv_px(img[3 * i], img[3 * i + 1], img[3 * i + 2], ih);
+        if (bg_is_image) orc_bgr2hsv_px(bg[3 * i], bg[3 * i + 1], bg[3 * i + 2], bh);
+        int ok = 1;
+        for (int c = 0; c < 3; c++) {
+            int lo = orc_clampi((int)bh[c] - half[c], 10, 255), hi = orc_clampi((int)bh[c] + half[c], 10, 255);
+            ok &= (ih[c] >= lo) && (ih[c] <= hi);
+        }
+        out[i] = (uint8_t)ok;
+    }
+}
+
+/* unscreen/trimap/agent.py:63-101 TrimapAgent.generate_trimap_withbg:
+ *  :88-89  empty mask -> returned unchanged (all zeros)
+ *  :90-91  bgmask = is_pixel_inrange(img, bg); fuzzy = (mask > 0) & bgmask
+ *  :94     if fuzzy.sum() / (mask > 0).sum() > 0.1 (double division): plain trimap of the mask
+ *  :97-100 else zero the fuzzy pixels, trimap, then force the fuzzy pixels to 128 */
+ORC_API void orc_trimap_withbg(const uint8_t* mask, const uint8_t* img, const uint8_t* bg, int bg_is_image, const int* winsize,
+                               int H, int W, int long_side, int ksize, int iters, uint8_t* out)
+{
+    size_t n = (size_t)H * W;
+    long long nm = 0, nf = 0;
+    uint8_t* bgmask = (uint8_t*)malloc(n);
+    orc_inrange_hsv(img, bg, bg_is_image, winsize, n, bgmask);
+    for (size_t i = 0; i < n; i++) { nm += mask[i] > 0; nf += (mask[i] > 0) && bgmask[i]; }
+    if (nm == 0) { memcpy(out, mask, n); free(bgmask); return; }
+    if ((double)nf / (double)nm > 0.1) {
+        orc_trimap(mask, H, W, long_side, ksize, iters, out);
+    } else {
+        uint8_t* ens = (uint8_t*)malloc(n);
+        for (size_t i = 0; i < n; i++) ens[i] = (mask[i] > 0 && bgmask[i]) ? 0 : mask[i];
+        orc_trimap(ens, H, W, long_side, ksize, iters, out);
+        for (size_t i = 0; i < n; i++) if (mask[i] > 0 && bgmask[i]) out[i] = 128;
+        free(ens);
+    }
+    free(bgmask);
+}
+
 /* ------------------------------------------------------------------------------------------
  * remove_invalid_objects (unscreen/utils/maskprocess.py:77-189)
  * ---------------------------------------------------------------------------------------- */

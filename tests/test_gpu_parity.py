@@ -237,3 +237,35 @@ def test_pipelined_run_equals_step(nv, cfg):
         assert int(da.max()) <= 1 and float((da > 0).float().mean()) < 1e-3
         same = (da == 0).unsqueeze(-1).expand_as(f)
         assert torch.equal(f[same], f2[same])                       # foreground identical wherever alpha is
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920), (270, 480), (33, 47), (2, 5)])
+def test_inrange_and_trimap_withbg_bit_exact(nv, oracle_lib, H, W):
+    """is_pixel_inrange (fgfuncs.py:9-65) and generate_trimap_withbg (trimap/agent.py:63-101): green-mode path."""
+    rng = np.random.default_rng(H + W)
+    bgc = np.array([60, 200, 60], np.uint8)
+    img = rand_img(H, W, 51, smooth=False)
+    green = np.clip(bgc.astype(int) + rng.integers(-12, 13, (H, W, 3)), 0, 255).astype(np.uint8)
+    fgm = blob_mask(H, W, 52, q=0.6)
+    img = np.where(fgm[..., None] > 0, img, green)
+    bgimg = np.clip(green.astype(int) + rng.integers(-3, 4, (H, W, 3)), 0, 255).astype(np.uint8)
+    for win in ((10, 100, 180), (20, 20, 120), (0, 0, 0)):
+        for bg in (bgc, bgimg):
+            want = oracle_lib.is_pixel_inrange(img, bg, win)
+            got = host(nv.is_pixel_inrange(dev(img), dev(bg) if bg.ndim == 3 else bg, win)) > 0
+            assert np.array_equal(got, want)                                     # bit-exact
+    # trimap with background: both branches of the fuzzy-ratio test, plus the empty mask
+    mask_consistent = fgm.copy()                                               # few fuzzy pixels -> ensemble branch
+    mask_inconsistent = blob_mask(H, W, 53, q=0.2)                             # covers lots of green -> trust-mask branch
+    for m in (mask_consistent, mask_inconsistent, np.zeros((H, W), np.uint8)):
+        for bg in (bgc, bgimg):
+            want = oracle_lib.trimap_withbg(m, img, bg, (10, 100, 180), 960, 3, 5)
+            got = host(nv.trimap_withbg(dev(m), dev(img), dev(bg) if bg.ndim == 3 else bg, (10, 100, 180), 960, 3, 5))
+            assert np.array_equal(got, want), f"{(got != want).sum()} pixels differ"   # bit-exact
+    from video_unscreen_amd.trimap import TrimapAgent
+    from video_unscreen_amd.utils import is_pixel_inrange
+    agent = TrimapAgent()
+    assert np.array_equal(agent.forward(mask_consistent.copy(), img, bgc), oracle_lib.trimap_withbg(mask_consistent, img, bgc))
+    empty = np.zeros((H, W), np.uint8)
+    assert agent.forward(empty, img, bgc) is empty                              # reference returns the input object
+    assert np.array_equal(is_pixel_inrange(img, bgc, (10, 100, 180)), oracle_lib.is_pixel_inrange(img, bgc, (10, 100, 180)))

@@ -1,0 +1,107 @@
+"""bg_step / bg_offline mode on MI355X: the stage-3 loop of the reference's tools/unscreen/bg_offline.py:133-177
+(stages 1-2 are disabled in the reference), device-resident and optionally frame-sharded over GPUs.
+
+Same CLI as the reference (--cfg, -vid/--video_id, --range a-b) plus --data_root (the reference hard-codes its
+dataset path, bg_offline.py:187).  Inputs, as in the reference: <data_root>/src_img/<vid>/*.jpg frames and, in
+<data_root>/test_img/<vid>/, segmask_*.jpg, bg_*.jpg and always_bg.jpg.  Outputs alphamask_%06d.jpg and
+fg_%06d.jpg next to them.  Under torchrun every rank takes a contiguous frame range (equivalent to the
+reference's --range) and writes its own files; rank 0 muxes the video.
+"""
+import argparse
+import json
+import os
+import os.path as osp
+import sys
+import time
+from glob import glob
+
+ROOT = osp.dirname(osp.dirname(osp.dirname(osp.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+from video_unscreen_amd.dist import broadcast_state, shard_range
+from video_unscreen_amd.pipeline import BgStepPipeline
+from video_unscreen_amd.utils.fileio import parallel_read_img, read_img, save_img, save_video
+
+
+def main(cfg):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    print("Processing ", cfg['data'])
+    src_img_dir, dst_img_dir = cfg["data"]["src_img_dir"], cfg["data"]["dst_img_dir"]
+    os.makedirs(dst_img_dir, exist_ok=True)
+
+    st = time.time()
+    frame_paths = sorted(glob(osp.join(src_img_dir, cfg["data"]["src_img_tmpl"])))
+    mask_paths = sorted(glob(osp.join(dst_img_dir, 'segmask_*.jpg')))
+    bg_paths = sorted(glob(osp.join(dst_img_dir, 'bg_*.jpg')))
+    first = 0
+    if cfg["data"]["range"]:
+        a, b = cfg["data"]["range"]
+        frame_paths, first = frame_paths[a:b], a
+    assert len(frame_paths) == len(mask_paths) == len(bg_paths), "frames, segmask_* and bg_* must pair up"
+    lo, hi = shard_range(len(frame_paths), rank, world)          # this rank's contiguous range
+    frames = parallel_read_img(frame_paths[lo:hi])
+    masks = parallel_read_img(mask_paths[lo:hi])
+    bgs = parallel_read_img(bg_paths[lo:hi])
+    h, w = frames[0].shape[:2]
+    print('{} frames. Reading Data Done! {:.2f}s'.format(len(frames), time.time() - st))
+
+    st = time.time()
+    # rank 0 owns the checkpoint and the overall background; RCCL broadcast to the others
+    sd = None
+    if rank == 0:
+        sd = torch.load(cfg["vmatting"]["model_path"], map_location="cpu")["state_dict"]
+    bg_always = torch.from_numpy(read_img(osp.join(dst_img_dir, 'always_bg.jpg'))) if rank == 0 else \
+        torch.empty((h, w, 3), dtype=torch.uint8)
+    sd, bg_always = broadcast_state(sd, bg_always, dev, world)
+    pipe = BgStepPipeline(cfg, h, w, device=dev, state_dict=sd)
+    print('Building Agents Done! {:.2f}s'.format(time.time() - st))
+
+    def inputs():
+        for f, m, b in zip(frames, masks, bgs):
+            yield (torch.from_numpy(f).to(dev), torch.from_numpy(m).to(dev), torch.from_numpy(b).to(dev), bg_always)
+
+    def on_result(i, out):
+        fid = first + lo + i
+        save_img(out["alpha"].cpu().numpy(), osp.join(dst_img_dir, 'alphamask_{:06d}.jpg'.format(fid)))
+        save_img(out["fg"].cpu().numpy(), osp.join(dst_img_dir, 'fg_{:06d}.jpg'.format(fid)))
+
+    print("calculate fg image according to bg image")
+    st = time.time()
+    n = pipe.run(inputs(), on_result=on_result)
+    torch.cuda.synchronize()
+    print('{} frames in {:.2f}s on rank {}'.format(n, time.time() - st, rank))
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        save_video(cfg, 'fg')
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--cfg', type=str, default='./configs/bg.json')
+    parser.add_argument('-vid', '--video_id', type=str, default="1")
+    parser.add_argument('--range', type=str, default=None, help="eg. 400-700")
+    parser.add_argument('--data_root', type=str, default=os.environ.get("UNSCREEN_DATA_ROOT", "./data/greenmat"))
+    args = parser.parse_args()
+
+    cfg = json.load(open(args.cfg))
+    cfg["data"] = {"range": [int(i) for i in args.range.split('-')] if args.range else None,
+                   "video_id": args.video_id,
+                   "src_img_dir": osp.join(args.data_root, 'src_img', args.video_id),
+                   "src_img_tmpl": '*.jpg',
+                   "dst_img_dir": osp.join(args.data_root, 'test_img', args.video_id),
+                   "dst_vid_dir": osp.join(args.data_root, 'video')}
+    main(cfg)

@@ -30,6 +30,10 @@ _SIGNATURES = {
     "usc_morph_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
     "usc_trimap_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "usc_trimap_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    "usc_inrange_hsv_u8": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int), C.c_int, C.c_int, _vp, _vp]),
+    "usc_trimap_withbg_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "usc_trimap_withbg_u8": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       _vp, _vp, C.c_size_t, _vp]),
     "usc_bgdiff_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "usc_bgdiff_mask_u8": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
                                      _vp, _vp, _vp, C.c_size_t, _vp]),
@@ -135,6 +139,42 @@ def trimap(mask, long_side=960, ksize=3, iters=5, out=None, ws=None):
         ws = _ws(need, mask.device)
     _check(load().usc_trimap_u8(pm, H, W, int(long_side), int(ksize), int(iters), po, ws.data_ptr(), ws.numel(), _stream()),
            "usc_trimap_u8")
+    return out
+
+
+def _bg_args(bg, H, W):
+    """bg: CUDA (H, W, 3) uint8 tensor, or a 3-element colour (NumPy / list / CPU tensor) passed by host pointer."""
+    if isinstance(bg, torch.Tensor) and bg.is_cuda:
+        return _dev_u8(bg, "bg", (H, W, 3)), None, None
+    col = np.ascontiguousarray(np.asarray(bg.cpu() if isinstance(bg, torch.Tensor) else bg, dtype=np.uint8).reshape(3))
+    return None, col.ctypes.data, col
+
+
+def is_pixel_inrange(img, bg, winsize=(20, 20, 120), out=None):
+    """Returns a (H, W) uint8 CUDA tensor: 1 where the pixel is within the HSV window of the background."""
+    H, W, _ = img.shape
+    pi = _dev_u8(img, "inrange.img", (H, W, 3))
+    bg_dev, bg_host, keep = _bg_args(bg, H, W)
+    win = (C.c_int * 3)(*[int(v) for v in winsize])
+    out = torch.empty((H, W), dtype=torch.uint8, device=img.device) if out is None else out
+    _check(load().usc_inrange_hsv_u8(pi, bg_dev, bg_host, win, H, W, _dev_u8(out, "inrange.out", (H, W)), _stream()),
+           "usc_inrange_hsv_u8")
+    return out
+
+
+def trimap_withbg(mask, img, bg, winsize=(10, 100, 180), long_side=960, ksize=3, iters=5, out=None, ws=None):
+    H, W = mask.shape
+    pm = _dev_u8(mask, "trimap_withbg.mask")
+    pi = _dev_u8(img, "trimap_withbg.img", (H, W, 3))
+    bg_dev, bg_host, keep = _bg_args(bg, H, W)
+    win = (C.c_int * 3)(*[int(v) for v in winsize])
+    out = torch.empty_like(mask) if out is None else out
+    need = load().usc_trimap_withbg_ws_bytes(H, W, int(long_side))
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, mask.device)
+    _check(load().usc_trimap_withbg_u8(pm, pi, bg_dev, bg_host, win, H, W, int(long_side), int(ksize), int(iters),
+                                       _dev_u8(out, "trimap_withbg.out", (H, W)), ws.data_ptr(), ws.numel(), _stream()),
+           "usc_trimap_withbg_u8")
     return out
 
 

@@ -484,6 +484,146 @@ extern "C" int usc_trimap_u8(const uint8_t* mask, int H, int W, int long_side, i
 }
 
 // --------------------------------------------------------------------------------------------
+// HSV in-range test and the background-aware trimap (green mode)
+// --------------------------------------------------------------------------------------------
+
+// Host copy of the 8-bit BGR -> HSV integer formula (one colour; the kernels use the same formula per pixel).
+static void host_bgr2hsv(int b, int g, int r, int* hsv) {
+    int v = b > g ? b : g; if (r > v) v = r;
+    int vmin = b < g ? b : g; if (r < vmin) vmin = r;
+    const int diff = v - vmin;
+    const int sdiv = v ? div_round_half_even(255 << 12, v) : 0;
+    const int hdiv = diff ? div_round_half_even((180 << 12) / 6, diff) : 0;
+    const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+    const int s = (diff * sdiv + (1 << 11)) >> 12;
+    int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    h = (h * hdiv + (1 << 11)) >> 12;
+    if (h < 0) h += 180;
+    hsv[0] = h < 0 ? 0 : (h > 255 ? 255 : h); hsv[1] = s; hsv[2] = v;
+}
+
+struct HsvRange { int lo[3], hi[3], half[3]; };
+
+// bgmask (1 byte / pixel: in range or not); optionally the (mask > 0) and fuzzy = (mask > 0) & bgmask counts.
+// 4 pixels per lane; per-wave ballots + one atomic pair per workgroup.
+__global__ __launch_bounds__(256) void inrange_hsv_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ bg_img,
+                                                          HsvRange rg, const uint8_t* __restrict__ mask, size_t n,
+                                                          uint8_t* __restrict__ out, unsigned long long* __restrict__ counts) {
+    __shared__ int s_sdiv[256], s_hdiv[256];
+    __shared__ unsigned int s_cnt[2];
+    load_hsv_tables(s_sdiv, s_hdiv);
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned int nm = 0, nf = 0;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t i0 = q * 4;
+        const int cnt = (int)min((size_t)4, n - i0);
+        uint32_t packed = 0;
+        for (int k = 0; k < cnt; k++) {
+            const size_t i = i0 + k;
+            int h, s, v, lo[3], hi[3];
+            bgr2hsv_u8(img[3 * i], img[3 * i + 1], img[3 * i + 2], s_sdiv, s_hdiv, h, s, v);
+            if (bg_img) {
+                int bh[3];
+                bgr2hsv_u8(bg_img[3 * i], bg_img[3 * i + 1], bg_img[3 * i + 2], s_sdiv, s_hdiv, bh[0], bh[1], bh[2]);
+#pragma unroll
+                for (int c = 0; c < 3; c++) { lo[c] = clampi(bh[c] - rg.half[c], 10, 255); hi[c] = clampi(bh[c] + rg.half[c], 10, 255); }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; c++) { lo[c] = rg.lo[c]; hi[c] = rg.hi[c]; }
+            }
+            const int in = (h >= lo[0] && h <= hi[0] && s >= lo[1] && s <= hi[1] && v >= lo[2] && v <= hi[2]) ? 1 : 0;
+            packed |= (uint32_t)in << (8 * k);
+            if (mask) { const int m = mask[i] > 0; nm += m; nf += m & in; }
+        }
+        if (cnt == 4) *reinterpret_cast<uint32_t*>(out + i0) = packed;
+        else for (int k = 0; k < cnt; k++) out[i0 + k] = (packed >> (8 * k)) & 0xff;
+    }
+    if (counts) {
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) { nm += __shfl_down(nm, off, kWave); nf += __shfl_down(nf, off, kWave); }
+        if ((threadIdx.x & (kWave - 1)) == 0) { atomicAdd(&s_cnt[0], nm); atomicAdd(&s_cnt[1], nf); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (s_cnt[0]) atomicAdd(&counts[0], (unsigned long long)s_cnt[0]);
+            if (s_cnt[1]) atomicAdd(&counts[1], (unsigned long long)s_cnt[1]);
+        }
+    }
+}
+
+// trimap/agent.py:94-100 on the device: counts decide (uniformly) whether the fuzzy pixels are cut out of the mask
+// before the trimap (mode 0) and forced to 128 after it (mode 1).  ratio = double(nf) / double(nm) > 0.1.
+__global__ __launch_bounds__(256) void fuzzy_apply_kernel(const uint8_t* __restrict__ mask, const uint8_t* __restrict__ bgmask,
+                                                          const unsigned long long* __restrict__ counts, size_t n, int mode,
+                                                          uint8_t* __restrict__ io) {
+    const unsigned long long nm = counts[0], nf = counts[1];
+    const bool trust_mask = nm == 0 || ((double)nf / (double)nm > 0.1);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const bool fuzzy = mask[i] > 0 && bgmask[i];
+        if (mode == 0) io[i] = (!trust_mask && fuzzy) ? 0 : mask[i];
+        else if (!trust_mask && fuzzy) io[i] = 128;
+    }
+}
+
+static int make_range(const uint8_t* bg_color_host, const int* winsize, HsvRange& rg) {
+    for (int c = 0; c < 3; c++) rg.half[c] = winsize[c] / 2;
+    if (bg_color_host) {
+        int hsv[3];
+        host_bgr2hsv(bg_color_host[0], bg_color_host[1], bg_color_host[2], hsv);
+        for (int c = 0; c < 3; c++) {
+            int lo = hsv[c] - rg.half[c], hi = hsv[c] + rg.half[c];
+            rg.lo[c] = lo < 10 ? 10 : (lo > 255 ? 255 : lo);
+            rg.hi[c] = hi < 10 ? 10 : (hi > 255 ? 255 : hi);
+        }
+    }
+    return 0;
+}
+
+extern "C" int usc_inrange_hsv_u8(const uint8_t* img, const uint8_t* bg_img, const uint8_t* bg_color_host, const int* winsize,
+                                  int H, int W, uint8_t* out, usc_stream_t stream) {
+    if (!img || !out || !winsize || H <= 0 || W <= 0 || (!bg_img == !bg_color_host))
+        return fail(USC_E_ARG, "usc_inrange_hsv_u8: need img, out, winsize and exactly one of bg_img / bg_color_host");
+    HsvRange rg;
+    make_range(bg_color_host, winsize, rg);
+    const size_t n = (size_t)H * W;
+    hipLaunchKernelGGL(inrange_hsv_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       img, bg_img, rg, (const uint8_t*)nullptr, n, out, (unsigned long long*)nullptr);
+    return check_launch("inrange_hsv_kernel");
+}
+
+extern "C" size_t usc_trimap_withbg_ws_bytes(int H, int W, int long_side) {
+    const size_t n = (((size_t)H * W) + 255) & ~(size_t)255;
+    return 256 + 2 * n + usc_trimap_ws_bytes(H, W, long_side);
+}
+
+extern "C" int usc_trimap_withbg_u8(const uint8_t* mask, const uint8_t* img, const uint8_t* bg_img, const uint8_t* bg_color_host,
+                                    const int* winsize, int H, int W, int long_side, int ksize, int iters, uint8_t* out,
+                                    void* ws, size_t ws_bytes, usc_stream_t stream) {
+    if (!mask || !img || !out || !winsize || H <= 0 || W <= 0 || (!bg_img == !bg_color_host))
+        return fail(USC_E_ARG, "usc_trimap_withbg_u8: bad argument");
+    if (!ws || ws_bytes < usc_trimap_withbg_ws_bytes(H, W, long_side)) return fail(USC_E_WORKSPACE, "usc_trimap_withbg_u8: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)H * W, npad = (n + 255) & ~(size_t)255;
+    unsigned long long* counts = (unsigned long long*)ws;
+    uint8_t* bgmask = (uint8_t*)ws + 256;
+    uint8_t* ens = bgmask + npad;
+    uint8_t* tws = ens + npad;
+    HsvRange rg;
+    make_range(bg_color_host, winsize, rg);
+    if (hipMemsetAsync(counts, 0, 16, st) != hipSuccess) return fail(USC_E_LAUNCH, "usc_trimap_withbg_u8: memset failed");
+    hipLaunchKernelGGL(inrange_hsv_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, st, img, bg_img, rg, mask, n, bgmask, counts);
+    int rc = check_launch("inrange_hsv_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(fuzzy_apply_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, mask, bgmask, counts, n, 0, ens);
+    rc = check_launch("fuzzy_apply_kernel");
+    if (rc) return rc;
+    rc = usc_trimap_u8(ens, H, W, long_side, ksize, iters, out, tws, ws_bytes - 256 - 2 * npad, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fuzzy_apply_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, mask, bgmask, counts, n, 1, out);
+    return check_launch("fuzzy_apply_kernel");
+}
+
+// --------------------------------------------------------------------------------------------
 // background fusion + difference mask
 // --------------------------------------------------------------------------------------------
 

@@ -27,8 +27,17 @@ class TrimapAgent():
         """mask (h, w) uint8 -> trimap with values {0, 128, 255} (reference agent.py:35-61)."""
         return to_host(self.forward_device(to_dev(mask)))
 
+    def forward_device_withbg(self, mask, img, bg, out=None):
+        """mask (H, W), img (H, W, 3) CUDA uint8; bg: CUDA (H, W, 3) image or a 3-value BGR colour."""
+        return nv.trimap_withbg(mask, img, bg, self.color_winsize, self.input_long_side, self.kernelsize, self.iters, out=out)
+
     def generate_trimap_withbg(self, mask, img, bgimg):
-        raise NotImplementedError("generate_trimap_withbg (green mode, reference agent.py:63-101) is not built yet")
+        """Background-aware trimap (reference agent.py:63-101).  Like the reference, an empty mask is returned as
+        the very same object."""
+        if (mask > 0).sum() == 0:
+            return mask
+        bg = to_dev(bgimg) if getattr(bgimg, "ndim", 1) == 3 else bgimg
+        return to_host(self.forward_device_withbg(to_dev(mask), to_dev(img), bg))
 
     def forward(self, *args, **kwargs):
         if len(args) > 2:

@@ -11,3 +11,12 @@ def get_fg(img, alpha, bg):
 def get_bg(alpha, bg):
     """(1 - alpha) * bg in HSV (reference fgfuncs.py:113-137)."""
     return to_host(nv.get_bg(to_dev(alpha), to_dev(bg)))
+
+
+def is_pixel_inrange(img, bgimg, winsize=(20, 20, 120), long_side_input=-1):
+    """Pixels within (bg - winsize//2, bg + winsize//2) in 8-bit HSV (reference fgfuncs.py:9-65); bool mask."""
+    if long_side_input > 0:
+        raise NotImplementedError("is_pixel_inrange with long_side_input > 0 (only get_fg_with_colorremove uses it) is not built")
+    assert bgimg.ndim == 3 or bgimg.ndim == 1
+    bg = to_dev(bgimg) if bgimg.ndim == 3 else bgimg
+    return to_host(nv.is_pixel_inrange(to_dev(img), bg, winsize)) > 0
