@@ -126,6 +126,21 @@ int usc_remove_invalid_objects_host(uint8_t* alpha, const uint8_t* seg, int H, i
                                     double* score_cache, int* score_cache_valid);
 
 /* ---------------------------------------------------------------------------------------------
+ * HumanSegAgent pre / post processing (reference unscreen/binseg/agent_human.py:262-312).
+ * usc_humanseg_affine (host, pure): :247-260 _xywh2cs for the whole-frame box + :91-125 get_affine_transform
+ *   (cv2.getAffineTransform = 6x6 LU in double); inv = 0 maps frame -> network input, inv = 1 the reverse.
+ * usc_humanseg_pre: :277-294 cv2.warpAffine(frame -> in_h x in_w, LINEAR, zero border) + imnormalize; writes NHWC
+ *   float32 with 4 channels (R, G, B, 0).
+ * usc_humanseg_post: :296-311 + transform_logits :58-73: logits (lh x lw, NHWC with Cbuf >= C channels per pixel)
+ *   -> bilinear align_corners to in_h x in_w -> inverse affine warp of every class to H x W -> argmax > 0 -> 255. */
+void   usc_humanseg_affine(int w, int h, int in_w, int in_h, int inv, double* M2x3);
+int    usc_humanseg_pre(const uint8_t* frame, int H, int W, int in_h, int in_w, float* out_nhwc4, usc_stream_t stream);
+size_t usc_humanseg_post_ws_bytes(int C, int in_h, int in_w);
+int    usc_humanseg_post(const float* logits, int C, int Cbuf, int lh, int lw, int in_h, int in_w, int H, int W,
+                         uint8_t* out, void* ws, size_t ws_bytes, usc_stream_t stream);
+const char* usc_seg_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
  * Matting network convolutions (reference unscreen/vmatting/model.py:435-568: every nn.Conv2d /
  * nn.ConvTranspose2d of ResShortCut + ResShortCut_Dec with its BatchNorm / activation / residual).
  * One descriptor = one fused layer on NHWC float32 tensors:
@@ -135,10 +150,11 @@ int usc_remove_invalid_objects_host(uint8_t* alpha, const uint8_t* seg, int H, i
  * for (oy, ox) in [0, OH) x [0, OW); out-of-image taps contribute zero.  Optional pointers may be NULL.
  * wpk is W padded to a multiple of 32 rows of k = t*Cin + ci and packed [k/4][Cout][4]
  * (kind USC_CONV_HEAD: plain [k], Cout = 1, and the (tanh(.)+1)/2 of model.py:566 is applied).
- * Cin must be a multiple of 4, Cout a multiple of 32 (or 1 for the head), ntaps <= 16. */
+ * Cin must be a power of two >= 4 or a multiple of 32, Cout a multiple of 32 (or 1 for the head), ntaps <= 16. */
 #define USC_ACT_NONE  0
 #define USC_ACT_RELU  1
 #define USC_ACT_LEAKY 2            /* LeakyReLU(0.2) */
+#define USC_ACT_LEAKY01 3          /* LeakyReLU(0.01): InPlaceABNSync of the human-parsing net */
 #define USC_CONV_MFMA 0
 #define USC_CONV_HEAD 1
 

@@ -44,6 +44,9 @@ def lib():
         _lib.orc_get_bg.argtypes = [u8p, u8p, C.c_size_t, u8p]
         _lib.orc_blend.argtypes = [u8p, u8p, C.c_int, u8p, C.c_size_t, u8p]
         _lib.orc_score_map.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, f64p]
+        _lib.orc_humanseg_post.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, u8p]
+        _lib.orc_upsample_ac_f32.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, f32p, C.c_int, C.c_int]
         _lib.orc_inrange_hsv.argtypes = [u8p, u8p, C.c_int, C.POINTER(C.c_int), C.c_size_t, u8p]
         _lib.orc_trimap_withbg.argtypes = [u8p, u8p, u8p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, u8p]
@@ -240,6 +243,54 @@ def trimap_withbg(mask, img, bg, winsize=(10, 100, 180), long_side=960, ksize=3,
     out = np.empty_like(mask)
     lib().orc_trimap_withbg(pm, pi, pb, 1 if bg.ndim == 3 else 0, win, mask.shape[0], mask.shape[1], int(long_side),
                             int(ksize), int(iters), out.ctypes.data_as(u8p))
+    return out
+
+
+def humanseg_affine(w, h, in_w=473, in_h=473, inv=False):
+    """agent_human.py:91-125 + :247-260 for the whole-frame box; returns the 2x3 float64 matrix."""
+    M = np.empty(6, np.float64)
+    lib().orc_humanseg_affine(int(w), int(h), int(in_w), int(in_h), int(bool(inv)), M.ctypes.data_as(f64p))
+    return M.reshape(2, 3)
+
+
+def warp_affine(img, M, dh, dw):
+    """cv2.warpAffine(img, M, (dw, dh), INTER_LINEAR, BORDER_CONSTANT 0) for uint8 / float32 HWC or HW arrays."""
+    M = np.ascontiguousarray(M, np.float64).reshape(6)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    if img.dtype == np.uint8:
+        img, p = _u8(img)
+        out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
+        lib().orc_warp_affine_u8(p, img.shape[0], img.shape[1], cn, M.ctypes.data_as(f64p), out.ctypes.data_as(u8p), dh, dw)
+        return out
+    img, p = _f32(img)
+    out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.float32)
+    lib().orc_warp_affine_f32(p, img.shape[0], img.shape[1], cn, M.ctypes.data_as(f64p), out.ctypes.data_as(f32p), dh, dw)
+    return out
+
+
+def upsample_align_corners(chw, oh, ow):
+    """torch Upsample(bilinear, align_corners=True): (C, h, w) float32 -> (oh, ow, C)."""
+    chw, p = _f32(chw)
+    Cn, ih, iw = chw.shape
+    out = np.empty((oh, ow, Cn), np.float32)
+    lib().orc_upsample_ac_f32(p, Cn, ih, iw, C.c_size_t(ih * iw), C.c_size_t(1), out.ctypes.data_as(f32p), oh, ow)
+    return out
+
+
+def humanseg_pre(frame, in_h=473, in_w=473):
+    """agent_human.py:277-294 -> (3, in_h, in_w) float32 (normalised RGB)."""
+    frame, p = _u8(frame)
+    out = np.empty((3, in_h, in_w), np.float32)
+    lib().orc_humanseg_pre(p, frame.shape[0], frame.shape[1], in_h, in_w, out.ctypes.data_as(f32p))
+    return out
+
+
+def humanseg_post(logits_chw, H, W, in_h=473, in_w=473):
+    """agent_human.py:296-311: (C, lh, lw) float32 logits -> (H, W) uint8 mask {0, 255}."""
+    logits_chw, p = _f32(logits_chw)
+    Cn, lh, lw = logits_chw.shape
+    out = np.empty((H, W), np.uint8)
+    lib().orc_humanseg_post(p, Cn, lh, lw, C.c_size_t(lh * lw), C.c_size_t(1), in_h, in_w, H, W, out.ctypes.data_as(u8p))
     return out
 
 

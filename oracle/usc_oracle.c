@@ -828,6 +828,214 @@ ORC_API int orc_remove_invalid_objects(uint8_t* alpha, const uint8_t* segmask, i
 }
 
 /* ------------------------------------------------------------------------------------------
+ * HumanSegAgent pre / post processing (unscreen/binseg/agent_human.py:262-312)
+ * ---------------------------------------------------------------------------------------- */
+
+/* cv::getAffineTransform: the 6x6 system [x y 1 0 0 0; 0 0 0 x y 1] solved by cv::solve(DECOMP_LU) in double
+ * (partial pivoting, d = -1/pivot elimination, back substitution).  src / dst: 3 points (x, y). */
+static void orc_get_affine_transform(const double* src, const double* dst, double* M)
+{
+    double a[36], b[6];
+    for (int i = 0; i < 3; i++) {
+        int j = i * 12, k = i * 12 + 6;
+        a[j] = a[k + 3] = src[2 * i];
+        a[j + 1] = a[k + 4] = src[2 * i + 1];
+        a[j + 2] = a[k + 5] = 1;
+        a[j + 3] = a[j + 4] = a[j + 5] = 0;
+        a[k] = a[k + 1] = a[k + 2] = 0;
+        b[i * 2] = dst[2 * i];
+        b[i * 2 + 1] = dst[2 * i + 1];
+    }
+    const int m = 6;
+    for (int i = 0; i < m; i++) {
+        int k = i;
+        for (int j = i + 1; j < m; j++) if (fabs(a[j * m + i]) > fabs(a[k * m + i])) k = j;
+        if (k != i) {
+            for (int j = i; j < m; j++) { double t = a[i * m + j]; a[i * m + j] = a[k * m + j]; a[k * m + j] = t; }
+            double t = b[i]; b[i] = b[k]; b[k] = t;
+        }
+        double d = -1 / a[i * m + i];
+        for (int j = i + 1; j < m; j++) {
+            double alpha = a[j * m + i] * d;
+            for (k = i + 1; k < m; k++) a[j * m + k] += alpha * a[i * m + k];
+            b[j] += alpha * b[i];
+        }
+    }
+    for (int i = m - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int k = i + 1; k < m; k++) s -= a[i * m + k] * b[k];
+        b[i] = s / a[i * m + i];
+    }
+    for (int i = 0; i < 6; i++) M[i] = b[i];
+}
+
+/* agent_human.py:247-260 _box2cs / _xywh2cs with box [0, 0, w-1, h-1] and aspect ratio 1, then
+ * :91-125 get_affine_transform(center, scale, rot = 0, output_size = (in_h, in_w), inv): the two point triangles
+ * (all coordinates are integers or half-integers, exact in float32) and cv2.getAffineTransform.
+ * M maps image -> network input when inv = 0, network input -> image when inv = 1. */
+ORC_API void orc_humanseg_affine(int w, int h, int in_w, int in_h, int inv, double* M)
+{
+    float cx = (float)(0 + (w - 1) * 0.5), cy = (float)(0 + (h - 1) * 0.5);
+    double bw = w - 1, bh = h - 1;
+    if (bw > 1.0 * bh) bh = bw * 1.0 / 1.0; else if (bw < 1.0 * bh) bw = bh * 1.0;
+    float src_w = (float)bw;
+    (void)bh;
+    double src_dir1 = (double)src_w * -0.5;                       /* rot = 0: src_dir = [0, -src_w / 2] */
+    float dst_dir1 = (float)((in_w - 1) * -0.5);
+    float s0x = cx, s0y = cy;
+    float s1x = (float)((double)cx + 0.0), s1y = (float)((double)cy + src_dir1);
+    float d0x = (float)((in_w - 1) * 0.5), d0y = (float)((in_h - 1) * 0.5);
+    float d1x = d0x + 0.f, d1y = d0y + dst_dir1;
+    /* get_3rd_point(a, b) = b + (-(a - b).y, (a - b).x) */
+    float s2x = s1x + -(s0y - s1y), s2y = s1y + (s0x - s1x);
+    float d2x = d1x + -(d0y - d1y), d2y = d1y + (d0x - d1x);
+    double src[6] = {s0x, s0y, s1x, s1y, s2x, s2y}, dst[6] = {d0x, d0y, d1x, d1y, d2x, d2y};
+    if (inv) orc_get_affine_transform(dst, src, M); else orc_get_affine_transform(src, dst, M);
+}
+
+/* cv::warpAffine without WARP_INVERSE_MAP first inverts the 2x3 matrix (in place, double). */
+static void orc_invert_affine(const double* Min, double* M)
+{
+    for (int i = 0; i < 6; i++) M[i] = Min[i];
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D;
+    M[3] *= -D; M[4] = A22;
+    double b1 = -M[0] * M[2] - M[1] * M[5];
+    double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+}
+
+/* Fixed-point source coordinate of destination pixel (x, y): 10-bit products, 5 fractional bits kept
+ * (cv::WarpAffineInvoker, AB_BITS = 10, INTER_BITS = 5, round_delta = 16). */
+static void orc_warp_coord(const double* M, int x, int y, int* sx, int* sy, int* fx, int* fy)
+{
+    int X0 = orc_round_i((M[1] * y + M[2]) * 1024) + 16, Y0 = orc_round_i((M[4] * y + M[5]) * 1024) + 16;
+    int X = (X0 + orc_round_i(M[0] * x * 1024)) >> 5, Y = (Y0 + orc_round_i(M[3] * x * 1024)) >> 5;
+    int ix = X >> 5, iy = Y >> 5;
+    *sx = ix < -32768 ? -32768 : (ix > 32767 ? 32767 : ix);
+    *sy = iy < -32768 ? -32768 : (iy > 32767 ? 32767 : iy);
+    *fx = X & 31; *fy = Y & 31;
+}
+
+/* cv2.warpAffine(img, M, (dw, dh), flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0) on uint8:
+ * 15-bit weights (32-fx)(32-fy)*32 ..., (sum + 2^14) >> 15; taps outside the image read 0. */
+ORC_API void orc_warp_affine_u8(const uint8_t* src, int sh, int sw, int cn, const double* Mfwd, uint8_t* dst, int dh, int dw)
+{
+    double M[6];
+    orc_invert_affine(Mfwd, M);
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            int sx, sy, fx, fy;
+            orc_warp_coord(M, x, y, &sx, &sy, &fx, &fy);
+            int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+            for (int c = 0; c < cn; c++) {
+                int v[4];
+                for (int t = 0; t < 4; t++) {
+                    int xx = sx + (t & 1), yy = sy + (t >> 1);
+                    v[t] = (xx >= 0 && xx < sw && yy >= 0 && yy < sh) ? src[((size_t)yy * sw + xx) * cn + c] : 0;
+                }
+                int r = (v[0] * w00 + v[1] * w01 + v[2] * w10 + v[3] * w11 + (1 << 14)) >> 15;
+                dst[((size_t)y * dw + x) * cn + c] = orc_sat_u8(r);
+            }
+        }
+}
+
+/* The float32 form (one channel of interleaved data): weights (1 - fy/32)(1 - fx/32) ... as float products,
+ * v0*w0 + v1*w1 + v2*w2 + v3*w3 summed left to right. */
+ORC_API void orc_warp_affine_f32(const float* src, int sh, int sw, int cn, const double* Mfwd, float* dst, int dh, int dw)
+{
+    double M[6];
+    orc_invert_affine(Mfwd, M);
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            int sx, sy, fx, fy;
+            orc_warp_coord(M, x, y, &sx, &sy, &fx, &fy);
+            float ax = fx * (1.f / 32), ay = fy * (1.f / 32);
+            float wx0 = 1.f - ax, wx1 = ax, wy0 = 1.f - ay, wy1 = ay;
+            float w[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
+            for (int c = 0; c < cn; c++) {
+                float v[4];
+                for (int t = 0; t < 4; t++) {
+                    int xx = sx + (t & 1), yy = sy + (t >> 1);
+                    v[t] = (xx >= 0 && xx < sw && yy >= 0 && yy < sh) ? src[((size_t)yy * sw + xx) * cn + c] : 0.f;
+                }
+                float r = v[0] * w[0];
+                r = r + v[1] * w[1];
+                r = r + v[2] * w[2];
+                r = r + v[3] * w[3];
+                dst[((size_t)y * dw + x) * cn + c] = r;
+            }
+        }
+}
+
+/* torch.nn.Upsample(size, mode='bilinear', align_corners=True) (agent_human.py:299-300), float32:
+ * src = dst * (in-1)/(out-1) in float, i = (int)src, lambda = src - i,
+ * val = h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11).  src: (C, ih, iw) planes with plane pitch `cstride`
+ * elements and pixel pitch `pstride` (NCHW: cstride = ih*iw, pstride = 1; NHWC: cstride = 1, pstride = C_buf).
+ * dst: (oh, ow, C) interleaved. */
+ORC_API void orc_upsample_ac_f32(const float* src, int C, int ih, int iw, size_t cstride, size_t pstride, float* dst, int oh, int ow)
+{
+    float rh = oh > 1 ? (float)(ih - 1) / (oh - 1) : 0.f, rw = ow > 1 ? (float)(iw - 1) / (ow - 1) : 0.f;
+    for (int y = 0; y < oh; y++) {
+        float h1r = rh * y;
+        int h1 = (int)h1r, h1p = h1 < ih - 1 ? 1 : 0;
+        float h1l = h1r - h1, h0l = 1.f - h1l;
+        for (int x = 0; x < ow; x++) {
+            float w1r = rw * x;
+            int w1 = (int)w1r, w1p = w1 < iw - 1 ? 1 : 0;
+            float w1l = w1r - w1, w0l = 1.f - w1l;
+            for (int c = 0; c < C; c++) {
+                const float* p = src + (size_t)c * cstride;
+                float v00 = p[((size_t)h1 * iw + w1) * pstride], v01 = p[((size_t)h1 * iw + w1 + w1p) * pstride];
+                float v10 = p[((size_t)(h1 + h1p) * iw + w1) * pstride], v11 = p[((size_t)(h1 + h1p) * iw + w1 + w1p) * pstride];
+                float top = w0l * v00 + w1l * v01, bot = w0l * v10 + w1l * v11;
+                dst[((size_t)y * ow + x) * C + c] = h0l * top + h1l * bot;
+            }
+        }
+    }
+}
+
+/* agent_human.py:277-294: warp the frame into the in_h x in_w network input (affine about the image centre,
+ * LINEAR, zero border), imnormalize (BGR->RGB, /255, -mean, *1/std), NCHW float32. */
+ORC_API void orc_humanseg_pre(const uint8_t* frame, int H, int W, int in_h, int in_w, float* out)
+{
+    static const double mean[3] = {0.485, 0.456, 0.406}, std[3] = {0.229, 0.224, 0.225};
+    double M[6];
+    orc_humanseg_affine(W, H, in_w, in_h, 0, M);
+    uint8_t* warped = (uint8_t*)malloc((size_t)in_h * in_w * 3);
+    orc_warp_affine_u8(frame, H, W, 3, M, warped, in_h, in_w);
+    size_t n = (size_t)in_h * in_w;
+    for (size_t i = 0; i < n; i++)
+        for (int c = 0; c < 3; c++) {
+            float x = (float)warped[3 * i + (2 - c)] / 255.f;
+            x = x - (float)mean[c];
+            out[(size_t)c * n + i] = x * (float)(1 / std[c]);
+        }
+    free(warped);
+}
+
+/* agent_human.py:296-311 + transform_logits :58-73: logits (C, lh, lw) -> bilinear (align_corners) to in_h x in_w ->
+ * per-channel inverse affine warp to the W x H frame -> argmax over channels (first maximum wins) -> 255 where > 0. */
+ORC_API void orc_humanseg_post(const float* logits, int C, int lh, int lw, size_t cstride, size_t pstride,
+                               int in_h, int in_w, int H, int W, uint8_t* out)
+{
+    double M[6];
+    orc_humanseg_affine(W, H, in_w, in_h, 1, M);
+    float* up = (float*)malloc(sizeof(float) * (size_t)in_h * in_w * C);
+    float* full = (float*)malloc(sizeof(float) * (size_t)H * W * C);
+    orc_upsample_ac_f32(logits, C, lh, lw, cstride, pstride, up, in_h, in_w);
+    orc_warp_affine_f32(up, in_h, in_w, C, M, full, H, W);
+    for (size_t i = 0; i < (size_t)H * W; i++) {
+        int best = 0;
+        for (int c = 1; c < C; c++) if (full[i * C + c] > full[i * C + best]) best = c;
+        out[i] = best > 0 ? 255 : 0;
+    }
+    free(up); free(full);
+}
+
+/* ------------------------------------------------------------------------------------------
  * one bg_step stage-3 frame, pixel stages only (tools/unscreen/bg_offline.py:145-176); the
  * matting network runs between pre and post and is supplied by the caller.
  * ---------------------------------------------------------------------------------------- */

@@ -3,6 +3,8 @@
 
   unet_64x96.npz        reference unscreen/vmatting/model.py UNet (loaded by file path; torch-only module) with
                         the keyed-deterministic checkpoint of video_unscreen_amd.vmatting.net.synthetic_state_dict
+  schp_97x129.npz       reference unscreen/binseg/human_parse.py network(num_classes=20) (loaded by file path) with the
+                        keyed-deterministic checkpoint of video_unscreen_amd.binseg.schp_net.schp_synthetic_state_dict
   target_size.npz       reference unscreen/utils/imgprocess.py get_target_size over a grid (function extracted
                         with ast; the module itself needs cv2)
   score_map.npz         reference unscreen/utils/maskprocess.py get_score_map / build_score_map / exist_foreground
@@ -66,6 +68,24 @@ def main():
     np.savez_compressed(os.path.join(HERE, "unet_64x96.npz"), y=y.numpy(), seed=1234,
                         y2_sub=y2.numpy()[:, :, ::4, ::4], seed2=99)
     print("unet", y.shape, float(y.min()), float(y.max()), float(y.std()))
+
+    # ---- 1b. SCHP human-parsing network
+    from video_unscreen_amd.binseg.schp_net import schp_checkpoint_layout, schp_synthetic_state_dict
+    spec = importlib.util.spec_from_file_location("ref_schp", os.path.join(REF, "unscreen/binseg/human_parse.py"))
+    hp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hp)
+    rnet = hp.network(num_classes=20, pretrained=None).eval()
+    rsd = rnet.state_dict()
+    lay = schp_checkpoint_layout()
+    assert [k for k, _ in lay] == list(rsd.keys()) and all(tuple(rsd[k].shape) == tuple(sh) for k, sh in lay)
+    rnet.load_state_dict(schp_synthetic_state_dict(0))
+    g = torch.Generator().manual_seed(4321)
+    xs = torch.randn(1, 3, 97, 129, generator=g)
+    with torch.no_grad():
+        ys = rnet(xs)
+    np.savez_compressed(os.path.join(HERE, "schp_97x129.npz"), y=ys.numpy(), seed=4321, n_keys=len(lay),
+                        keys_crc=np.int64(sum(__import__("zlib").crc32((k + str(tuple(sh))).encode()) for k, sh in lay)))
+    print("schp", ys.shape, float(ys.std()))
 
     # ---- 2. get_target_size
     ns = extract(os.path.join(REF, "unscreen/utils/imgprocess.py"), {"get_target_size"})

@@ -1,0 +1,85 @@
+"""GPU tests of the human-parsing segmentation stage (reference unscreen/binseg/agent_human.py + human_parse.py).
+Pre / post processing: bit-exact against the oracle (float32 with the same operation order; index mask exact GIVEN the
+same logits).  Network: the HIP convs against the folded plan on torch-CPU float32, relative tolerance 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nv():
+    assert torch.cuda.is_available()
+    from video_unscreen_amd import _native
+    _native.load()
+    return _native
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920), (2160, 3840), (256, 256), (1920, 1080), (33, 47), (473, 473)])
+def test_humanseg_pre_bit_exact(nv, oracle_lib, H, W):
+    img = np.random.default_rng(H * 7 + W).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    want = oracle_lib.humanseg_pre(img)                                   # (3, 473, 473)
+    got = nv.humanseg_pre(dev(img)).cpu().numpy()                         # (473, 473, 4)
+    assert np.array_equal(got[..., :3].transpose(2, 0, 1), want)          # float32, bit-exact
+    assert np.all(got[..., 3] == 0)
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920), (2160, 3840), (256, 256), (1920, 1080), (33, 47)])
+def test_humanseg_post_bit_exact(nv, oracle_lib, H, W):
+    rng = np.random.default_rng(H + W)
+    import scipy.ndimage as ndi
+    lg = ndi.gaussian_filter(rng.normal(size=(20, 119, 119)), (0, 6, 6)).astype(np.float32) * 20
+    lg[0] = lg[1:].max(0) + ndi.gaussian_filter(rng.normal(size=(119, 119)), 8).astype(np.float32) * 30   # ~half background
+    want = oracle_lib.humanseg_post(lg, H, W)
+    buf = np.zeros((119, 119, 32), np.float32)
+    buf[..., :20] = lg.transpose(1, 2, 0)
+    buf[..., 20:] = 1e9                                                   # padding channels must never be read
+    got = nv.humanseg_post(dev(buf), 20, H, W).cpu().numpy()
+    assert 0.02 < (want > 0).mean() < 0.98
+    assert np.array_equal(got, want), f"{(got != want).sum()} pixels differ"      # index mask: bit-exact
+
+
+@pytest.mark.parametrize("H,W", [(97, 129), (473, 473)])
+def test_schp_hip_convs_match_torch_plan(nv, H, W):
+    from video_unscreen_amd.binseg.schp_net import HipSchpNet, SchpNetTorch, schp_synthetic_state_dict
+    sd = schp_synthetic_state_dict(0)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 3, H, W, generator=g)
+    want = SchpNetTorch(sd)(x)[0].permute(1, 2, 0)                        # (h, w, 20) on the CPU, float32
+    net = HipSchpNet(sd, H, W)
+    x4 = torch.cat([x, torch.zeros(1, 1, H, W)], 1)[0].permute(1, 2, 0).contiguous().cuda()
+    got = net(x4).cpu()
+    assert got.shape[:2] == want.shape[:2]
+    err = float((got[..., :20] - want).abs().max() / want.abs().max())
+    assert err < 1e-4, err                                               # 150+ stacked f32 convs, different summation order
+    assert float(got[..., 20:].abs().max()) == 0.0                        # padded output channels stay zero
+    again = net(x4).cpu()
+    assert torch.equal(again, got)                                       # deterministic
+
+
+@pytest.mark.parametrize("H,W", [(270, 480), (1080, 1920)])
+def test_humanseg_agent_vs_oracle_chain(nv, oracle_lib, H, W):
+    """Whole agent vs oracle pre -> folded plan on torch-CPU -> oracle post.  The mask is an argmax of float logits,
+    so pixels whose top-2 margin is below the conv round-off may flip: bounded at 0.05 % here; given the SAME logits
+    the post-processing is bit-exact (test above)."""
+    from video_unscreen_amd.binseg import HumanSegAgent
+    from video_unscreen_amd.binseg.schp_net import SchpNetTorch
+    from video_unscreen_amd.synth import SyntheticClip
+    agent = HumanSegAgent(model_path=None)
+    frame = SyntheticClip(H, W, 1, config_id=2, device="cpu").frame(0)["frame"].numpy()
+    got = agent.forward(frame)
+    x = torch.from_numpy(oracle_lib.humanseg_pre(frame))[None]
+    logits = SchpNetTorch(agent.state_dict)(x)[0].numpy()
+    want = oracle_lib.humanseg_post(logits, H, W)
+    assert got.shape == (H, W) and got.dtype == np.uint8 and set(np.unique(got)) <= {0, 255}
+    assert 0.02 < (want > 0).mean() < 0.98
+    assert (got != want).mean() < 5e-4, (got != want).mean()
+    # and bit-exact when fed the device logits themselves
+    mask_dev, lg = agent.forward_device(dev(frame), return_logits=True)
+    want2 = oracle_lib.humanseg_post(lg.cpu().numpy()[..., :20].transpose(2, 0, 1), H, W)
+    assert np.array_equal(mask_dev.cpu().numpy(), want2)

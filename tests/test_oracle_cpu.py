@@ -168,3 +168,50 @@ def test_unet_restatement_matches_reference_golden():
     assert np.abs(y - z["y"]).max() < 1e-5
     y2 = net(unet_input(96, 160, int(z["seed2"]))).numpy()[:, :, ::4, ::4]
     assert np.abs(y2 - z["y2_sub"]).max() < 1e-5
+
+
+def test_schp_plan_matches_reference_golden():
+    """Folded SCHP plan (BN folded, dead heads dropped) on torch-CPU against the reference network's own output."""
+    import zlib
+    import torch
+    from video_unscreen_amd.binseg.schp_net import SchpNetTorch, schp_checkpoint_layout, schp_synthetic_state_dict
+    z = np.load(os.path.join(GOLD, "schp_97x129.npz"))
+    lay = schp_checkpoint_layout()
+    assert len(lay) == int(z["n_keys"])
+    assert sum(zlib.crc32((k + str(tuple(sh))).encode()) for k, sh in lay) == int(z["keys_crc"])    # reference key / shape list
+    g = torch.Generator().manual_seed(int(z["seed"]))
+    x = torch.randn(1, 3, 97, 129, generator=g)
+    y = SchpNetTorch(schp_synthetic_state_dict(0))(x).numpy()
+    assert np.abs(y - z["y"]).max() < 2e-5 * np.abs(z["y"]).max()
+    # a DataParallel-style checkpoint (module.* keys, agent_human.py:141-148) loads the same way
+    sd = {"module." + k: v for k, v in schp_synthetic_state_dict(0).items()}
+    y2 = SchpNetTorch(sd)(x).numpy()
+    assert np.array_equal(y, y2)
+
+
+def test_humanseg_affine_and_warps(oracle_lib):
+    """Whole-frame affine (agent_human.py:91-125, 247-260): uniform scale about the centre, letterboxed."""
+    for (w, h) in ((1920, 1080), (1080, 1920), (256, 256), (47, 33)):
+        M = oracle_lib.humanseg_affine(w, h)
+        a = 472.0 / (max(w, h) - 1)
+        assert abs(M[0, 0] - a) < 1e-12 and abs(M[1, 1] - a) < 1e-12 and abs(M[0, 1]) < 1e-12 and abs(M[1, 0]) < 1e-12
+        assert abs(M[0, 2] - (236 - a * (w - 1) / 2)) < 1e-9 and abs(M[1, 2] - (236 - a * (h - 1) / 2)) < 1e-9
+        Mi = oracle_lib.humanseg_affine(w, h, inv=True)
+        full = np.vstack([M, [0, 0, 1]]) @ np.vstack([Mi, [0, 0, 1]])
+        assert np.abs(full - np.eye(3)).max() < 1e-9
+    # identity warp reproduces the image; a one-pixel shift moves it; outside reads 0
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    I = np.array([[1, 0, 0], [0, 1, 0]], float)
+    assert np.array_equal(oracle_lib.warp_affine(img, I, 20, 30), img)
+    S = np.array([[1, 0, 1], [0, 1, 0]], float)
+    sh = oracle_lib.warp_affine(img, S, 20, 30)
+    assert np.array_equal(sh[:, 1:], img[:, :-1]) and np.all(sh[:, 0] == 0)
+    f = rng.random((20, 30)).astype(np.float32)
+    assert np.array_equal(oracle_lib.warp_affine(f, I, 20, 30), f)
+    half = oracle_lib.warp_affine(f, np.array([[1, 0, 0.5], [0, 1, 0]], float), 20, 30)
+    assert np.allclose(half[:, 1:], 0.5 * (f[:, :-1] + f[:, 1:]), atol=1e-6)
+    # align_corners upsample hits the source samples exactly on the coarse grid
+    lg = rng.normal(size=(5, 7, 9)).astype(np.float32)
+    up = oracle_lib.upsample_align_corners(lg, 13, 17)
+    assert np.array_equal(up[::2, ::2].transpose(2, 0, 1), lg)

@@ -45,6 +45,12 @@ _SIGNATURES = {
     "usc_count_ge_u8": (C.c_int, [_vp, C.c_size_t, C.c_int, _vp, _vp]),
     "usc_remove_invalid_objects_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                   C.c_double, _vp, C.POINTER(C.c_int)]),
+    "usc_humanseg_affine": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "usc_humanseg_pre": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "usc_humanseg_post_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "usc_humanseg_post": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
+                                    C.c_size_t, _vp]),
+    "usc_seg_last_error": (C.c_char_p, []),
     "usc_conv_sequence_f32": (C.c_int, [_vp, C.c_int, _vp]),
     "usc_conv_last_error": (C.c_char_p, []),
     "usc_conv_graph_create": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
@@ -263,6 +269,39 @@ def count_ge(mask, thr=128, out=None):
     pm = _dev_u8(mask, "count_ge.mask")
     out = torch.empty(1, dtype=torch.int64, device=mask.device) if out is None else out
     _check(load().usc_count_ge_u8(pm, mask.numel(), int(thr), out.data_ptr(), _stream()), "usc_count_ge_u8")
+    return out
+
+
+def humanseg_affine(w, h, in_w=473, in_h=473, inv=False):
+    M = (C.c_double * 6)()
+    load().usc_humanseg_affine(int(w), int(h), int(in_w), int(in_h), int(bool(inv)), M)
+    return np.array(M[:], np.float64).reshape(2, 3)
+
+
+def humanseg_pre(frame, in_h=473, in_w=473, out=None):
+    """frame (H, W, 3) uint8 CUDA -> (in_h, in_w, 4) float32 NHWC (normalised R, G, B, 0)."""
+    H, W, _ = frame.shape
+    pf = _dev_u8(frame, "humanseg_pre.frame", (H, W, 3))
+    out = torch.empty((in_h, in_w, 4), dtype=torch.float32, device=frame.device) if out is None else out
+    rc = load().usc_humanseg_pre(pf, H, W, int(in_h), int(in_w), out.data_ptr(), _stream())
+    if rc != 0:
+        raise NativeError(f"usc_humanseg_pre failed ({rc}): {load().usc_seg_last_error().decode()}")
+    return out
+
+
+def humanseg_post(logits, C_classes, H, W, in_h=473, in_w=473, out=None, ws=None):
+    """logits: (lh, lw, Cbuf) float32 NHWC CUDA buffer whose first C_classes channels are the classes -> (H, W) uint8."""
+    if not (logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous() and logits.dim() == 3):
+        raise NativeError("humanseg_post.logits: expected a contiguous (lh, lw, C) float32 CUDA tensor")
+    lh, lw, cbuf = logits.shape
+    out = torch.empty((H, W), dtype=torch.uint8, device=logits.device) if out is None else out
+    need = load().usc_humanseg_post_ws_bytes(int(C_classes), int(in_h), int(in_w))
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, logits.device)
+    rc = load().usc_humanseg_post(logits.data_ptr(), int(C_classes), cbuf, lh, lw, int(in_h), int(in_w), H, W,
+                                  _dev_u8(out, "humanseg_post.out", (H, W)), ws.data_ptr(), ws.numel(), _stream())
+    if rc != 0:
+        raise NativeError(f"usc_humanseg_post failed ({rc}): {load().usc_seg_last_error().decode()}")
     return out
 
 

@@ -1,0 +1,49 @@
+"""HumanSegAgent: same constructor and forward() as the reference (unscreen/binseg/agent_human.py:128-157, 262-312).
+
+forward(img) = affine-warp the whole frame into the 473 x 473 network input, SCHP human parsing, bilinear
+(align_corners) upsample of the 20 class logits, inverse affine warp back to the frame, argmax > 0 -> 255.
+Pre- and post-processing are HIP kernels (csrc/usc_seg.hip); every convolution of the network runs on the
+f32-MFMA kernel (schp_net.HipSchpNet).  Like the reference, this agent has no CPU path (agent_human.py:141, 295).
+"""
+import torch
+
+from .. import _native as nv
+from ..utils._dev import device, to_dev, to_host
+from .schp_net import NUM_CLASSES, HipSchpNet, schp_synthetic_state_dict, strip_module_prefix
+
+INPUT_SIZE = (473, 473)            # dataset_settings['lip']['input_size'] (agent_human.py:19-31)
+
+
+class HumanSegAgent():
+    def __init__(self, model_path=None, input_long_side=912, downscale=1, crop_h=473, crop_w=473,
+                 stride_ratio=1 / 2., flip=True, cuda_device=0):
+        self.input_size = INPUT_SIZE
+        self.model_path = model_path
+        self.cuda_device = cuda_device if cuda_device is not None and cuda_device >= 0 else 0
+        self.device = device(self.cuda_device)
+        if model_path is None or model_path == "synthetic":
+            sd = schp_synthetic_state_dict(0)          # no trained checkpoint exists offline
+        else:
+            sd = strip_module_prefix(torch.load(model_path, map_location="cpu"))   # DataParallel keys: module.*
+        self.state_dict = sd
+        self.net = HipSchpNet(sd, INPUT_SIZE[0], INPUT_SIZE[1], device=self.device)
+        # kept for signature compatibility; the reference's forward() does not use them either (agent_human.py:277-312)
+        self.crop_h, self.crop_w, self.flip = crop_h, crop_w, flip
+        self.input_long_side, self.stride_ratio, self.division = input_long_side, stride_ratio, 1
+        self._ws = None
+
+    def forward_device(self, img, out=None, return_logits=False):
+        """img: (H, W, 3) uint8 BGR CUDA tensor -> (H, W) uint8 mask {0, 255} on the device."""
+        H, W, _ = img.shape
+        nv.humanseg_pre(img, INPUT_SIZE[0], INPUT_SIZE[1], out=self.net.x4)
+        logits = self.net.forward(None)
+        need = nv.load().usc_humanseg_post_ws_bytes(NUM_CLASSES, INPUT_SIZE[0], INPUT_SIZE[1])
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        mask = nv.humanseg_post(logits, NUM_CLASSES, H, W, INPUT_SIZE[0], INPUT_SIZE[1], out=out, ws=self._ws)
+        return (mask, logits) if return_logits else mask
+
+    def forward(self, img):
+        """img (h, w, 3) uint8 BGR -> (h, w) uint8, 255 = person (reference agent_human.py:262-312)."""
+        with torch.cuda.device(self.device):
+            return to_host(self.forward_device(to_dev(img, self.device)))

@@ -1,0 +1,397 @@
+"""SCHP / CE2P human-parsing network (deep-stem ResNet-101, PSP context, edge branch, fusion head) as a folded
+inference plan: reference unscreen/binseg/human_parse.py:194-265 (`ResNet`), :42-80 (`Bottleneck`), :83-111
+(`PSPModule`), :114-156 (`EdgeModule`), :159-191 (`DecoderModule`), :25-39 (`InPlaceABNSync` = BN + LeakyReLU(0.01)).
+
+Only what reaches the returned tensor is kept: `fusion_result` (human_parse.py:265).  The edge maps (edge.conv4/5)
+and the parsing head (decoder.conv4) are computed by the reference and thrown away, so they are not built.
+
+* `schp_checkpoint_layout()` reproduces the reference state-dict keys (722 tensors); the checkpoint the reference
+  loads carries a `module.` prefix from nn.DataParallel (agent_human.py:141-148) - both spellings are accepted.
+* `SchpPlan` folds every BatchNorm into its conv; `SchpNetTorch` runs the plan with torch ops (CPU oracle of the
+  network / MIOpen path); `HipSchpNet` runs every convolution on csrc/usc_conv.hip.
+"""
+import ctypes as C
+import zlib
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+LAYERS = (3, 4, 23, 3)
+PLANES = (64, 128, 256, 512)
+STRIDES = (1, 2, 2, 1)
+DILATIONS = (1, 1, 1, 2)
+PSP_SIZES = (1, 2, 3, 6)
+NUM_CLASSES = 20
+
+
+def _bn(prefix, c):
+    return [(prefix + ".weight", (c,)), (prefix + ".bias", (c,)), (prefix + ".running_mean", (c,)),
+            (prefix + ".running_var", (c,)), (prefix + ".num_batches_tracked", ())]
+
+
+def schp_checkpoint_layout():
+    """Ordered (key, shape) list of the reference network's state dict."""
+    k = [("conv1.weight", (64, 3, 3, 3))] + _bn("bn1", 64) + [("conv2.weight", (64, 64, 3, 3))] + _bn("bn2", 64) + \
+        [("conv3.weight", (128, 64, 3, 3))] + _bn("bn3", 128)
+    inpl = 128
+    for li, (n, planes, stride) in enumerate(zip(LAYERS, PLANES, STRIDES), start=1):
+        for b in range(n):
+            p = f"layer{li}.{b}."
+            k += [(p + "conv1.weight", (planes, inpl, 1, 1))] + _bn(p + "bn1", planes)
+            k += [(p + "conv2.weight", (planes, planes, 3, 3))] + _bn(p + "bn2", planes)
+            k += [(p + "conv3.weight", (planes * 4, planes, 1, 1))] + _bn(p + "bn3", planes * 4)
+            if b == 0 and (stride != 1 or inpl != planes * 4):
+                k += [(p + "downsample.0.weight", (planes * 4, inpl, 1, 1))] + _bn(p + "downsample.1", planes * 4)
+            inpl = planes * 4
+    for i in range(4):
+        k += [(f"context_encoding.stages.{i}.1.weight", (512, 2048, 1, 1))] + _bn(f"context_encoding.stages.{i}.2.bn", 512)
+    k += [("context_encoding.bottleneck.0.weight", (512, 4096, 3, 3))] + _bn("context_encoding.bottleneck.1.bn", 512)
+    for i, cin in enumerate((256, 512, 1024), start=1):
+        k += [(f"edge.conv{i}.0.weight", (256, cin, 1, 1))] + _bn(f"edge.conv{i}.1.bn", 256)
+    k += [("edge.conv4.weight", (2, 256, 3, 3)), ("edge.conv4.bias", (2,)), ("edge.conv5.weight", (2, 6, 1, 1)), ("edge.conv5.bias", (2,))]
+    k += [("decoder.conv1.0.weight", (256, 512, 1, 1))] + _bn("decoder.conv1.1.bn", 256)
+    k += [("decoder.conv2.0.weight", (48, 256, 1, 1))] + _bn("decoder.conv2.1.bn", 48)
+    k += [("decoder.conv3.0.weight", (256, 304, 1, 1))] + _bn("decoder.conv3.1.bn", 256)
+    k += [("decoder.conv3.2.weight", (256, 256, 1, 1))] + _bn("decoder.conv3.3.bn", 256)
+    k += [("decoder.conv4.weight", (NUM_CLASSES, 256, 1, 1)), ("decoder.conv4.bias", (NUM_CLASSES,))]
+    k += [("fushion.0.weight", (256, 1024, 1, 1))] + _bn("fushion.1.bn", 256)
+    k += [("fushion.3.weight", (NUM_CLASSES, 256, 1, 1)), ("fushion.3.bias", (NUM_CLASSES,))]
+    return k
+
+
+_SYNTH = {}
+
+
+def schp_synthetic_state_dict(seed=0):
+    """Keyed-deterministic weights (no trained checkpoint exists offline).  The last BN of every bottleneck gets a
+    small gamma so 33 residual blocks of random weights do not blow the activations up."""
+    if seed not in _SYNTH:
+        sd = OrderedDict()
+        for key, shape in schp_checkpoint_layout():
+            g = torch.Generator().manual_seed((zlib.crc32(key.encode()) ^ seed ^ 0x5c4b) & 0x7FFFFFFF)
+            if key.endswith("num_batches_tracked"):
+                t = torch.tensor(1000, dtype=torch.long)
+            elif key.endswith("running_var"):
+                t = 0.6 + 0.8 * torch.rand(shape, generator=g)
+            elif key.endswith("running_mean"):
+                t = 0.1 * torch.randn(shape, generator=g)
+            elif key.endswith("bn3.weight"):
+                t = 0.15 + 0.1 * torch.rand(shape, generator=g)
+            elif key.endswith(".weight") and len(shape) == 1:
+                t = 0.8 + 0.4 * torch.rand(shape, generator=g)
+            elif key.endswith(".bias"):
+                t = 0.05 * torch.randn(shape, generator=g)
+            else:
+                fan_in = shape[1] * shape[2] * shape[3]
+                t = torch.randn(shape, generator=g) * (1.6 / fan_in) ** 0.5
+                if key == "fushion.3.weight":
+                    t = t * 4.0
+            sd[key] = t
+        _SYNTH[seed] = sd
+        # Random features have a large constant component, so one class would win everywhere.  Calibrate the
+        # background bias on a fixed seeded input until background and person classes split the image about evenly:
+        # the mask (argmax > 0) then depends on the input, which is what the parity tests need.
+        from ..synth import SyntheticClip                     # a smooth frame with a textured blob, like the clips
+        fr = SyntheticClip(128, 160, 1, config_id=2, device="cpu").frame(0)["frame"].float()
+        probe = fr.permute(2, 0, 1)[None].flip(1) / 255.
+        probe = (probe - torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+        o = SchpNetTorch(sd)(probe)
+        margin = (o[:, 0] - o[:, 1:].max(1)[0]).flatten()
+        sd["fushion.3.bias"][0] -= margin.median()
+    return OrderedDict((k, v.clone()) for k, v in _SYNTH[seed].items())
+
+
+def strip_module_prefix(sd):
+    if all(k.startswith("module.") for k in sd):
+        return OrderedDict((k[len("module."):], v) for k, v in sd.items())
+    return sd
+
+
+class FConv:
+    """conv + folded BN (+ activation): w (Cout, Cin, k, k), b (Cout,)."""
+
+    def __init__(self, w, b, stride=1, pad=0, dil=1, act="none"):
+        self.w, self.b, self.stride, self.pad, self.dil, self.act = w, b, stride, pad, dil, act
+
+    def torch_forward(self, x, residual=None):
+        y = F.conv2d(x, self.w.to(x.device), self.b.to(x.device), stride=self.stride, padding=self.pad, dilation=self.dil)
+        if residual is not None:
+            y = y + residual
+        if self.act == "relu":
+            y = F.relu(y)
+        elif self.act == "leaky01":
+            y = F.leaky_relu(y, 0.01)
+        return y
+
+
+def _fold(sd, conv_key, bn_prefix, **kw):
+    w = sd[conv_key].double()
+    g, b = sd[bn_prefix + ".weight"].double(), sd[bn_prefix + ".bias"].double()
+    m, v = sd[bn_prefix + ".running_mean"].double(), sd[bn_prefix + ".running_var"].double()
+    s = g / torch.sqrt(v + BN_EPS)
+    return FConv((w * s.view(-1, 1, 1, 1)).float(), (b - m * s).float(), **kw)
+
+
+class SchpPlan:
+    def __init__(self, state_dict):
+        sd = strip_module_prefix(state_dict)
+        self.stem = [_fold(sd, "conv1.weight", "bn1", stride=2, pad=1, act="relu"),
+                     _fold(sd, "conv2.weight", "bn2", pad=1, act="relu"),
+                     _fold(sd, "conv3.weight", "bn3", pad=1, act="relu")]
+        self.layers = []
+        for li, (n, stride, dil) in enumerate(zip(LAYERS, STRIDES, DILATIONS), start=1):
+            blocks = []
+            for b in range(n):
+                p = f"layer{li}.{b}."
+                blk = {"c1": _fold(sd, p + "conv1.weight", p + "bn1", act="relu"),
+                       "c2": _fold(sd, p + "conv2.weight", p + "bn2", stride=stride if b == 0 else 1, pad=dil, dil=dil, act="relu"),
+                       "c3": _fold(sd, p + "conv3.weight", p + "bn3", act="relu"),          # relu after the residual add
+                       "down": None}
+                if (p + "downsample.0.weight") in sd:
+                    blk["down"] = _fold(sd, p + "downsample.0.weight", p + "downsample.1", stride=stride)
+                blocks.append(blk)
+            self.layers.append(blocks)
+        self.psp = [_fold(sd, f"context_encoding.stages.{i}.1.weight", f"context_encoding.stages.{i}.2.bn", act="leaky01") for i in range(4)]
+        self.psp_bottleneck = _fold(sd, "context_encoding.bottleneck.0.weight", "context_encoding.bottleneck.1.bn", pad=1, act="leaky01")
+        self.edge = [_fold(sd, f"edge.conv{i}.0.weight", f"edge.conv{i}.1.bn", act="leaky01") for i in (1, 2, 3)]
+        self.dec1 = _fold(sd, "decoder.conv1.0.weight", "decoder.conv1.1.bn", act="leaky01")
+        self.dec2 = _fold(sd, "decoder.conv2.0.weight", "decoder.conv2.1.bn", act="leaky01")
+        self.dec3a = _fold(sd, "decoder.conv3.0.weight", "decoder.conv3.1.bn", act="leaky01")
+        self.dec3b = _fold(sd, "decoder.conv3.2.weight", "decoder.conv3.3.bn", act="leaky01")
+        self.fuse1 = _fold(sd, "fushion.0.weight", "fushion.1.bn", act="leaky01")
+        self.fuse2 = FConv(sd["fushion.3.weight"].float().clone(), sd["fushion.3.bias"].float().clone())
+
+
+def _interp(x, size):
+    return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+
+
+class SchpNetTorch:
+    """The folded plan on torch ops: forward((1, 3, H, W) normalised RGB) -> (1, 20, ~H/4, ~W/4) logits."""
+
+    def __init__(self, state_dict, device="cpu"):
+        self.plan = SchpPlan(state_dict)
+        self.device = torch.device(device)
+
+    @torch.no_grad()
+    def forward(self, x):
+        p = self.plan
+        x = x.to(self.device, torch.float32)
+        for c in p.stem:
+            x = c.torch_forward(x)
+        x = F.max_pool2d(x, 3, 2, 1)
+        feats = []
+        for blocks in p.layers:
+            for blk in blocks:
+                idt = blk["down"].torch_forward(x) if blk["down"] is not None else x
+                y = blk["c1"].torch_forward(x)
+                y = blk["c2"].torch_forward(y)
+                x = blk["c3"].torch_forward(y, residual=idt)
+            feats.append(x)
+        x2, x3, x4, x5 = feats
+        h, w = x5.shape[2:]
+        priors = [_interp(c.torch_forward(F.adaptive_avg_pool2d(x5, s)), (h, w)) for c, s in zip(p.psp, PSP_SIZES)] + [x5]
+        ctx = p.psp_bottleneck.torch_forward(torch.cat(priors, 1))
+        h2, w2 = x2.shape[2:]
+        xt = _interp(p.dec1.torch_forward(ctx), (h2, w2))
+        xl = p.dec2.torch_forward(x2)
+        parsing_fea = p.dec3b.torch_forward(p.dec3a.torch_forward(torch.cat([xt, xl], 1)))
+        e1 = p.edge[0].torch_forward(x2)
+        e2 = _interp(p.edge[1].torch_forward(x3), (h2, w2))
+        e3 = _interp(p.edge[2].torch_forward(x4), (h2, w2))
+        fused = p.fuse1.torch_forward(torch.cat([parsing_fea, e1, e2, e3], 1))
+        return p.fuse2.torch_forward(fused)
+
+    __call__ = forward
+
+
+# --------------------------------------------------------------------------------------------
+# HIP executor
+# --------------------------------------------------------------------------------------------
+
+def _out_size(n, k, stride, pad, dil):
+    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+class HipSchpNet:
+    """Every convolution on the f32-MFMA kernel (csrc/usc_conv.hip), NHWC buffers; pooling / bilinear glue between
+    conv segments stays on torch ops (a handful of tiny tensors)."""
+
+    def __init__(self, state_dict, H=473, W=473, device="cuda:0"):
+        from .. import _native as nv
+        from ..vmatting.net_hip import ConvDesc, conv_taps, pack_k_major
+        self.nv, self.ConvDesc, self.conv_taps, self.pack = nv, ConvDesc, conv_taps, pack_k_major
+        nv.load()
+        self.device = torch.device(device)
+        self.H, self.W = H, W
+        self.plan = SchpPlan(state_dict)
+        self._keep = []
+        self.slab = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=self.device)
+        self._slab_used = 0
+        self._segments = []            # list of ("conv", ctypes array, n) | ("glue", callable)
+        self._cur = []
+        self._build()
+
+    # ---- buffers / descriptors
+    def _buf(self, h, w, c):
+        t = torch.empty((h, w, c), dtype=torch.float32, device=self.device)
+        self._keep.append(t)
+        return t
+
+    def _dev(self, t):
+        t = t.detach().to(self.device, torch.float32).contiguous()
+        self._keep.append(t)
+        return t
+
+    @staticmethod
+    def nchw(buf):
+        """(H, W, C) NHWC buffer viewed as a channels-last (1, C, H, W) tensor (no copy)."""
+        return buf.permute(2, 0, 1).unsqueeze(0)
+
+    def _conv(self, c, x, IH, IW, cin_buf, out=None, res1=None, act=None, cout_pad=None):
+        """x: (IH, IW, cin_buf) buffer; cin_buf >= c.w.shape[1] (extra channels must be zero-weighted)."""
+        w = c.w
+        co, ci, k, _ = w.shape
+        if cin_buf != ci:
+            w = F.pad(w, (0, 0, 0, 0, 0, cin_buf - ci))
+        b = c.b
+        if cout_pad and cout_pad != co:
+            w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - co))
+            b = F.pad(b, (0, cout_pad - co))
+            co = cout_pad
+        taps = [((ky - (k // 2)) * c.dil, (kx - (k // 2)) * c.dil) for ky in range(k) for kx in range(k)] if k > 1 else [(0, 0)]
+        if k > 1:
+            assert c.pad == c.dil * (k // 2)
+        wk = w.permute(2, 3, 1, 0).reshape(k * k * cin_buf, co)
+        OH, OW = _out_size(IH, k, c.stride, c.pad, c.dil), _out_size(IW, k, c.stride, c.pad, c.dil)
+        out = out if out is not None else self._buf(OH, OW, co)
+        d = self.ConvDesc()
+        d.inp, d.out = x.data_ptr(), out.data_ptr()
+        d.wpk = self._dev(self.pack(wk.float())).data_ptr()
+        d.bias = self._dev(b).data_ptr()
+        d.res1 = res1.data_ptr() if res1 is not None else None
+        d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = IH, IW, cin_buf, OH, OW, OH, OW, co
+        d.in_stride, d.out_stride = c.stride, 1
+        d.act = {"none": 0, "relu": 1, "leaky": 2, "leaky01": 3}[act or c.act]
+        d.ntaps, d.kind, d.nphase = len(taps), 0, 1
+        need = 16 * OH * OW * co * 4
+        if self._slab_used + need <= self.slab.numel() * 4:
+            d.slab, d.slab_bytes = self.slab.data_ptr() + self._slab_used, need
+            self._slab_used += need
+        for i, (dy, dx) in enumerate(taps):
+            d.dy[i], d.dx[i] = dy, dx
+        self._cur.append(d)
+        return out, OH, OW
+
+    def _flush(self):
+        if self._cur:
+            arr = (self.ConvDesc * len(self._cur))(*self._cur)
+            handle = C.c_void_p()
+            rc = self.nv.load().usc_conv_graph_create(arr, len(self._cur), C.byref(handle))
+            if rc != 0:
+                raise self.nv.NativeError(f"usc_conv_graph_create failed ({rc}): {self.nv.load().usc_conv_last_error().decode()}")
+            self._segments.append(("conv", handle, arr))
+            self._cur = []
+
+    def _glue(self, fn):
+        self._flush()
+        self._segments.append(("glue", fn, None))
+
+    # ---- graph
+    def _build(self):
+        p, H, W = self.plan, self.H, self.W
+        self.x4 = self._buf(H, W, 4)                                   # RGB + one zero channel
+        t, h, w = self._conv(p.stem[0], self.x4, H, W, 4)
+        t, h, w = self._conv(p.stem[1], t, h, w, 64)
+        t, h, w = self._conv(p.stem[2], t, h, w, 64)
+        ph, pw = _out_size(h, 3, 2, 1, 1), _out_size(w, 3, 2, 1, 1)
+        pooled = self._buf(ph, pw, 128)
+        src = t
+        self._glue(lambda: self.nchw(pooled).copy_(F.max_pool2d(self.nchw(src), 3, 2, 1)))
+        t, h, w = pooled, ph, pw
+        feats = []
+        for blocks in p.layers:
+            for blk in blocks:
+                cin = t.shape[2]
+                if blk["down"] is not None:
+                    idt, _, _ = self._conv(blk["down"], t, h, w, cin)
+                else:
+                    idt = t
+                y, _, _ = self._conv(blk["c1"], t, h, w, cin)
+                y, h2, w2 = self._conv(blk["c2"], y, h, w, y.shape[2])
+                t, h, w = self._conv(blk["c3"], y, h2, w2, y.shape[2], res1=idt)
+            feats.append((t, h, w))
+        (x2, h2, w2), (x3, h3, w3), (x4, h4, w4), (x5, h5, w5) = feats
+        # PSP: adaptive pools (tiny) -> 1x1 conv + ABN -> bilinear (align_corners) back to h5 x w5, concat with x5
+        cat5 = self._buf(h5, w5, 4096)
+        pools = [self._buf(s, s, 2048) for s in PSP_SIZES]
+
+        def pool_all():
+            for s, pb in zip(PSP_SIZES, pools):
+                self.nchw(pb).copy_(F.adaptive_avg_pool2d(self.nchw(x5), s))
+        self._glue(pool_all)
+        stage_out = [self._conv(c, pb, s, s, 2048)[0] for c, pb, s in zip(p.psp, pools, PSP_SIZES)]
+
+        def assemble5():
+            dst = self.nchw(cat5)
+            for i, so in enumerate(stage_out):
+                dst[:, 512 * i:512 * (i + 1)].copy_(_interp(self.nchw(so), (h5, w5)))
+            dst[:, 2048:].copy_(self.nchw(x5))
+        self._glue(assemble5)
+        ctx, _, _ = self._conv(p.psp_bottleneck, cat5, h5, w5, 4096)
+        d1, _, _ = self._conv(p.dec1, ctx, h5, w5, 512)
+        xl, _, _ = self._conv(p.dec2, x2, h2, w2, 256, cout_pad=64)       # 48 real channels + 16 zeros
+        e1, _, _ = self._conv(p.edge[0], x2, h2, w2, 256)
+        e2, _, _ = self._conv(p.edge[1], x3, h3, w3, 512)
+        e3, _, _ = self._conv(p.edge[2], x4, h4, w4, 1024)
+        cat_dec = self._buf(h2, w2, 320)
+        cat_fuse = self._buf(h2, w2, 1024)
+
+        def assemble_dec():
+            dst = self.nchw(cat_dec)
+            dst[:, :256].copy_(_interp(self.nchw(d1), (h2, w2)))
+            dst[:, 256:].copy_(self.nchw(xl))
+            f = self.nchw(cat_fuse)
+            f[:, 256:512].copy_(self.nchw(e1))
+            f[:, 512:768].copy_(_interp(self.nchw(e2), (h2, w2)))
+            f[:, 768:].copy_(_interp(self.nchw(e3), (h2, w2)))
+        self._glue(assemble_dec)
+        # decoder.conv3: 304 input channels in the reference = 256 + 48; here 256 + 64 with zero weights for the pad
+        w3a = self.plan.dec3a.w
+        dec3a = FConv(torch.cat([w3a, w3a.new_zeros(w3a.shape[0], 16, 1, 1)], 1), self.plan.dec3a.b, act="leaky01")
+        y, _, _ = self._conv(dec3a, cat_dec, h2, w2, 320)
+        fea_view = self._buf(h2, w2, 256)
+        self._conv(p.dec3b, y, h2, w2, 256, out=fea_view)
+        self._glue(lambda: self.nchw(cat_fuse)[:, :256].copy_(self.nchw(fea_view)))
+        y, _, _ = self._conv(p.fuse1, cat_fuse, h2, w2, 1024)
+        self.logits32, _, _ = self._conv(p.fuse2, y, h2, w2, 256, cout_pad=32)
+        self._flush()
+        self.out_h, self.out_w = h2, w2
+
+    def forward(self, x4=None):
+        """x4: (H, W, 4) float32 NHWC normalised RGB + zero channel (or None if the caller wrote self.x4).
+        Returns the (out_h, out_w, 32) logits buffer: channels 0..19 are the classes."""
+        if x4 is not None and x4.data_ptr() != self.x4.data_ptr():
+            self.x4.copy_(x4)
+        st = torch.cuda.current_stream().cuda_stream
+        lib = self.nv.load()
+        for kind, a, b in self._segments:
+            if kind == "conv":
+                rc = lib.usc_conv_graph_launch(a, st)
+                if rc != 0:
+                    raise self.nv.NativeError(f"conv launch failed ({rc}): {lib.usc_conv_last_error().decode()}")
+            else:
+                a()
+        return self.logits32
+
+    __call__ = forward
+
+    def __del__(self):
+        try:
+            for kind, a, b in getattr(self, "_segments", []):
+                if kind == "conv" and a:
+                    self.nv.load().usc_conv_graph_destroy(a)
+        except Exception:
+            pass

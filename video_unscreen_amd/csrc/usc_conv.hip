@@ -57,7 +57,6 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
     const float* __restrict__ wpk = d.wpk + (size_t)ph * d.wphase_stride;
     const int out_py = d.nphase > 1 ? (ph >> 1) : d.out_py, out_px = d.nphase > 1 ? (ph & 1) : d.out_px;
 
-    if (d.reserved & 8) return;                                  // debug probe: launch cost only
 
     // ---- per-tile tables, one output pixel per thread (tid < 128), everything that does not change from K step
     // to K step: byte offset of the pixel's row in the output / residual tensors, byte offset of its (0,0) tap in
@@ -109,7 +108,8 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
 
     // ---- staging assignment: thread -> (4 pixels 32 apart, one float4 of the 32-wide K slice)
     const int q = tid & 7;
-    const int log2cin = 31 - __builtin_clz(d.Cin);           // Cin is a power of two (checked by the host)
+    const bool cin_pow2 = (d.Cin & (d.Cin - 1)) == 0;
+    const int log2cin = 31 - __builtin_clz(d.Cin);
     int vbase[4];
     unsigned vmask[4];
 #pragma unroll
@@ -133,8 +133,10 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
     auto load_chunk = [&](int c, float4 (&ra)[4], float4 (&rb)[NT]) {
         const bool live = c < c_end;
         const int k0 = c * KC + 4 * q;
-        const int tap = k0 >> log2cin;                          // >= ntaps in the zero-padded K tail: mask bit is 0
-        const int koff = ((d.reserved & 1) ? 0 : s_toff[tap & 15]) + ((k0 & (d.Cin - 1)) << 2);   // reserved&1: debug probe
+        // tap of this thread's float4: a shift when Cin is a power of two (a 32-wide K slice may then span several
+        // taps, Cin = 4 / 8 / 16); otherwise Cin is a multiple of 32 and the whole slice lies in one tap
+        const int tap = cin_pow2 ? (k0 >> log2cin) : (c * KC) / d.Cin;      // >= ntaps in the zero-padded K tail: mask bit is 0
+        const int koff = s_toff[tap & 15] + ((k0 - tap * d.Cin) << 2);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const bool ok = live && ((vmask[j] >> tap) & 1u);
@@ -179,7 +181,6 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
         }
     };
 
-    if (d.reserved & 4) return;                                  // debug probe: prologue only
     load_chunk(c_begin, ra0, rb0);
     load_chunk(c_begin + 1, ra1, rb1);
     store_chunk(0, ra0, rb0);
@@ -196,7 +197,6 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
         __syncthreads();
     }
     if (c < c_end) compute(0);          // odd chunk count: the last chunk is already staged in buffer 0
-    if (d.reserved & 2) { if (acc[0][0] == 123.456f) d.out[0] = 1.f; return; }   // debug probe: no epilogue
 
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
     // 32-bit byte offsets + buffer instructions: rows past the end of the image carry an out-of-range offset and
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
             v += r1v[r];
             if (d.act == USC_ACT_RELU) v = fmaxf(v, 0.f);
             else if (d.act == USC_ACT_LEAKY) v = v > 0.f ? v : v * 0.2f;
+            else if (d.act == USC_ACT_LEAKY01) v = v > 0.f ? v : v * 0.01f;
             if (has_aff) v = v * sc + sh;
             v += r2v[r];
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), out_rsrc, ops[r] + nb4, 0, 0);
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(usc_conv_desc d) {
             if (has_r1) x += d.res1[ro + k];
             if (d.act == USC_ACT_RELU) x = fmaxf(x, 0.f);
             else if (d.act == USC_ACT_LEAKY) x = x > 0.f ? x : x * 0.2f;
+            else if (d.act == USC_ACT_LEAKY01) x = x > 0.f ? x : x * 0.01f;
             if (has_aff) x = x * d.scale[n + k] + d.shift[n + k];
             if (has_r2) x += d.res2[o + k];
             a[k] = x;
@@ -370,7 +372,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
         return USC_OK;
     }
     if (d.Cout % 32) return conv_fail(USC_E_UNSUPPORTED, "usc_conv: Cout must be a multiple of 32");
-    if (d.Cin & (d.Cin - 1)) return conv_fail(USC_E_UNSUPPORTED, "usc_conv: Cin must be a power of two");
+    if ((d.Cin & (d.Cin - 1)) && d.Cin % 32) return conv_fail(USC_E_UNSUPPORTED, "usc_conv: Cin must be a power of two or a multiple of 32");
     if ((long long)d.IH * d.IW * d.Cin * 4 >= 0x7fff0000ll || (long long)d.OHf * d.OWf * d.Cout * 4 >= 0x7fff0000ll)
         return conv_fail(USC_E_UNSUPPORTED, "usc_conv: tensor >= 2 GiB");
     const int nphase = d.nphase > 1 ? d.nphase : 1;

@@ -1,0 +1,239 @@
+// usc_seg.hip - pre / post processing of the human-parsing segmentation stage
+// (reference unscreen/binseg/agent_human.py:262-312, transform_logits :58-73, get_affine_transform :91-125).
+//
+//   pre : affine warp of the BGR frame into the 473 x 473 network input (cv2.warpAffine fixed-point coordinates and
+//         15-bit bilinear weights, zero border) fused with imnormalize; output NHWC with 4 channels (R, G, B, 0) so the
+//         first convolution reads 16-byte pixels.
+//   post: (1) torch Upsample(bilinear, align_corners=True) of the 20 class logits to 473 x 473, channel-interleaved
+//         so the 20 values of one tap are 80 contiguous bytes; (2) one lane per frame pixel: inverse affine warp of
+//         all 20 channels (float bilinear, zero border) + argmax + (> 0 -> 255).  The reference materialises a
+//         H x W x 20 float tensor on the CPU for this (166 MB at 1080p, 663 MB at 4K); here it never exists.
+// All coordinate math follows cv::WarpAffineInvoker (AB_BITS = 10, INTER_BITS = 5) in double / int on the device.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/unscreen_hip.h"
+
+namespace {
+
+thread_local char g_seg_err[256] = "";
+int seg_fail(int code, const char* msg) { snprintf(g_seg_err, sizeof(g_seg_err), "%s", msg); return code; }
+
+struct Affine { double m[6]; };
+
+// cv::getAffineTransform = cv::solve(DECOMP_LU) of the 6x6 system, in double.
+void get_affine_transform(const double* src, const double* dst, double* M) {
+    double a[36], b[6];
+    for (int i = 0; i < 3; i++) {
+        const int j = i * 12, k = i * 12 + 6;
+        a[j] = a[k + 3] = src[2 * i];
+        a[j + 1] = a[k + 4] = src[2 * i + 1];
+        a[j + 2] = a[k + 5] = 1;
+        a[j + 3] = a[j + 4] = a[j + 5] = 0;
+        a[k] = a[k + 1] = a[k + 2] = 0;
+        b[2 * i] = dst[2 * i];
+        b[2 * i + 1] = dst[2 * i + 1];
+    }
+    for (int i = 0; i < 6; i++) {
+        int piv = i;
+        for (int j = i + 1; j < 6; j++) if (fabs(a[j * 6 + i]) > fabs(a[piv * 6 + i])) piv = j;
+        if (piv != i) {
+            for (int j = i; j < 6; j++) { const double t = a[i * 6 + j]; a[i * 6 + j] = a[piv * 6 + j]; a[piv * 6 + j] = t; }
+            const double t = b[i]; b[i] = b[piv]; b[piv] = t;
+        }
+        const double d = -1 / a[i * 6 + i];
+        for (int j = i + 1; j < 6; j++) {
+            const double alpha = a[j * 6 + i] * d;
+            for (int k = i + 1; k < 6; k++) a[j * 6 + k] += alpha * a[i * 6 + k];
+            b[j] += alpha * b[i];
+        }
+    }
+    for (int i = 5; i >= 0; i--) {
+        double s = b[i];
+        for (int k = i + 1; k < 6; k++) s -= a[i * 6 + k] * b[k];
+        b[i] = s / a[i * 6 + i];
+    }
+    for (int i = 0; i < 6; i++) M[i] = b[i];
+}
+
+void invert_affine(const double* in, double* M) {       // cv::warpAffine without WARP_INVERSE_MAP
+    for (int i = 0; i < 6; i++) M[i] = in[i];
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D;
+    M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5];
+    const double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+}
+
+__device__ __forceinline__ void warp_coord(const Affine& A, int x, int y, int& sx, int& sy, int& fx, int& fy) {
+    const int X0 = __double2int_rn((A.m[1] * y + A.m[2]) * 1024) + 16, Y0 = __double2int_rn((A.m[4] * y + A.m[5]) * 1024) + 16;
+    const int X = (X0 + __double2int_rn(A.m[0] * x * 1024)) >> 5, Y = (Y0 + __double2int_rn(A.m[3] * x * 1024)) >> 5;
+    sx = min(max(X >> 5, -32768), 32767);
+    sy = min(max(Y >> 5, -32768), 32767);
+    fx = X & 31; fy = Y & 31;
+}
+
+__global__ __launch_bounds__(256) void seg_pre_kernel(const uint8_t* __restrict__ frame, int H, int W, Affine A, int in_h, int in_w,
+                                                      float* __restrict__ out, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int n = in_h * in_w;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int y = i / in_w, x = i - y * in_w;
+        int sx, sy, fx, fy;
+        warp_coord(A, x, y, sx, sy, fx, fy);
+        const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+        int bgr[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            int v[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int xx = sx + (t & 1), yy = sy + (t >> 1);
+                v[t] = (xx >= 0 && xx < W && yy >= 0 && yy < H) ? frame[((size_t)yy * W + xx) * 3 + c] : 0;
+            }
+            const int r = (v[0] * w00 + v[1] * w01 + v[2] * w10 + v[3] * w11 + (1 << 14)) >> 15;
+            bgr[c] = min(max(r, 0), 255);
+        }
+        float4 o;
+        o.x = ((float)bgr[2] / 255.f - m0) * s0;
+        o.y = ((float)bgr[1] / 255.f - m1) * s1;
+        o.z = ((float)bgr[0] / 255.f - m2) * s2;
+        o.w = 0.f;
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+}
+
+// torch upsample_bilinear2d (align_corners = True): src = dst * (in-1)/(out-1) in float.
+__global__ __launch_bounds__(256) void seg_up_kernel(const float* __restrict__ logits, int C, int Cbuf, int lh, int lw,
+                                                     float* __restrict__ up, int oh, int ow, float rh, float rw) {
+    const int n = oh * ow * C;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int c = i % C, p = i / C;
+        const int y = p / ow, x = p - y * ow;
+        const float h1r = rh * y, w1r = rw * x;
+        const int h1 = (int)h1r, w1 = (int)w1r;
+        const int h1p = h1 < lh - 1 ? 1 : 0, w1p = w1 < lw - 1 ? 1 : 0;
+        const float h1l = h1r - h1, h0l = 1.f - h1l, w1l = w1r - w1, w0l = 1.f - w1l;
+        const float v00 = logits[((size_t)h1 * lw + w1) * Cbuf + c], v01 = logits[((size_t)h1 * lw + w1 + w1p) * Cbuf + c];
+        const float v10 = logits[((size_t)(h1 + h1p) * lw + w1) * Cbuf + c], v11 = logits[((size_t)(h1 + h1p) * lw + w1 + w1p) * Cbuf + c];
+        const float top = w0l * v00 + w1l * v01, bot = w0l * v10 + w1l * v11;
+        up[i] = h0l * top + h1l * bot;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void seg_warp_argmax_kernel(const float* __restrict__ up, int in_h, int in_w, Affine A,
+                                                              uint8_t* __restrict__ out, int H, int W) {
+    const uint32_t n = (uint32_t)H * (uint32_t)W;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += gridDim.x * blockDim.x) {
+        const uint32_t i0 = q * 4;
+        uint32_t y = i0 / (uint32_t)W, x = i0 - y * (uint32_t)W;
+        const int cnt = (int)min(4u, n - i0);
+        uint32_t packed = 0;
+        for (int k = 0; k < cnt; k++) {
+            int sx, sy, fx, fy;
+            warp_coord(A, (int)x, (int)y, sx, sy, fx, fy);
+            const float ax = fx * (1.f / 32), ay = fy * (1.f / 32);
+            const float wx0 = 1.f - ax, wx1 = ax, wy0 = 1.f - ay, wy1 = ay;
+            const float w0 = wy0 * wx0, w1 = wy0 * wx1, w2 = wy1 * wx0, w3 = wy1 * wx1;
+            const bool in0 = sx >= 0 && sx < in_w, in1 = sx + 1 >= 0 && sx + 1 < in_w;
+            const bool jn0 = sy >= 0 && sy < in_h, jn1 = sy + 1 >= 0 && sy + 1 < in_h;
+            const int cx0 = min(max(sx, 0), in_w - 1), cx1 = min(max(sx + 1, 0), in_w - 1);
+            const int cy0 = min(max(sy, 0), in_h - 1), cy1 = min(max(sy + 1, 0), in_h - 1);
+            const float4* p00 = reinterpret_cast<const float4*>(up + ((size_t)cy0 * in_w + cx0) * C);
+            const float4* p01 = reinterpret_cast<const float4*>(up + ((size_t)cy0 * in_w + cx1) * C);
+            const float4* p10 = reinterpret_cast<const float4*>(up + ((size_t)cy1 * in_w + cx0) * C);
+            const float4* p11 = reinterpret_cast<const float4*>(up + ((size_t)cy1 * in_w + cx1) * C);
+            const float m00 = (in0 && jn0) ? 1.f : 0.f, m01 = (in1 && jn0) ? 1.f : 0.f, m10 = (in0 && jn1) ? 1.f : 0.f, m11 = (in1 && jn1) ? 1.f : 0.f;
+            float best = 0.f;
+            int besti = 0;
+#pragma unroll
+            for (int c4 = 0; c4 < C / 4; c4++) {
+                const float4 a = p00[c4], b = p01[c4], c = p10[c4], d = p11[c4];
+                const float va[4] = {a.x, a.y, a.z, a.w}, vb[4] = {b.x, b.y, b.z, b.w}, vc[4] = {c.x, c.y, c.z, c.w}, vd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    // out-of-image taps read the border value 0 (select, not multiply: -0 / NaN safe)
+                    const float t0 = m00 != 0.f ? va[e] : 0.f, t1 = m01 != 0.f ? vb[e] : 0.f;
+                    const float t2 = m10 != 0.f ? vc[e] : 0.f, t3 = m11 != 0.f ? vd[e] : 0.f;
+                    float r = t0 * w0;
+                    r = r + t1 * w1;
+                    r = r + t2 * w2;
+                    r = r + t3 * w3;
+                    const int ci = c4 * 4 + e;
+                    if (ci == 0 || r > best) { best = r; besti = ci; }       // np.argmax: the first maximum wins
+                }
+            }
+            packed |= (uint32_t)(besti > 0 ? 255 : 0) << (8 * k);
+            if (++x == (uint32_t)W) { x = 0; y++; }
+        }
+        if (cnt == 4) *reinterpret_cast<uint32_t*>(out + i0) = packed;
+        else for (int k = 0; k < cnt; k++) out[i0 + k] = (packed >> (8 * k)) & 0xff;
+    }
+}
+
+int grid_for(long long items, int threads) {
+    long long b = (items + threads - 1) / threads;
+    if (b < 1) b = 1;
+    if (b > 256 * 16) b = 256 * 16;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" const char* usc_seg_last_error(void) { return g_seg_err; }
+
+extern "C" void usc_humanseg_affine(int w, int h, int in_w, int in_h, int inv, double* M) {
+    // agent_human.py:247-260 (box [0, 0, w-1, h-1], aspect ratio 1) and :91-125 (rot = 0, shift = 0): every triangle
+    // coordinate is an integer or half-integer, so the float32 arrays of the reference hold them exactly.
+    const float cx = (float)((w - 1) * 0.5), cy = (float)((h - 1) * 0.5);
+    const double side = (w - 1) > (h - 1) ? (w - 1) : (h - 1);
+    const float src_w = (float)side;
+    const float s0x = cx, s0y = cy, s1x = cx, s1y = (float)((double)cy + (double)src_w * -0.5);
+    const float d0x = (float)((in_w - 1) * 0.5), d0y = (float)((in_h - 1) * 0.5);
+    const float d1x = d0x, d1y = d0y + (float)((in_w - 1) * -0.5);
+    const float s2x = s1x + -(s0y - s1y), s2y = s1y + (s0x - s1x);
+    const float d2x = d1x + -(d0y - d1y), d2y = d1y + (d0x - d1x);
+    const double src[6] = {s0x, s0y, s1x, s1y, s2x, s2y}, dst[6] = {d0x, d0y, d1x, d1y, d2x, d2y};
+    if (inv) get_affine_transform(dst, src, M); else get_affine_transform(src, dst, M);
+}
+
+extern "C" int usc_humanseg_pre(const uint8_t* frame, int H, int W, int in_h, int in_w, float* out_nhwc4, usc_stream_t stream) {
+    if (!frame || !out_nhwc4 || H <= 0 || W <= 0 || in_h <= 0 || in_w <= 0) return seg_fail(USC_E_ARG, "usc_humanseg_pre: bad argument");
+    if ((long long)H * W >= (1ll << 29)) return seg_fail(USC_E_UNSUPPORTED, "usc_humanseg_pre: image too large");
+    double M[6];
+    Affine A;
+    usc_humanseg_affine(W, H, in_w, in_h, 0, M);
+    invert_affine(M, A.m);
+    static const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+    hipLaunchKernelGGL(seg_pre_kernel, dim3(grid_for((long long)in_h * in_w, 256)), dim3(256), 0, (hipStream_t)stream, frame, H, W, A,
+                       in_h, in_w, out_nhwc4, (float)mean[0], (float)mean[1], (float)mean[2],
+                       (float)(1 / stdv[0]), (float)(1 / stdv[1]), (float)(1 / stdv[2]));
+    return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "seg_pre_kernel launch failed");
+}
+
+extern "C" size_t usc_humanseg_post_ws_bytes(int C, int in_h, int in_w) { return (size_t)in_h * in_w * C * sizeof(float); }
+
+extern "C" int usc_humanseg_post(const float* logits, int C, int Cbuf, int lh, int lw, int in_h, int in_w, int H, int W,
+                                 uint8_t* out, void* ws, size_t ws_bytes, usc_stream_t stream) {
+    if (!logits || !out || !ws || lh <= 0 || lw <= 0 || H <= 0 || W <= 0 || in_h <= 1 || in_w <= 1 || Cbuf < C)
+        return seg_fail(USC_E_ARG, "usc_humanseg_post: bad argument");
+    if (C != 20) return seg_fail(USC_E_UNSUPPORTED, "usc_humanseg_post: built for the 20 LIP classes");
+    if (ws_bytes < usc_humanseg_post_ws_bytes(C, in_h, in_w)) return seg_fail(USC_E_WORKSPACE, "usc_humanseg_post: workspace too small");
+    if ((long long)H * W >= (1ll << 31)) return seg_fail(USC_E_UNSUPPORTED, "usc_humanseg_post: image too large");
+    hipStream_t st = (hipStream_t)stream;
+    float* up = (float*)ws;
+    const float rh = (float)(lh - 1) / (in_h - 1), rw = (float)(lw - 1) / (in_w - 1);
+    hipLaunchKernelGGL(seg_up_kernel, dim3(grid_for((long long)in_h * in_w * C, 256)), dim3(256), 0, st, logits, C, Cbuf, lh, lw, up, in_h, in_w, rh, rw);
+    if (hipGetLastError() != hipSuccess) return seg_fail(USC_E_LAUNCH, "seg_up_kernel launch failed");
+    double M[6];
+    Affine A;
+    usc_humanseg_affine(W, H, in_w, in_h, 1, M);
+    invert_affine(M, A.m);
+    hipLaunchKernelGGL(seg_warp_argmax_kernel<20>, dim3(grid_for(((long long)H * W + 3) / 4, 256)), dim3(256), 0, st, up, in_h, in_w, A, out, H, W);
+    return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "seg_warp_argmax_kernel launch failed");
+}
