@@ -138,6 +138,10 @@ int    usc_humanseg_pre(const uint8_t* frame, int H, int W, int in_h, int in_w, 
 size_t usc_humanseg_post_ws_bytes(int C, int in_h, int in_w);
 int    usc_humanseg_post(const float* logits, int C, int Cbuf, int lh, int lw, int in_h, int in_w, int H, int W,
                          uint8_t* out, void* ws, size_t ws_bytes, usc_stream_t stream);
+/* F.interpolate(bilinear, align_corners=True) of an NHWC float32 tensor (sh x sw x C) into channels [c0, c0 + C) of a
+ * (dh x dw x ld) tensor: the glue between the conv segments of the parsing net (human_parse.py:108, 147-150, 186). */
+int    usc_upsample_ac_nhwc_f32(const float* src, int sh, int sw, int C, float* dst, int dh, int dw, int ld, int c0,
+                                usc_stream_t stream);
 const char* usc_seg_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -148,6 +152,7 @@ const char* usc_seg_last_error(void);
  *                             + bias[n] + res1[Y >> res1_shift, X >> res1_shift, n] ) ) + res2[Y, X, n]
  *   (Y, X) = (oy*out_stride + out_py, ox*out_stride + out_px),  post(v) = v*scale[n] + shift[n]
  * for (oy, ox) in [0, OH) x [0, OW); out-of-image taps contribute zero.  Optional pointers may be NULL.
+ * `in` (and res1 / res2) may themselves be channel slices of wider tensors only if dense; `out` may be a slice (out_ld).
  * wpk is W padded to a multiple of 32 rows of k = t*Cin + ci and packed [k/4][Cout][4]
  * (kind USC_CONV_HEAD: plain [k], Cout = 1, and the (tanh(.)+1)/2 of model.py:566 is applied).
  * Cin must be a power of two >= 4 or a multiple of 32, Cout a multiple of 32 (or 1 for the head), ntaps <= 16. */
@@ -185,6 +190,8 @@ typedef struct usc_conv_desc {
     int reserved;
     float* slab;                   /* optional scratch for split-K partial sums (small-M layers), may be NULL */
     size_t slab_bytes;
+    int out_ld, out_c0;            /* 0 / 0: `out` is a dense [pixel][Cout] tensor; otherwise `out` has out_ld channels per pixel
+                                      and this layer writes channels [out_c0, out_c0 + Cout) (concat buffers) */
 } usc_conv_desc;
 
 /* Enqueue `n` layers in order on `stream` (one kernel launch each, no host synchronisation). */

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "usc_humanseg_post_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "usc_humanseg_post": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
                                     C.c_size_t, _vp]),
+    "usc_upsample_ac_nhwc_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "usc_seg_last_error": (C.c_char_p, []),
     "usc_conv_sequence_f32": (C.c_int, [_vp, C.c_int, _vp]),
     "usc_conv_last_error": (C.c_char_p, []),
@@ -270,6 +271,16 @@ def count_ge(mask, thr=128, out=None):
     out = torch.empty(1, dtype=torch.int64, device=mask.device) if out is None else out
     _check(load().usc_count_ge_u8(pm, mask.numel(), int(thr), out.data_ptr(), _stream()), "usc_count_ge_u8")
     return out
+
+
+def upsample_ac(src, dst, c0=0):
+    """src (sh, sw, C) -> channels [c0, c0+C) of dst (dh, dw, ld), both contiguous float32 CUDA NHWC buffers."""
+    sh, sw, Cn = src.shape
+    dh, dw, ld = dst.shape
+    rc = load().usc_upsample_ac_nhwc_f32(src.data_ptr(), sh, sw, Cn, dst.data_ptr(), dh, dw, ld, int(c0), _stream())
+    if rc != 0:
+        raise NativeError(f"usc_upsample_ac_nhwc_f32 failed ({rc}): {load().usc_seg_last_error().decode()}")
+    return dst
 
 
 def humanseg_affine(w, h, in_w=473, in_h=473, inv=False):

@@ -250,7 +250,7 @@ class HipSchpNet:
         """(H, W, C) NHWC buffer viewed as a channels-last (1, C, H, W) tensor (no copy)."""
         return buf.permute(2, 0, 1).unsqueeze(0)
 
-    def _conv(self, c, x, IH, IW, cin_buf, out=None, res1=None, act=None, cout_pad=None):
+    def _conv(self, c, x, IH, IW, cin_buf, out=None, res1=None, act=None, cout_pad=None, out_ld=0, out_c0=0):
         """x: (IH, IW, cin_buf) buffer; cin_buf >= c.w.shape[1] (extra channels must be zero-weighted)."""
         w = c.w
         co, ci, k, _ = w.shape
@@ -276,6 +276,7 @@ class HipSchpNet:
         d.in_stride, d.out_stride = c.stride, 1
         d.act = {"none": 0, "relu": 1, "leaky": 2, "leaky01": 3}[act or c.act]
         d.ntaps, d.kind, d.nphase = len(taps), 0, 1
+        d.out_ld, d.out_c0 = out_ld, out_c0
         need = 16 * OH * OW * co * 4
         if self._slab_used + need <= self.slab.numel() * 4:
             d.slab, d.slab_bytes = self.slab.data_ptr() + self._slab_used, need
@@ -312,8 +313,11 @@ class HipSchpNet:
         self._glue(lambda: self.nchw(pooled).copy_(F.max_pool2d(self.nchw(src), 3, 2, 1)))
         t, h, w = pooled, ph, pw
         feats = []
-        for blocks in p.layers:
-            for blk in blocks:
+        nv = self.nv
+        cat5 = None
+        nlayers = len(p.layers)
+        for li, blocks in enumerate(p.layers):
+            for bi, blk in enumerate(blocks):
                 cin = t.shape[2]
                 if blk["down"] is not None:
                     idt, _, _ = self._conv(blk["down"], t, h, w, cin)
@@ -321,50 +325,48 @@ class HipSchpNet:
                     idt = t
                 y, _, _ = self._conv(blk["c1"], t, h, w, cin)
                 y, h2, w2 = self._conv(blk["c2"], y, h, w, y.shape[2])
-                t, h, w = self._conv(blk["c3"], y, h2, w2, y.shape[2], res1=idt)
+                last = li == nlayers - 1 and bi == len(blocks) - 1
+                if last:                       # x5 goes straight into channels [2048, 4096) of the PSP concat buffer
+                    cat5 = self._buf(h2, w2, 4096)
+                    self._conv(blk["c3"], y, h2, w2, y.shape[2], out=cat5, res1=idt, out_ld=4096, out_c0=2048)
+                    t, h, w = None, h2, w2
+                else:
+                    t, h, w = self._conv(blk["c3"], y, h2, w2, y.shape[2], res1=idt)
             feats.append((t, h, w))
-        (x2, h2, w2), (x3, h3, w3), (x4, h4, w4), (x5, h5, w5) = feats
-        # PSP: adaptive pools (tiny) -> 1x1 conv + ABN -> bilinear (align_corners) back to h5 x w5, concat with x5
-        cat5 = self._buf(h5, w5, 4096)
+        (x2, h2, w2), (x3, h3, w3), (x4, h4, w4), (_, h5, w5) = feats
+        x5_view = self.nchw(cat5)[:, 2048:]                            # (1, 2048, h5, w5) strided view, no copy
+        # PSP: adaptive pools (tiny) -> 1x1 conv + ABN -> bilinear (align_corners) into channels [512 i, 512 (i+1))
         pools = [self._buf(s, s, 2048) for s in PSP_SIZES]
 
         def pool_all():
             for s, pb in zip(PSP_SIZES, pools):
-                self.nchw(pb).copy_(F.adaptive_avg_pool2d(self.nchw(x5), s))
+                self.nchw(pb).copy_(F.adaptive_avg_pool2d(x5_view, s))
         self._glue(pool_all)
         stage_out = [self._conv(c, pb, s, s, 2048)[0] for c, pb, s in zip(p.psp, pools, PSP_SIZES)]
 
         def assemble5():
-            dst = self.nchw(cat5)
             for i, so in enumerate(stage_out):
-                dst[:, 512 * i:512 * (i + 1)].copy_(_interp(self.nchw(so), (h5, w5)))
-            dst[:, 2048:].copy_(self.nchw(x5))
+                nv.upsample_ac(so, cat5, 512 * i)
         self._glue(assemble5)
         ctx, _, _ = self._conv(p.psp_bottleneck, cat5, h5, w5, 4096)
         d1, _, _ = self._conv(p.dec1, ctx, h5, w5, 512)
-        xl, _, _ = self._conv(p.dec2, x2, h2, w2, 256, cout_pad=64)       # 48 real channels + 16 zeros
-        e1, _, _ = self._conv(p.edge[0], x2, h2, w2, 256)
-        e2, _, _ = self._conv(p.edge[1], x3, h3, w3, 512)
-        e3, _, _ = self._conv(p.edge[2], x4, h4, w4, 1024)
         cat_dec = self._buf(h2, w2, 320)
         cat_fuse = self._buf(h2, w2, 1024)
+        self._conv(p.dec2, x2, h2, w2, 256, out=cat_dec, cout_pad=64, out_ld=320, out_c0=256)   # 48 real channels + 16 zeros
+        self._conv(p.edge[0], x2, h2, w2, 256, out=cat_fuse, out_ld=1024, out_c0=256)
+        e2, _, _ = self._conv(p.edge[1], x3, h3, w3, 512)
+        e3, _, _ = self._conv(p.edge[2], x4, h4, w4, 1024)
 
         def assemble_dec():
-            dst = self.nchw(cat_dec)
-            dst[:, :256].copy_(_interp(self.nchw(d1), (h2, w2)))
-            dst[:, 256:].copy_(self.nchw(xl))
-            f = self.nchw(cat_fuse)
-            f[:, 256:512].copy_(self.nchw(e1))
-            f[:, 512:768].copy_(_interp(self.nchw(e2), (h2, w2)))
-            f[:, 768:].copy_(_interp(self.nchw(e3), (h2, w2)))
+            nv.upsample_ac(d1, cat_dec, 0)
+            nv.upsample_ac(e2, cat_fuse, 512)
+            nv.upsample_ac(e3, cat_fuse, 768)
         self._glue(assemble_dec)
         # decoder.conv3: 304 input channels in the reference = 256 + 48; here 256 + 64 with zero weights for the pad
         w3a = self.plan.dec3a.w
         dec3a = FConv(torch.cat([w3a, w3a.new_zeros(w3a.shape[0], 16, 1, 1)], 1), self.plan.dec3a.b, act="leaky01")
         y, _, _ = self._conv(dec3a, cat_dec, h2, w2, 320)
-        fea_view = self._buf(h2, w2, 256)
-        self._conv(p.dec3b, y, h2, w2, 256, out=fea_view)
-        self._glue(lambda: self.nchw(cat_fuse)[:, :256].copy_(self.nchw(fea_view)))
+        self._conv(p.dec3b, y, h2, w2, 256, out=cat_fuse, out_ld=1024, out_c0=0)
         y, _, _ = self._conv(p.fuse1, cat_fuse, h2, w2, 1024)
         self.logits32, _, _ = self._conv(p.fuse2, y, h2, w2, 256, cout_pad=32)
         self._flush()

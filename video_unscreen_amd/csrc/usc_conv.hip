@@ -81,12 +81,12 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
     }
     if (tid < BM) {
         const int m = m0 + tid;
-        int opb = INVALID, rpb = INVALID, vb = 0;
+        int opix = -1, rpb = INVALID, vb = 0;
         unsigned mk = 0;
         if (m < M) {
             const int oy = m / d.OW, ox = m - oy * d.OW;
             const int Y = oy * d.out_stride + out_py, X = ox * d.out_stride + out_px;
-            opb = (Y * d.OWf + X) * d.Cout * 4;
+            opix = Y * d.OWf + X;
             rpb = ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (X >> d.res1_shift)) * d.Cout * 4;
             const int iy0 = oy * d.in_stride, ix0 = ox * d.in_stride;
             vb = (iy0 * d.IW + ix0) * d.Cin * 4;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
                 }
             }
         }
-        s_outpix[tid] = opb;
+        s_outpix[tid] = opix;
         s_res1pix[tid] = rpb;
         s_vbase[tid] = vb;
         s_vmask[tid] = (int)mk;
@@ -201,11 +201,16 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
     // 32-bit byte offsets + buffer instructions: rows past the end of the image carry an out-of-range offset and
     // are dropped (stores) or read as zero (residuals) by the range check.
-    int ops[16], rps[16];
+    // ops: byte offset of the row in a dense [pixel][Cout] tensor (slab, res2); oos: in the output tensor, which may be
+    // wider than Cout (out_ld channels per pixel, this layer's channels starting at out_c0: concat buffers).
+    const int out_ld = d.out_ld > 0 ? d.out_ld : d.Cout;
+    int ops[16], oos[16], rps[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int p = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        ops[r] = s_outpix[p];
+        const int opix = s_outpix[p];
+        ops[r] = opix < 0 ? INVALID : opix * d.Cout * 4;
+        oos[r] = opix < 0 ? INVALID : (opix * out_ld + d.out_c0) * 4;
         rps[r] = s_res1pix[p];
     }
     const int out_bytes = d.OHf * d.OWf * d.Cout * 4;
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
         return;
     }
     const bool has_r1 = d.res1 != nullptr, has_r2 = d.res2 != nullptr, has_aff = d.scale != nullptr;
-    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, d.OHf * d.OWf * out_ld * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(d.res1), 0, has_r1 ? (d.OHf >> d.res1_shift) * (d.OWf >> d.res1_shift) * d.Cout * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
             else if (d.act == USC_ACT_LEAKY01) v = v > 0.f ? v : v * 0.01f;
             if (has_aff) v = v * sc + sh;
             v += r2v[r];
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), out_rsrc, ops[r] + nb4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), out_rsrc, oos[r] + nb4, 0, 0);
         }
     }
 }
@@ -286,7 +291,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(usc_conv_desc d) {
             if (has_r2) x += d.res2[o + k];
             a[k] = x;
         }
-        *reinterpret_cast<float4*>(d.out + o) = make_float4(a[0], a[1], a[2], a[3]);
+        const int out_ld = d.out_ld > 0 ? d.out_ld : d.Cout;
+        *reinterpret_cast<float4*>(d.out + (size_t)op * out_ld + d.out_c0 + n) = make_float4(a[0], a[1], a[2], a[3]);
     }
 }
 
@@ -373,7 +379,9 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     }
     if (d.Cout % 32) return conv_fail(USC_E_UNSUPPORTED, "usc_conv: Cout must be a multiple of 32");
     if ((d.Cin & (d.Cin - 1)) && d.Cin % 32) return conv_fail(USC_E_UNSUPPORTED, "usc_conv: Cin must be a power of two or a multiple of 32");
-    if ((long long)d.IH * d.IW * d.Cin * 4 >= 0x7fff0000ll || (long long)d.OHf * d.OWf * d.Cout * 4 >= 0x7fff0000ll)
+    if (d.out_ld && (d.out_ld < d.Cout + d.out_c0 || d.out_c0 < 0 || d.out_ld % 4 || d.out_c0 % 4))
+        return conv_fail(USC_E_ARG, "usc_conv: out_ld / out_c0 must satisfy out_c0 + Cout <= out_ld, both multiples of 4");
+    if ((long long)d.IH * d.IW * d.Cin * 4 >= 0x7fff0000ll || (long long)d.OHf * d.OWf * (d.out_ld > d.Cout ? d.out_ld : d.Cout) * 4 >= 0x7fff0000ll)
         return conv_fail(USC_E_UNSUPPORTED, "usc_conv: tensor >= 2 GiB");
     const int nphase = d.nphase > 1 ? d.nphase : 1;
     if (nphase != 1 && nphase != 4) return conv_fail(USC_E_ARG, "usc_conv: nphase must be 1 or 4");

@@ -176,6 +176,33 @@ __global__ __launch_bounds__(256) void seg_warp_argmax_kernel(const float* __res
     }
 }
 
+// F.interpolate(mode='bilinear', align_corners=True) on NHWC float32, 4 channels per lane, written into channels
+// [c0, c0 + C) of a destination with ld channels per pixel (human_parse.py:108, 147-150, 186: PSP priors, edge and
+// decoder features are upsampled straight into their concat buffers).
+__global__ __launch_bounds__(256) void upsample_ac_nhwc_kernel(const float* __restrict__ src, int sh, int sw, int C,
+                                                               float* __restrict__ dst, int dh, int dw, int ld, int c0,
+                                                               float rh, float rw) {
+    const int c4n = C / 4, n = dh * dw * c4n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int c4 = i % c4n, p = i / c4n;
+        const int y = p / dw, x = p - y * dw;
+        const float h1r = rh * y, w1r = rw * x;
+        const int h1 = (int)h1r, w1 = (int)w1r;
+        const int h1p = h1 < sh - 1 ? 1 : 0, w1p = w1 < sw - 1 ? 1 : 0;
+        const float h1l = h1r - h1, h0l = 1.f - h1l, w1l = w1r - w1, w0l = 1.f - w1l;
+        const float4 v00 = reinterpret_cast<const float4*>(src + ((size_t)h1 * sw + w1) * C)[c4];
+        const float4 v01 = reinterpret_cast<const float4*>(src + ((size_t)h1 * sw + w1 + w1p) * C)[c4];
+        const float4 v10 = reinterpret_cast<const float4*>(src + ((size_t)(h1 + h1p) * sw + w1) * C)[c4];
+        const float4 v11 = reinterpret_cast<const float4*>(src + ((size_t)(h1 + h1p) * sw + w1 + w1p) * C)[c4];
+        float4 o;
+        o.x = h0l * (w0l * v00.x + w1l * v01.x) + h1l * (w0l * v10.x + w1l * v11.x);
+        o.y = h0l * (w0l * v00.y + w1l * v01.y) + h1l * (w0l * v10.y + w1l * v11.y);
+        o.z = h0l * (w0l * v00.z + w1l * v01.z) + h1l * (w0l * v10.z + w1l * v11.z);
+        o.w = h0l * (w0l * v00.w + w1l * v01.w) + h1l * (w0l * v10.w + w1l * v11.w);
+        *reinterpret_cast<float4*>(dst + (size_t)p * ld + c0 + 4 * c4) = o;
+    }
+}
+
 int grid_for(long long items, int threads) {
     long long b = (items + threads - 1) / threads;
     if (b < 1) b = 1;
@@ -236,4 +263,14 @@ extern "C" int usc_humanseg_post(const float* logits, int C, int Cbuf, int lh, i
     invert_affine(M, A.m);
     hipLaunchKernelGGL(seg_warp_argmax_kernel<20>, dim3(grid_for(((long long)H * W + 3) / 4, 256)), dim3(256), 0, st, up, in_h, in_w, A, out, H, W);
     return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "seg_warp_argmax_kernel launch failed");
+}
+
+extern "C" int usc_upsample_ac_nhwc_f32(const float* src, int sh, int sw, int C, float* dst, int dh, int dw, int ld, int c0,
+                                        usc_stream_t stream) {
+    if (!src || !dst || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || C <= 0 || C % 4 || ld % 4 || c0 % 4 || c0 + C > ld)
+        return seg_fail(USC_E_ARG, "usc_upsample_ac_nhwc_f32: bad argument (C, ld, c0 must be multiples of 4, c0 + C <= ld)");
+    const float rh = dh > 1 ? (float)(sh - 1) / (dh - 1) : 0.f, rw = dw > 1 ? (float)(sw - 1) / (dw - 1) : 0.f;
+    hipLaunchKernelGGL(upsample_ac_nhwc_kernel, dim3(grid_for((long long)dh * dw * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                       src, sh, sw, C, dst, dh, dw, ld, c0, rh, rw);
+    return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "upsample_ac_nhwc_kernel launch failed");
 }
