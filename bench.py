@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--sync-loop", action="store_true", help="use the synchronous step() instead of the pipelined run()")
     ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--no-seg", action="store_true",
+                    help="stage-3 loop only (segmentation masks are inputs, as in the reference's bg_offline.py with its "
+                         "stages 1-2 disabled); default: the human-parsing net runs on every frame (binseg + trimap + vmatting)")
     ap.add_argument("--net", default="hip", choices=["hip", "miopen"],
                     help="conv stack: hand-written f32-MFMA kernels (default) or PyTorch-ROCm / MIOpen")
     return ap.parse_args()
@@ -98,14 +101,19 @@ def kernel_table(pipe, sample, H, W):
 
 
 def cpu_baseline(cfg, pipe, clip_cpu_frames, bg_always, nframes):
-    """The CPU oracle (C restatement, 1 thread) + the same network on torch-CPU, on a bounded sample."""
+    """The CPU oracle (C restatement, 1 thread) + the same networks on torch-CPU, on a bounded sample."""
     import __graft_entry__ as ge
     import oracle
     oracle.build()
+    seg_cpu = None
+    if pipe.seg_agent is not None:
+        from video_unscreen_amd.binseg.schp_net import SchpNetTorch
+        seg_cpu = SchpNetTorch(pipe.seg_agent.state_dict)
+    pipe.cpu_net()
     alpha_pre = None
     t0 = time.time()
     for f in clip_cpu_frames[:nframes]:
-        o = ge.oracle_frame(oracle, cfg, pipe, f["frame"], f["seg"], f["bg"], bg_always, alpha_pre)
+        o = ge.oracle_frame(oracle, cfg, pipe, f["frame"], f["seg"], f["bg"], bg_always, alpha_pre, seg_net_cpu=seg_cpu)
         alpha_pre = o["alpha"]
     dt = time.time() - t0
     return nframes / dt, dt
@@ -144,7 +152,11 @@ def main():
     clip = SyntheticClip(H, W, (K + Wm) * world, config_id=2, device=dev)
     sd = synthetic_state_dict(0) if rank == 0 else None
     sd, bg_always = broadcast_state(sd, clip.bg_always if rank == 0 else torch.empty_like(clip.bg_always), dev, world)
-    pipe = BgStepPipeline(cfg, H, W, device=dev, dtype=dtype, state_dict=sd, net_backend=args.net)
+    seg_agent = None
+    if not args.no_seg:
+        from video_unscreen_amd.binseg import HumanSegAgent
+        seg_agent = HumanSegAgent(model_path=None, cuda_device=local)       # synthetic SCHP weights, same on every rank
+    pipe = BgStepPipeline(cfg, H, W, device=dev, dtype=dtype, state_dict=sd, net_backend=args.net, seg_agent=seg_agent)
 
     # this rank's contiguous frame range, generated straight into HBM (not timed)
     lo, hi = shard_range((K + Wm) * world, rank, world)
@@ -189,8 +201,10 @@ def main():
             "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"float32": "f32", "float16": "f16", "bfloat16": "bf16"}[args.dtype],
             "data": "synthetic",
-            "config": {"workload": f"bg_step stage-3 loop (bgdiff mask + object filter + trimap + matting UNet-18 + get_fg), "
-                                   f"{W}x{H}, {K} frames/GPU, frame-sharded x{world}",
+            "config": {"workload": ("bg_step: " + ("human-parsing segmentation (SCHP ResNet-101) + " if seg_agent is not None else "")
+                                    + "stage-3 loop (bgdiff mask + object filter + trimap + matting UNet-18 + get_fg), "
+                                    + f"{W}x{H}, {K} frames/GPU, frame-sharded x{world}"),
+                       "binseg": "HumanSegAgent per frame" if seg_agent is not None else "masks are inputs (--no-seg)",
                        "net_input": [pipe.in_h, pipe.in_w], "loop": "sync" if args.sync_loop else "pipelined", "convs": args.net,
                        "weights": "keyed-deterministic synthetic (no checkpoint offline)"},
         }
@@ -231,7 +245,7 @@ def main():
             result["cpu_baseline"] = {"value": round(cpu_fps, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
                                       "kind": "port",
                                       "sample": f"{args.cpu_frames} frames {W}x{H}: C oracle (1 thread) for the pixel stages + the same "
-                                                f"network on torch-CPU ({torch.get_num_threads()} threads), {cpu_dt:.1f} s",
+                                                f"network(s) on torch-CPU ({torch.get_num_threads()} threads), {cpu_dt:.1f} s",
                                       "host_cpus": os.cpu_count()}
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -49,6 +49,7 @@ class _Slot:
         self.gate = torch.empty((H, W), **u8)
         self.alphaor = torch.empty((H, W), **u8)
         self.trimap = torch.empty((H, W), **u8)
+        self.seg = torch.empty((H, W), **u8)
         self.host = torch.empty((H, W), dtype=torch.uint8).pin_memory()
         self.ready = torch.cuda.Event()
         self.copied = torch.cuda.Event()
@@ -56,7 +57,11 @@ class _Slot:
 
 
 class BgStepPipeline:
-    def __init__(self, cfg, H, W, device="cuda:0", dtype=torch.float32, state_dict=None, net_backend="hip"):
+    def __init__(self, cfg, H, W, device="cuda:0", dtype=torch.float32, state_dict=None, net_backend="hip",
+                 seg_agent=None):
+        """seg_agent: optional HumanSegAgent.  When given, the coarse segmentation mask of every frame is computed on
+        the device (reference bg_offline.py:63 `segagent.forward(frame)`, the untracked branch of stage 1) instead of
+        being read from the caller; it runs in the front half, concurrently with the previous frame's matting net."""
         self.cfg = cfg
         self.H, self.W = H, W
         self.device = torch.device(device)
@@ -95,6 +100,7 @@ class BgStepPipeline:
         else:
             raise ValueError(f"unknown net_backend {net_backend!r}")
         self.slots = [_Slot(H, W, dev) for _ in range(3)]
+        self.seg_agent = seg_agent
         self.alpha_pre = None
 
     def cpu_net(self):
@@ -108,6 +114,8 @@ class BgStepPipeline:
 
     # ------------------------------------------------------------------ stages
     def _front_device(self, slot, frame, seg, bg_i, bg_always):
+        if self.seg_agent is not None:
+            seg = self.seg_agent.forward_device(frame, out=slot.seg)
         nv.bgdiff_mask(frame, bg_i, bg_always, seg, self.beta, self.thr, out_bg=slot.bg, out_alpha=slot.gate,
                        ws=self.ws_bgdiff)
         slot.host.copy_(slot.gate, non_blocking=True)
@@ -129,7 +137,7 @@ class BgStepPipeline:
         fg = nv.get_fg(frame, alpha, slot.bg, paste_thr=1)
         self.alpha_pre = alpha
         return {"alpha": alpha, "alpha_f32": alpha_f, "fg": fg, "trimap": slot.trimap, "bg": slot.bg,
-                "gate": slot.gate, "alphaor": slot.alphaor, "pred": pred}
+                "gate": slot.gate, "alphaor": slot.alphaor, "pred": pred, "seg": slot.seg}
 
     # ------------------------------------------------------------------ synchronous form
     def step(self, frame, seg, bg_i, bg_always, want_float=False):
