@@ -1,0 +1,55 @@
+"""Turn rocprofv3 CSVs (kernel-trace --stats run + two --pmc runs) into the markdown tables committed under profiles/.
+
+usage: summarize_profiles.py <kernel_stats.csv> <fetch_counter_collection.csv> <write_counter_collection.csv> <frames_in_pmc_run> <title>
+FETCH_SIZE / WRITE_SIZE are in KiB.  Per MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half the bytes
+of wide (16 B/lane) coalesced streaming reads; narrower access widths are uncalibrated, so both the raw and the x2 value
+are listed for the read side and the one that applies is named per kernel."""
+import collections
+import csv
+import sys
+
+stats_f, fetch_f, write_f, frames, title = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
+OURS = ("conv_mfma_kernel", "splitk_reduce_kernel", "head_conv_kernel", "bgdiff_point_kernel", "gate_kernel", "trimap_small_kernel",
+        "trimap_up_kernel", "vmat_pre_kernel", "vmat_post_kernel", "get_fg_kernel", "seg_pre_kernel", "seg_up_kernel",
+        "seg_warp_argmax_kernel", "upsample_ac_nhwc_kernel", "count_ge_kernel", "morph_tile_kernel", "inrange_hsv_kernel")
+
+
+def short(name):
+    for o in OURS:
+        if o in name:
+            return o + ("<2>" if "ILi2E" in name or "<2>" in name else "<1>" if ("ILi1E" in name or "<1>" in name) and o == "conv_mfma_kernel" else "")
+    return None
+
+
+stats = {}
+tot = 0.0
+for r in csv.DictReader(open(stats_f)):
+    tot += float(r["TotalDurationNs"])
+    s = short(r["Name"])
+    if s:
+        e = stats.setdefault(s, [0, 0.0])
+        e[0] += int(r["Calls"]); e[1] += float(r["TotalDurationNs"])
+
+
+def pmc(path):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        s = short(r["Kernel_Name"])
+        if s:
+            agg[s][0] += 1; agg[s][1] += float(r["Counter_Value"])
+    return agg
+
+
+fe, wr = pmc(fetch_f), pmc(write_f)
+print(f"## {title}\n")
+print("| kernel | launches (trace run) | avg duration us | share of GPU time | FETCH_SIZE KiB / launch | x2 (wide-read correction) MB | WRITE_SIZE MB / launch |")
+print("|---|---|---|---|---|---|---|")
+for k, (c, t) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
+    f = fe.get(k, [0, 0.0]); w = wr.get(k, [0, 0.0])
+    fk = f[1] / f[0] if f[0] else float("nan")
+    wk = w[1] / w[0] if w[0] else float("nan")
+    print(f"| {k} | {c} | {t/c/1e3:.2f} | {100*t/tot:.1f}% | {fk:.0f} | {2*fk*1024/1e6:.2f} | {wk*1024/1e6:.2f} |")
+conv_f = sum(v[1] for k, v in fe.items() if k.startswith(("conv_mfma", "splitk", "head_conv")))
+conv_w = sum(v[1] for k, v in wr.items() if k.startswith(("conv_mfma", "splitk", "head_conv")))
+print(f"\nAll conv-stack launches (conv_mfma + splitk_reduce + head), per frame over {frames} profiled frames: "
+      f"FETCH_SIZE {conv_f/frames*1024/1e6:.1f} MB raw / {2*conv_f/frames*1024/1e6:.1f} MB x2, WRITE_SIZE {conv_w/frames*1024/1e6:.1f} MB.")

@@ -277,10 +277,8 @@ class HipSchpNet:
         d.act = {"none": 0, "relu": 1, "leaky": 2, "leaky01": 3}[act or c.act]
         d.ntaps, d.kind, d.nphase = len(taps), 0, 1
         d.out_ld, d.out_c0 = out_ld, out_c0
-        need = 16 * OH * OW * co * 4
-        if self._slab_used + need <= self.slab.numel() * 4:
-            d.slab, d.slab_bytes = self.slab.data_ptr() + self._slab_used, need
-            self._slab_used += need
+        # one shared split-K scratch: the net is a chain, and the graph builder orders layers that share a slab
+        d.slab, d.slab_bytes = self.slab.data_ptr(), self.slab.numel() * 4
         for i, (dy, dx) in enumerate(taps):
             d.dy[i], d.dx[i] = dy, dx
         self._cur.append(d)

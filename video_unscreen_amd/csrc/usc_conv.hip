@@ -394,9 +394,11 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     const long long blocks = (long long)mblocks * nblocks * nphase;
     const int nch = (d.ntaps * d.Cin + KC - 1) / KC;
     int S = 1;
-    if (d.slab && blocks < 384) {
-        S = (int)((768 + blocks - 1) / blocks);
-        if (S > nch) S = nch;
+    static const int split_below = getenv("USC_SPLIT_BELOW") ? atoi(getenv("USC_SPLIT_BELOW")) : 384;      // tuning knobs
+    static const int split_target = getenv("USC_SPLIT_TARGET") ? atoi(getenv("USC_SPLIT_TARGET")) : 768;
+    if (d.slab && blocks < split_below) {
+        S = (int)((split_target + blocks - 1) / blocks);
+        if (S > nch / 6) S = nch / 6;          // a slice needs >= 6 K steps to amortise its prologue / epilogue / reduce
         if (S > 16) S = 16;
         const size_t need = (size_t)S * d.OHf * d.OWf * d.Cout * sizeof(float);
         if (need > d.slab_bytes) S = (int)(d.slab_bytes / ((size_t)d.OHf * d.OWf * d.Cout * sizeof(float)));

@@ -120,8 +120,11 @@ class HipMattingNet:
         d.wpk = wp.data_ptr()
         # every layer gets its own 16-slice region of the split-K scratch, so layers on different graph branches
         # never share partial-sum memory
-        need = 16 * d_out_elems(OH, OW, out_stride, OHf, OWf, Cout) * 4
-        if kind == 0 and self._slab_used + need <= self.slab.numel() * 4 and need <= 32 * 1024 * 1024:
+        tiles = ((OH * OW + 127) // 128) * max(Cout // 32, 1) * (4 if phases is not None else 1)
+        nch = (len(taps) * Cin + 31) // 32
+        slices = max(1, min(16, -(-768 // tiles), nch // 6))            # the library's own split rule (usc_conv.hip plan_layer)
+        need = slices * d_out_elems(OH, OW, out_stride, OHf, OWf, Cout) * 4
+        if kind == 0 and tiles < 384 and slices > 1 and self._slab_used + need <= self.slab.numel() * 4:
             d.slab, d.slab_bytes = self.slab.data_ptr() + self._slab_used, need
             self._slab_used += need
         d.bias = self._dev(bias).data_ptr() if bias is not None else None
