@@ -113,6 +113,20 @@ int usc_get_bg_u8(const uint8_t* alpha, const uint8_t* bg, int H, int W, uint8_t
 int usc_blend_u8(const uint8_t* fg, const uint8_t* mask, int mask_cn, const uint8_t* bg, int H, int W,
                  uint8_t* out, usc_stream_t stream);
 
+/* Replace mode (tools/replace/replace.py:59-82) geometry:
+ * usc_resize_u8: cv2.resize on uint8, 1 or 3 channels; interp 0 = INTER_NEAREST, 1 = INTER_LINEAR (incl. OpenCV's exact-2x
+ *   box reroute), 2 = INTER_CUBIC (unscreen/utils/imgprocess.py:33-37 adaptive_resize uses 1).
+ * usc_rescale_fg_u8: imgprocess.py:40-52 rescale_fg - cubic zoom by `scale` and centre crop, fused (only the crop is computed).
+ * usc_warp_affine_u8: cv2.warpAffine(LINEAR, zero border) with a host 2x3 double matrix (imgprocess.py:55-64 shift_fg
+ *   passes [[1,0,dx],[0,1,dy]] as float32).
+ * usc_composite_fgbg_u8: unscreen/utils/fgfuncs.py:172-214 composite_fgbg (extend=False), background resize fused in. */
+int usc_resize_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw, int interp, usc_stream_t stream);
+int usc_rescale_fg_u8(const uint8_t* src, int h, int w, int cn, double scale, uint8_t* dst, usc_stream_t stream);
+int usc_warp_affine_u8(const uint8_t* src, int sh, int sw, int cn, const double* M2x3_host, uint8_t* dst, int dh, int dw,
+                       usc_stream_t stream);
+int usc_composite_fgbg_u8(const uint8_t* fg, const uint8_t* alpha, int fh, int fw, const uint8_t* bg, int bh, int bw,
+                          uint8_t* out, usc_stream_t stream);
+
 /* unscreen/utils/maskprocess.py:56-60 exist_foreground: *out_count (device, 8 bytes) = #(mask >= thr). */
 int usc_count_ge_u8(const uint8_t* mask, size_t n, int thr, unsigned long long* out_count, usc_stream_t stream);
 

@@ -98,6 +98,39 @@ def resize_linear(img, dh, dw):
     return out
 
 
+def resize_cubic(img, dh, dw):
+    img, p = _u8(img)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
+    lib().orc_resize_cubic_u8(p, img.shape[0], img.shape[1], cn, out.ctypes.data_as(u8p), dh, dw)
+    return out
+
+
+def rescale_fg(img, scale_factor=1.1):
+    """imgprocess.py:40-52."""
+    img, p = _u8(img)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty_like(img)
+    lib().orc_rescale_fg(p, img.shape[0], img.shape[1], cn, C.c_double(scale_factor), out.ctypes.data_as(u8p))
+    return out
+
+
+def shift_fg(img, dx=0, dy=0):
+    """imgprocess.py:55-64: warpAffine with the float32 matrix [[1, 0, dx], [0, 1, dy]]."""
+    M = np.float32([[1, 0, dx], [0, 1, dy]]).astype(np.float64)
+    return warp_affine(img, M, img.shape[0], img.shape[1])
+
+
+def composite_fgbg(fg, alpha, bg):
+    """fgfuncs.py:172-214 with extend=False."""
+    fg, pf = _u8(fg)
+    alpha, pa = _u8(alpha)
+    bg, pb = _u8(bg)
+    out = np.empty_like(fg)
+    lib().orc_composite_fgbg(pf, pa, fg.shape[0], fg.shape[1], pb, bg.shape[0], bg.shape[1], out.ctypes.data_as(u8p))
+    return out
+
+
 def pad_reflect(img, dh, dw):
     img, p = _u8(img)
     cn = 1 if img.ndim == 2 else img.shape[2]

@@ -195,6 +195,90 @@ ORC_API void orc_resize_linear_f32(const float* src, int sh, int sw, int sstride
     free(tx); free(ty);
 }
 
+/* cv2.resize(..., interpolation=cv2.INTER_CUBIC) on uint8 (unscreen/utils/imgprocess.py:48 rescale_fg):
+ * Keys cubic with A = -0.75, float coefficients rounded to 11-bit fixed point (no sum correction), taps clamped to
+ * the image (replicate) in both directions, horizontal pass kept as int, vertical pass
+ * (sum + 2^21) >> 22 with saturation (FixedPtCast<int, uchar, 22>). */
+static void orc_cubic_coeffs(float x, short* c)
+{
+    const float A = -0.75f;
+    float f[4];
+    f[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    f[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    f[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    f[3] = 1.f - f[0] - f[1] - f[2];
+    for (int k = 0; k < 4; k++) c[k] = orc_sat_s16(orc_round_i(f[k] * 2048.f));
+}
+
+ORC_API void orc_resize_cubic_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw)
+{
+    double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    for (int y = 0; y < dh; y++) {
+        float fy = (float)((y + 0.5) * scale_y - 0.5);
+        int sy = orc_floor_i(fy);
+        fy -= sy;
+        short cy[4];
+        orc_cubic_coeffs(fy, cy);
+        for (int x = 0; x < dw; x++) {
+            float fx = (float)((x + 0.5) * scale_x - 0.5);
+            int sx = orc_floor_i(fx);
+            fx -= sx;
+            short cx[4];
+            orc_cubic_coeffs(fx, cx);
+            for (int c = 0; c < cn; c++) {
+                int acc = 0;
+                for (int j = 0; j < 4; j++) {
+                    int yy = orc_clampi(sy - 1 + j, 0, sh - 1);
+                    int row = 0;
+                    for (int i = 0; i < 4; i++) {
+                        int xx = orc_clampi(sx - 1 + i, 0, sw - 1);
+                        row += src[((size_t)yy * sw + xx) * cn + c] * cx[i];
+                    }
+                    acc += row * cy[j];
+                }
+                dst[((size_t)y * dw + x) * cn + c] = orc_sat_u8((acc + (1 << 21)) >> 22);
+            }
+        }
+    }
+}
+
+/* unscreen/utils/imgprocess.py:40-52 rescale_fg: cv2.resize(img, None, fx=s, fy=s, INTER_CUBIC) (dsize = round(size*s)),
+ * then the centre crop back to the original size (offsets int((new - old) / 2)). */
+ORC_API void orc_rescale_fg(const uint8_t* src, int h, int w, int cn, double scale, uint8_t* dst)
+{
+    int nh = orc_round_i(h * scale), nw = orc_round_i(w * scale);
+    uint8_t* big = (uint8_t*)malloc((size_t)nh * nw * cn);
+    orc_resize_cubic_u8(src, h, w, cn, big, nh, nw);
+    int h_off = (int)((nh - h) / 2.0), w_off = (int)((nw - w) / 2.0);
+    for (int y = 0; y < h; y++)
+        memcpy(dst + (size_t)y * w * cn, big + ((size_t)(y + h_off) * nw + w_off) * cn, (size_t)w * cn);
+    free(big);
+}
+
+/* unscreen/utils/fgfuncs.py:172-214 composite_fgbg (extend = False): bg bilinear-resized to cover the fg, centre ROI,
+ * alpha = a/255 (float64) with alpha > 0.9 -> 1, out = clip(fg + bg_roi * (1 - alpha), 0, 255) truncated. */
+ORC_API void orc_composite_fgbg(const uint8_t* fg, const uint8_t* alpha, int fh, int fw, const uint8_t* bg, int bh, int bw, uint8_t* out)
+{
+    int nbw, nbh;
+    if ((double)fh / fw > (double)bh / bw) { nbh = fh; nbw = (int)((double)bw * nbh / bh); }
+    else { nbw = fw; nbh = (int)((double)bh * nbw / bw); }
+    uint8_t* rb = (uint8_t*)malloc((size_t)nbh * nbw * 3);
+    orc_resize_linear_u8(bg, bh, bw, 3, rb, nbh, nbw);
+    int left = nbw / 2 - fw / 2; if (left < 0) left = 0;
+    int top = nbh / 2 - fh / 2; if (top < 0) top = 0;
+    for (int y = 0; y < fh; y++)
+        for (int x = 0; x < fw; x++) {
+            double a = (double)alpha[(size_t)y * fw + x] / 255.;
+            if (a > 0.9) a = 1;
+            for (int c = 0; c < 3; c++) {
+                double v = (double)fg[((size_t)y * fw + x) * 3 + c] + (double)rb[((size_t)(y + top) * nbw + x + left) * 3 + c] * (1 - a);
+                v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                out[((size_t)y * fw + x) * 3 + c] = (uint8_t)v;
+            }
+        }
+    free(rb);
+}
+
 /* cv2.copyMakeBorder(img, 0, pad_h, 0, pad_w, cv2.BORDER_REFLECT)  (unscreen/utils/imgprocess.py:96):
  * fedcba|abcdefgh|hgfedcb - the edge sample is repeated. */
 ORC_API void orc_pad_reflect_u8(const uint8_t* src, int h, int w, int cn, uint8_t* dst, int dh, int dw)

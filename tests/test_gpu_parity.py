@@ -269,3 +269,61 @@ def test_inrange_and_trimap_withbg_bit_exact(nv, oracle_lib, H, W):
     empty = np.zeros((H, W), np.uint8)
     assert agent.forward(empty, img, bgc) is empty                              # reference returns the input object
     assert np.array_equal(is_pixel_inrange(img, bgc, (10, 100, 180)), oracle_lib.is_pixel_inrange(img, bgc, (10, 100, 180)))
+
+
+def test_vmatting_agent_numpy_api(nv, oracle_lib, cfg):
+    """VMattingAgent.forward (NumPy in / out, reference vmatting/agent.py:134-163) against the oracle chain."""
+    import __graft_entry__ as ge  # noqa: F401
+    from video_unscreen_amd.vmatting import VMattingAgent
+    from video_unscreen_amd.vmatting.net import MattingNet, synthetic_state_dict
+    H, W = 270, 480
+    rng = np.random.default_rng(5)
+    frame = rand_img(H, W, 61)
+    alpha_pre = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    tri = oracle_lib.trimap(blob_mask(H, W, 62), 960, 3, 5)
+    agent = VMattingAgent("synthetic", input_long_side=960)
+    got = agent.forward(frame.copy(), alpha_pre.copy(), tri.copy())
+    in_h, in_w = oracle_lib.vmat_input_size(H, W, 960)
+    x7 = oracle_lib.vmat_pre(frame, alpha_pre, tri, in_h, in_w)
+    pred = MattingNet(synthetic_state_dict(0), device="cpu")(torch.from_numpy(x7)[None]).numpy()[0, 0]
+    want = oracle_lib.vmat_post(pred, tri)
+    assert got.shape == (H, W) and got.dtype == np.uint8
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1          # 1 LSB: a *255 truncation may flip
+    assert np.array_equal(got[tri == 0], want[tri == 0]) and np.array_equal(got[tri == 255], want[tri == 255])
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920), (135, 241), (33, 47)])
+def test_replace_geometry_and_composites_bit_exact(nv, oracle_lib, H, W):
+    """Replace mode (tools/replace/replace.py:59-82): resize, shift_fg, rescale_fg, the float64 blend, composite_fgbg,
+    fuse_fgbg - all uint8 / fixed point or float64: bit-exact."""
+    img = rand_img(H, W, 71, smooth=False)
+    g = np.ascontiguousarray(img[..., 1])
+    for (dh, dw) in ((H // 2, W // 2), (H * 2, W + 7), (max(H // 3, 1), max(W // 3, 1)), (H, W)):
+        if dh * dw > 3_000_000:
+            continue
+        assert np.array_equal(host(nv.resize(dev(img), dh, dw, 1)), oracle_lib.resize_linear(img, dh, dw))
+        assert np.array_equal(host(nv.resize(dev(g), dh, dw, 1)), oracle_lib.resize_linear(g, dh, dw))
+        assert np.array_equal(host(nv.resize(dev(img), dh, dw, 0)), oracle_lib.resize_nearest(img, dh, dw))
+        assert np.array_equal(host(nv.resize(dev(img), dh, dw, 2)), oracle_lib.resize_cubic(img, dh, dw))
+    from video_unscreen_amd.utils import composite_fgbg, fuse_fgbg, rescale_fg, shift_fg
+    for (dx, dy) in ((-1.725405405405406, 8.128108108108108), (-0.2072, -2.6028), (3, 0), (0, 0)):
+        assert np.array_equal(shift_fg(img, dx, dy), oracle_lib.shift_fg(img, dx, dy))
+        assert np.array_equal(shift_fg(g, dx, dy), oracle_lib.shift_fg(g, dx, dy))
+    for sc in (1.2, 1.1, 1.0):
+        assert np.array_equal(rescale_fg(img, sc), oracle_lib.rescale_fg(img, sc))
+        assert np.array_equal(rescale_fg(g, sc), oracle_lib.rescale_fg(g, sc))
+    alpha = np.random.default_rng(72).integers(0, 256, (H, W), dtype=np.uint8)
+    alpha[::3] = 255
+    bg = rand_img(max(H // 2, 2), W + 11, 73, smooth=False)
+    assert np.array_equal(composite_fgbg(img, alpha, bg), oracle_lib.composite_fgbg(img, alpha, bg))
+    bg2 = rand_img(H, W, 74, smooth=False)
+    assert np.array_equal(fuse_fgbg(img, bg2, alpha), oracle_lib.blend(img, alpha, bg2))
+    # the replace frame: shift + zoom of fg and 3-channel mask, float64 blend, truncation
+    m3 = np.stack([alpha, alpha, alpha], -1)
+    M = np.float32([[1, 0, -0.2072], [0, 1, -2.6028]]).astype(np.float64)
+    fg_s = nv.rescale_fg(nv.warp_affine(dev(img), M, H, W), 1.2)
+    m_s = nv.rescale_fg(nv.warp_affine(dev(m3), M, H, W), 1.2)
+    got = host(nv.blend(fg_s, m_s, dev(bg2)))
+    want = oracle_lib.blend(oracle_lib.rescale_fg(oracle_lib.shift_fg(img, -0.2072, -2.6028), 1.2),
+                            oracle_lib.rescale_fg(oracle_lib.shift_fg(m3, -0.2072, -2.6028), 1.2), bg2)
+    assert np.array_equal(got, want)

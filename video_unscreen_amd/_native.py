@@ -43,6 +43,10 @@ _SIGNATURES = {
     "usc_get_bg_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "usc_blend_u8": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
     "usc_count_ge_u8": (C.c_int, [_vp, C.c_size_t, C.c_int, _vp, _vp]),
+    "usc_resize_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "usc_rescale_fg_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp]),
+    "usc_warp_affine_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _vp, C.c_int, C.c_int, _vp]),
+    "usc_composite_fgbg_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
     "usc_remove_invalid_objects_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                   C.c_double, _vp, C.POINTER(C.c_int)]),
     "usc_humanseg_affine": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -262,6 +266,47 @@ def blend(fg, mask, bg, out=None):
     _check(load().usc_blend_u8(_dev_u8(fg, "blend.fg", (H, W, 3)), _dev_u8(mask, "blend.mask"), mask_cn,
                                _dev_u8(bg, "blend.bg", (H, W, 3)), H, W, _dev_u8(out, "blend.out", (H, W, 3)), _stream()),
            "usc_blend_u8")
+    return out
+
+
+def _img_dims(t):
+    return (t.shape[0], t.shape[1], 1) if t.dim() == 2 else (t.shape[0], t.shape[1], t.shape[2])
+
+
+def resize(img, dh, dw, interp=1, out=None):
+    """cv2.resize on a uint8 CUDA image (H, W) or (H, W, 3); interp 0 nearest / 1 linear / 2 cubic."""
+    sh, sw, cn = _img_dims(img)
+    out = torch.empty((dh, dw) if img.dim() == 2 else (dh, dw, cn), dtype=torch.uint8, device=img.device) if out is None else out
+    _check(load().usc_resize_u8(_dev_u8(img, "resize.img"), sh, sw, cn, _dev_u8(out, "resize.out"), int(dh), int(dw), int(interp), _stream()),
+           "usc_resize_u8")
+    return out
+
+
+def rescale_fg(img, scale_factor=1.1, out=None):
+    h, w, cn = _img_dims(img)
+    out = torch.empty_like(img) if out is None else out
+    _check(load().usc_rescale_fg_u8(_dev_u8(img, "rescale_fg.img"), h, w, cn, float(scale_factor), _dev_u8(out, "rescale_fg.out"), _stream()),
+           "usc_rescale_fg_u8")
+    return out
+
+
+def warp_affine(img, M, dh, dw, out=None):
+    sh, sw, cn = _img_dims(img)
+    Mc = (C.c_double * 6)(*[float(v) for v in np.asarray(M, np.float64).reshape(6)])
+    out = torch.empty((dh, dw) if img.dim() == 2 else (dh, dw, cn), dtype=torch.uint8, device=img.device) if out is None else out
+    rc = load().usc_warp_affine_u8(_dev_u8(img, "warp.img"), sh, sw, cn, Mc, _dev_u8(out, "warp.out"), int(dh), int(dw), _stream())
+    if rc != 0:
+        raise NativeError(f"usc_warp_affine_u8 failed ({rc}): {load().usc_seg_last_error().decode()}")
+    return out
+
+
+def composite_fgbg(fg, alpha, bg, out=None):
+    fh, fw, _ = fg.shape
+    bh, bw, _ = bg.shape
+    out = torch.empty_like(fg) if out is None else out
+    _check(load().usc_composite_fgbg_u8(_dev_u8(fg, "composite.fg", (fh, fw, 3)), _dev_u8(alpha, "composite.alpha", (fh, fw)), fh, fw,
+                                        _dev_u8(bg, "composite.bg", (bh, bw, 3)), bh, bw, _dev_u8(out, "composite.out", (fh, fw, 3)), _stream()),
+           "usc_composite_fgbg_u8")
     return out
 
 

@@ -198,67 +198,79 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
     }
     if (c < c_end) compute(0);          // odd chunk count: the last chunk is already staged in buffer 0
 
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-    // 32-bit byte offsets + buffer instructions: rows past the end of the image carry an out-of-range offset and
-    // are dropped (stores) or read as zero (residuals) by the range check.
-    // ops: byte offset of the row in a dense [pixel][Cout] tensor (slab, res2); oos: in the output tensor, which may be
-    // wider than Cout (out_ld channels per pixel, this layer's channels starting at out_c0: concat buffers).
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): a lane
+    // holds ONE channel of 16 rows, which would mean 16 scattered dword stores per tile.  Each wave therefore bounces its
+    // 32 x 32 tile through its own rows of LDS buffer 1 (free since the last barrier; only this wave touches them) and
+    // re-reads it row-major, 4 channels per lane: every global access of the epilogue is then 16 bytes per lane and a
+    // wave instruction covers eight 128-byte rows.  Offsets are 32-bit and go through buffer instructions: rows past the
+    // end of the image carry an out-of-range offset and are dropped (stores) / read as zero (residuals).
+    float* const T = &As[1][(32 * wave) * APITCH];
     const int out_ld = d.out_ld > 0 ? d.out_ld : d.Cout;
-    int ops[16], oos[16], rps[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int p = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int opix = s_outpix[p];
-        ops[r] = opix < 0 ? INVALID : opix * d.Cout * 4;
-        oos[r] = opix < 0 ? INVALID : (opix * out_ld + d.out_c0) * 4;
-        rps[r] = s_res1pix[p];
-    }
     const int out_bytes = d.OHf * d.OWf * d.Cout * 4;
-    if (S > 1) {                 // partial sums only; splitk_reduce_kernel finishes the layer
-        const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            d.slab + (size_t)ks * d.OHf * d.OWf * d.Cout, 0, out_bytes, 0x00020000);
+    const int erow = lane >> 3, ec4 = (lane & 7) * 4;            // this lane's row (per pass of 8 rows) and first channel
+    int ops[4], oos[4], rps[4];                                   // dense [pixel][Cout] offset, output offset, residual offset
 #pragma unroll
-        for (int j = 0; j < NT; j++) {
-            const int nb4 = (nb0 + j * 32 + (lane & 31)) * 4;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float a = acc[j][r];          // (bit_cast straight from the vector element miscompiles: all 16 stores got element 0)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a), slab_rsrc, ops[r] + nb4, 0, 0);
-            }
-        }
-        return;
+    for (int ps = 0; ps < 4; ps++) {
+        const int p = 32 * wave + ps * 8 + erow;
+        const int opix = s_outpix[p];
+        ops[ps] = opix < 0 ? INVALID : opix * d.Cout * 4;
+        oos[ps] = opix < 0 ? INVALID : (opix * out_ld + d.out_c0) * 4;
+        rps[ps] = s_res1pix[p];
     }
     const bool has_r1 = d.res1 != nullptr, has_r2 = d.res2 != nullptr, has_aff = d.scale != nullptr;
-    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, d.OHf * d.OWf * out_ld * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = S > 1
+        ? __builtin_amdgcn_make_buffer_rsrc(d.slab + (size_t)ks * d.OHf * d.OWf * d.Cout, 0, out_bytes, 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(d.out, 0, d.OHf * d.OWf * out_ld * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(d.res1), 0, has_r1 ? (d.OHf >> d.res1_shift) * (d.OWf >> d.res1_shift) * d.Cout * 4 : 0, 0x00020000);
+        const_cast<float*>(d.res1), 0, (has_r1 && S == 1) ? (d.OHf >> d.res1_shift) * (d.OWf >> d.res1_shift) * d.Cout * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(d.res2), 0, has_r2 ? out_bytes : 0, 0x00020000);
+        const_cast<float*>(d.res2), 0, (has_r2 && S == 1) ? out_bytes : 0, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-        const int n = nb0 + j * 32 + (lane & 31);
-        const int nb4 = n * 4;
-        const float bias = d.bias ? d.bias[n] : 0.f;
-        const float sc = has_aff ? d.scale[n] : 1.f;
-        const float sh = has_aff ? d.shift[n] : 0.f;
-        // all residual loads of a tile are issued before their first use so they overlap (one wait, not sixteen);
-        // a zero-sized descriptor (no residual) turns them into zeros without touching memory
-        float r1v[16], r2v[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            r1v[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1_rsrc, rps[r] + nb4, 0, 0));
-            r2v[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2_rsrc, ops[r] + nb4, 0, 0));
+            const float a = acc[j][r];
+            T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * APITCH + (lane & 31)] = a;
+        }
+        const int n = nb0 + j * 32 + ec4;
+        const int nb4 = n * 4;
+        if (S > 1) {                 // partial sums only; splitk_reduce_kernel finishes the layer
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++) {
+                const float4 v = *reinterpret_cast<const float4*>(&T[(ps * 8 + erow) * APITCH + ec4]);
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), out_rsrc, ops[ps] + nb4, 0, 0);
+            }
+            continue;
+        }
+        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bias;
+        if (d.bias) bias = *reinterpret_cast<const float4*>(d.bias + n);
+        if (has_aff) { sc = *reinterpret_cast<const float4*>(d.scale + n); sh = *reinterpret_cast<const float4*>(d.shift + n); }
+        // residual loads of all four passes are issued before their first use (one wait); a zero-sized descriptor
+        // (no residual) turns them into zeros without touching memory
+        u32x4 r1v[4], r2v[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ps++) {
+            r1v[ps] = __builtin_amdgcn_raw_buffer_load_b128(r1_rsrc, rps[ps] + nb4, 0, 0);
+            r2v[ps] = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, ops[ps] + nb4, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            float v = acc[j][r] + bias;
-            v += r1v[r];
-            if (d.act == USC_ACT_RELU) v = fmaxf(v, 0.f);
-            else if (d.act == USC_ACT_LEAKY) v = v > 0.f ? v : v * 0.2f;
-            else if (d.act == USC_ACT_LEAKY01) v = v > 0.f ? v : v * 0.01f;
-            if (has_aff) v = v * sc + sh;
-            v += r2v[r];
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), out_rsrc, oos[r] + nb4, 0, 0);
+        for (int ps = 0; ps < 4; ps++) {
+            const float4 t = *reinterpret_cast<const float4*>(&T[(ps * 8 + erow) * APITCH + ec4]);
+            const float4 r1 = *reinterpret_cast<const float4*>(&r1v[ps]), r2 = *reinterpret_cast<const float4*>(&r2v[ps]);
+            float v[4] = {t.x + bias.x, t.y + bias.y, t.z + bias.z, t.w + bias.w};
+            const float a1[4] = {r1.x, r1.y, r1.z, r1.w}, a2[4] = {r2.x, r2.y, r2.z, r2.w};
+            const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float x = v[e] + a1[e];
+                if (d.act == USC_ACT_RELU) x = fmaxf(x, 0.f);
+                else if (d.act == USC_ACT_LEAKY) x = x > 0.f ? x : x * 0.2f;
+                else if (d.act == USC_ACT_LEAKY01) x = x > 0.f ? x : x * 0.01f;
+                if (has_aff) x = x * s4[e] + h4[e];
+                v[e] = x + a2[e];
+            }
+            const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), out_rsrc, oos[ps] + nb4, 0, 0);
         }
     }
 }

@@ -988,3 +988,123 @@ extern "C" int usc_count_ge_u8(const uint8_t* mask, size_t n, int thr, unsigned 
     hipLaunchKernelGGL(count_ge_kernel, dim3(grid_for((n + 15) / 16, 256)), dim3(256), 0, st, mask, n, thr, out_count);
     return check_launch("count_ge_kernel");
 }
+
+// --------------------------------------------------------------------------------------------
+// generic 8-bit resize / affine warp / composite (replace mode: tools/replace/replace.py:59-82)
+// --------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void cubic_coeffs(float x, int* c) {      // cv::interpolateCubic, A = -0.75, 11-bit fixed point
+    const float A = -0.75f;
+    const float f0 = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    const float f1 = ((A + 2) * x - (A + 3)) * x * x + 1;
+    const float f2 = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    const float f3 = 1.f - f0 - f1 - f2;
+    c[0] = coef11(f0); c[1] = coef11(f1); c[2] = coef11(f2); c[3] = coef11(f3);
+}
+
+// One channel value of cv::resize at destination (y, x) of a virtual (dh x dw) image.  interp: 0 nearest, 1 linear
+// (mode = copy / 2x2 box / fixed-point bilinear as OpenCV would choose), 2 cubic.
+__device__ __forceinline__ int resize_sample_u8(const uint8_t* __restrict__ s, int sh, int sw, int cn, int c, int y, int x,
+                                                int interp, int mode, double scale_y, double scale_x, double ify, double ifx) {
+    if (interp == 0) {
+        const int sy = min((int)floor(y * ify), sh - 1), sx = min((int)floor(x * ifx), sw - 1);
+        return s[((size_t)sy * sw + sx) * cn + c];
+    }
+    if (interp == 1) {
+        if (mode == RS_COPY) return s[((size_t)y * sw + x) * cn + c];
+        if (mode == RS_AREA2) {
+            const uint8_t* p = s + ((size_t)(2 * y) * sw + 2 * x) * cn + c;
+            return (p[0] + p[cn] + p[(size_t)sw * cn] + p[(size_t)sw * cn + cn] + 2) >> 2;
+        }
+        Tap tx = linear_tap_x(x, scale_x, sw), ty = linear_tap(y, scale_y);
+        const int x0 = tx.s, x1 = min(x0 + 1, sw - 1);
+        const int y0 = clampi(ty.s, 0, sh - 1), y1 = clampi(ty.s + 1, 0, sh - 1);
+        return bilinear_u8(s[((size_t)y0 * sw + x0) * cn + c], s[((size_t)y0 * sw + x1) * cn + c],
+                           s[((size_t)y1 * sw + x0) * cn + c], s[((size_t)y1 * sw + x1) * cn + c],
+                           coef11(1.f - tx.f), coef11(tx.f), coef11(1.f - ty.f), coef11(ty.f));
+    }
+    const Tap tx = linear_tap(x, scale_x), ty = linear_tap(y, scale_y);
+    int cx[4], cy[4];
+    cubic_coeffs(tx.f, cx);
+    cubic_coeffs(ty.f, cy);
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int yy = clampi(ty.s - 1 + j, 0, sh - 1);
+        int row = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) row += s[((size_t)yy * sw + clampi(tx.s - 1 + i, 0, sw - 1)) * cn + c] * cx[i];
+        acc += row * cy[j];
+    }
+    return min(max((acc + (1 << 21)) >> 22, 0), 255);
+}
+
+// dst (oh x ow) = window [y_off, y_off + oh) x [x_off, x_off + ow) of the virtual resize of src to (dh x dw).
+__global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw, int cn,
+                                                        uint8_t* __restrict__ dst, int oh, int ow, int y_off, int x_off,
+                                                        int interp, int mode, double scale_y, double scale_x, double ify, double ifx) {
+    const uint32_t n = (uint32_t)oh * (uint32_t)ow;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int y = (int)(i / (uint32_t)ow), x = (int)(i - (uint32_t)y * (uint32_t)ow);
+        for (int c = 0; c < cn; c++)
+            dst[(size_t)i * cn + c] = (uint8_t)resize_sample_u8(src, sh, sw, cn, c, y + y_off, x + x_off, interp, mode, scale_y, scale_x, ify, ifx);
+    }
+}
+
+static int launch_resize(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw, int oh, int ow, int y_off, int x_off,
+                         int interp, hipStream_t st) {
+    ResizeGeom rg = resize_geom(sh, sw, dh, dw);
+    const double ifx = 1. / ((double)dw / sw), ify = 1. / ((double)dh / sh);
+    hipLaunchKernelGGL(resize_u8_kernel, dim3(grid_for((size_t)oh * ow, 256)), dim3(256), 0, st, src, sh, sw, cn, dst, oh, ow, y_off, x_off,
+                       interp, rg.mode, rg.scale_y, rg.scale_x, ify, ifx);
+    return check_launch("resize_u8_kernel");
+}
+
+extern "C" int usc_resize_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw, int interp, usc_stream_t stream) {
+    if (!src || !dst || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || (cn != 1 && cn != 3) || interp < 0 || interp > 2)
+        return fail(USC_E_ARG, "usc_resize_u8: bad argument");
+    if (too_big(sh, sw) || too_big(dh, dw)) return fail(USC_E_UNSUPPORTED, "usc_resize_u8: image too large");
+    return launch_resize(src, sh, sw, cn, dst, dh, dw, dh, dw, 0, 0, interp, (hipStream_t)stream);
+}
+
+extern "C" int usc_rescale_fg_u8(const uint8_t* src, int h, int w, int cn, double scale, uint8_t* dst, usc_stream_t stream) {
+    if (!src || !dst || h <= 0 || w <= 0 || (cn != 1 && cn != 3) || !(scale >= 1.0)) return fail(USC_E_ARG, "usc_rescale_fg_u8: bad argument (scale >= 1)");
+    const int nh = (int)lrint(h * scale), nw = (int)lrint(w * scale);
+    const int h_off = (int)((nh - h) / 2.0), w_off = (int)((nw - w) / 2.0);
+    return launch_resize(src, h, w, cn, dst, nh, nw, h, w, h_off, w_off, 2, (hipStream_t)stream);
+}
+
+// fgfuncs.py:172-214 composite_fgbg (extend = False), the background resize fused in.
+__global__ __launch_bounds__(256) void composite_kernel(const uint8_t* __restrict__ fg, const uint8_t* __restrict__ alpha, int fh, int fw,
+                                                        const uint8_t* __restrict__ bg, int bh, int bw, int nbh, int nbw, int top, int left,
+                                                        int mode, double scale_y, double scale_x, uint8_t* __restrict__ out) {
+    const uint32_t n = (uint32_t)fh * (uint32_t)fw;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int y = (int)(i / (uint32_t)fw), x = (int)(i - (uint32_t)y * (uint32_t)fw);
+        double a = (double)alpha[i] / 255.;
+        if (a > 0.9) a = 1;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int b = resize_sample_u8(bg, bh, bw, 3, c, y + top, x + left, 1, mode, scale_y, scale_x, 0., 0.);
+            double v = (double)fg[(size_t)i * 3 + c] + (double)b * (1 - a);
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            out[(size_t)i * 3 + c] = (uint8_t)(int)v;
+        }
+    }
+}
+
+extern "C" int usc_composite_fgbg_u8(const uint8_t* fg, const uint8_t* alpha, int fh, int fw, const uint8_t* bg, int bh, int bw,
+                                     uint8_t* out, usc_stream_t stream) {
+    if (!fg || !alpha || !bg || !out || fh <= 0 || fw <= 0 || bh <= 0 || bw <= 0) return fail(USC_E_ARG, "usc_composite_fgbg_u8: bad argument");
+    int nbw, nbh;
+    if ((double)fh / fw > (double)bh / bw) { nbh = fh; nbw = (int)((double)bw * nbh / bh); }
+    else { nbw = fw; nbh = (int)((double)bh * nbw / bw); }
+    int left = nbw / 2 - fw / 2, top = nbh / 2 - fh / 2;
+    if (left < 0) left = 0;
+    if (top < 0) top = 0;
+    if (top + fh > nbh || left + fw > nbw) return fail(USC_E_UNSUPPORTED, "usc_composite_fgbg_u8: resized background does not cover the foreground");
+    ResizeGeom rg = resize_geom(bh, bw, nbh, nbw);
+    hipLaunchKernelGGL(composite_kernel, dim3(grid_for((size_t)fh * fw, 256)), dim3(256), 0, (hipStream_t)stream, fg, alpha, fh, fw, bg, bh, bw,
+                       nbh, nbw, top, left, rg.mode, rg.scale_y, rg.scale_x, out);
+    return check_launch("composite_kernel");
+}

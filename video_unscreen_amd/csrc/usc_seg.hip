@@ -203,6 +203,28 @@ __global__ __launch_bounds__(256) void upsample_ac_nhwc_kernel(const float* __re
     }
 }
 
+// cv2.warpAffine(img, M, (dw, dh), INTER_LINEAR, BORDER_CONSTANT 0) on uint8, 1 or 3 channels (imgprocess.py:55-64 shift_fg).
+__global__ __launch_bounds__(256) void warp_affine_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw, int cn, Affine A,
+                                                             uint8_t* __restrict__ dst, int dh, int dw) {
+    const uint32_t n = (uint32_t)dh * (uint32_t)dw;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int y = (int)(i / (uint32_t)dw), x = (int)(i - (uint32_t)y * (uint32_t)dw);
+        int sx, sy, fx, fy;
+        warp_coord(A, x, y, sx, sy, fx, fy);
+        const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+        for (int c = 0; c < cn; c++) {
+            int v[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int xx = sx + (t & 1), yy = sy + (t >> 1);
+                v[t] = (xx >= 0 && xx < sw && yy >= 0 && yy < sh) ? src[((size_t)yy * sw + xx) * cn + c] : 0;
+            }
+            const int r = (v[0] * w00 + v[1] * w01 + v[2] * w10 + v[3] * w11 + (1 << 14)) >> 15;
+            dst[(size_t)i * cn + c] = (uint8_t)min(max(r, 0), 255);
+        }
+    }
+}
+
 int grid_for(long long items, int threads) {
     long long b = (items + threads - 1) / threads;
     if (b < 1) b = 1;
@@ -273,4 +295,14 @@ extern "C" int usc_upsample_ac_nhwc_f32(const float* src, int sh, int sw, int C,
     hipLaunchKernelGGL(upsample_ac_nhwc_kernel, dim3(grid_for((long long)dh * dw * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream,
                        src, sh, sw, C, dst, dh, dw, ld, c0, rh, rw);
     return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "upsample_ac_nhwc_kernel launch failed");
+}
+
+extern "C" int usc_warp_affine_u8(const uint8_t* src, int sh, int sw, int cn, const double* M2x3, uint8_t* dst, int dh, int dw,
+                                  usc_stream_t stream) {
+    if (!src || !dst || !M2x3 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || (cn != 1 && cn != 3)) return seg_fail(USC_E_ARG, "usc_warp_affine_u8: bad argument");
+    if ((long long)dh * dw >= (1ll << 31)) return seg_fail(USC_E_UNSUPPORTED, "usc_warp_affine_u8: image too large");
+    Affine A;
+    invert_affine(M2x3, A.m);
+    hipLaunchKernelGGL(warp_affine_u8_kernel, dim3(grid_for((long long)dh * dw, 256)), dim3(256), 0, (hipStream_t)stream, src, sh, sw, cn, A, dst, dh, dw);
+    return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "warp_affine_u8_kernel launch failed");
 }

@@ -20,3 +20,15 @@ def is_pixel_inrange(img, bgimg, winsize=(20, 20, 120), long_side_input=-1):
     assert bgimg.ndim == 3 or bgimg.ndim == 1
     bg = to_dev(bgimg) if bgimg.ndim == 3 else bgimg
     return to_host(nv.is_pixel_inrange(to_dev(img), bg, winsize)) > 0
+
+
+def composite_fgbg(fg, alpha, bg, extend=False):
+    """fg + resized bg * (1 - alpha) (reference fgfuncs.py:172-214)."""
+    if extend:
+        raise NotImplementedError("composite_fgbg(extend=True) is not built (no caller in the reference tools)")
+    return to_host(nv.composite_fgbg(to_dev(fg), to_dev(alpha), to_dev(bg)))
+
+
+def fuse_fgbg(fg, bg, mask):
+    """alpha-blend two images with a 0..255 mask in float64, truncated (reference utils/visualize.py:7-24)."""
+    return to_host(nv.blend(to_dev(fg), to_dev(mask), to_dev(bg)))

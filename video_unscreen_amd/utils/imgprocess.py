@@ -1,6 +1,9 @@
 """Geometry helpers of the path (reference unscreen/utils/imgprocess.py:67-192), computed by the C ABI's
 pure host functions so that the Python side and the kernels can never disagree on a size."""
+import numpy as np
+
 from .. import _native as nv
+from ._dev import to_dev, to_host
 
 
 def get_target_size(h, w, target_long_side, division=1):
@@ -17,3 +20,19 @@ def pad_resize_size(h, w, target_size):
 def inv_pad_resize_size(h, w, ori_size):
     """Size of the un-padded region (reference inv_pad_resize, imgprocess.py:100-132)."""
     return nv.inv_pad_geometry(h, w, ori_size[0], ori_size[1])
+
+
+def adaptive_resize(img, img_target):
+    """cv2.resize(img, size of img_target), default bilinear (reference imgprocess.py:33-37)."""
+    return to_host(nv.resize(to_dev(img), img_target.shape[0], img_target.shape[1], 1))
+
+
+def rescale_fg(img, scale_factor=1.1):
+    """Bicubic zoom + centre crop to the original size (reference imgprocess.py:40-52)."""
+    return to_host(nv.rescale_fg(to_dev(img), scale_factor))
+
+
+def shift_fg(img, dx=0, dy=0):
+    """Translate with cv2.warpAffine; the matrix is float32 like the reference's (imgprocess.py:55-64)."""
+    M = np.float32([[1, 0, dx], [0, 1, dy]]).astype(np.float64)
+    return to_host(nv.warp_affine(to_dev(img), M, img.shape[0], img.shape[1]))
