@@ -127,6 +127,37 @@ int usc_warp_affine_u8(const uint8_t* src, int sh, int sw, int cn, const double*
 int usc_composite_fgbg_u8(const uint8_t* fg, const uint8_t* alpha, int fh, int fw, const uint8_t* bg, int bh, int bw,
                           uint8_t* out, usc_stream_t stream);
 
+/* Green-screen mode (tools/unscreen/green.py:70-126).
+ * usc_cvt_color_u8: cv2.cvtColor on uint8, n pixels; code USC_CVT_* (BGR2HSV: colorfiltering/agent.py:311; HSV2BGR: :352;
+ *   BGR2LAB: utils/imgprocess.py:281-283, harmonization/agent.py:63-64; BGR2GRAY: tools/unscreen/bg_offline.py:152).  BGR2LAB
+ *   needs `lab_tables`: a device copy of the usc_lab_tables_bytes() blob that usc_lab_tables_host() fills (others: NULL).
+ * usc_gmm_lut_host: unscreen/colorfiltering/agent.py:201-230 get_prob_by_gmm evaluated at the 256 uint8 sample values
+ *   (HOST, float32 arithmetic; means / stds / weights of one fitted 1-D mixture).
+ * usc_gmm_alpha_u8: colorfiltering/agent.py:232-257 get_alpha_by_gmm; luts = device float[6][256] (bg h,s,v then fg h,s,v);
+ *   prob_out (float per pixel) may be NULL.
+ * usc_cf_threshold_u8: colorfiltering/agent.py:259-280 postprocess, adaptive threshold (in place on alpha); the
+ *   close/open that follows is four usc_morph_u8 calls.
+ * usc_color_correct_u8: unscreen/utils/imgprocess.py:263-300 color_correct; bg_color_host = 3 host bytes (B, G, R);
+ *   *n_sqrt_out (device int, may be NULL) receives the number of sqrt passes the while loop took.
+ * usc_box_filter_u8: cv2.boxFilter(img, -1, (k, k)) of unscreen/harmonization/agent.py:91-92, 110-111. */
+#define USC_CVT_BGR2HSV  0
+#define USC_CVT_HSV2BGR  1
+#define USC_CVT_BGR2GRAY 2
+#define USC_CVT_BGR2LAB  3
+size_t usc_lab_tables_bytes(void);
+void usc_lab_tables_host(void* blob);
+int usc_cvt_color_u8(const uint8_t* src, size_t n, int code, uint8_t* dst, const void* lab_tables, usc_stream_t stream);
+int usc_gmm_lut_host(const double* means, const double* stds, const double* weights, int K, float* lut256);
+int usc_gmm_alpha_u8(const uint8_t* hsv, size_t n, const float* luts, uint8_t* alpha, float* prob_out, usc_stream_t stream);
+size_t usc_cf_threshold_ws_bytes(void);
+int usc_cf_threshold_u8(uint8_t* alpha, const uint8_t* mask, size_t n, double thr_ratio, void* ws, size_t ws_bytes,
+                        usc_stream_t stream);
+size_t usc_color_correct_ws_bytes(int H, int W, int long_side);
+int usc_color_correct_u8(const uint8_t* img, const uint8_t* alpha, int H, int W, const uint8_t* bg_color_host, int long_side,
+                         double mean_exp, const void* lab_tables, uint8_t* out, int* n_sqrt_out, void* ws, size_t ws_bytes,
+                         usc_stream_t stream);
+int usc_box_filter_u8(const uint8_t* src, int H, int W, int cn, int ksize, uint8_t* dst, usc_stream_t stream);
+
 /* unscreen/utils/maskprocess.py:56-60 exist_foreground: *out_count (device, 8 bytes) = #(mask >= thr). */
 int usc_count_ge_u8(const uint8_t* mask, size_t n, int thr, unsigned long long* out_count, usc_stream_t stream);
 

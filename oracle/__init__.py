@@ -50,7 +50,12 @@ def lib():
         _lib.orc_inrange_hsv.argtypes = [u8p, u8p, C.c_int, C.POINTER(C.c_int), C.c_size_t, u8p]
         _lib.orc_trimap_withbg.argtypes = [u8p, u8p, u8p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, u8p]
-        for name in ("orc_bgr2gray_u8", "orc_bgr2hsv_u8", "orc_hsv2bgr_u8"):
+        _lib.orc_gmm_lut.argtypes = [f64p, f64p, f64p, C.c_int, f32p]
+        _lib.orc_gmm_alpha.argtypes = [u8p, C.c_size_t, f32p, f32p, u8p, f32p]
+        _lib.orc_cf_threshold.argtypes = [u8p, u8p, C.c_size_t, C.c_double]
+        _lib.orc_color_correct.argtypes = [u8p, u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_double, u8p, C.POINTER(C.c_int)]
+        _lib.orc_box_filter_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+        for name in ("orc_bgr2gray_u8", "orc_bgr2hsv_u8", "orc_hsv2bgr_u8", "orc_bgr2lab_u8"):
             getattr(_lib, name).argtypes = [u8p, u8p, C.c_size_t]
     return _lib
 
@@ -166,6 +171,67 @@ def hsv2bgr(img):
     img, p = _u8(img)
     out = np.empty_like(img)
     lib().orc_hsv2bgr_u8(p, out.ctypes.data_as(u8p), img.size // 3)
+    return out
+
+
+def bgr2lab(img):
+    """cv2.cvtColor(img, cv2.COLOR_BGR2Lab) on uint8."""
+    img, p = _u8(img)
+    out = np.empty_like(img)
+    lib().orc_bgr2lab_u8(p, out.ctypes.data_as(u8p), img.size // 3)
+    return out
+
+
+def gmm_lut(means, stds, weights):
+    """colorfiltering/agent.py:201-230 evaluated at the 256 uint8 sample values -> float32 (256,)."""
+    m = np.ascontiguousarray(np.atleast_1d(means), np.float64)
+    sd = np.ascontiguousarray(np.atleast_1d(stds), np.float64)
+    w = np.ascontiguousarray(np.atleast_1d(weights), np.float64)
+    out = np.empty(256, np.float32)
+    lib().orc_gmm_lut(m.ctypes.data_as(f64p), sd.ctypes.data_as(f64p), w.ctypes.data_as(f64p), len(m), out.ctypes.data_as(f32p))
+    return out
+
+
+def gmm_alpha(img_hsv, lut_bg, lut_fg, want_prob=False):
+    """colorfiltering/agent.py:232-257; lut_* float32 (3, 256)."""
+    img_hsv, p = _u8(img_hsv)
+    lb, lbp = _f32(lut_bg)
+    lf, lfp = _f32(lut_fg)
+    h, w = img_hsv.shape[:2]
+    alpha = np.empty((h, w), np.uint8)
+    prob = np.empty((h, w), np.float32)
+    lib().orc_gmm_alpha(p, h * w, lbp, lfp, alpha.ctypes.data_as(u8p), prob.ctypes.data_as(f32p))
+    return (alpha, prob) if want_prob else alpha
+
+
+def cf_postprocess(alpha, mask, thr_ratio=0.8):
+    """colorfiltering/agent.py:259-283: adaptive threshold, then close and open with the 3x3 cross, 2 iterations each."""
+    alpha = np.array(alpha, dtype=np.uint8, order="C")
+    mask, mp = _u8(mask)
+    lib().orc_cf_threshold(alpha.ctypes.data_as(u8p), mp, alpha.size, float(thr_ratio))
+    alpha = morph(morph(alpha, 3, 2, "dilate"), 3, 2, "erode")
+    alpha = morph(morph(alpha, 3, 2, "erode"), 3, 2, "dilate")
+    return alpha
+
+
+def color_correct(img, alpha, bg_color, target_long_side=960, mean_exp=0.95, want_iters=False):
+    """utils/imgprocess.py:263-300."""
+    img, ip = _u8(img)
+    alpha, ap = _u8(alpha)
+    bg, bp = _u8(np.asarray(bg_color).reshape(3))
+    out = np.empty_like(alpha)
+    it = C.c_int(0)
+    lib().orc_color_correct(ip, ap, img.shape[0], img.shape[1], bp, target_long_side, float(mean_exp), out.ctypes.data_as(u8p),
+                            C.byref(it))
+    return (out, it.value) if want_iters else out
+
+
+def box_filter(img, ksize=3):
+    """cv2.boxFilter(img, -1, (k, k)) on uint8."""
+    img, p = _u8(img)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty_like(img)
+    lib().orc_box_filter_u8(p, img.shape[0], img.shape[1], cn, ksize, out.ctypes.data_as(u8p))
     return out
 
 

@@ -1124,3 +1124,195 @@ ORC_API void orc_humanseg_post(const float* logits, int C, int lh, int lw, size_
  * matting network runs between pre and post and is supplied by the caller.
  * ---------------------------------------------------------------------------------------- */
 ORC_API const char* orc_version(void) { return "usc-oracle 1 (OpenCV-4.x generic-path restatement, parity unpinned)"; }
+
+/* ============================================================================================
+ * green mode (tools/unscreen/green.py:70-126): colour filtering, colour correction, harmonization helpers
+ * ============================================================================================ */
+
+/* cv2.COLOR_BGR2Lab on uint8 (unscreen/utils/imgprocess.py:281,283 color_correct; unscreen/harmonization/agent.py:63-64).
+ * OpenCV's RGB2Lab_b integer path: lab_shift 12, gamma_shift 3; sRGB gamma table (256 x u16, scale 255*8), cube-root table
+ * (256*3/2*8 = 3072 x u16, scale 2^15), XYZ coefficients = round(4096 * sRGB2XYZ_D65 / D65 white point),
+ * L = descale(296*fY - Lshift), a = descale(500*(fX-fY) + 128<<15), b = descale(200*(fY-fZ) + 128<<15), descale by 15 bits.
+ * PARITY UNPINNED: OpenCV 4 builds the two tables with its softfloat pow / cbrt; here libm powf / cbrtf (float, then
+ * round-half-even).  A table entry could differ by 1 where softfloat and libm differ in the last ulp next to a .5 tie. */
+static uint16_t orc_srgb_gamma_b[256], orc_lab_cbrt_b[3072];
+static int orc_lab_coeffs[9], orc_lab_ready = 0;
+ORC_API void orc_lab_tables(uint16_t* gamma256, uint16_t* cbrt3072, int* coeffs9)
+{
+    static const double xyz[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+    static const double white[3] = {0.950456, 1., 1.088754};
+    for (int i = 0; i < 256; i++) {
+        float x = (float)i / 255.f;
+        float g = x <= 0.04045f ? x / 12.92f : powf((x + 0.055f) / 1.055f, 2.4f);
+        gamma256[i] = (uint16_t)orc_round_i((double)(2040.f * g));
+    }
+    const float lthresh = 216.f / 24389.f, lscale = 841.f / 108.f, lbias = 16.f / 116.f;
+    for (int i = 0; i < 3072; i++) {
+        float x = (float)i / 2040.f;
+        float v = x < lthresh ? fmaf(x, lscale, lbias) : cbrtf(x);
+        cbrt3072[i] = (uint16_t)orc_round_i((double)(32768.f * v));
+    }
+    for (int i = 0; i < 3; i++) {                       /* BGR source order: blueIdx = 0 */
+        coeffs9[i * 3 + 2] = orc_round_i(4096. * xyz[i * 3 + 0] / white[i]);
+        coeffs9[i * 3 + 1] = orc_round_i(4096. * xyz[i * 3 + 1] / white[i]);
+        coeffs9[i * 3 + 0] = orc_round_i(4096. * xyz[i * 3 + 2] / white[i]);
+    }
+}
+static inline int orc_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+static inline void orc_bgr2lab_px(const uint8_t* s, uint8_t* d)
+{
+    if (!orc_lab_ready) { orc_lab_tables(orc_srgb_gamma_b, orc_lab_cbrt_b, orc_lab_coeffs); orc_lab_ready = 1; }
+    const int* C = orc_lab_coeffs;
+    const int Lscale = (116 * 255 + 50) / 100, Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
+    int c0 = orc_srgb_gamma_b[s[0]], c1 = orc_srgb_gamma_b[s[1]], c2 = orc_srgb_gamma_b[s[2]];
+    int fX = orc_lab_cbrt_b[orc_descale(c0 * C[0] + c1 * C[1] + c2 * C[2], 12)];
+    int fY = orc_lab_cbrt_b[orc_descale(c0 * C[3] + c1 * C[4] + c2 * C[5], 12)];
+    int fZ = orc_lab_cbrt_b[orc_descale(c0 * C[6] + c1 * C[7] + c2 * C[8], 12)];
+    d[0] = orc_sat_u8(orc_descale(Lscale * fY + Lshift, 15));
+    d[1] = orc_sat_u8(orc_descale(500 * (fX - fY) + 128 * (1 << 15), 15));
+    d[2] = orc_sat_u8(orc_descale(200 * (fY - fZ) + 128 * (1 << 15), 15));
+}
+ORC_API void orc_bgr2lab_u8(const uint8_t* src, uint8_t* dst, size_t n)
+{
+    for (size_t i = 0; i < n; i++) orc_bgr2lab_px(src + 3 * i, dst + 3 * i);
+}
+
+/* unscreen/colorfiltering/agent.py:201-230 get_prob_by_gmm for the 256 possible sample values: float32 throughout,
+ * x = (s - mean)/std ; y = 1/(std*sqrt(2 pi)) * exp(-0.5 * x*x) ; prob = sum_k w_k * y_k (torch.mm; summed here in
+ * component order without fma - the BLAS order is unspecified, agreement is to float rounding). */
+ORC_API void orc_gmm_lut(const double* means, const double* stds, const double* weights, int K, float* lut256)
+{
+    const float s2pi = (float)sqrt(2 * 3.141592653589793);
+    for (int v = 0; v < 256; v++) {
+        float acc = 0.f;
+        for (int k = 0; k < K; k++) {
+            float m = (float)means[k], sd = (float)stds[k], w = (float)weights[k];
+            float x = ((float)v - m) / sd;
+            float y = (1.f / (sd * s2pi)) * expf(-0.5f * (x * x));
+            acc = acc + w * y;
+        }
+        lut256[v] = acc;
+    }
+}
+
+/* unscreen/colorfiltering/agent.py:232-257 get_alpha_by_gmm on an HSV image (n pixels), per-channel likelihood tables
+ * lut_bg / lut_fg [3][256]: prob products in f32, cube root (torch.pow(., 1/3.): restated as the correctly rounded
+ * float of the double cube root), fg/(bg+fg+1e-6), clip(prob*255, 0, 255) truncated to uint8. */
+ORC_API void orc_gmm_alpha(const uint8_t* hsv, size_t n, const float* lut_bg, const float* lut_fg, uint8_t* alpha, float* prob_out)
+{
+    for (size_t i = 0; i < n; i++) {
+        float bg = 1.f, fg = 1.f;
+        for (int c = 0; c < 3; c++) {
+            bg = bg * lut_bg[c * 256 + hsv[3 * i + c]];
+            fg = fg * lut_fg[c * 256 + hsv[3 * i + c]];
+        }
+        bg = (float)cbrt((double)bg);
+        fg = (float)cbrt((double)fg);
+        float p = fg / (bg + fg + 1e-6f);
+        if (prob_out) prob_out[i] = p;
+        float a = p * 255.f;
+        a = a < 0.f ? 0.f : (a > 255.f ? 255.f : a);
+        alpha[i] = (uint8_t)a;
+    }
+}
+
+/* unscreen/colorfiltering/agent.py:259-280 postprocess, first half: score_thr = mean(alpha[(alpha>128)&(mask>0)]) * thr_ratio
+ * in float64 (an empty set gives nan: nothing is zeroed); alpha[alpha < score_thr] = 0.  In place. */
+ORC_API void orc_cf_threshold(uint8_t* alpha, const uint8_t* mask, size_t n, double thr_ratio)
+{
+    unsigned long long sum = 0, cnt = 0;
+    for (size_t i = 0; i < n; i++) if (alpha[i] > 128 && mask[i] > 0) { sum += alpha[i]; cnt++; }
+    double thr = ((double)sum / (double)cnt) * thr_ratio;        /* 0/0 = nan */
+    for (size_t i = 0; i < n; i++) if ((double)alpha[i] < thr) alpha[i] = 0;
+}
+
+/* torch.nn.functional.interpolate(x, (H, W)) default mode='nearest' source index (ATen UpSample.h nearest_idx). */
+static inline int orc_torch_nearest_idx(int o, int in, int out)
+{
+    if (out == in) return o;
+    if (out == 2 * in) return o >> 1;
+    float scale = (float)in / (float)out;
+    int s = (int)floorf((float)o * scale);
+    return s < in - 1 ? s : in - 1;
+}
+
+/* unscreen/utils/imgprocess.py:263-300 color_correct.  Working size (th, tw) = get_target_size(H, W, long_side);
+ * Lab distance of the (bilinear-resized) frame to the background colour on the a/b channels in float32, min-max
+ * normalised, square-rooted until the mean over {alpha_r > 0, dist > 0} reaches mean_exp (the mean is accumulated in
+ * float64 here; torch's float32 cascade sum could decide differently only when the mean is within ~1e-6 of mean_exp),
+ * zeroed where the resized alpha is 0, nearest-upsampled (torch indices) and multiplied into alpha, truncated. */
+ORC_API int orc_color_correct(const uint8_t* img, const uint8_t* alpha, int H, int W, const uint8_t* bg_color, int long_side,
+                              double mean_exp, uint8_t* out, int* n_sqrt_out)
+{
+    int th, tw;
+    orc_get_target_size(H, W, long_side, 1, &th, &tw);
+    size_t n = (size_t)th * tw;
+    uint8_t* small = (uint8_t*)malloc(n * 3);
+    uint8_t* ar = (uint8_t*)malloc(n);
+    float* dist = (float*)malloc(n * sizeof(float));
+    orc_resize_linear_u8(img, H, W, 3, small, th, tw);
+    orc_resize_linear_u8(alpha, H, W, 1, ar, th, tw);
+    uint8_t bl[3];
+    orc_bgr2lab_px(bg_color, bl);
+    float ba = (float)bl[1] / 255.f, bb = (float)bl[2] / 255.f;
+    float dmin = INFINITY, dmax = -INFINITY;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t lab[3];
+        orc_bgr2lab_px(small + 3 * i, lab);
+        float da = (float)lab[1] / 255.f - ba, db = (float)lab[2] / 255.f - bb;
+        float d = sqrtf(da * da + db * db);
+        dist[i] = d;
+        if (d < dmin) dmin = d;
+        if (d > dmax) dmax = d;
+    }
+    float range = dmax - dmin;
+    for (size_t i = 0; i < n; i++) dist[i] = (dist[i] - dmin) / range;
+    int iters = 0;
+    for (;; iters++) {
+        double s = 0; size_t c = 0;
+        for (size_t i = 0; i < n; i++) if (ar[i] > 0 && dist[i] > 0.f) { s += dist[i]; c++; }
+        float mean = (float)(s / (double)c);
+        if (!(mean < (float)mean_exp)) break;
+        for (size_t i = 0; i < n; i++) dist[i] = sqrtf(dist[i]);
+        if (iters > 64) break;
+    }
+    if (n_sqrt_out) *n_sqrt_out = iters;
+    for (size_t i = 0; i < n; i++) if (ar[i] == 0) dist[i] = 0.f;
+    for (int y = 0; y < H; y++) {
+        int sy = orc_torch_nearest_idx(y, th, H);
+        for (int x = 0; x < W; x++) {
+            int sx = orc_torch_nearest_idx(x, tw, W);
+            float v = (float)alpha[(size_t)y * W + x] * dist[(size_t)sy * tw + sx];
+            out[(size_t)y * W + x] = (uint8_t)v;        /* numpy astype(uint8) of a value in [0, 255] (nan -> 0 on x86) */
+        }
+    }
+    free(small); free(ar); free(dist);
+    return 0;
+}
+
+/* cv2.boxFilter(img, -1, (k, k)) on uint8 (unscreen/harmonization/agent.py:91-92, 110-111): normalised box, anchor centre,
+ * BORDER_REFLECT_101; 8-bit sums up to 256 taps go through a 16-bit column sum with the integer reciprocal
+ * D = ((s + divDelta) * divScale) >> 16.  PARITY UNPINNED (restated from the OpenCV 4 generic path; an IPP build may differ). */
+ORC_API void orc_box_filter_u8(const uint8_t* src, int H, int W, int cn, int k, uint8_t* dst)
+{
+    int d = k * k, a = k / 2;
+    double scalef = 65536.0 / d;
+    int divScale = (int)floor(scalef), divDelta = d / 2;
+    if (scalef - divScale < 0.5) divDelta++; else divScale++;
+    if (k == 1) { divScale = 65536; divDelta = 0; }
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++)
+            for (int c = 0; c < cn; c++) {
+                int s = 0;
+                for (int j = -a; j < k - a; j++) {
+                    int yy = y + j;
+                    if (H == 1) yy = 0; else { while (yy < 0 || yy >= H) yy = yy < 0 ? -yy : 2 * (H - 1) - yy; }
+                    for (int i = -a; i < k - a; i++) {
+                        int xx = x + i;
+                        if (W == 1) xx = 0; else { while (xx < 0 || xx >= W) xx = xx < 0 ? -xx : 2 * (W - 1) - xx; }
+                        s += src[((size_t)yy * W + xx) * cn + c];
+                    }
+                }
+                dst[((size_t)y * W + x) * cn + c] = (uint8_t)(((unsigned)(s + divDelta) * (unsigned)divScale) >> 16);
+            }
+}

@@ -215,3 +215,76 @@ def test_humanseg_affine_and_warps(oracle_lib):
     lg = rng.normal(size=(5, 7, 9)).astype(np.float32)
     up = oracle_lib.upsample_align_corners(lg, 13, 17)
     assert np.array_equal(up[::2, ::2].transpose(2, 0, 1), lg)
+
+
+def test_green_mode_oracle_pieces(oracle_lib):
+    """BGR2Lab against known OpenCV 8-bit values and the CIE formula (fixed-point error <= 3 levels), the mixture tables against
+    float64, the adaptive threshold and colour correction against straight NumPy restatements of the reference lines."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from green_ref import green_screen_clip
+    px = np.array([[[255, 255, 255], [0, 0, 0], [0, 255, 0], [255, 0, 0], [0, 0, 255]]], np.uint8)
+    assert oracle_lib.bgr2lab(px).tolist() == [[[255, 128, 128], [0, 128, 128], [224, 42, 211], [82, 207, 20], [136, 208, 195]]]
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    b, g, r = [img[..., i].astype(np.float64) / 255 for i in range(3)]
+    gam = lambda x: np.where(x <= 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)  # noqa: E731
+    R, G, B = gam(r), gam(g), gam(b)
+    X = (0.412453 * R + 0.357580 * G + 0.180423 * B) / 0.950456
+    Y = 0.212671 * R + 0.715160 * G + 0.072169 * B
+    Z = (0.019334 * R + 0.119193 * G + 0.950227 * B) / 1.088754
+    f = lambda t: np.where(t > 0.008856, np.cbrt(t), 7.787 * t + 16 / 116)  # noqa: E731
+    ref = np.stack([np.where(Y > 0.008856, 116 * np.cbrt(Y) - 16, 903.3 * Y) * 2.55, 500 * (f(X) - f(Y)) + 128, 200 * (f(Y) - f(Z)) + 128], -1)
+    assert np.abs(oracle_lib.bgr2lab(img).astype(np.float64) - ref).max() < 3.0
+    # mixture table
+    m, s, w = np.array([20., 90., 200.]), np.array([3., 12., 30.]), np.array([0.2, 0.5, 0.3])
+    x = np.arange(256)[None, :]
+    ref = (w[:, None] / (s[:, None] * np.sqrt(2 * np.pi)) * np.exp(-0.5 * ((x - m[:, None]) / s[:, None]) ** 2)).sum(0)
+    assert np.abs(oracle_lib.gmm_lut(m, s, w) - ref).max() < 1e-7
+    # likelihood ratio: NumPy float32 restatement of agent.py:232-257
+    hsv = rng.integers(0, 256, (40, 50, 3), dtype=np.uint8)
+    lb = np.stack([oracle_lib.gmm_lut(m + 5 * i, s, w) for i in range(3)])
+    lf = np.stack([oracle_lib.gmm_lut(m[::-1] - 3 * i, s, w) for i in range(3)])
+    bgp = np.ones((40, 50), np.float32)
+    fgp = np.ones((40, 50), np.float32)
+    for i in range(3):
+        bgp *= lb[i][hsv[..., i]]
+        fgp *= lf[i][hsv[..., i]]
+    bgp, fgp = np.cbrt(bgp.astype(np.float64)).astype(np.float32), np.cbrt(fgp.astype(np.float64)).astype(np.float32)
+    prob = fgp / (bgp + fgp + np.float32(1e-6))
+    alpha, p = oracle_lib.gmm_alpha(hsv, lb, lf, want_prob=True)
+    assert np.array_equal(p, prob) and np.array_equal(alpha, np.clip(prob * 255, 0, 255).astype(np.uint8))
+    # adaptive threshold (agent.py:275-278)
+    mask = (rng.random((40, 50)) > 0.4).astype(np.uint8) * 255
+    a = rng.integers(0, 256, (40, 50), dtype=np.uint8)
+    want = a.copy()
+    thr = a.astype(np.float64)[(a > 128) & (mask > 0)].mean() * 0.8
+    want[want < thr] = 0
+    want = oracle_lib.morph(oracle_lib.morph(want, 3, 2, "dilate"), 3, 2, "erode")
+    want = oracle_lib.morph(oracle_lib.morph(want, 3, 2, "erode"), 3, 2, "dilate")
+    assert np.array_equal(oracle_lib.cf_postprocess(a, mask), want)
+    # colour correction (imgprocess.py:263-300) in NumPy float32
+    frame, coarse = green_screen_clip(120, 200, 3)
+    al = np.where(coarse > 0, 180, 0).astype(np.uint8)
+    th, tw = oracle_lib.get_target_size(120, 200, 960)
+    small = oracle_lib.bgr2lab(oracle_lib.resize_linear(frame, th, tw)).astype(np.float32) / np.float32(255)
+    bgl = oracle_lib.bgr2lab(frame[0:1, 0:1]).astype(np.float32) / np.float32(255)
+    d = np.sqrt(((small - bgl)[:, :, 1:] ** 2).sum(-1, dtype=np.float32))
+    d = (d - d.min()) / (d.max() - d.min())
+    ar = oracle_lib.resize_linear(al, th, tw).astype(np.float32)
+    n = 0
+    while d[(ar > 0) & (d > 0)].mean(dtype=np.float64) < np.float32(0.95):
+        d = np.sqrt(d)
+        n += 1
+    d[ar == 0] = 0
+    sy = np.minimum(np.floor(np.arange(120, dtype=np.float32) * np.float32(th / 120)).astype(int), th - 1)
+    sx = np.minimum(np.floor(np.arange(200, dtype=np.float32) * np.float32(tw / 200)).astype(int), tw - 1)
+    want = (al.astype(np.float32) * d[sy][:, sx]).astype(np.uint8)
+    got, it = oracle_lib.color_correct(frame, al, frame[0, 0], want_iters=True)
+    assert it == n and np.array_equal(got, want)
+    # box filter: constants preserved, 3x3 mean of an impulse = round(255 / 9)
+    imp = np.zeros((9, 9), np.uint8)
+    imp[4, 4] = 255
+    out = oracle_lib.box_filter(imp, 3)
+    assert out[4, 4] == 28 and out[3:6, 3:6].min() == 28 and out.sum() == 28 * 9
+    assert np.array_equal(oracle_lib.box_filter(np.full((5, 7, 3), 9, np.uint8), 5), np.full((5, 7, 3), 9, np.uint8))

@@ -47,6 +47,16 @@ _SIGNATURES = {
     "usc_rescale_fg_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp]),
     "usc_warp_affine_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _vp, C.c_int, C.c_int, _vp]),
     "usc_composite_fgbg_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "usc_lab_tables_bytes": (C.c_size_t, []),
+    "usc_lab_tables_host": (None, [_vp]),
+    "usc_cvt_color_u8": (C.c_int, [_vp, C.c_size_t, C.c_int, _vp, _vp, _vp]),
+    "usc_gmm_lut_host": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, _vp]),
+    "usc_gmm_alpha_u8": (C.c_int, [_vp, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "usc_cf_threshold_ws_bytes": (C.c_size_t, []),
+    "usc_cf_threshold_u8": (C.c_int, [_vp, _vp, C.c_size_t, C.c_double, _vp, C.c_size_t, _vp]),
+    "usc_color_correct_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "usc_color_correct_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_double, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "usc_box_filter_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "usc_remove_invalid_objects_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                   C.c_double, _vp, C.POINTER(C.c_int)]),
     "usc_humanseg_affine": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -307,6 +317,95 @@ def composite_fgbg(fg, alpha, bg, out=None):
     _check(load().usc_composite_fgbg_u8(_dev_u8(fg, "composite.fg", (fh, fw, 3)), _dev_u8(alpha, "composite.alpha", (fh, fw)), fh, fw,
                                         _dev_u8(bg, "composite.bg", (bh, bw, 3)), bh, bw, _dev_u8(out, "composite.out", (fh, fw, 3)), _stream()),
            "usc_composite_fgbg_u8")
+    return out
+
+
+# ---------------------------------------------------------------- green mode
+BGR2HSV, HSV2BGR, BGR2GRAY, BGR2LAB = 0, 1, 2, 3
+_lab_tables = {}
+
+
+def lab_tables(device):
+    """Device copy of the 8-bit BGR->Lab lookup tables (built by the library on the host, uploaded once per device)."""
+    key = str(device)
+    if key not in _lab_tables:
+        blob = np.empty(load().usc_lab_tables_bytes(), np.uint8)
+        load().usc_lab_tables_host(blob.ctypes.data)
+        _lab_tables[key] = torch.from_numpy(blob).to(device)
+    return _lab_tables[key]
+
+
+def cvt_color(img, code, out=None):
+    """cv2.cvtColor on a (H, W, 3) uint8 CUDA tensor; code BGR2HSV / HSV2BGR / BGR2GRAY / BGR2LAB."""
+    H, W, _ = img.shape
+    pi = _dev_u8(img, "cvt_color.img", (H, W, 3))
+    shape = (H, W) if code == BGR2GRAY else (H, W, 3)
+    out = torch.empty(shape, dtype=torch.uint8, device=img.device) if out is None else out
+    tab = lab_tables(img.device).data_ptr() if code == BGR2LAB else None
+    _check(load().usc_cvt_color_u8(pi, H * W, int(code), _dev_u8(out, "cvt_color.out", shape), tab, _stream()), "usc_cvt_color_u8")
+    return out
+
+
+def gmm_lut(means, stds, weights):
+    """Likelihood of one fitted 1-D mixture at the 256 uint8 values (host, float32) -> np.float32 (256,)."""
+    m = np.ascontiguousarray(np.atleast_1d(means), np.float64)
+    sd = np.ascontiguousarray(np.atleast_1d(stds), np.float64)
+    w = np.ascontiguousarray(np.atleast_1d(weights), np.float64)
+    if not (m.shape == sd.shape == w.shape and m.ndim == 1):
+        raise NativeError("gmm_lut: means / stds / weights must be 1-D and of equal length")
+    out = np.empty(256, np.float32)
+    dp = C.POINTER(C.c_double)
+    _check(load().usc_gmm_lut_host(m.ctypes.data_as(dp), sd.ctypes.data_as(dp), w.ctypes.data_as(dp), len(m), out.ctypes.data),
+           "usc_gmm_lut_host")
+    return out
+
+
+def gmm_alpha(img_hsv, luts, out=None, want_prob=False):
+    """img_hsv (h, w, 3) uint8 CUDA; luts (6, 256) float32 CUDA (bg h, s, v then fg h, s, v) -> alpha (h, w) uint8."""
+    h, w, _ = img_hsv.shape
+    pi = _dev_u8(img_hsv, "gmm_alpha.img_hsv", (h, w, 3))
+    if not (luts.is_cuda and luts.dtype == torch.float32 and luts.is_contiguous() and luts.numel() == 6 * 256):
+        raise NativeError("gmm_alpha.luts: expected a contiguous (6, 256) float32 CUDA tensor")
+    out = torch.empty((h, w), dtype=torch.uint8, device=img_hsv.device) if out is None else out
+    prob = torch.empty((h, w), dtype=torch.float32, device=img_hsv.device) if want_prob else None
+    _check(load().usc_gmm_alpha_u8(pi, h * w, luts.data_ptr(), _dev_u8(out, "gmm_alpha.out", (h, w)),
+                                   prob.data_ptr() if want_prob else None, _stream()), "usc_gmm_alpha_u8")
+    return (out, prob) if want_prob else out
+
+
+def cf_threshold(alpha, mask, thr_ratio=0.8, ws=None):
+    """In place: alpha[alpha < mean(alpha[(alpha > 128) & (mask > 0)]) * thr_ratio] = 0."""
+    h, w = alpha.shape
+    need = load().usc_cf_threshold_ws_bytes()
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, alpha.device)
+    _check(load().usc_cf_threshold_u8(_dev_u8(alpha, "cf_threshold.alpha"), _dev_u8(mask, "cf_threshold.mask", (h, w)), h * w,
+                                      float(thr_ratio), ws.data_ptr(), ws.numel(), _stream()), "usc_cf_threshold_u8")
+    return alpha
+
+
+def color_correct(img, alpha, bg_color, target_long_side=960, mean_exp=0.95, out=None, ws=None, want_iters=False):
+    H, W, _ = img.shape
+    pi = _dev_u8(img, "color_correct.img", (H, W, 3))
+    pa = _dev_u8(alpha, "color_correct.alpha", (H, W))
+    col = np.ascontiguousarray(np.asarray(bg_color.cpu() if isinstance(bg_color, torch.Tensor) else bg_color, dtype=np.uint8).reshape(3))
+    out = torch.empty_like(alpha) if out is None else out
+    need = load().usc_color_correct_ws_bytes(H, W, int(target_long_side))
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, img.device)
+    it = torch.zeros(1, dtype=torch.int32, device=img.device) if want_iters else None
+    _check(load().usc_color_correct_u8(pi, pa, H, W, col.ctypes.data, int(target_long_side), float(mean_exp),
+                                       lab_tables(img.device).data_ptr(), _dev_u8(out, "color_correct.out", (H, W)),
+                                       it.data_ptr() if want_iters else None, ws.data_ptr(), ws.numel(), _stream()),
+           "usc_color_correct_u8")
+    return (out, int(it.item())) if want_iters else out
+
+
+def box_filter(img, ksize=3, out=None):
+    H, W, cn = _img_dims(img)
+    out = torch.empty_like(img) if out is None else out
+    _check(load().usc_box_filter_u8(_dev_u8(img, "box_filter.img"), H, W, cn, int(ksize), _dev_u8(out, "box_filter.out", tuple(img.shape)),
+                                    _stream()), "usc_box_filter_u8")
     return out
 
 

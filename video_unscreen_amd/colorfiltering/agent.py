@@ -1,0 +1,164 @@
+"""ColorFilteringAgent: per-channel HSV mixture models of screen and foreground -> alpha (reference
+unscreen/colorfiltering/agent.py:9-354, same constructor / method names / return values).
+
+Split by where the work is:
+  * fitting (get_color_prior, fit_bg_gmms, fit_fg_gmms): <= 10 000 scalar samples per channel through sklearn's EM,
+    exactly the reference's dependency - host work on the 540x960 HSV image, only on training frames
+    (every `colorfiltering_update_duration` frames);
+  * inference on every frame (HIP, libunscreen_hip.so): BGR->HSV, bilinear resize, the mixture likelihood ratio
+    (each 1-D mixture collapses to a 256-entry table: usc_gmm_lut_host + usc_gmm_alpha_u8), the adaptive threshold
+    (usc_cf_threshold_u8), close/open (usc_morph_u8) and the resize back.
+"""
+import numpy as np
+import torch
+
+from .. import _native as nv
+from ..utils._dev import to_dev, to_host
+
+
+class ColorFilteringAgent():
+
+    def __init__(self, input_long_side=960, bg_ncomp=(3, 5, 5), fg_ncomp=(10, 10, 10), max_num_samples=10000,
+                 color_prior_winsize=30, use_opencv_gmm=False, random_state=None):
+        assert isinstance(input_long_side, int)
+        assert len(bg_ncomp) == 3 and len(fg_ncomp) == 3
+        assert isinstance(max_num_samples, int) and max_num_samples > 2
+        assert isinstance(color_prior_winsize, int) and color_prior_winsize > 0
+        if use_opencv_gmm:
+            raise NotImplementedError("use_opencv_gmm=True needs cv2.ml.EM; this build fits with sklearn (the reference default)")
+        self.input_long_side = input_long_side
+        self.bg_ncomp = bg_ncomp
+        self.fg_ncomp = fg_ncomp
+        self.max_num_samples = max_num_samples
+        self.color_prior_winsize = color_prior_winsize
+        self.use_opencv_gmm = use_opencv_gmm
+        self.random_state = random_state          # None = unseeded, as the reference (agent.py:101-110)
+        self._luts = None
+        self._ws = None
+        self.reset_gmms()
+
+    def is_trained(self):
+        return self._is_trained
+
+    def reset_gmms(self):
+        """Fresh spherical, warm-started mixtures for the three HSV channels of screen and foreground (agent.py:81-111)."""
+        from sklearn import mixture
+        mk = lambda k: mixture.GaussianMixture(n_components=k, covariance_type='spherical', warm_start=True,  # noqa: E731
+                                               random_state=self.random_state)
+        self.bg_gmms = [mk(self.bg_ncomp[i]) for i in range(3)]
+        self.fg_gmms = [mk(self.fg_ncomp[i]) for i in range(3)]
+        self._is_trained = False
+        self._luts = None
+
+    # ------------------------------------------------------------------ host: sampling + EM (training frames only)
+    def _subsample(self, samples):
+        if len(samples) > self.max_num_samples:
+            samples = samples[::len(samples) // self.max_num_samples]
+        return samples
+
+    def get_color_prior(self, img_hsv, mask, color_prior_winsize=None):
+        """Pixels whose hue lies strictly inside (peak - w//2, peak + w//2) of the masked hue histogram (agent.py:113-149)."""
+        if color_prior_winsize is None:
+            color_prior_winsize = self.color_prior_winsize
+        hue = img_hsv[:, :, 0]
+        samples = self._subsample(hue[mask].astype(np.float64))
+        hist, _ = np.histogram(samples, 256, [0, 256])
+        peak = int(np.argmax(hist))
+        half = color_prior_winsize // 2
+        return (hue.astype(np.int64) > peak - half) & (hue.astype(np.int64) < peak + half)
+
+    def _fit(self, gmms, img_hsv, mask):
+        for i in range(3):
+            samples = self._subsample(img_hsv[:, :, i][mask].astype(np.float64))
+            gmms[i].fit(samples[..., np.newaxis])
+        self._is_trained = True
+        self._luts = None
+
+    def fit_bg_gmms(self, img_hsv, mask, mask_by_prior=None):
+        """Screen model from (coarse background) & (hue prior) (agent.py:151-176)."""
+        if mask_by_prior is None:
+            mask_by_prior = self.get_color_prior(img_hsv, mask)
+        self._fit(self.bg_gmms, img_hsv, mask & mask_by_prior)
+
+    def fit_fg_gmms(self, img_hsv, mask, mask_by_prior=None):
+        """Foreground model; screen-hued pixels are dropped when enough others remain (agent.py:178-199)."""
+        if mask_by_prior is None:
+            mask_by_prior = self.get_color_prior(img_hsv, ~mask, self.color_prior_winsize // 5)
+        keep = mask & ~mask_by_prior
+        if keep.sum() > max(self.fg_ncomp) * 5:
+            mask = keep
+        self._fit(self.fg_gmms, img_hsv, mask)
+
+    # ------------------------------------------------------------------ device: inference
+    def get_prob_by_gmm(self, samples, gmm):
+        """Mixture likelihood of uint8-valued samples (agent.py:201-230): a gather from the 256-entry table."""
+        lut = nv.gmm_lut(gmm.means_.squeeze(), np.sqrt(gmm.covariances_.squeeze()), gmm.weights_.squeeze())
+        return torch.from_numpy(lut[np.asarray(samples).reshape(-1).astype(np.int64)])
+
+    def _device_luts(self, device):
+        if self._luts is None or self._luts.device != device:
+            tabs = [nv.gmm_lut(g.means_.squeeze(), np.sqrt(g.covariances_.squeeze()), g.weights_.squeeze())
+                    for g in (self.bg_gmms + self.fg_gmms)]
+            self._luts = torch.from_numpy(np.stack(tabs)).to(device)
+        return self._luts
+
+    def get_alpha_by_gmm_device(self, img_hsv):
+        alpha, prob = nv.gmm_alpha(img_hsv, self._device_luts(img_hsv.device), want_prob=True)
+        return alpha, float(torch.std(prob))
+
+    def get_alpha_by_gmm(self, img_hsv):
+        """(alpha uint8 (h, w), confidence) (agent.py:232-257; the reference returns the unbound `.item` as
+        confidence - here it is the float it meant)."""
+        alpha, conf = self.get_alpha_by_gmm_device(to_dev(img_hsv))
+        return to_host(alpha), conf
+
+    def postprocess_device(self, alpha, mask, thr_ratio=0.8):
+        if self._ws is None or self._ws.device != alpha.device:
+            self._ws = torch.empty(256, dtype=torch.uint8, device=alpha.device)
+        nv.cf_threshold(alpha, mask, thr_ratio, ws=self._ws)
+        alpha = nv.morph(nv.morph(alpha, 3, 2, nv.DILATE), 3, 2, nv.ERODE)
+        return nv.morph(nv.morph(alpha, 3, 2, nv.ERODE), 3, 2, nv.DILATE)
+
+    def postprocess(self, alpha, mask, thr_ratio=0.8):
+        """Adaptive threshold, then close and open (agent.py:259-283)."""
+        return to_host(self.postprocess_device(to_dev(np.array(alpha, copy=True)), to_dev(mask), thr_ratio))
+
+    def forward_device(self, img, mask, iters=1):
+        """img (H, W, 3), mask (H, W) uint8 CUDA -> (alpha CUDA (H, W), bg_img CUDA (H, W, 3), confidence)."""
+        n = mask.numel()
+        n_ge129 = int(nv.count_ge(mask, 129).item())
+        n_ge128 = int(nv.count_ge(mask, 128).item())
+        if n_ge129 < max(self.fg_ncomp) * 5:                 # no foreground
+            return mask, img, 1.0
+        if n - n_ge128 < max(self.bg_ncomp) * 5:             # no background
+            return mask, torch.zeros_like(img), 1.0
+        ori_h, ori_w = mask.shape
+        th, tw = nv.get_target_size(ori_h, ori_w, self.input_long_side)
+        img_hsv = nv.resize(nv.cvt_color(img, nv.BGR2HSV), th, tw, 1)
+        mask = nv.resize(mask, th, tw, 1)
+        if iters == 0:
+            alpha, confidence = self.get_alpha_by_gmm_device(img_hsv)
+            alpha = self.postprocess_device(alpha, mask)
+        else:
+            hsv_host = to_host(img_hsv)
+            for _ in range(iters):
+                mask_host = to_host(mask)
+                bg_prior = self.get_color_prior(hsv_host, mask_host < 128, self.color_prior_winsize)
+                fg_prior = self.get_color_prior(hsv_host, mask_host < 128, self.color_prior_winsize // 5)
+                self.fit_bg_gmms(hsv_host, mask_host < 128, bg_prior)
+                self.fit_fg_gmms(hsv_host, mask_host > 128, fg_prior)
+                alpha, confidence = self.get_alpha_by_gmm_device(img_hsv)
+                alpha = self.postprocess_device(alpha, mask)
+                mask = (alpha > 128).to(torch.uint8) * 255
+                nfg = int(nv.count_ge(mask, 129).item())
+                if nfg < max(self.fg_ncomp) * 5 or mask.numel() - nfg < max(self.bg_ncomp) * 5:
+                    break
+        alpha = nv.resize(alpha, ori_h, ori_w, 1)
+        bg_hsv = torch.tensor([[[int(np.mean(g.means_[0, 0])) for g in self.bg_gmms]]], dtype=torch.uint8, device=img.device)
+        bg_bgr = nv.cvt_color(bg_hsv, nv.HSV2BGR)
+        return alpha, bg_bgr.expand(ori_h, ori_w, 3).contiguous(), confidence
+
+    def forward(self, img, mask, iters=1):
+        """NumPy API of the reference (agent.py:285-354)."""
+        a, b, c = self.forward_device(to_dev(img), to_dev(mask), iters)
+        return to_host(a), to_host(b), c

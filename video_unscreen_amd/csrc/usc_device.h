@@ -142,4 +142,53 @@ __device__ __forceinline__ Px4 pack12(const int* c) {
     return p;
 }
 
+// How cv::resize(INTER_LINEAR, 8-bit) treats a (src -> dst) size pair (chosen on the host, usc_host.h resize_geom).
+enum ResizeMode { RS_COPY = 0, RS_AREA2 = 1, RS_LINEAR = 2 };
+
+__device__ __forceinline__ void cubic_coeffs(float x, int* c) {      // cv::interpolateCubic, A = -0.75, 11-bit fixed point
+    const float A = -0.75f;
+    const float f0 = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    const float f1 = ((A + 2) * x - (A + 3)) * x * x + 1;
+    const float f2 = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    const float f3 = 1.f - f0 - f1 - f2;
+    c[0] = coef11(f0); c[1] = coef11(f1); c[2] = coef11(f2); c[3] = coef11(f3);
+}
+
+// One channel value of cv::resize at destination (y, x) of a virtual (dh x dw) image.  interp: 0 nearest, 1 linear
+// (mode = copy / 2x2 box / fixed-point bilinear as OpenCV would choose), 2 cubic.
+__device__ __forceinline__ int resize_sample_u8(const uint8_t* __restrict__ s, int sh, int sw, int cn, int c, int y, int x,
+                                                int interp, int mode, double scale_y, double scale_x, double ify, double ifx) {
+    if (interp == 0) {
+        const int sy = min((int)floor(y * ify), sh - 1), sx = min((int)floor(x * ifx), sw - 1);
+        return s[((size_t)sy * sw + sx) * cn + c];
+    }
+    if (interp == 1) {
+        if (mode == RS_COPY) return s[((size_t)y * sw + x) * cn + c];
+        if (mode == RS_AREA2) {
+            const uint8_t* p = s + ((size_t)(2 * y) * sw + 2 * x) * cn + c;
+            return (p[0] + p[cn] + p[(size_t)sw * cn] + p[(size_t)sw * cn + cn] + 2) >> 2;
+        }
+        Tap tx = linear_tap_x(x, scale_x, sw), ty = linear_tap(y, scale_y);
+        const int x0 = tx.s, x1 = min(x0 + 1, sw - 1);
+        const int y0 = clampi(ty.s, 0, sh - 1), y1 = clampi(ty.s + 1, 0, sh - 1);
+        return bilinear_u8(s[((size_t)y0 * sw + x0) * cn + c], s[((size_t)y0 * sw + x1) * cn + c],
+                           s[((size_t)y1 * sw + x0) * cn + c], s[((size_t)y1 * sw + x1) * cn + c],
+                           coef11(1.f - tx.f), coef11(tx.f), coef11(1.f - ty.f), coef11(ty.f));
+    }
+    const Tap tx = linear_tap(x, scale_x), ty = linear_tap(y, scale_y);
+    int cx[4], cy[4];
+    cubic_coeffs(tx.f, cx);
+    cubic_coeffs(ty.f, cy);
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int yy = clampi(ty.s - 1 + j, 0, sh - 1);
+        int row = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) row += s[((size_t)yy * sw + clampi(tx.s - 1 + i, 0, sw - 1)) * cn + c] * cx[i];
+        acc += row * cy[j];
+    }
+    return min(max((acc + (1 << 21)) >> 22, 0), 255);
+}
+
 }  // namespace usc

@@ -12,6 +12,7 @@
 
 #include "../../include/unscreen_hip.h"
 #include "usc_device.h"
+#include "usc_host.h"
 
 using namespace usc;
 
@@ -19,14 +20,14 @@ using namespace usc;
 // error plumbing
 // --------------------------------------------------------------------------------------------
 static thread_local char g_err[256] = "";
-static int fail(int code, const char* fmt, ...) {
+int usc::fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
 }
-static int check_launch(const char* what) {
+int usc::check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(USC_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return USC_OK;
@@ -56,23 +57,6 @@ extern "C" void usc_pad_resize_geometry(int h, int w, int target_h, int target_w
 extern "C" void usc_inv_pad_geometry(int h, int w, int ori_h, int ori_w, int* rh, int* rw) {
     if ((double)ori_h / ori_w > (double)h / w) { *rh = h; *rw = (int)((double)h * ori_w / ori_h); }
     else { *rw = w; *rh = (int)((double)w * ori_h / ori_w); }
-}
-
-// How cv::resize(INTER_LINEAR, 8-bit) treats a (src -> dst) size pair.
-enum ResizeMode { RS_COPY = 0, RS_AREA2 = 1, RS_LINEAR = 2 };
-struct ResizeGeom { int mode; double scale_x, scale_y; };
-static ResizeGeom resize_geom(int sh, int sw, int dh, int dw) {
-    ResizeGeom g;
-    g.scale_x = 1. / ((double)dw / sw);
-    g.scale_y = 1. / ((double)dh / sh);
-    g.mode = RS_LINEAR;
-    if (sh == dh && sw == dw) g.mode = RS_COPY;
-    else {
-        int ix = (int)lrint(g.scale_x), iy = (int)lrint(g.scale_y);
-        if (fabs(g.scale_x - ix) < 2.220446049250313e-16 && fabs(g.scale_y - iy) < 2.220446049250313e-16 && ix == 2 && iy == 2)
-            g.mode = RS_AREA2;        // OpenCV reroutes exact 2x bilinear decimation to the 2x2 box average
-    }
-    return g;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -445,15 +429,6 @@ extern "C" size_t usc_trimap_ws_bytes(int H, int W, int long_side) {
     int h, w;
     usc_get_target_size(H, W, long_side, 1, &h, &w);
     return ((size_t)h * w + 255) & ~(size_t)255;
-}
-
-static bool too_big(int H, int W) { return (long long)H * W >= (1ll << 31); }   // kernels index pixels with 32 bits
-
-static int grid_for(size_t work_items, int threads) {
-    size_t blocks = (work_items + threads - 1) / threads;
-    if (blocks < 1) blocks = 1;
-    if (blocks > 256 * 16) blocks = 256 * 16;       // 16 workgroups per CU, grid-stride beyond that
-    return (int)blocks;
 }
 
 extern "C" int usc_trimap_u8(const uint8_t* mask, int H, int W, int long_side, int ksize, int iters, uint8_t* out,
@@ -992,52 +967,6 @@ extern "C" int usc_count_ge_u8(const uint8_t* mask, size_t n, int thr, unsigned 
 // --------------------------------------------------------------------------------------------
 // generic 8-bit resize / affine warp / composite (replace mode: tools/replace/replace.py:59-82)
 // --------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ void cubic_coeffs(float x, int* c) {      // cv::interpolateCubic, A = -0.75, 11-bit fixed point
-    const float A = -0.75f;
-    const float f0 = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
-    const float f1 = ((A + 2) * x - (A + 3)) * x * x + 1;
-    const float f2 = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
-    const float f3 = 1.f - f0 - f1 - f2;
-    c[0] = coef11(f0); c[1] = coef11(f1); c[2] = coef11(f2); c[3] = coef11(f3);
-}
-
-// One channel value of cv::resize at destination (y, x) of a virtual (dh x dw) image.  interp: 0 nearest, 1 linear
-// (mode = copy / 2x2 box / fixed-point bilinear as OpenCV would choose), 2 cubic.
-__device__ __forceinline__ int resize_sample_u8(const uint8_t* __restrict__ s, int sh, int sw, int cn, int c, int y, int x,
-                                                int interp, int mode, double scale_y, double scale_x, double ify, double ifx) {
-    if (interp == 0) {
-        const int sy = min((int)floor(y * ify), sh - 1), sx = min((int)floor(x * ifx), sw - 1);
-        return s[((size_t)sy * sw + sx) * cn + c];
-    }
-    if (interp == 1) {
-        if (mode == RS_COPY) return s[((size_t)y * sw + x) * cn + c];
-        if (mode == RS_AREA2) {
-            const uint8_t* p = s + ((size_t)(2 * y) * sw + 2 * x) * cn + c;
-            return (p[0] + p[cn] + p[(size_t)sw * cn] + p[(size_t)sw * cn + cn] + 2) >> 2;
-        }
-        Tap tx = linear_tap_x(x, scale_x, sw), ty = linear_tap(y, scale_y);
-        const int x0 = tx.s, x1 = min(x0 + 1, sw - 1);
-        const int y0 = clampi(ty.s, 0, sh - 1), y1 = clampi(ty.s + 1, 0, sh - 1);
-        return bilinear_u8(s[((size_t)y0 * sw + x0) * cn + c], s[((size_t)y0 * sw + x1) * cn + c],
-                           s[((size_t)y1 * sw + x0) * cn + c], s[((size_t)y1 * sw + x1) * cn + c],
-                           coef11(1.f - tx.f), coef11(tx.f), coef11(1.f - ty.f), coef11(ty.f));
-    }
-    const Tap tx = linear_tap(x, scale_x), ty = linear_tap(y, scale_y);
-    int cx[4], cy[4];
-    cubic_coeffs(tx.f, cx);
-    cubic_coeffs(ty.f, cy);
-    int acc = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int yy = clampi(ty.s - 1 + j, 0, sh - 1);
-        int row = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) row += s[((size_t)yy * sw + clampi(tx.s - 1 + i, 0, sw - 1)) * cn + c] * cx[i];
-        acc += row * cy[j];
-    }
-    return min(max((acc + (1 << 21)) >> 22, 0), 255);
-}
 
 // dst (oh x ow) = window [y_off, y_off + oh) x [x_off, x_off + ow) of the virtual resize of src to (dh x dw).
 __global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw, int cn,

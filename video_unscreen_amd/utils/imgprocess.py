@@ -36,3 +36,9 @@ def shift_fg(img, dx=0, dy=0):
     """Translate with cv2.warpAffine; the matrix is float32 like the reference's (imgprocess.py:55-64)."""
     M = np.float32([[1, 0, dx], [0, 1, dy]]).astype(np.float64)
     return to_host(nv.warp_affine(to_dev(img), M, img.shape[0], img.shape[1]))
+
+
+def color_correct(img, alpha, bg_color, target_long_side=960, mean_exp=0.95):
+    """Scale alpha by the (min-max normalised, repeatedly square-rooted) Lab a/b distance to the screen colour
+    (reference imgprocess.py:263-300): three kernels, the data-dependent sqrt loop resolved on the device."""
+    return to_host(nv.color_correct(to_dev(img), to_dev(alpha), np.asarray(bg_color), target_long_side, mean_exp))
