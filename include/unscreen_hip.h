@@ -158,6 +158,32 @@ int usc_color_correct_u8(const uint8_t* img, const uint8_t* alpha, int H, int W,
                          usc_stream_t stream);
 int usc_box_filter_u8(const uint8_t* src, int H, int W, int cn, int ksize, uint8_t* dst, usc_stream_t stream);
 
+/* SegAgent (unscreen/binseg/agent.py), everything but the convolutions.
+ * usc_segagent_target_size: agent.py:70-100 get_target_size (host).
+ * usc_grid_crop_locations: agent.py:102-141 grid_crop locations, 4 ints (s_h, e_h, s_w, e_w) per crop, a mirrored crop has
+ *   s_w > e_w; returns the crop count (locs == NULL: count only) or a negative error (host).
+ * usc_segagent_pre: agent.py:176-198 preprocess of ONE crop (loc_host = its 4 ints): pad_resize + imnormalize + crop
+ *   (+ cv2.flip), out = (crop_h, crop_w, 4) float32 NHWC (R, G, B, 0).
+ * usc_im2col_nhwc_f32: patch matrix [OH*OW][Kpad] (k = (ky*kw + kx)*cuse + c, zero beyond kh*kw*cuse) of a k x k stride-s
+ *   convolution over the first `cuse` channels of an NHWC input: the 7x7/2 ResNet stem (deeplab/backbone/resnet.py:183-184)
+ *   then runs as a 1x1 layer of usc_conv_*.
+ * usc_upsample_nc_nhwc_f32: F.interpolate(bilinear, align_corners=False) (deeplab/_deeplab.py:51-55) into channels
+ *   [c0, c0 + C) of a destination with ld channels per pixel.
+ * usc_segagent_post: agent.py:200-237 postprocess: the model's last upsample (deeplab/utils.py:20-21), softmax, float64 merge
+ *   of the crops (agent.py:143-174), inv_pad_resize (utils/imgprocess.py:100-132), argmax * 255.  logits = ncrops
+ *   consecutive (lh, lw, cbuf) NHWC buffers (classes in channels 0, 1); score_out (H*W*2 doubles) may be NULL. */
+void usc_segagent_target_size(int h, int w, int long_side, int division, int crop_h, int crop_w, int* th, int* tw);
+int usc_grid_crop_locations(int h, int w, int crop_h, int crop_w, double stride_ratio, int flip, int* locs, int max_crops);
+int usc_segagent_pre(const uint8_t* img, int H, int W, int th, int tw, const int* loc_host, float* out, usc_stream_t stream);
+int usc_im2col_nhwc_f32(const float* in, int IH, int IW, int cpitch, int cuse, int kh, int kw, int stride, int pad, float* out,
+                        int OH, int OW, int Kpad, usc_stream_t stream);
+int usc_upsample_nc_nhwc_f32(const float* src, int sh, int sw, int C, float* dst, int dh, int dw, int ld, int c0,
+                             usc_stream_t stream);
+size_t usc_segagent_post_ws_bytes(int th, int tw);
+int usc_segagent_post(const float* logits, int ncrops, int lh, int lw, int cbuf, const int* locs_host, int crop_h, int crop_w,
+                      int th, int tw, int H, int W, uint8_t* out, double* score_out, void* ws, size_t ws_bytes,
+                      usc_stream_t stream);
+
 /* unscreen/utils/maskprocess.py:56-60 exist_foreground: *out_count (device, 8 bytes) = #(mask >= thr). */
 int usc_count_ge_u8(const uint8_t* mask, size_t n, int thr, unsigned long long* out_count, usc_stream_t stream);
 

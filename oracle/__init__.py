@@ -50,6 +50,10 @@ def lib():
         _lib.orc_inrange_hsv.argtypes = [u8p, u8p, C.c_int, C.POINTER(C.c_int), C.c_size_t, u8p]
         _lib.orc_trimap_withbg.argtypes = [u8p, u8p, u8p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, u8p]
+        _lib.orc_grid_crop_locations.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]
+        _lib.orc_upsample_nc_f32.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, f32p, C.c_int, C.c_int]
+        _lib.orc_segagent_post.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, u8p, f64p]
         _lib.orc_gmm_lut.argtypes = [f64p, f64p, f64p, C.c_int, f32p]
         _lib.orc_gmm_alpha.argtypes = [u8p, C.c_size_t, f32p, f32p, u8p, f32p]
         _lib.orc_cf_threshold.argtypes = [u8p, u8p, C.c_size_t, C.c_double]
@@ -391,6 +395,53 @@ def humanseg_post(logits_chw, H, W, in_h=473, in_w=473):
     out = np.empty((H, W), np.uint8)
     lib().orc_humanseg_post(p, Cn, lh, lw, C.c_size_t(lh * lw), C.c_size_t(1), in_h, in_w, H, W, out.ctypes.data_as(u8p))
     return out
+
+
+def segagent_target_size(h, w, long_side, division=1, crop_h=513, crop_w=513):
+    """binseg/agent.py:70-100."""
+    a, b = C.c_int(), C.c_int()
+    lib().orc_segagent_target_size(int(h), int(w), int(long_side), int(division), int(crop_h), int(crop_w), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def grid_crop_locations(h, w, crop_h=513, crop_w=513, stride_ratio=0.5, flip=True):
+    """binseg/agent.py:102-141 -> (N, 4) int32 (s_h, e_h, s_w, e_w); mirrored crops have s_w > e_w."""
+    n = lib().orc_grid_crop_locations(int(h), int(w), int(crop_h), int(crop_w), float(stride_ratio), int(bool(flip)), None)
+    locs = np.empty((n, 4), np.int32)
+    lib().orc_grid_crop_locations(int(h), int(w), int(crop_h), int(crop_w), float(stride_ratio), int(bool(flip)),
+                                  locs.ctypes.data_as(C.POINTER(C.c_int)))
+    return locs
+
+
+def segagent_pre(img, th, tw, loc):
+    """binseg/agent.py:176-198 for one crop -> (crop_h, crop_w, 4) float32 NHWC (R, G, B, 0)."""
+    img, p = _u8(img)
+    loc = np.ascontiguousarray(np.asarray(loc, np.int32).reshape(4))
+    out = np.empty((int(loc[1] - loc[0]), int(abs(loc[3] - loc[2])), 4), np.float32)
+    lib().orc_segagent_pre(p, img.shape[0], img.shape[1], int(th), int(tw), loc.ctypes.data_as(C.POINTER(C.c_int)),
+                           out.ctypes.data_as(f32p))
+    return out
+
+
+def upsample_nc(hwc, oh, ow):
+    """F.interpolate(bilinear, align_corners=False) of an (h, w, C) float32 array -> (oh, ow, C)."""
+    a, p = _f32(hwc)
+    h, w, c = a.shape
+    out = np.empty((oh, ow, c), np.float32)
+    lib().orc_upsample_nc_f32(p, c, h, w, 1, c, out.ctypes.data_as(f32p), oh, ow)
+    return out
+
+
+def segagent_post(logits, locs, crop_h, crop_w, th, tw, H, W, want_score=False):
+    """binseg/agent.py:200-237; logits (ncrops, lh, lw, cbuf) float32 NHWC with the classes in channels 0, 1."""
+    a, p = _f32(logits)
+    n, lh, lw, cbuf = a.shape
+    locs = np.ascontiguousarray(np.asarray(locs, np.int32).reshape(n, 4))
+    out = np.empty((H, W), np.uint8)
+    score = np.empty((H, W, 2), np.float64)
+    lib().orc_segagent_post(p, n, lh, lw, cbuf, locs.ctypes.data_as(C.POINTER(C.c_int)), int(crop_h), int(crop_w), int(th), int(tw),
+                            int(H), int(W), out.ctypes.data_as(u8p), score.ctypes.data_as(f64p))
+    return (out, score) if want_score else out
 
 
 def score_map(h, w, center):

@@ -1316,3 +1316,200 @@ ORC_API void orc_box_filter_u8(const uint8_t* src, int H, int W, int cn, int k, 
                 dst[((size_t)y * W + x) * cn + c] = (uint8_t)(((unsigned)(s + divDelta) * (unsigned)divScale) >> 16);
             }
 }
+
+/* ============================================================================================
+ * SegAgent (unscreen/binseg/agent.py): resize/pad, normalise, overlapping crops (+ mirrored copies), network,
+ * softmax, float64 merge, inverse pad-resize, argmax
+ * ============================================================================================ */
+
+/* unscreen/binseg/agent.py:70-100 SegAgent.get_target_size: long side -> input_long_side, short side scaled (rounded up to
+ * `division`), then each side raised to the crop size. */
+ORC_API void orc_segagent_target_size(int h, int w, int long_side, int division, int crop_h, int crop_w, int* th, int* tw)
+{
+    int t_h, t_w;
+    if (h > w) {
+        t_h = long_side;
+        t_w = (int)((double)long_side * w / h);
+        if (t_w % division != 0) t_w = (t_w / division + 1) * division;
+    } else {
+        t_w = long_side;
+        t_h = (int)((double)long_side * h / w);
+        if (t_h % division != 0) t_h = (t_h / division + 1) * division;
+    }
+    if (crop_h > t_h) t_h = crop_h;
+    if (crop_w > t_w) t_w = crop_w;
+    *th = t_h; *tw = t_w;
+}
+
+/* unscreen/binseg/agent.py:102-141 grid_crop: locations (s_h, e_h, s_w, e_w) row-major over the grid, stride
+ * ceil(crop * stride_ratio), the last crop of a row / column aligned to the far edge; with flip every crop is followed by
+ * its mirrored copy whose location is (s_h, e_h, e_w, s_w).  Returns the number of crops (locs may be NULL to count). */
+ORC_API int orc_grid_crop_locations(int h, int w, int crop_h, int crop_w, double stride_ratio, int flip, int* locs)
+{
+    int stride_h = (int)ceil(crop_h * stride_ratio), stride_w = (int)ceil(crop_w * stride_ratio);
+    int grid_h = (int)(ceil((double)(h - crop_h) / stride_h) + 1), grid_w = (int)(ceil((double)(w - crop_w) / stride_w) + 1);
+    int n = 0;
+    for (int ih = 0; ih < grid_h; ih++)
+        for (int iw = 0; iw < grid_w; iw++) {
+            int e_h = ih * stride_h + crop_h; if (e_h > h) e_h = h;
+            int s_h = e_h - crop_h;
+            int e_w = iw * stride_w + crop_w; if (e_w > w) e_w = w;
+            int s_w = e_w - crop_w;
+            if (locs) { locs[4 * n] = s_h; locs[4 * n + 1] = e_h; locs[4 * n + 2] = s_w; locs[4 * n + 3] = e_w; }
+            n++;
+            if (flip) {
+                if (locs) { locs[4 * n] = s_h; locs[4 * n + 1] = e_h; locs[4 * n + 2] = e_w; locs[4 * n + 3] = s_w; }
+                n++;
+            }
+        }
+    return n;
+}
+
+static inline int orc_reflect(int p, int n)          /* BORDER_REFLECT, any distance: ...cba|abc...xyz|zyx... */
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p - 1 : 2 * n - 1 - p;
+    return p;
+}
+
+/* unscreen/binseg/agent.py:176-198 preprocess for ONE crop: pad_resize(img, (th, tw)) (utils/imgprocess.py:67-97: bilinear
+ * to (nh, nw) + BORDER_REFLECT bottom/right), imnormalize (:135-161), crop loc = (s_h, e_h, s_w, e_w), mirrored when
+ * s_w > e_w (cv2.flip(crop, 1)).  out: (crop_h, crop_w, 4) float32 NHWC, channels R, G, B, 0. */
+ORC_API void orc_segagent_pre(const uint8_t* img, int H, int W, int th, int tw, const int* loc, float* out)
+{
+    static const double mean[3] = {0.485, 0.456, 0.406}, std[3] = {0.229, 0.224, 0.225};
+    int nh, nw;
+    orc_pad_resize_geometry(H, W, th, tw, &nh, &nw);
+    uint8_t* r = (uint8_t*)malloc((size_t)nh * nw * 3);
+    orc_resize_linear_u8(img, H, W, 3, r, nh, nw);
+    int s_h = loc[0], e_h = loc[1], s_w = loc[2], e_w = loc[3];
+    int flip = s_w > e_w;
+    if (flip) { int t = s_w; s_w = e_w; e_w = t; }
+    int ch = e_h - s_h, cw = e_w - s_w;
+    for (int y = 0; y < ch; y++)
+        for (int x = 0; x < cw; x++) {
+            int px = s_w + (flip ? cw - 1 - x : x), py = s_h + y;
+            const uint8_t* p = r + ((size_t)orc_reflect(py, nh) * nw + orc_reflect(px, nw)) * 3;
+            float* o = out + ((size_t)y * cw + x) * 4;
+            for (int c = 0; c < 3; c++) {
+                float v = (float)p[2 - c] / 255.f;
+                v = v - (float)mean[c];
+                o[c] = v * (float)(1 / std[c]);
+            }
+            o[3] = 0.f;
+        }
+    free(r);
+}
+
+/* exp on float32 restated with IEEE basic operations only (Cephes expf: Cody-Waite reduction by ln 2 and a degree-5
+ * polynomial), so that the HIP kernel and this oracle agree bit for bit.  torch's CPU softmax uses Sleef's expf; both are
+ * within ~1 ulp of exp, i.e. the softmax below agrees with the reference's to float rounding, not bit for bit. */
+static inline float orc_det_expf(float x)
+{
+    if (x < -87.f) return 0.f;
+    if (x > 88.f) return INFINITY;
+    float kf = rintf(x * 1.44269504088896341f);
+    float r = x - kf * 0.693359375f;
+    r = r - kf * -2.12194440e-4f;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    p = p * (r * r) + r;
+    p = p + 1.f;
+    return ldexpf(p, (int)kf);
+}
+
+/* F.interpolate(x, size, mode='bilinear', align_corners=False) source coordinate (ATen area_pixel_compute_source_index). */
+static inline void orc_bilinear_nc_tap(int d, int in, int out, int* i0, int* i1, float* l0, float* l1)
+{
+    float scale = (float)in / (float)out;
+    float s = scale * ((float)d + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    *i0 = (int)s;
+    *i1 = *i0 + (*i0 < in - 1 ? 1 : 0);
+    *l1 = s - (float)*i0;
+    *l0 = 1.f - *l1;
+}
+
+/* F.interpolate(..., mode='bilinear', align_corners=False) (deeplab/_deeplab.py:51-55, deeplab/utils.py:20-21), float32.
+ * src (ih, iw) pixels with pixel pitch `pstride` and channel pitch `cstride` elements; dst (oh, ow, C) interleaved. */
+ORC_API void orc_upsample_nc_f32(const float* src, int C, int ih, int iw, size_t cstride, size_t pstride, float* dst, int oh, int ow)
+{
+    for (int y = 0; y < oh; y++) {
+        int y0, y1; float hy0, hy1;
+        orc_bilinear_nc_tap(y, ih, oh, &y0, &y1, &hy0, &hy1);
+        for (int x = 0; x < ow; x++) {
+            int x0, x1; float wx0, wx1;
+            orc_bilinear_nc_tap(x, iw, ow, &x0, &x1, &wx0, &wx1);
+            for (int c = 0; c < C; c++) {
+                const float* p = src + (size_t)c * cstride;
+                float top = wx0 * p[((size_t)y0 * iw + x0) * pstride] + wx1 * p[((size_t)y0 * iw + x1) * pstride];
+                float bot = wx0 * p[((size_t)y1 * iw + x0) * pstride] + wx1 * p[((size_t)y1 * iw + x1) * pstride];
+                dst[((size_t)y * ow + x) * C + c] = hy0 * top + hy1 * bot;
+            }
+        }
+    }
+}
+
+/* unscreen/binseg/agent.py:200-237 postprocess + :143-174 inv_grid_crop + utils/imgprocess.py:100-132 inv_pad_resize.
+ * logits: ncrops x (lh, lw, cbuf) float32 NHWC network outputs (2 classes in channels 0, 1) at the classifier's resolution;
+ * the model's own final upsample to the crop size (deeplab/utils.py:20-21, align_corners=False) is applied here.
+ * softmax over the 2 classes in float32; crops are summed in order into a float64 (th, tw, 2) map (mirrored crops
+ * un-mirrored), divided by the cover count; the pad is cut, the map resized to (H, W) by cv2.resize on float64 (float
+ * weights, double products), argmax (first maximum) * 255. */
+ORC_API void orc_segagent_post(const float* logits, int ncrops, int lh, int lw, int cbuf, const int* locs, int crop_h, int crop_w,
+                               int th, int tw, int H, int W, uint8_t* out, double* score_out)
+{
+    size_t n = (size_t)th * tw;
+    double* pred = (double*)calloc(n * 2, sizeof(double));
+    double* cnt = (double*)calloc(n, sizeof(double));
+    float* up = (float*)malloc(sizeof(float) * (size_t)crop_h * crop_w * 2);
+    for (int i = 0; i < ncrops; i++) {
+        const float* lg = logits + (size_t)i * lh * lw * cbuf;
+        orc_upsample_nc_f32(lg, 2, lh, lw, 1, cbuf, up, crop_h, crop_w);
+        int s_h = locs[4 * i], s_w = locs[4 * i + 2], e_w = locs[4 * i + 3];
+        int flip = s_w > e_w;
+        int x0 = flip ? e_w : s_w;
+        for (int y = 0; y < crop_h; y++)
+            for (int x = 0; x < crop_w; x++) {
+                int sx = flip ? crop_w - 1 - x : x;
+                float a = up[((size_t)y * crop_w + sx) * 2], b = up[((size_t)y * crop_w + sx) * 2 + 1];
+                float m = a > b ? a : b;
+                float ea = orc_det_expf(a - m), eb = orc_det_expf(b - m);
+                float s = ea + eb;
+                size_t o = (size_t)(s_h + y) * tw + (x0 + x);
+                pred[2 * o] += (double)(ea / s);
+                pred[2 * o + 1] += (double)(eb / s);
+                cnt[o] += 1.0;
+            }
+    }
+    for (size_t i = 0; i < n; i++) { pred[2 * i] /= cnt[i]; pred[2 * i + 1] /= cnt[i]; }
+    int rh, rw;
+    orc_inv_pad_geometry(th, tw, H, W, &rh, &rw);
+    orc_tap* tx = (orc_tap*)malloc(sizeof(orc_tap) * W);
+    orc_tap* ty = (orc_tap*)malloc(sizeof(orc_tap) * H);
+    int same = (rh == H && rw == W);
+    orc_linear_taps(W, rw, tx, 1);
+    orc_linear_taps(H, rh, ty, 0);
+    for (int y = 0; y < H; y++) {
+        int y0 = orc_clampi(ty[y].ofs, 0, rh - 1), y1 = orc_clampi(ty[y].ofs + 1, 0, rh - 1);
+        double b0 = ty[y].f0, b1 = ty[y].f1;
+        for (int x = 0; x < W; x++) {
+            int x0 = tx[x].ofs, x1 = x0 + 1 < rw ? x0 + 1 : x0;
+            double a0 = tx[x].f0, a1 = tx[x].f1;
+            double v[2];
+            for (int c = 0; c < 2; c++) {
+                if (same) { v[c] = pred[((size_t)y * tw + x) * 2 + c]; continue; }
+                double r0 = pred[((size_t)y0 * tw + x0) * 2 + c] * a0 + pred[((size_t)y0 * tw + x1) * 2 + c] * a1;
+                double r1 = pred[((size_t)y1 * tw + x0) * 2 + c] * a0 + pred[((size_t)y1 * tw + x1) * 2 + c] * a1;
+                v[c] = r0 * b0 + r1 * b1;
+            }
+            if (score_out) { score_out[((size_t)y * W + x) * 2] = v[0]; score_out[((size_t)y * W + x) * 2 + 1] = v[1]; }
+            out[(size_t)y * W + x] = v[1] > v[0] ? 255 : 0;
+        }
+    }
+    free(tx); free(ty); free(pred); free(cnt); free(up);
+}

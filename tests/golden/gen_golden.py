@@ -5,6 +5,11 @@
                         the keyed-deterministic checkpoint of video_unscreen_amd.vmatting.net.synthetic_state_dict
   schp_97x129.npz       reference unscreen/binseg/human_parse.py network(num_classes=20) (loaded by file path) with the
                         keyed-deterministic checkpoint of video_unscreen_amd.binseg.schp_net.schp_synthetic_state_dict
+  deeplab_97x129.npz    reference unscreen/binseg/deeplab/{backbone/resnet,utils,_deeplab,modeling}.py deeplabv3plus_resnet50(num_classes=2,
+                        pretrained_backbone=False): the files' own definitions executed without their import lines (the
+                        package imports torchvision, absent here, only for the pretrained-weights download helper), with the
+                        keyed-deterministic checkpoint of video_unscreen_amd.binseg.deeplab_net; plus SegAgent.get_target_size /
+                        grid_crop locations (unscreen/binseg/agent.py, methods extracted with ast)
   target_size.npz       reference unscreen/utils/imgprocess.py get_target_size over a grid (function extracted
                         with ast; the module itself needs cv2)
   score_map.npz         reference unscreen/utils/maskprocess.py get_score_map / build_score_map / exist_foreground
@@ -38,6 +43,60 @@ def extract(path, names, extra_globals=None):
     return ns
 
 
+def exec_defs(path, ns):
+    """exec a reference file's top-level definitions (everything but its import statements) in namespace `ns`."""
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body if not isinstance(n, (ast.Import, ast.ImportFrom))]
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def deeplab_golden():
+    import types
+    from collections import OrderedDict
+
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from video_unscreen_amd.binseg.deeplab_net import deeplab_checkpoint_layout, deeplab_synthetic_state_dict
+    d = os.path.join(REF, "unscreen/binseg/deeplab")
+    base = {"torch": torch, "nn": nn, "F": F, "OrderedDict": OrderedDict}
+    rn = exec_defs(os.path.join(d, "backbone/resnet.py"), dict(base))
+    ns = dict(base)
+    exec_defs(os.path.join(d, "utils.py"), ns)
+    exec_defs(os.path.join(d, "_deeplab.py"), ns)
+    ns["resnet"] = types.SimpleNamespace(**rn)
+    ns["mobilenetv2"] = None
+    exec_defs(os.path.join(d, "modeling.py"), ns)
+    model = ns["deeplabv3plus_resnet50"](num_classes=2, output_stride=8, pretrained_backbone=False).eval()
+    rsd = model.state_dict()
+    lay = deeplab_checkpoint_layout()
+    assert [k for k, _ in lay] == list(rsd.keys()), "state-dict keys differ"
+    assert all(tuple(rsd[k].shape) == tuple(sh) for k, sh in lay)
+    model.load_state_dict(deeplab_synthetic_state_dict(0))
+    g = torch.Generator().manual_seed(2468)
+    x = torch.randn(1, 3, 97, 129, generator=g)
+    with torch.no_grad():
+        y = model(x)                                   # (1, 2, 97, 129): includes the final bilinear upsample
+    # SegAgent geometry (methods of the class, exec'd as plain functions on a stand-in `self`)
+    tree = ast.parse(open(os.path.join(REF, "unscreen/binseg/agent.py")).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "SegAgent"][0]
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("get_target_size", "grid_crop")]
+    gns = {"np": np, "cv2": types.SimpleNamespace(flip=lambda a, code: a[:, ::-1])}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "agent.py", "exec"), gns)
+    rows, locs = [], {}
+    for (h, w) in [(1080, 1920), (2160, 3840), (256, 256), (1920, 1080), (200, 1920), (720, 1280), (513, 513), (600, 513)]:
+        for L in (962, 912, 600):
+            me = types.SimpleNamespace(input_long_side=L, division=1, crop_h=513, crop_w=513, flip=True)
+            th, tw = gns["get_target_size"](me, h, w)
+            rows.append((h, w, L, th, tw))
+            _, loc = gns["grid_crop"](me, np.zeros((th, tw, 1), np.uint8), 0.5)
+            locs[f"loc_{h}x{w}_{L}"] = np.asarray(loc, np.int64)
+    np.savez_compressed(os.path.join(HERE, "deeplab_97x129.npz"), y=y.numpy(), seed=2468, n_keys=len(lay),
+                        keys_crc=np.int64(sum(__import__("zlib").crc32((k + str(tuple(sh))).encode()) for k, sh in lay)),
+                        target_sizes=np.array(rows, np.int64), **locs)
+    print("deeplab", y.shape, float(y.std()), len(rows), "geometry rows")
+
+
 def unet_input(h, w, seed):
     """Deterministic, realistic 7-channel input: normalised image, alpha in [0,1], one-hot trimap."""
     g = torch.Generator().manual_seed(seed)
@@ -52,6 +111,8 @@ def unet_input(h, w, seed):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "deeplab":
+        return deeplab_golden()
     from video_unscreen_amd.vmatting.net import synthetic_state_dict
 
     # ---- 1. UNet
@@ -86,6 +147,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "schp_97x129.npz"), y=ys.numpy(), seed=4321, n_keys=len(lay),
                         keys_crc=np.int64(sum(__import__("zlib").crc32((k + str(tuple(sh))).encode()) for k, sh in lay)))
     print("schp", ys.shape, float(ys.std()))
+
+    deeplab_golden()
 
     # ---- 2. get_target_size
     ns = extract(os.path.join(REF, "unscreen/utils/imgprocess.py"), {"get_target_size"})

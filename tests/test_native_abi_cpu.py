@@ -43,6 +43,17 @@ def test_host_geometry_matches_reference_table(nv, oracle_lib):
     assert nv.pad_resize_geometry(1920, 1080, 960, 544) == (960, 540)
 
 
+def test_segagent_host_geometry_matches_reference(nv, oracle_lib):
+    z = np.load(os.path.join(GOLD, "deeplab_97x129.npz"))
+    for h, w, L, th, tw in z["target_sizes"]:
+        assert nv.segagent_target_size(h, w, L) == (th, tw)
+        assert np.array_equal(nv.grid_crop_locations(th, tw), z[f"loc_{h}x{w}_{L}"])
+    assert len(nv.grid_crop_locations(541, 962)) == 12 and len(nv.grid_crop_locations(962, 962)) == 18      # 12 / 18 crops
+    assert len(nv.grid_crop_locations(541, 962, flip=False)) == 6
+    with pytest.raises(nv.NativeError):
+        nv.grid_crop_locations(500, 962)            # smaller than the crop
+
+
 def test_device_entry_points_reject_host_arrays(nv):
     import torch
     with pytest.raises(nv.NativeError):

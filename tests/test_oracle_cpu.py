@@ -189,6 +189,30 @@ def test_schp_plan_matches_reference_golden():
     assert np.array_equal(y, y2)
 
 
+def test_deeplab_plan_and_segagent_geometry_match_reference_golden(oracle_lib):
+    """Folded DeepLabv3+/R50 plan on torch-CPU against the reference model's own output (incl. its final upsample), and
+    SegAgent.get_target_size / grid_crop locations against the reference's."""
+    import zlib
+    import torch
+    from video_unscreen_amd.binseg.deeplab_net import DeepLabNetTorch, deeplab_checkpoint_layout, deeplab_synthetic_state_dict
+    z = np.load(os.path.join(GOLD, "deeplab_97x129.npz"))
+    lay = deeplab_checkpoint_layout()
+    assert len(lay) == int(z["n_keys"])
+    assert sum(zlib.crc32((k + str(tuple(sh))).encode()) for k, sh in lay) == int(z["keys_crc"])
+    g = torch.Generator().manual_seed(int(z["seed"]))
+    x = torch.randn(1, 3, 97, 129, generator=g)
+    net = DeepLabNetTorch(deeplab_synthetic_state_dict(0))
+    y = net.full(x).numpy()
+    assert np.abs(y - z["y"]).max() < 2e-5 * np.abs(z["y"]).max()
+    # the oracle's align_corners=False upsample is the one the model ends with
+    low = net(x).numpy()[0].transpose(1, 2, 0)
+    up = oracle_lib.upsample_nc(low, 97, 129)
+    assert np.abs(up.transpose(2, 0, 1) - z["y"][0]).max() < 2e-5 * np.abs(z["y"]).max()
+    for h, w, L, th, tw in z["target_sizes"]:
+        assert oracle_lib.segagent_target_size(h, w, L) == (th, tw)
+        assert np.array_equal(oracle_lib.grid_crop_locations(th, tw), z[f"loc_{h}x{w}_{L}"])
+
+
 def test_humanseg_affine_and_warps(oracle_lib):
     """Whole-frame affine (agent_human.py:91-125, 247-260): uniform scale about the centre, letterboxed."""
     for (w, h) in ((1920, 1080), (1080, 1920), (256, 256), (47, 33)):

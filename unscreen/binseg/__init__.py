@@ -1,1 +1,1 @@
-from video_unscreen_amd.binseg import HumanSegAgent  # noqa
+from video_unscreen_amd.binseg import HumanSegAgent, SegAgent  # noqa

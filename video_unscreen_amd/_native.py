@@ -57,6 +57,15 @@ _SIGNATURES = {
     "usc_color_correct_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "usc_color_correct_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_double, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "usc_box_filter_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "usc_segagent_target_size": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "usc_grid_crop_locations": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _vp, C.c_int]),
+    "usc_segagent_pre": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "usc_im2col_nhwc_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int,
+                                      C.c_int, C.c_int, _vp]),
+    "usc_upsample_nc_nhwc_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "usc_segagent_post_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "usc_segagent_post": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    _vp, _vp, _vp, C.c_size_t, _vp]),
     "usc_remove_invalid_objects_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                   C.c_double, _vp, C.POINTER(C.c_int)]),
     "usc_humanseg_affine": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -425,6 +434,69 @@ def upsample_ac(src, dst, c0=0):
     if rc != 0:
         raise NativeError(f"usc_upsample_ac_nhwc_f32 failed ({rc}): {load().usc_seg_last_error().decode()}")
     return dst
+
+
+def upsample_nc(src, dst, c0=0):
+    """F.interpolate(bilinear, align_corners=False): src (sh, sw, C) f32 NHWC -> channels [c0, c0 + C) of dst (dh, dw, ld)."""
+    sh, sw, Cc = src.shape
+    dh, dw, ld = dst.shape
+    _check(load().usc_upsample_nc_nhwc_f32(src.data_ptr(), sh, sw, Cc, dst.data_ptr(), dh, dw, ld, int(c0), _stream()),
+           "usc_upsample_nc_nhwc_f32")
+    return dst
+
+
+def im2col(src, cuse, kh, kw, stride, pad, out):
+    """src (IH, IW, cpitch) f32 NHWC -> out (OH, OW, Kpad) patch matrix of a kh x kw / stride convolution over `cuse` channels."""
+    IH, IW, cp = src.shape
+    OH, OW, Kp = out.shape
+    _check(load().usc_im2col_nhwc_f32(src.data_ptr(), IH, IW, cp, int(cuse), int(kh), int(kw), int(stride), int(pad), out.data_ptr(),
+                                      OH, OW, Kp, _stream()), "usc_im2col_nhwc_f32")
+    return out
+
+
+def segagent_target_size(h, w, long_side, division=1, crop_h=513, crop_w=513):
+    a, b = C.c_int(), C.c_int()
+    load().usc_segagent_target_size(int(h), int(w), int(long_side), int(division), int(crop_h), int(crop_w), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def grid_crop_locations(h, w, crop_h=513, crop_w=513, stride_ratio=0.5, flip=True):
+    """(N, 4) int32 array of (s_h, e_h, s_w, e_w); mirrored crops have s_w > e_w (reference agent.py:102-141)."""
+    n = load().usc_grid_crop_locations(int(h), int(w), int(crop_h), int(crop_w), float(stride_ratio), int(bool(flip)), None, 0)
+    if n < 0:
+        _check(n, "usc_grid_crop_locations")
+    locs = np.empty((n, 4), np.int32)
+    _check(min(load().usc_grid_crop_locations(int(h), int(w), int(crop_h), int(crop_w), float(stride_ratio), int(bool(flip)),
+                                              locs.ctypes.data, n), 0), "usc_grid_crop_locations")
+    return locs
+
+
+def segagent_pre(img, th, tw, loc, out=None):
+    """One normalised crop (crop_h, crop_w, 4) f32 NHWC of the pad-resized frame; loc = (s_h, e_h, s_w, e_w)."""
+    H, W, _ = img.shape
+    loc = np.ascontiguousarray(np.asarray(loc, np.int32).reshape(4))
+    ch, cw = int(loc[1] - loc[0]), int(abs(loc[3] - loc[2]))
+    out = torch.empty((ch, cw, 4), dtype=torch.float32, device=img.device) if out is None else out
+    _check(load().usc_segagent_pre(_dev_u8(img, "segagent_pre.img", (H, W, 3)), H, W, int(th), int(tw), loc.ctypes.data, out.data_ptr(),
+                                   _stream()), "usc_segagent_pre")
+    return out
+
+
+def segagent_post(logits, locs, crop_h, crop_w, th, tw, H, W, out=None, ws=None, want_score=False):
+    """logits (ncrops, lh, lw, cbuf) f32 CUDA; locs (ncrops, 4) host ints -> (H, W) uint8 mask (0 / 255)."""
+    if not (logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous() and logits.dim() == 4):
+        raise NativeError("segagent_post.logits: expected a contiguous (ncrops, lh, lw, cbuf) float32 CUDA tensor")
+    n, lh, lw, cbuf = logits.shape
+    locs = np.ascontiguousarray(np.asarray(locs, np.int32).reshape(n, 4))
+    out = torch.empty((H, W), dtype=torch.uint8, device=logits.device) if out is None else out
+    need = load().usc_segagent_post_ws_bytes(int(th), int(tw))
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, logits.device)
+    score = torch.empty((H, W, 2), dtype=torch.float64, device=logits.device) if want_score else None
+    _check(load().usc_segagent_post(logits.data_ptr(), n, lh, lw, cbuf, locs.ctypes.data, int(crop_h), int(crop_w), int(th), int(tw),
+                                    int(H), int(W), _dev_u8(out, "segagent_post.out", (H, W)), score.data_ptr() if want_score else None,
+                                    ws.data_ptr(), ws.numel(), _stream()), "usc_segagent_post")
+    return (out, score) if want_score else out
 
 
 def humanseg_affine(w, h, in_w=473, in_h=473, inv=False):

@@ -1,1 +1,2 @@
+from .agent import SegAgent  # noqa
 from .agent_human import HumanSegAgent  # noqa

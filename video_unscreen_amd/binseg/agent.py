@@ -1,0 +1,68 @@
+"""SegAgent: same constructor and forward() as the reference (unscreen/binseg/agent.py:14-260).
+
+forward(img) = resize / reflect-pad to the target, normalise, overlapping 513 x 513 crops (+ mirrored copies),
+DeepLabv3+/ResNet-50 per crop, softmax, float64 merge, inverse pad-resize, argmax.  Pre- and post-processing are HIP
+kernels (csrc/usc_segagent.hip); every convolution runs on the f32-MFMA kernel (deeplab_net.HipDeepLabNet), one crop
+after the other through one set of activation buffers - a crop already fills the chip (>= 136 workgroups per layer,
+split-K below that), so batching the crops would only multiply the activation memory by 12.
+"""
+import numpy as np
+import torch
+
+from .. import _native as nv
+from ..utils._dev import device, to_dev, to_host
+from .deeplab_net import HipDeepLabNet, deeplab_synthetic_state_dict
+
+
+class SegAgent():
+
+    def __init__(self, model_path=None, input_long_side=912, crop_h=513, crop_w=513, stride_ratio=1 / 2., flip=True,
+                 cuda_device=0):
+        self.cuda_device = cuda_device if cuda_device is not None and cuda_device >= 0 else 0
+        self.device = device(self.cuda_device)
+        if model_path is None or model_path == "synthetic":
+            sd = deeplab_synthetic_state_dict(0)       # no trained checkpoint exists offline
+        else:
+            sd = torch.load(model_path, map_location="cpu")        # a bare state dict (reference agent.py:58)
+        self.state_dict = sd
+        self.division = 1
+        self.crop_h, self.crop_w = crop_h, crop_w
+        self.flip = flip
+        self.input_long_side = input_long_side
+        self.stride_ratio = stride_ratio
+        self.model = HipDeepLabNet(sd, crop_h, crop_w, device=self.device)
+        self._logits = None
+        self._ws = None
+
+    def get_target_size(self, h, w):
+        """reference agent.py:70-100."""
+        return nv.segagent_target_size(h, w, self.input_long_side, self.division, self.crop_h, self.crop_w)
+
+    def grid_crop_locations(self, h, w, stride_ratio=None):
+        """Locations of reference grid_crop (agent.py:102-141) on an (h, w) image; the crops themselves are gathered on the
+        device by usc_segagent_pre."""
+        return nv.grid_crop_locations(h, w, self.crop_h, self.crop_w, self.stride_ratio if stride_ratio is None else stride_ratio,
+                                      self.flip)
+
+    def forward_device(self, img, out=None, return_logits=False):
+        """img: (H, W, 3) uint8 BGR CUDA tensor -> (H, W) uint8 mask {0, 255} on the device."""
+        H, W, _ = img.shape
+        th, tw = self.get_target_size(H, W)
+        locs = self.grid_crop_locations(th, tw)
+        net = self.model
+        n = len(locs)
+        if self._logits is None or self._logits.shape[0] != n:
+            self._logits = torch.empty((n, net.out_h, net.out_w, 32), dtype=torch.float32, device=self.device)
+        for i, loc in enumerate(locs):
+            nv.segagent_pre(img, th, tw, loc, out=net.x4)
+            self._logits[i].copy_(net.forward(None))
+        need = nv.load().usc_segagent_post_ws_bytes(th, tw)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        mask = nv.segagent_post(self._logits, locs, self.crop_h, self.crop_w, th, tw, H, W, out=out, ws=self._ws)
+        return (mask, self._logits, locs) if return_logits else mask
+
+    def forward(self, img):
+        """img (h, w, 3) uint8 BGR -> (h, w) uint8, 255 = foreground (reference agent.py:239-260)."""
+        with torch.cuda.device(self.device):
+            return to_host(self.forward_device(to_dev(np.ascontiguousarray(img), self.device)))

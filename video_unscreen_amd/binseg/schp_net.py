@@ -17,6 +17,8 @@ from collections import OrderedDict
 import torch
 import torch.nn.functional as F
 
+from ..convnet import ConvGraphNet, _out_size
+
 BN_EPS = 1e-5
 LAYERS = (3, 4, 23, 3)
 PLANES = (64, 128, 256, 512)
@@ -211,92 +213,16 @@ class SchpNetTorch:
 # HIP executor
 # --------------------------------------------------------------------------------------------
 
-def _out_size(n, k, stride, pad, dil):
-    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
-
-class HipSchpNet:
+class HipSchpNet(ConvGraphNet):
     """Every convolution on the f32-MFMA kernel (csrc/usc_conv.hip), NHWC buffers; pooling / bilinear glue between
     conv segments stays on torch ops (a handful of tiny tensors)."""
 
     def __init__(self, state_dict, H=473, W=473, device="cuda:0"):
-        from .. import _native as nv
-        from ..vmatting.net_hip import ConvDesc, conv_taps, pack_k_major
-        self.nv, self.ConvDesc, self.conv_taps, self.pack = nv, ConvDesc, conv_taps, pack_k_major
-        nv.load()
-        self.device = torch.device(device)
+        super().__init__(device, slab_floats=64 * 1024 * 1024)
         self.H, self.W = H, W
         self.plan = SchpPlan(state_dict)
-        self._keep = []
-        self.slab = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=self.device)
-        self._slab_used = 0
-        self._segments = []            # list of ("conv", ctypes array, n) | ("glue", callable)
-        self._cur = []
         self._build()
-
-    # ---- buffers / descriptors
-    def _buf(self, h, w, c):
-        t = torch.empty((h, w, c), dtype=torch.float32, device=self.device)
-        self._keep.append(t)
-        return t
-
-    def _dev(self, t):
-        t = t.detach().to(self.device, torch.float32).contiguous()
-        self._keep.append(t)
-        return t
-
-    @staticmethod
-    def nchw(buf):
-        """(H, W, C) NHWC buffer viewed as a channels-last (1, C, H, W) tensor (no copy)."""
-        return buf.permute(2, 0, 1).unsqueeze(0)
-
-    def _conv(self, c, x, IH, IW, cin_buf, out=None, res1=None, act=None, cout_pad=None, out_ld=0, out_c0=0):
-        """x: (IH, IW, cin_buf) buffer; cin_buf >= c.w.shape[1] (extra channels must be zero-weighted)."""
-        w = c.w
-        co, ci, k, _ = w.shape
-        if cin_buf != ci:
-            w = F.pad(w, (0, 0, 0, 0, 0, cin_buf - ci))
-        b = c.b
-        if cout_pad and cout_pad != co:
-            w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - co))
-            b = F.pad(b, (0, cout_pad - co))
-            co = cout_pad
-        taps = [((ky - (k // 2)) * c.dil, (kx - (k // 2)) * c.dil) for ky in range(k) for kx in range(k)] if k > 1 else [(0, 0)]
-        if k > 1:
-            assert c.pad == c.dil * (k // 2)
-        wk = w.permute(2, 3, 1, 0).reshape(k * k * cin_buf, co)
-        OH, OW = _out_size(IH, k, c.stride, c.pad, c.dil), _out_size(IW, k, c.stride, c.pad, c.dil)
-        out = out if out is not None else self._buf(OH, OW, co)
-        d = self.ConvDesc()
-        d.inp, d.out = x.data_ptr(), out.data_ptr()
-        d.wpk = self._dev(self.pack(wk.float())).data_ptr()
-        d.bias = self._dev(b).data_ptr()
-        d.res1 = res1.data_ptr() if res1 is not None else None
-        d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = IH, IW, cin_buf, OH, OW, OH, OW, co
-        d.in_stride, d.out_stride = c.stride, 1
-        d.act = {"none": 0, "relu": 1, "leaky": 2, "leaky01": 3}[act or c.act]
-        d.ntaps, d.kind, d.nphase = len(taps), 0, 1
-        d.out_ld, d.out_c0 = out_ld, out_c0
-        # one shared split-K scratch: the net is a chain, and the graph builder orders layers that share a slab
-        d.slab, d.slab_bytes = self.slab.data_ptr(), self.slab.numel() * 4
-        for i, (dy, dx) in enumerate(taps):
-            d.dy[i], d.dx[i] = dy, dx
-        self._cur.append(d)
-        return out, OH, OW
-
-    def _flush(self):
-        if self._cur:
-            arr = (self.ConvDesc * len(self._cur))(*self._cur)
-            handle = C.c_void_p()
-            rc = self.nv.load().usc_conv_graph_create(arr, len(self._cur), C.byref(handle))
-            if rc != 0:
-                raise self.nv.NativeError(f"usc_conv_graph_create failed ({rc}): {self.nv.load().usc_conv_last_error().decode()}")
-            self._segments.append(("conv", handle, arr))
-            self._cur = []
-
-    def _glue(self, fn):
-        self._flush()
-        self._segments.append(("glue", fn, None))
 
     # ---- graph
     def _build(self):
@@ -375,23 +301,7 @@ class HipSchpNet:
         Returns the (out_h, out_w, 32) logits buffer: channels 0..19 are the classes."""
         if x4 is not None and x4.data_ptr() != self.x4.data_ptr():
             self.x4.copy_(x4)
-        st = torch.cuda.current_stream().cuda_stream
-        lib = self.nv.load()
-        for kind, a, b in self._segments:
-            if kind == "conv":
-                rc = lib.usc_conv_graph_launch(a, st)
-                if rc != 0:
-                    raise self.nv.NativeError(f"conv launch failed ({rc}): {lib.usc_conv_last_error().decode()}")
-            else:
-                a()
+        self.run()
         return self.logits32
 
     __call__ = forward
-
-    def __del__(self):
-        try:
-            for kind, a, b in getattr(self, "_segments", []):
-                if kind == "conv" and a:
-                    self.nv.load().usc_conv_graph_destroy(a)
-        except Exception:
-            pass

@@ -1,0 +1,115 @@
+"""ConvGraphNet: builder / runner shared by the networks that execute on csrc/usc_conv.hip (the f32-MFMA implicit-GEMM
+kernel).  A network is a list of segments: runs of fused convolution layers, each captured as one hipGraph
+(usc_conv_graph_create), separated by "glue" callables (pooling, bilinear resampling into concat slices) that are
+enqueued on the same stream.  All activations are NHWC float32 buffers allocated once."""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+
+def _out_size(n, k, stride, pad, dil):
+    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+class ConvGraphNet:
+    ACTS = {"none": 0, "relu": 1, "leaky": 2, "leaky01": 3}
+
+    def __init__(self, device="cuda:0", slab_floats=64 * 1024 * 1024):
+        from . import _native as nv
+        from .vmatting.net_hip import ConvDesc, conv_taps, pack_k_major
+        self.nv, self.ConvDesc, self.conv_taps, self.pack = nv, ConvDesc, conv_taps, pack_k_major
+        nv.load()
+        self.device = torch.device(device)
+        self._keep = []
+        self.slab = torch.empty(slab_floats, dtype=torch.float32, device=self.device)     # split-K partial sums
+        self._segments = []            # list of ("conv", graph handle, ctypes array) | ("glue", callable, None)
+        self._cur = []
+
+    # ---- buffers / descriptors
+    def _buf(self, h, w, c):
+        t = torch.empty((h, w, c), dtype=torch.float32, device=self.device)
+        self._keep.append(t)
+        return t
+
+    def _dev(self, t):
+        t = t.detach().to(self.device, torch.float32).contiguous()
+        self._keep.append(t)
+        return t
+
+    @staticmethod
+    def nchw(buf):
+        """(H, W, C) NHWC buffer viewed as a channels-last (1, C, H, W) tensor (no copy)."""
+        return buf.permute(2, 0, 1).unsqueeze(0)
+
+    def _conv(self, c, x, IH, IW, cin_buf, out=None, res1=None, act=None, cout_pad=None, out_ld=0, out_c0=0, bias_buf=None):
+        """c: folded conv (w (Cout, Cin, k, k), b, stride, pad, dil, act).  x: (IH, IW, cin_buf) buffer; cin_buf >= Cin (the
+        extra channels get zero weights).  bias_buf: a device buffer that replaces c.b (a bias computed on the device)."""
+        w = c.w
+        co, ci, k, _ = w.shape
+        if cin_buf != ci:
+            w = F.pad(w, (0, 0, 0, 0, 0, cin_buf - ci))
+        b = c.b
+        if cout_pad and cout_pad != co:
+            w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - co))
+            b = F.pad(b, (0, cout_pad - co))
+            co = cout_pad
+        taps = [((ky - (k // 2)) * c.dil, (kx - (k // 2)) * c.dil) for ky in range(k) for kx in range(k)] if k > 1 else [(0, 0)]
+        if k > 1:
+            assert c.pad == c.dil * (k // 2)
+        wk = w.permute(2, 3, 1, 0).reshape(k * k * cin_buf, co)
+        OH, OW = _out_size(IH, k, c.stride, c.pad, c.dil), _out_size(IW, k, c.stride, c.pad, c.dil)
+        out = out if out is not None else self._buf(OH, OW, co)
+        d = self.ConvDesc()
+        d.inp, d.out = x.data_ptr(), out.data_ptr()
+        d.wpk = self._dev(self.pack(wk.float())).data_ptr()
+        d.bias = bias_buf.data_ptr() if bias_buf is not None else self._dev(b).data_ptr()
+        d.res1 = res1.data_ptr() if res1 is not None else None
+        d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = IH, IW, cin_buf, OH, OW, OH, OW, co
+        d.in_stride, d.out_stride = c.stride, 1
+        d.act = self.ACTS[act or c.act]
+        d.ntaps, d.kind, d.nphase = len(taps), 0, 1
+        d.out_ld, d.out_c0 = out_ld, out_c0
+        # one shared split-K scratch: the nets are chains, and the graph builder orders layers that share a slab
+        d.slab, d.slab_bytes = self.slab.data_ptr(), self.slab.numel() * 4
+        for i, (dy, dx) in enumerate(taps):
+            d.dy[i], d.dx[i] = dy, dx
+        self._cur.append(d)
+        return out, OH, OW
+
+    def _flush(self):
+        if self._cur:
+            arr = (self.ConvDesc * len(self._cur))(*self._cur)
+            handle = C.c_void_p()
+            rc = self.nv.load().usc_conv_graph_create(arr, len(self._cur), C.byref(handle))
+            if rc != 0:
+                raise self.nv.NativeError(f"usc_conv_graph_create failed ({rc}): {self.nv.load().usc_conv_last_error().decode()}")
+            self._segments.append(("conv", handle, arr))
+            self._cur = []
+
+    def _glue(self, fn):
+        self._flush()
+        self._segments.append(("glue", fn, None))
+
+    def run(self):
+        """Enqueue every segment on the current stream."""
+        st = torch.cuda.current_stream().cuda_stream
+        lib = self.nv.load()
+        for kind, a, _ in self._segments:
+            if kind == "conv":
+                rc = lib.usc_conv_graph_launch(a, st)
+                if rc != 0:
+                    raise self.nv.NativeError(f"conv launch failed ({rc}): {lib.usc_conv_last_error().decode()}")
+            else:
+                a()
+
+    def n_layers(self):
+        return sum(len(arr) for kind, _, arr in self._segments if kind == "conv")
+
+    def __del__(self):
+        try:
+            for kind, a, _ in getattr(self, "_segments", []):
+                if kind == "conv" and a:
+                    self.nv.load().usc_conv_graph_destroy(a)
+        except Exception:
+            pass
