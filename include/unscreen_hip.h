@@ -184,6 +184,24 @@ int usc_segagent_post(const float* logits, int ncrops, int lh, int lw, int cbuf,
                       int th, int tw, int H, int W, uint8_t* out, double* score_out, void* ws, size_t ws_bytes,
                       usc_stream_t stream);
 
+/* STMAgent (unscreen/stm/agent.py), everything but the convolutions.
+ * usc_stm_pre: agent.py:62-98 preprocess of one frame (+ the first frame's mask, or NULL): out = (in_h, in_w, 8) float32 NHWC
+ *   (R, G, B, object, background, 0, 0, 0), (in_h, in_w) = usc_get_target_size(H, W, long_side, 16).
+ * usc_pack_kn_f32: dst[k/4][n][k%4] = src[k*sk + n*sn] (zero padded to Kpad x Npad): puts a matrix that lives in HBM (memory
+ *   keys / values) into the weight layout of usc_conv_*, so the two products of the memory read (stm/model.py:137-156) run as
+ *   1x1 layers.
+ * usc_row_softmax_f32: in place softmax(x / div) over the first `cols` of `ld` columns of every row (stm/model.py:148-150).
+ * usc_stm_post: decoder logits p2 (lh, lw, cbuf) -> x4 bilinear, softmax, soft aggregation, softmax (stm/model.py:135-136,
+ *   195-219; agent.py:164) -> prob (in_h, in_w, 2) float32 (written) -> inv_pad_resize + argmax * 255 (agent.py:172-201). */
+int usc_stm_pre(const uint8_t* frame, const uint8_t* mask, int H, int W, int in_h, int in_w, float* out, usc_stream_t stream);
+int usc_pack_kn_f32(const float* src, int K, int N, long long sk, long long sn, int Kpad, int Npad, float* dst, usc_stream_t stream);
+int usc_row_softmax_f32(float* x, int rows, int cols, int ld, float div, usc_stream_t stream);
+int usc_stm_post(const float* p2, int lh, int lw, int cbuf, int in_h, int in_w, int H, int W, uint8_t* out, float* prob,
+                 usc_stream_t stream);
+/* The second half of usc_stm_post alone: (in_h, in_w, 2) float32 probabilities -> inv_pad_resize + argmax * 255 (the
+ * reference derives the first frame's output mask this way from the one-hot of mask0, agent.py:127, 172-201). */
+int usc_stm_mask_from_prob(const float* prob, int in_h, int in_w, int H, int W, uint8_t* out, usc_stream_t stream);
+
 /* unscreen/utils/maskprocess.py:56-60 exist_foreground: *out_count (device, 8 bytes) = #(mask >= thr). */
 int usc_count_ge_u8(const uint8_t* mask, size_t n, int thr, unsigned long long* out_count, usc_stream_t stream);
 
@@ -258,7 +276,7 @@ typedef struct usc_conv_desc {
                                       writes (2*oy + (p >> 1), 2*ox + (p & 1)); out_py / out_px are then ignored */
     int wphase_stride;             /* floats between the packed weights of consecutive phases */
     int ksplit;                    /* set by the library */
-    int reserved;
+    int in_relu;                   /* 1: the layer computes conv(relu(in)) (pre-activation residual blocks, stm/model.py:25-30) */
     float* slab;                   /* optional scratch for split-K partial sums (small-M layers), may be NULL */
     size_t slab_bytes;
     int out_ld, out_c0;            /* 0 / 0: `out` is a dense [pixel][Cout] tensor; otherwise `out` has out_ld channels per pixel

@@ -54,6 +54,8 @@ def lib():
         _lib.orc_upsample_nc_f32.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, f32p, C.c_int, C.c_int]
         _lib.orc_segagent_post.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, u8p, f64p]
+        _lib.orc_stm_pre.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+        _lib.orc_stm_post.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, f32p]
         _lib.orc_gmm_lut.argtypes = [f64p, f64p, f64p, C.c_int, f32p]
         _lib.orc_gmm_alpha.argtypes = [u8p, C.c_size_t, f32p, f32p, u8p, f32p]
         _lib.orc_cf_threshold.argtypes = [u8p, u8p, C.c_size_t, C.c_double]
@@ -442,6 +444,27 @@ def segagent_post(logits, locs, crop_h, crop_w, th, tw, H, W, want_score=False):
     lib().orc_segagent_post(p, n, lh, lw, cbuf, locs.ctypes.data_as(C.POINTER(C.c_int)), int(crop_h), int(crop_w), int(th), int(tw),
                             int(H), int(W), out.ctypes.data_as(u8p), score.ctypes.data_as(f64p))
     return (out, score) if want_score else out
+
+
+def stm_pre(frame, mask, in_h, in_w):
+    """stm/agent.py:62-98 for one frame -> (in_h, in_w, 8) float32 NHWC (R, G, B, object, background, 0, 0, 0); mask may be None."""
+    frame, fp = _u8(frame)
+    mp = None
+    if mask is not None:
+        mask, mp = _u8(mask)
+    out = np.empty((in_h, in_w, 8), np.float32)
+    lib().orc_stm_pre(fp, mp, frame.shape[0], frame.shape[1], int(in_h), int(in_w), out.ctypes.data_as(f32p))
+    return out
+
+
+def stm_post(p2, in_h, in_w, H, W, want_prob=False):
+    """Decoder logits (lh, lw, cbuf) -> frame mask (stm/model.py:135-136, 195-219; stm/agent.py:164, 172-201)."""
+    a, p = _f32(p2)
+    lh, lw, cbuf = a.shape
+    out = np.empty((H, W), np.uint8)
+    prob = np.empty((in_h, in_w, 2), np.float32)
+    lib().orc_stm_post(p, lh, lw, cbuf, int(in_h), int(in_w), int(H), int(W), out.ctypes.data_as(u8p), prob.ctypes.data_as(f32p))
+    return (out, prob) if want_prob else out
 
 
 def score_map(h, w, center):

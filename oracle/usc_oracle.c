@@ -1513,3 +1513,115 @@ ORC_API void orc_segagent_post(const float* logits, int ncrops, int lh, int lw, 
     }
     free(tx); free(ty); free(pred); free(cnt); free(up);
 }
+
+/* ============================================================================================
+ * STMAgent (unscreen/stm/agent.py): pre / post processing around the space-time memory network
+ * ============================================================================================ */
+
+/* log on float32 restated with IEEE basic operations only (Cephes logf), the partner of orc_det_expf. */
+static inline float orc_det_logf(float x)
+{
+    if (!(x > 0.f)) return x == 0.f ? -INFINITY : NAN;
+    int e;
+    float m = frexpf(x, &e);
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; } else m = m - 1.0f;
+    float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = y * m + -1.1514610310e-1f;
+    y = y * m + 1.1676998740e-1f;
+    y = y * m + -1.2420140846e-1f;
+    y = y * m + 1.4249322787e-1f;
+    y = y * m + -1.6668057665e-1f;
+    y = y * m + 2.0000714765e-1f;
+    y = y * m + -2.4999993993e-1f;
+    y = y * m + 3.3333331174e-1f;
+    y = y * m * z;
+    float fe = (float)e;
+    y = y + -2.12194440e-4f * fe;
+    y = y + -0.5f * z;
+    z = m + y;
+    z = z + 0.693359375f * fe;
+    return z;
+}
+
+/* unscreen/stm/agent.py:62-98 preprocess of one frame (+ optionally the first frame's mask): pad_resize to (in_h, in_w) =
+ * get_target_size(h, w, long_side, 16) (bilinear + BORDER_REFLECT), imnormalize; mask0 = resized > 127, channel 3 = object
+ * (1 / 0), channel 4 = background.  out: (in_h, in_w, 8) float32 NHWC (R, G, B, m, o, 0, 0, 0); mask == NULL: m = o = 0. */
+ORC_API void orc_stm_pre(const uint8_t* frame, const uint8_t* mask, int H, int W, int in_h, int in_w, float* out)
+{
+    static const double mean[3] = {0.485, 0.456, 0.406}, std[3] = {0.229, 0.224, 0.225};
+    int nh, nw;
+    orc_pad_resize_geometry(H, W, in_h, in_w, &nh, &nw);
+    uint8_t* fr = (uint8_t*)malloc((size_t)nh * nw * 3);
+    uint8_t* mr = mask ? (uint8_t*)malloc((size_t)nh * nw) : NULL;
+    orc_resize_linear_u8(frame, H, W, 3, fr, nh, nw);
+    if (mask) orc_resize_linear_u8(mask, H, W, 1, mr, nh, nw);
+    for (int y = 0; y < in_h; y++)
+        for (int x = 0; x < in_w; x++) {
+            size_t s = (size_t)orc_reflect(y, nh) * nw + orc_reflect(x, nw);
+            float* o = out + ((size_t)y * in_w + x) * 8;
+            for (int c = 0; c < 3; c++) {
+                float v = (float)fr[3 * s + (2 - c)] / 255.f;
+                v = v - (float)mean[c];
+                o[c] = v * (float)(1 / std[c]);
+            }
+            int fg = mask ? mr[s] > 127 : 0;
+            o[3] = mask ? (float)fg : 0.f;
+            o[4] = mask ? (float)(1 - fg) : 0.f;
+            o[5] = o[6] = o[7] = 0.f;
+        }
+    free(fr); free(mr);
+}
+
+/* From the decoder's 1/4-resolution logits p2 (lh, lw, cbuf; classes in channels 0, 1) to the frame mask:
+ * x4 bilinear (align_corners=False, stm/model.py:135-136), softmax -> ps (:215), soft aggregation (:195-202: em = (1-ps, ps)
+ * clamped to [1e-7, 1-1e-7], logit = log(em / (1 - em))), softmax again (stm/agent.py:164) -> prob (in_h, in_w, 2) float32;
+ * inv_pad_resize (utils/imgprocess.py:100-132: cut the pad, cv2.resize float32 bilinear) and argmax * 255 (stm/agent.py:172-201). */
+ORC_API void orc_stm_post(const float* p2, int lh, int lw, int cbuf, int in_h, int in_w, int H, int W, uint8_t* out, float* prob_out)
+{
+    size_t n = (size_t)in_h * in_w;
+    float* up = (float*)malloc(sizeof(float) * n * 2);
+    float* prob = prob_out ? prob_out : (float*)malloc(sizeof(float) * n * 2);
+    orc_upsample_nc_f32(p2, 2, lh, lw, 1, cbuf, up, in_h, in_w);
+    for (size_t i = 0; i < n; i++) {
+        float a = up[2 * i], b = up[2 * i + 1];
+        float m = a > b ? a : b;
+        float ea = orc_det_expf(a - m), eb = orc_det_expf(b - m);
+        float ps = eb / (ea + eb);
+        float e0 = 1.f - ps, e1 = ps;
+        const float lo = 1e-7f, hi = 1.f - 1e-7f;
+        e0 = e0 < lo ? lo : (e0 > hi ? hi : e0);
+        e1 = e1 < lo ? lo : (e1 > hi ? hi : e1);
+        float l0 = orc_det_logf(e0 / (1.f - e0)), l1 = orc_det_logf(e1 / (1.f - e1));
+        float mm = l0 > l1 ? l0 : l1;
+        float x0 = orc_det_expf(l0 - mm), x1 = orc_det_expf(l1 - mm);
+        float s = x0 + x1;
+        prob[2 * i] = x0 / s;
+        prob[2 * i + 1] = x1 / s;
+    }
+    int rh, rw;
+    orc_inv_pad_geometry(in_h, in_w, H, W, &rh, &rw);
+    int same = (rh == H && rw == W);
+    orc_tap* tx = (orc_tap*)malloc(sizeof(orc_tap) * W);
+    orc_tap* ty = (orc_tap*)malloc(sizeof(orc_tap) * H);
+    orc_linear_taps(W, rw, tx, 1);
+    orc_linear_taps(H, rh, ty, 0);
+    for (int y = 0; y < H; y++) {
+        int y0 = orc_clampi(ty[y].ofs, 0, rh - 1), y1 = orc_clampi(ty[y].ofs + 1, 0, rh - 1);
+        float b0 = ty[y].f0, b1 = ty[y].f1;
+        for (int x = 0; x < W; x++) {
+            int x0 = tx[x].ofs, x1 = x0 + 1 < rw ? x0 + 1 : x0;
+            float a0 = tx[x].f0, a1 = tx[x].f1;
+            float v[2];
+            for (int c = 0; c < 2; c++) {
+                if (same) { v[c] = prob[((size_t)y * in_w + x) * 2 + c]; continue; }
+                float r0 = prob[((size_t)y0 * in_w + x0) * 2 + c] * a0 + prob[((size_t)y0 * in_w + x1) * 2 + c] * a1;
+                float r1 = prob[((size_t)y1 * in_w + x0) * 2 + c] * a0 + prob[((size_t)y1 * in_w + x1) * 2 + c] * a1;
+                v[c] = r0 * b0 + r1 * b1;
+            }
+            out[(size_t)y * W + x] = v[1] > v[0] ? 255 : 0;
+        }
+    }
+    free(tx); free(ty); free(up);
+    if (!prob_out) free(prob);
+}

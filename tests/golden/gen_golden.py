@@ -10,6 +10,10 @@
                         package imports torchvision, absent here, only for the pretrained-weights download helper), with the
                         keyed-deterministic checkpoint of video_unscreen_amd.binseg.deeplab_net; plus SegAgent.get_target_size /
                         grid_crop locations (unscreen/binseg/agent.py, methods extracted with ast)
+  stm_64x96.npz         reference unscreen/stm/model.py STM (definitions executed without the import lines; its `models.resnet50` is
+                        torchvision's, absent here, so the trunk class comes from the reference's own copy of that file,
+                        unscreen/binseg/deeplab/backbone/resnet.py, built with pretrained=False) with the keyed-deterministic
+                        checkpoint of video_unscreen_amd.stm.net: memorize() key / value and segment() logit
   target_size.npz       reference unscreen/utils/imgprocess.py get_target_size over a grid (function extracted
                         with ast; the module itself needs cv2)
   score_map.npz         reference unscreen/utils/maskprocess.py get_score_map / build_score_map / exist_foreground
@@ -97,6 +101,47 @@ def deeplab_golden():
     print("deeplab", y.shape, float(y.std()), len(rows), "geometry rows")
 
 
+def stm_golden():
+    import math
+    import types
+
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from video_unscreen_amd.stm.net import stm_checkpoint_layout, stm_synthetic_state_dict
+    base = {"torch": torch, "nn": nn, "F": F, "math": math}
+    rn = exec_defs(os.path.join(REF, "unscreen/binseg/deeplab/backbone/resnet.py"), dict(base))
+    ns = dict(base)
+    ns["models"] = types.SimpleNamespace(resnet50=lambda pretrained=True: rn["resnet50"](pretrained=False))
+    exec_defs(os.path.join(REF, "unscreen/stm/model.py"), ns)
+    model = ns["STM"]().eval()
+    rsd = model.state_dict()
+    lay = stm_checkpoint_layout()
+    assert [k for k, _ in lay] == list(rsd.keys()), "state-dict keys differ"
+    assert all(tuple(rsd[k].shape) == tuple(sh) for k, sh in lay)
+    model.load_state_dict(stm_synthetic_state_dict(0))
+    # soft_aggregation puts its scratch tensor on the GPU (`.cuda(ps.device)`, model.py:197); on this CPU-only box the same
+    # lines run with that call returning the tensor itself
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        g = torch.Generator().manual_seed(1357)
+        f0, f1 = torch.randn(1, 3, 64, 96, generator=g), torch.randn(1, 3, 64, 96, generator=g)
+        m = (torch.rand(1, 1, 64, 96, generator=g) > 0.5).float()
+        masks = torch.cat([1 - m, m], 1)
+        with torch.no_grad():
+            k4, v4 = model(f0, masks)
+            keys, values = k4.unsqueeze(2), v4.unsqueeze(2)
+            logit1 = model(f1, keys, values)
+            keys2, values2 = torch.cat([keys, keys * 0.5 + 0.1], 2), torch.cat([values, values.flip(3)], 2)   # T = 2 memory frames
+            logit2 = model(f1, keys2, values2)
+    finally:
+        torch.Tensor.cuda = _cuda
+    np.savez_compressed(os.path.join(HERE, "stm_64x96.npz"), k4=k4.numpy(), v4=v4.numpy(), logit1=logit1.numpy(), logit2=logit2.numpy(),
+                        seed=1357, n_keys=len(lay),
+                        keys_crc=np.int64(sum(__import__("zlib").crc32((k + str(tuple(sh))).encode()) for k, sh in lay)))
+    print("stm", k4.shape, v4.shape, logit1.shape, float(logit1.std()), float((logit1[:, 1] > logit1[:, 0]).float().mean()))
+
+
 def unet_input(h, w, seed):
     """Deterministic, realistic 7-channel input: normalised image, alpha in [0,1], one-hot trimap."""
     g = torch.Generator().manual_seed(seed)
@@ -113,6 +158,8 @@ def unet_input(h, w, seed):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "deeplab":
         return deeplab_golden()
+    if len(sys.argv) > 1 and sys.argv[1] == "stm":
+        return stm_golden()
     from video_unscreen_amd.vmatting.net import synthetic_state_dict
 
     # ---- 1. UNet
@@ -149,6 +196,7 @@ def main():
     print("schp", ys.shape, float(ys.std()))
 
     deeplab_golden()
+    stm_golden()
 
     # ---- 2. get_target_size
     ns = extract(os.path.join(REF, "unscreen/utils/imgprocess.py"), {"get_target_size"})

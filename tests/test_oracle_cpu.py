@@ -213,6 +213,37 @@ def test_deeplab_plan_and_segagent_geometry_match_reference_golden(oracle_lib):
         assert np.array_equal(oracle_lib.grid_crop_locations(th, tw), z[f"loc_{h}x{w}_{L}"])
 
 
+def test_stm_plan_matches_reference_golden(oracle_lib):
+    """Folded STM plan on torch-CPU against the reference model's own memorize() / segment() outputs."""
+    import zlib
+    import torch
+    from video_unscreen_amd.stm.net import StmNetTorch, stm_checkpoint_layout, stm_synthetic_state_dict
+    z = np.load(os.path.join(GOLD, "stm_64x96.npz"))
+    lay = stm_checkpoint_layout()
+    assert len(lay) == int(z["n_keys"])
+    assert sum(zlib.crc32((k + str(tuple(sh))).encode()) for k, sh in lay) == int(z["keys_crc"])
+    g = torch.Generator().manual_seed(int(z["seed"]))
+    f0, f1 = torch.randn(1, 3, 64, 96, generator=g), torch.randn(1, 3, 64, 96, generator=g)
+    m = (torch.rand(1, 1, 64, 96, generator=g) > 0.5).float()
+    net = StmNetTorch(stm_synthetic_state_dict(0))
+    k4, v4 = net.memorize(f0, torch.cat([1 - m, m], 1))
+    assert np.abs(k4.numpy() - z["k4"]).max() < 2e-5 * np.abs(z["k4"]).max()
+    assert np.abs(v4.numpy() - z["v4"]).max() < 2e-5 * np.abs(z["v4"]).max()
+    keys, values = k4.unsqueeze(2), v4.unsqueeze(2)
+    l1 = net.segment(f1, keys, values).numpy()
+    assert np.abs(l1 - z["logit1"]).max() < 2e-3                   # log-odds of a float32 probability: 1e-4 relative
+    keys2, values2 = torch.cat([keys, keys * 0.5 + 0.1], 2), torch.cat([values, values.flip(3)], 2)
+    l2 = net.segment(f1, keys2, values2).numpy()
+    assert np.abs(l2 - z["logit2"]).max() < 2e-3
+    assert ((l1[:, 1] > l1[:, 0]) != (z["logit1"][:, 1] > z["logit1"][:, 0])).mean() < 1e-3
+    # the oracle's post-processing reproduces segment() + the agent's softmax from the decoder logits
+    p2 = net.decoder_logits(f1, keys, values)[0].permute(1, 2, 0).numpy()
+    mask, prob = oracle_lib.stm_post(p2, 64, 96, 64, 96, want_prob=True)
+    ref = torch.softmax(torch.from_numpy(z["logit1"]), 1)[0].permute(1, 2, 0).numpy()
+    assert np.abs(prob - ref).max() < 1e-4
+    assert (mask != (ref[..., 1] > ref[..., 0]) * 255).mean() < 1e-3
+
+
 def test_humanseg_affine_and_warps(oracle_lib):
     """Whole-frame affine (agent_human.py:91-125, 247-260): uniform scale about the centre, letterboxed."""
     for (w, h) in ((1920, 1080), (1080, 1920), (256, 256), (47, 33)):

@@ -66,6 +66,11 @@ _SIGNATURES = {
     "usc_segagent_post_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "usc_segagent_post": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     _vp, _vp, _vp, C.c_size_t, _vp]),
+    "usc_stm_pre": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "usc_pack_kn_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_int, _vp, _vp]),
+    "usc_row_softmax_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
+    "usc_stm_post": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "usc_stm_mask_from_prob": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "usc_remove_invalid_objects_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                   C.c_double, _vp, C.POINTER(C.c_int)]),
     "usc_humanseg_affine": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -497,6 +502,49 @@ def segagent_post(logits, locs, crop_h, crop_w, th, tw, H, W, out=None, ws=None,
                                     int(H), int(W), _dev_u8(out, "segagent_post.out", (H, W)), score.data_ptr() if want_score else None,
                                     ws.data_ptr(), ws.numel(), _stream()), "usc_segagent_post")
     return (out, score) if want_score else out
+
+
+def stm_pre(frame, mask, in_h, in_w, out=None):
+    """frame (H, W, 3) u8 [+ mask (H, W) u8 or None] -> (in_h, in_w, 8) float32 NHWC (R, G, B, object, background, 0, 0, 0)."""
+    H, W, _ = frame.shape
+    out = torch.empty((in_h, in_w, 8), dtype=torch.float32, device=frame.device) if out is None else out
+    _check(load().usc_stm_pre(_dev_u8(frame, "stm_pre.frame", (H, W, 3)), _dev_u8(mask, "stm_pre.mask", (H, W)) if mask is not None else None,
+                              H, W, int(in_h), int(in_w), out.data_ptr(), _stream()), "usc_stm_pre")
+    return out
+
+
+def pack_kn(src, K, N, sk, sn, dst):
+    """dst (Kpad/4, Npad, 4) f32 <- src[k*sk + n*sn], zero padded (the weight layout of the conv kernel)."""
+    k4, npad, four = dst.shape
+    _check(load().usc_pack_kn_f32(src.data_ptr(), int(K), int(N), int(sk), int(sn), k4 * 4, npad, dst.data_ptr(), _stream()),
+           "usc_pack_kn_f32")
+    return dst
+
+
+def row_softmax(x, cols, div=1.0):
+    """In place softmax(x / div) over the first `cols` columns of every row of a 2-D float32 CUDA tensor."""
+    rows, ld = x.shape
+    _check(load().usc_row_softmax_f32(x.data_ptr(), rows, int(cols), ld, float(div), _stream()), "usc_row_softmax_f32")
+    return x
+
+
+def stm_post(p2, in_h, in_w, H, W, out=None, prob=None):
+    """p2 (lh, lw, cbuf) f32 CUDA decoder logits -> (mask (H, W) u8, prob (in_h, in_w, 2) f32)."""
+    lh, lw, cbuf = p2.shape
+    out = torch.empty((H, W), dtype=torch.uint8, device=p2.device) if out is None else out
+    prob = torch.empty((in_h, in_w, 2), dtype=torch.float32, device=p2.device) if prob is None else prob
+    _check(load().usc_stm_post(p2.data_ptr(), lh, lw, cbuf, int(in_h), int(in_w), int(H), int(W), _dev_u8(out, "stm_post.out", (H, W)),
+                               prob.data_ptr(), _stream()), "usc_stm_post")
+    return out, prob
+
+
+def stm_mask_from_prob(prob, H, W, out=None):
+    """(in_h, in_w, 2) float32 CUDA probabilities (bg, fg) -> inv_pad_resize + argmax * 255 -> (H, W) uint8."""
+    in_h, in_w, _ = prob.shape
+    out = torch.empty((H, W), dtype=torch.uint8, device=prob.device) if out is None else out
+    _check(load().usc_stm_mask_from_prob(prob.data_ptr(), in_h, in_w, int(H), int(W), _dev_u8(out, "stm_mask.out", (H, W)), _stream()),
+           "usc_stm_mask_from_prob")
+    return out
 
 
 def humanseg_affine(w, h, in_w=473, in_h=473, inv=False):

@@ -42,9 +42,12 @@ class ConvGraphNet:
         """(H, W, C) NHWC buffer viewed as a channels-last (1, C, H, W) tensor (no copy)."""
         return buf.permute(2, 0, 1).unsqueeze(0)
 
-    def _conv(self, c, x, IH, IW, cin_buf, out=None, res1=None, act=None, cout_pad=None, out_ld=0, out_c0=0, bias_buf=None):
+    def _conv(self, c, x, IH, IW, cin_buf, out=None, res1=None, act=None, cout_pad=None, out_ld=0, out_c0=0, bias_buf=None,
+              res2=None, in_relu=False, wpk_buf=None):
         """c: folded conv (w (Cout, Cin, k, k), b, stride, pad, dil, act).  x: (IH, IW, cin_buf) buffer; cin_buf >= Cin (the
-        extra channels get zero weights).  bias_buf: a device buffer that replaces c.b (a bias computed on the device)."""
+        extra channels get zero weights).  bias_buf: a device buffer that replaces c.b (a bias computed on the device).
+        res2: added after the activation; in_relu: the layer computes conv(relu(x)); wpk_buf: a device buffer already in the
+        kernel's [K/4][Cout][4] layout that replaces the packed c.w (operands produced on the device, see usc_pack_kn_f32)."""
         w = c.w
         co, ci, k, _ = w.shape
         if cin_buf != ci:
@@ -62,9 +65,11 @@ class ConvGraphNet:
         out = out if out is not None else self._buf(OH, OW, co)
         d = self.ConvDesc()
         d.inp, d.out = x.data_ptr(), out.data_ptr()
-        d.wpk = self._dev(self.pack(wk.float())).data_ptr()
+        d.wpk = wpk_buf.data_ptr() if wpk_buf is not None else self._dev(self.pack(wk.float())).data_ptr()
         d.bias = bias_buf.data_ptr() if bias_buf is not None else self._dev(b).data_ptr()
         d.res1 = res1.data_ptr() if res1 is not None else None
+        d.res2 = res2.data_ptr() if res2 is not None else None
+        d.in_relu = 1 if in_relu else 0
         d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = IH, IW, cin_buf, OH, OW, OH, OW, co
         d.in_stride, d.out_stride = c.stride, 1
         d.act = self.ACTS[act or c.act]

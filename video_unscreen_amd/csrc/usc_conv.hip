@@ -36,7 +36,7 @@ constexpr int KC = 32;         // K slice per step
 constexpr int APITCH = 36;     // floats per A row in LDS (32 + 4 pad: b128 reads hit 64 distinct banks)
 constexpr int THREADS = 256;
 
-template <int NT>
+template <int NT, bool IN_RELU>
 __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
     __shared__ __attribute__((aligned(16))) float As[2][BM * APITCH];
     __shared__ __attribute__((aligned(16))) float Bs[2][8 * 32 * NT * 4];
@@ -152,8 +152,11 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
     };
     auto store_chunk = [&](int buf, const float4 (&ra)[4], const float4 (&rb)[NT]) {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * j) * APITCH + 4 * q]) = ra[j];
+        for (int j = 0; j < 4; j++) {
+            float4 a = ra[j];
+            if (IN_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }   // conv(relu(x))
+            *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * j) * APITCH + 4 * q]) = a;
+        }
 #pragma unroll
         for (int j = 0; j < NT; j++)
             *reinterpret_cast<float4*>(&Bs[buf][(bkq * (32 * NT) + bn + 32 * j) * 4]) = rb[j];
@@ -385,6 +388,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     if (d.kind == USC_CONV_HEAD) {
         if (d.Cout != 1 || d.Cin != 32 || d.ntaps != 9 || d.in_stride != 1 || d.IH != d.OH || d.IW != d.OW)
             return conv_fail(USC_E_UNSUPPORTED, "usc_conv: the head kernel is Conv2d(32, 1, 3, padding=1)");
+        if (d.in_relu) return conv_fail(USC_E_UNSUPPORTED, "usc_conv: in_relu is not offered by the head kernel");
         p.fn = (void*)head_conv_kernel;
         p.grid = dim3((d.OW + HT_W - 1) / HT_W, (d.OH + HT_H - 1) / HT_H);
         return USC_OK;
@@ -419,7 +423,10 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     p.d.ksplit = S;
     p.d.nphase = nphase;
     p.grid = dim3(mblocks, nblocks, nphase * S);
-    p.fn = nt2 ? (void*)conv_mfma_kernel<2> : (void*)conv_mfma_kernel<1>;
+    if (d.in_relu)
+        p.fn = nt2 ? (void*)conv_mfma_kernel<2, true> : (void*)conv_mfma_kernel<1, true>;
+    else
+        p.fn = nt2 ? (void*)conv_mfma_kernel<2, false> : (void*)conv_mfma_kernel<1, false>;
     if (S > 1) {
         const long long items = (long long)d.OHf * d.OWf * (d.Cout / 4);
         int rb = (int)((items + 255) / 256);

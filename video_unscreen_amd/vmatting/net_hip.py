@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
                 ("out_stride", C.c_int), ("out_py", C.c_int), ("out_px", C.c_int),
                 ("res1_shift", C.c_int), ("act", C.c_int), ("ntaps", C.c_int), ("kind", C.c_int),
                 ("dy", C.c_byte * 16), ("dx", C.c_byte * 16),
-                ("nphase", C.c_int), ("wphase_stride", C.c_int), ("ksplit", C.c_int), ("reserved", C.c_int),
+                ("nphase", C.c_int), ("wphase_stride", C.c_int), ("ksplit", C.c_int), ("in_relu", C.c_int),
                 ("slab", C.c_void_p), ("slab_bytes", C.c_size_t), ("out_ld", C.c_int), ("out_c0", C.c_int)]
 
 
