@@ -202,6 +202,15 @@ int usc_stm_post(const float* p2, int lh, int lw, int cbuf, int in_h, int in_w, 
  * reference derives the first frame's output mask this way from the one-hot of mask0, agent.py:127, 172-201). */
 int usc_stm_mask_from_prob(const float* prob, int in_h, int in_w, int H, int W, uint8_t* out, usc_stream_t stream);
 
+/* unscreen/utils/region_fill.py:7-63 regionfill for the three channels of a BGR image at once (tools/unscreen/bg.py:79-81):
+ * inside mask > 0 the discrete Laplace equation with the surrounding pixels as boundary values, solved by conjugate gradients
+ * in float64 until every channel's residual norm has dropped by `rtol` (checked every 32 iterations: this call synchronises
+ * the stream) or `max_iters`; the result is truncated to uint8 like the reference's astype (values agree with the reference's
+ * direct solve to ~1e4 * rtol grey levels).  *iters_out (host, may be NULL) = iterations run. */
+size_t usc_regionfill_ws_bytes(int H, int W);
+int usc_regionfill_u8(const uint8_t* img, const uint8_t* mask, int H, int W, uint8_t* out, double rtol, int max_iters,
+                      int* iters_out, void* ws, size_t ws_bytes, usc_stream_t stream);
+
 /* unscreen/utils/maskprocess.py:56-60 exist_foreground: *out_count (device, 8 bytes) = #(mask >= thr). */
 int usc_count_ge_u8(const uint8_t* mask, size_t n, int thr, unsigned long long* out_count, usc_stream_t stream);
 

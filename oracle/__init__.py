@@ -262,6 +262,9 @@ def trimap(mask, long_side=960, ksize=3, iters=5):
 def bgdiff_mask(frame, bg_i, bg_always, seg, beta, thr):
     frame, pf = _u8(frame)
     bg_i, pi = _u8(bg_i)
+    if bg_always is None:                  # tools/unscreen/bg.py:85: a single background image = fusion weight 1 (b*1 + 0*b = b)
+        assert float(beta) == 1.0
+        bg_always = bg_i
     bg_always, pa = _u8(bg_always)
     seg, ps = _u8(seg)
     H, W = frame.shape[:2]
@@ -465,6 +468,45 @@ def stm_post(p2, in_h, in_w, H, W, want_prob=False):
     prob = np.empty((in_h, in_w, 2), np.float32)
     lib().orc_stm_post(p, lh, lw, cbuf, int(in_h), int(in_w), int(H), int(W), out.ctypes.data_as(u8p), prob.ctypes.data_as(f32p))
     return (out, prob) if want_prob else out
+
+
+def regionfill(I, mask):
+    """utils/region_fill.py:7-63 (factor = 1): inside mask != 0 solve  n(p) x(p) - sum_{q in N4(p) & mask} x(q) =
+    sum_{q in N4(p) \\ mask} I(q)  with scipy's sparse direct solver, like the reference; float64 result, I elsewhere."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    I = np.asarray(I)
+    m = np.asarray(mask) != 0
+    out = I.astype(np.float64).copy()
+    n = int(m.sum())
+    if n == 0:
+        return out
+    H, W = m.shape
+    idx = -np.ones((H, W), np.int64)
+    idx[m] = np.arange(n)
+    nn = np.full((H, W), 4.0)
+    nn[0, :] = 3
+    nn[-1, :] = 3
+    nn[:, 0] = 3
+    nn[:, -1] = 3
+    nn[0, 0] = nn[0, -1] = nn[-1, 0] = nn[-1, -1] = 2
+    ys, xs = np.nonzero(m)
+    rows, cols, vals = [np.arange(n)], [np.arange(n)], [nn[m]]
+    b = np.zeros(n)
+    If = I.astype(np.float64)
+    for dy, dx in ((-1, 0), (0, 1), (1, 0), (0, -1)):
+        yy, xx = ys + dy, xs + dx
+        ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+        inm = np.zeros(n, bool)
+        inm[ok] = m[yy[ok], xx[ok]]
+        rows.append(np.nonzero(inm)[0])
+        cols.append(idx[yy[inm], xx[inm]])
+        vals.append(-np.ones(int(inm.sum())))
+        bd = ok & ~inm
+        b[bd] += If[yy[bd], xx[bd]]
+    A = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+    out[m] = spl.spsolve(A, b)
+    return out
 
 
 def score_map(h, w, center):

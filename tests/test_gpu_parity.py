@@ -327,3 +327,33 @@ def test_replace_geometry_and_composites_bit_exact(nv, oracle_lib, H, W):
     want = oracle_lib.blend(oracle_lib.rescale_fg(oracle_lib.shift_fg(img, -0.2072, -2.6028), 1.2),
                             oracle_lib.rescale_fg(oracle_lib.shift_fg(m3, -0.2072, -2.6028), 1.2), bg2)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("H,W", [(270, 480), (135, 241), (64, 96)])
+def test_regionfill_matches_direct_solve(nv, oracle_lib, H, W):
+    """Conjugate gradients on the device vs the oracle's sparse direct solve (the reference's own method, region_fill.py:63):
+    equal to +-1 grey level after the uint8 truncation, and only where the exact value sits next to an integer."""
+    from video_unscreen_amd.synth import SyntheticClip
+    from video_unscreen_amd.utils import regionfill
+    f = SyntheticClip(H, W, 1, config_id=2, device="cpu").frame(0)
+    alpha = (f["alpha_true"].numpy() * 255).astype(np.uint8)
+    bg = oracle_lib.get_bg(alpha, f["frame"].numpy())
+    mask = oracle_lib.morph(np.where(alpha > 128, 255, 0).astype(np.uint8), 3, 2, "dilate")
+    mask[:6, :9] = 255                    # a region touching the image corner (2- and 3-neighbour rows of the matrix)
+    mask[-5:, W // 2:W // 2 + 7] = 255
+    got, iters = nv.regionfill(dev(bg), dev(mask), want_iters=True)
+    got = host(got)
+    assert 32 <= iters < 5000
+    exact = np.stack([oracle_lib.regionfill(bg[..., c], mask) for c in range(3)], -1)
+    want = exact.astype(np.uint8)
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1
+    near = np.abs(exact - np.round(exact)) < 2e-2
+    assert (near | (d == 0)).all()                       # a flip needs the exact value within 0.02 of an integer
+    assert np.array_equal(got[mask == 0], bg[mask == 0])
+    assert np.array_equal(host(nv.regionfill(dev(bg), dev(mask))), got)          # fixed-order reductions: reproducible
+    one = regionfill(bg[..., 1], mask)
+    assert one.dtype == np.float64 and np.array_equal(one, got[..., 1])
+    # nothing to fill: the image comes back
+    z = np.zeros((H, W), np.uint8)
+    assert np.array_equal(host(nv.regionfill(dev(bg), dev(z))), bg)

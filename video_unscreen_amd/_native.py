@@ -71,6 +71,8 @@ _SIGNATURES = {
     "usc_row_softmax_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
     "usc_stm_post": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "usc_stm_mask_from_prob": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "usc_regionfill_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "usc_regionfill_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_double, C.c_int, C.POINTER(C.c_int), _vp, C.c_size_t, _vp]),
     "usc_remove_invalid_objects_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                   C.c_double, _vp, C.POINTER(C.c_int)]),
     "usc_humanseg_affine": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -545,6 +547,20 @@ def stm_mask_from_prob(prob, H, W, out=None):
     _check(load().usc_stm_mask_from_prob(prob.data_ptr(), in_h, in_w, int(H), int(W), _dev_u8(out, "stm_mask.out", (H, W)), _stream()),
            "usc_stm_mask_from_prob")
     return out
+
+
+def regionfill(img, mask, rtol=1e-7, max_iters=20000, out=None, ws=None, want_iters=False):
+    """Laplace inpainting of the three channels of img (H, W, 3) inside mask > 0 (reference utils/region_fill.py)."""
+    H, W, _ = img.shape
+    out = torch.empty_like(img) if out is None else out
+    need = load().usc_regionfill_ws_bytes(H, W)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, img.device)
+    it = C.c_int(0)
+    _check(load().usc_regionfill_u8(_dev_u8(img, "regionfill.img", (H, W, 3)), _dev_u8(mask, "regionfill.mask", (H, W)), H, W,
+                                    _dev_u8(out, "regionfill.out", (H, W, 3)), float(rtol), int(max_iters), C.byref(it), ws.data_ptr(),
+                                    ws.numel(), _stream()), "usc_regionfill_u8")
+    return (out, it.value) if want_iters else out
 
 
 def humanseg_affine(w, h, in_w=473, in_h=473, inv=False):

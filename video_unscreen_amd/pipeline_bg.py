@@ -1,0 +1,87 @@
+"""Device-resident bg online mode: tools/unscreen/bg.py:45-104 of the reference.
+
+Per frame:
+    segmask   = STMAgent([prev frame, frame], binarised alpha_pre)[-1]  (tracking)  |  HumanSegAgent(frame)      bg.py:49-56
+    exist_foreground(segmask)                                                                                    :60
+    alphaor   = remove_invalid_objects(segmask)  (host) -> trimap -> matting net            (pass 1)             :67-70
+    bg        = get_bg(alpha, frame);  hole = dilate3x3x2(alpha > 128);  bgimg = regionfill(bg, hole) per channel :71-81
+    alphabg   = dilate4x4x2(gray(|frame - bgimg|) > thr);  alpha_ensm = alpha * (alphabg // 255)                  :85-92
+    alphaor   = remove_invalid_objects(alpha_ensm) (host) -> trimap -> matting net          (pass 2)             :93-95
+    bgimg[alpha == 0] = frame[alpha == 0];  fg = get_fg(frame, alpha, bgimg)                                      :99-100
+    alpha_pre = alpha;  tracking = exist_foreground(alpha)                                                        :103-104
+"""
+import torch
+
+from . import _native as nv
+from .binseg import HumanSegAgent
+from .stm import STMAgent
+from .trimap import TrimapAgent
+from .vmatting import VMattingAgent
+
+
+class BgOnlinePipeline:
+    def __init__(self, cfg, H, W, device="cuda:0", segagent=None, stmagent=None, vmatagent=None, fill_rtol=1e-7):
+        self.cfg = cfg
+        self.H, self.W = H, W
+        self.device = torch.device(device)
+        idx = self.device.index or 0
+        self.segagent = segagent if segagent is not None else HumanSegAgent(**dict(cfg["binseg"], cuda_device=idx))
+        self.stmagent = stmagent if stmagent is not None else STMAgent(**dict(cfg["stm"], cuda_device=idx))
+        self.trimapagent = TrimapAgent(**cfg["trimap"])
+        self.vmatagent = vmatagent if vmatagent is not None else VMattingAgent(**dict(cfg["vmatting"], cuda_device=idx))
+        centers = cfg["objectremoval"]["score_map_center"]
+        self.center = centers["landscape"] if W > H else centers["portrait"]
+        self.filter = nv.ObjectFilter()
+        self.fill_rtol = fill_rtol
+        self._host = torch.empty((H, W), dtype=torch.uint8).pin_memory()
+        self._cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._ws_fill = torch.empty(nv.load().usc_regionfill_ws_bytes(H, W), dtype=torch.uint8, device=self.device)
+        self._ws_diff = torch.empty(nv.load().usc_bgdiff_ws_bytes(H, W), dtype=torch.uint8, device=self.device)
+        self.reset()
+
+    def reset(self):
+        self.tracking_flag = False
+        self.alpha_pre = torch.zeros((self.H, self.W), dtype=torch.uint8, device=self.device)
+        self.prev_frame = None
+        self.fill_iters = 0
+
+    def _exist_foreground(self, mask):
+        return int(nv.count_ge(mask, 128, out=self._cnt).item()) > self.cfg["fg_exist_thr"] * self.H * self.W
+
+    def _object_filter(self, mask):
+        self._host.copy_(mask)
+        self.filter(self._host.numpy(), None, self.center, self.cfg["objectremoval"]["saliency_thr"],
+                    self.cfg["objectremoval"]["consensus_thr"])
+        return self._host.to(self.device)
+
+    def step(self, frame):
+        """frame (H, W, 3) uint8 BGR CUDA -> dict(segmask, alpha, fg, bg, + the intermediates of every stage)."""
+        cfg = self.cfg
+        tracking = self.tracking_flag
+        if tracking:
+            seed = torch.where(self.alpha_pre >= 128, torch.full_like(self.alpha_pre, 255), self.alpha_pre)
+            segmask = self.stmagent.forward_device([self.prev_frame, frame], seed)[-1]
+        else:
+            segmask = self.segagent.forward_device(frame)
+        out = {"segmask": segmask, "tracking": tracking}
+        if not self._exist_foreground(segmask):
+            alpha, fg = torch.zeros_like(segmask), torch.zeros_like(frame)
+        else:
+            alphaor1 = self._object_filter(segmask)
+            trimap1 = self.trimapagent.forward_device(alphaor1)
+            alpha1 = self.vmatagent.forward_device(frame, self.alpha_pre, trimap1)
+            bg = nv.get_bg(alpha1, frame)
+            hole = nv.morph((alpha1 > 128).to(torch.uint8) * 255, 3, 2, nv.DILATE)
+            bgimg, self.fill_iters = nv.regionfill(bg, hole, rtol=self.fill_rtol, ws=self._ws_fill, want_iters=True)
+            _, alpha_ensm = nv.bgdiff_mask(frame, bgimg, None, alpha1, 1.0, cfg["bg_mask"]["thr"], ws=self._ws_diff)
+            alphaor2 = self._object_filter(alpha_ensm)
+            trimap2 = self.trimapagent.forward_device(alphaor2)
+            alpha = self.vmatagent.forward_device(frame, self.alpha_pre, trimap2)
+            fg, bgp = nv.get_fg(frame, alpha, bgimg, paste_thr=1, want_bg=True)
+            out.update(alphaor1=alphaor1, trimap1=trimap1, alpha1=alpha1, bg_holes=bg, hole=hole, bgimg=bgimg, alpha_ensm=alpha_ensm,
+                       alphaor2=alphaor2, trimap2=trimap2, bg=bgp)
+        self.alpha_pre = alpha
+        self.tracking_flag = self._exist_foreground(alpha)
+        self.prev_frame = frame
+        out.update(alpha=alpha, fg=fg)
+        return out

@@ -42,3 +42,16 @@ def color_correct(img, alpha, bg_color, target_long_side=960, mean_exp=0.95):
     """Scale alpha by the (min-max normalised, repeatedly square-rooted) Lab a/b distance to the screen colour
     (reference imgprocess.py:263-300): three kernels, the data-dependent sqrt loop resolved on the device."""
     return to_host(nv.color_correct(to_dev(img), to_dev(alpha), np.asarray(bg_color), target_long_side, mean_exp))
+
+
+def regionfill(I, mask, factor=1.0):
+    """Membrane (Laplace) inpainting of one channel inside mask != 0 (reference utils/region_fill.py:7-18, factor = 1 as every
+    caller passes).  Returns float64 like the reference; the values are already truncated to whole grey levels, which is what
+    the callers do next (tools/unscreen/bg.py:81)."""
+    if factor != 1.0:
+        raise NotImplementedError("regionfill: only factor = 1.0 (the reference's only use)")
+    m = (np.asarray(mask) != 0).astype(np.uint8)
+    if not m.any():
+        return np.asarray(I).copy()
+    img3 = np.repeat(np.asarray(I, np.uint8)[..., None], 3, axis=2)
+    return to_host(nv.regionfill(to_dev(img3), to_dev(m)))[..., 0].astype(np.float64)
