@@ -343,7 +343,7 @@ def test_regionfill_matches_direct_solve(nv, oracle_lib, H, W):
     mask[-5:, W // 2:W // 2 + 7] = 255
     got, iters = nv.regionfill(dev(bg), dev(mask), want_iters=True)
     got = host(got)
-    assert 32 <= iters < 5000
+    assert 4 <= iters <= 100                             # multigrid-preconditioned: tens of iterations at any size
     exact = np.stack([oracle_lib.regionfill(bg[..., c], mask) for c in range(3)], -1)
     want = exact.astype(np.uint8)
     d = np.abs(got.astype(int) - want.astype(int))
