@@ -16,9 +16,7 @@ net()
 torch.cuda.synchronize()
 tot_t = tot_f = 0
 rows = []
-DBG = int(os.environ.get("USC_DBG", "0"))
 for i, d in enumerate(net._descs):
-    d.reserved = DBG
     arr = (ConvDesc * 1)(d)
     for _ in range(3):
         lib.usc_conv_sequence_f32(arr, 1, st)
@@ -34,24 +32,6 @@ for i, d in enumerate(net._descs):
     mb = (M + 127) // 128
     print(f"{i:3d} M={M:7d} Cin={d.Cin:4d} Cout={d.Cout:4d} taps={d.ntaps:2d} s={d.in_stride} os={d.out_stride} "
           f"blocks={mb}x{max(d.Cout // 32, 1)} {t*1e6:8.1f} us {fl/1e9:6.2f} GF {fl/t/1e12:6.1f} TF/s")
-if os.environ.get("USC_SWEEP"):
-    print("debug sweep on selected layers: full / no-epilogue / prologue-only / launch-only (us)")
-    for i in (1, 3, 9, 23, 44, 47, 49):
-        d = net._descs[i]
-        res = []
-        for flag in (0, 2, 4, 8):
-            d.reserved = flag
-            arr = (ConvDesc * 1)(d)
-            for _ in range(3):
-                lib.usc_conv_sequence_f32(arr, 1, st)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                lib.usc_conv_sequence_f32(arr, 1, st)
-            e1.record(); e1.synchronize()
-            res.append(e0.elapsed_time(e1) / 20 * 1e3)
-        d.reserved = 0
-        print(f"layer {i:2d} M={d.OH*d.OW:7d} Cin={d.Cin:3d} Cout={d.Cout:3d} taps={d.ntaps}: " + "  ".join(f"{r:7.1f}" for r in res))
 print(f"sum of layers {tot_t*1e3:.3f} ms, {tot_f/1e9:.1f} GF, {tot_f/tot_t/1e12:.1f} TF/s")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()

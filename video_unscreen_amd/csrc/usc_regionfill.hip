@@ -83,17 +83,22 @@ __device__ __forceinline__ Nbr neighbours(int y, int x, int H, int W) {
     return nb;
 }
 
-// (A v)(i) / s for one masked pixel and channel block: n v_i - sum of in-mask neighbours
+// (A v)(i) / s for one masked pixel and channel block: n v_i - sum of in-mask neighbours.  All loads are issued
+// unconditionally (out-of-image neighbours alias cell 0) and de-selected afterwards, so they do not wait for the mask bytes.
 __device__ __forceinline__ void stencil3(const uint8_t* __restrict__ mask, const double* __restrict__ v, uint32_t i, const Nbr& nb, double* out3) {
-    bool inm[4];
+    uint8_t mk[4];
+    double nv[4][3];
 #pragma unroll
-    for (int k = 0; k < 4; k++) inm[k] = nb.in[k] && mask[nb.idx[k]];
+    for (int k = 0; k < 4; k++) {
+        mk[k] = mask[nb.idx[k]];
+#pragma unroll
+        for (int c = 0; c < 3; c++) nv[k][c] = v[3 * (size_t)nb.idx[k] + c];
+    }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         double a = (double)nb.n * v[3 * (size_t)i + c];
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (inm[k]) a -= v[3 * (size_t)nb.idx[k] + c];
+        for (int k = 0; k < 4; k++) a -= (nb.in[k] && mk[k]) ? nv[k][c] : 0.;
         out3[c] = a;
     }
 }
@@ -228,6 +233,13 @@ __global__ __launch_bounds__(kThreads) void rf_out_kernel(const uint8_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------- multigrid
+namespace {
+struct Level { int H, W; double s; uint8_t* mask; double *z, *zt, *r; };
+struct LevelSet { int L, first_tail; Level lv[kMaxLevels]; };
+constexpr int kTailThreads = 1024;
+constexpr int kTailCells = 9000;           // levels with at most this many cells run inside the single-workgroup tail kernel
+}  // namespace
+
 __global__ __launch_bounds__(kThreads) void mg_mask_down_kernel(const uint8_t* __restrict__ mf, int Hf, int Wf, uint8_t* __restrict__ mc,
                                                                 int Hc, int Wc) {
     const uint32_t n = (uint32_t)Hc * (uint32_t)Wc;
@@ -244,10 +256,10 @@ __global__ __launch_bounds__(kThreads) void mg_mask_down_kernel(const uint8_t* _
 }
 
 // z_out = z_in + omega / (s n) (r - s A' z_in)   (z_in == nullptr: z_in = 0).  A' is the unscaled masked stencil.
-__global__ __launch_bounds__(kThreads) void mg_jacobi_kernel(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ zin,
-                                                             const double* __restrict__ r, double* __restrict__ zout) {
+__device__ __forceinline__ void mg_jacobi_cells(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ zin,
+                                                const double* __restrict__ r, double* __restrict__ zout, uint32_t start, uint32_t stride) {
     const uint32_t n = (uint32_t)H * (uint32_t)W;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = start; i < n; i += stride) {
         if (!mask[i]) continue;
         const int y = (int)(i / (uint32_t)W), x = (int)(i - (uint32_t)y * (uint32_t)W);
         const Nbr nb = neighbours(y, x, H, W);
@@ -264,12 +276,17 @@ __global__ __launch_bounds__(kThreads) void mg_jacobi_kernel(const uint8_t* __re
     }
 }
 
+__global__ __launch_bounds__(kThreads) void mg_jacobi_kernel(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ zin,
+                                                             const double* __restrict__ r, double* __restrict__ zout) {
+    mg_jacobi_cells(mask, H, W, s, zin, r, zout, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
 // r_c(I) = sum over the children i of I inside the fine mask of (r_f - s_f A' z_f)(i)
-__global__ __launch_bounds__(kThreads) void mg_restrict_kernel(const uint8_t* __restrict__ mf, int Hf, int Wf, double sf, const double* __restrict__ zf,
-                                                               const double* __restrict__ rf, const uint8_t* __restrict__ mc, int Hc, int Wc,
-                                                               double* __restrict__ rc) {
+__device__ __forceinline__ void mg_restrict_cells(const uint8_t* __restrict__ mf, int Hf, int Wf, double sf, const double* __restrict__ zf,
+                                                  const double* __restrict__ rf, const uint8_t* __restrict__ mc, int Hc, int Wc,
+                                                  double* __restrict__ rc, uint32_t start, uint32_t stride) {
     const uint32_t n = (uint32_t)Hc * (uint32_t)Wc;
-    for (uint32_t I = blockIdx.x * blockDim.x + threadIdx.x; I < n; I += gridDim.x * blockDim.x) {
+    for (uint32_t I = start; I < n; I += stride) {
         if (!mc[I]) continue;
         const int Y = (int)(I / (uint32_t)Wc), X = (int)(I - (uint32_t)Y * (uint32_t)Wc);
         double acc[3] = {0., 0., 0.};
@@ -289,11 +306,17 @@ __global__ __launch_bounds__(kThreads) void mg_restrict_kernel(const uint8_t* __
     }
 }
 
+__global__ __launch_bounds__(kThreads) void mg_restrict_kernel(const uint8_t* __restrict__ mf, int Hf, int Wf, double sf, const double* __restrict__ zf,
+                                                               const double* __restrict__ rf, const uint8_t* __restrict__ mc, int Hc, int Wc,
+                                                               double* __restrict__ rc) {
+    mg_restrict_cells(mf, Hf, Wf, sf, zf, rf, mc, Hc, Wc, rc, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
 // z_f(i) += z_c(parent(i)) inside the fine mask
-__global__ __launch_bounds__(kThreads) void mg_prolong_kernel(const uint8_t* __restrict__ mf, int Hf, int Wf, double* __restrict__ zf,
-                                                              const double* __restrict__ zc, int Wc) {
+__device__ __forceinline__ void mg_prolong_cells(const uint8_t* __restrict__ mf, int Hf, int Wf, double* __restrict__ zf,
+                                                 const double* __restrict__ zc, int Wc, uint32_t start, uint32_t stride) {
     const uint32_t n = (uint32_t)Hf * (uint32_t)Wf;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = start; i < n; i += stride) {
         if (!mf[i]) continue;
         const int y = (int)(i / (uint32_t)Wf), x = (int)(i - (uint32_t)y * (uint32_t)Wf);
         const size_t I = (size_t)(y >> 1) * Wc + (x >> 1);
@@ -302,11 +325,51 @@ __global__ __launch_bounds__(kThreads) void mg_prolong_kernel(const uint8_t* __r
     }
 }
 
+__global__ __launch_bounds__(kThreads) void mg_prolong_kernel(const uint8_t* __restrict__ mf, int Hf, int Wf, double* __restrict__ zf,
+                                                              const double* __restrict__ zc, int Wc) {
+    mg_prolong_cells(mf, Hf, Wf, zf, zc, Wc, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// The coarse end of the V-cycle (levels first_tail .. L-1, a few thousand cells at most) inside ONE workgroup: the same
+// sweeps in the same order as the per-level kernels, separated by workgroup barriers instead of kernel boundaries
+// (every cell's arithmetic is identical, so the result does not depend on which path ran).
+__global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls) {
+    const uint32_t t = threadIdx.x, nt = blockDim.x;
+    for (int l = ls.first_tail; l < ls.L; l++) {
+        const Level& v = ls.lv[l];
+        if (l == ls.L - 1) {
+            mg_jacobi_cells(v.mask, v.H, v.W, v.s, nullptr, v.r, v.z, t, nt);
+            __syncthreads();
+            for (int k = 0; k < 8; k++) {
+                mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.z, v.r, v.zt, t, nt);
+                __syncthreads();
+                mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, t, nt);
+                __syncthreads();
+            }
+        } else {
+            mg_jacobi_cells(v.mask, v.H, v.W, v.s, nullptr, v.r, v.zt, t, nt);
+            __syncthreads();
+            mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, t, nt);
+            __syncthreads();
+            const Level& c = ls.lv[l + 1];
+            mg_restrict_cells(v.mask, v.H, v.W, v.s, v.z, v.r, c.mask, c.H, c.W, c.r, t, nt);
+            __syncthreads();
+        }
+    }
+    for (int l = ls.L - 2; l >= ls.first_tail; l--) {
+        const Level& v = ls.lv[l];
+        mg_prolong_cells(v.mask, v.H, v.W, v.z, ls.lv[l + 1].z, ls.lv[l + 1].W, t, nt);
+        __syncthreads();
+        mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.z, v.r, v.zt, t, nt);
+        __syncthreads();
+        mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, t, nt);
+        __syncthreads();
+    }
+}
+
 namespace {
 
 size_t rf_align(size_t v) { return (v + 255) & ~(size_t)255; }
-
-struct Level { int H, W; double s; uint8_t* mask; double *z, *zt, *r; };
 
 int level_dims(int H, int W, int* hs, int* ws) {
     int L = 0;
@@ -319,9 +382,9 @@ int level_dims(int H, int W, int* hs, int* ws) {
     return L + 1;
 }
 
-int grid_of(size_t n) {
+int grid_of(size_t n) {                 // element-wise multigrid kernels: one cell per thread up to 8192 workgroups
     size_t b = (n + kThreads - 1) / kThreads;
-    return (int)(b < 1 ? 1 : (b > (size_t)kBlocks ? (size_t)kBlocks : b));
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
 // Either launches on a stream or appends a kernel node to a linear-chain hipGraph (same call sites for both).
@@ -354,7 +417,7 @@ struct Launcher {
 };
 
 struct Solver {
-    int H, W, L;
+    int H, W, L, first_tail;
     uint32_t n;
     Level lv[kMaxLevels];
     double *scal, *part_rr, *part_pap, *part_rz[2], *x, *p, *Ap;
@@ -387,12 +450,17 @@ struct Solver {
             lv[l].mask = take((size_t)hs[l] * wsz[l]);                 // level 0: a private copy of the caller's mask
         }
         mask0 = lv[0].mask;
+        first_tail = L - 1;
+        while (first_tail > 1 && (size_t)lv[first_tail - 1].H * lv[first_tail - 1].W <= (size_t)kTailCells) first_tail--;
+        static const bool no_tail = getenv("USC_RF_NO_TAIL") != nullptr;           // debugging aid: per-level kernels all the way down
+        if (no_tail) first_tail = L;
     }
 
     // z_l = V-cycle(r_l): 2 pre-smoothing sweeps from zero, coarse correction, 2 post-smoothing sweeps; 17 sweeps on the last level
     void vcycle(Launcher& q) const {
         const dim3 b(kThreads);
-        for (int l = 0; l < L; l++) {
+        const int last = first_tail < L ? first_tail : L;          // levels [0, last) run as per-level kernels
+        for (int l = 0; l < last; l++) {
             const Level& v = lv[l];
             const dim3 g(grid_of((size_t)v.H * v.W));
             if (l == L - 1) {
@@ -408,7 +476,14 @@ struct Solver {
                 q.launch(mg_restrict_kernel, dim3(grid_of((size_t)c.H * c.W)), b, v.mask, v.H, v.W, v.s, v.z, v.r, c.mask, c.H, c.W, c.r);
             }
         }
-        for (int l = L - 2; l >= 0; l--) {
+        if (first_tail < L) {
+            LevelSet ls;
+            ls.L = L; ls.first_tail = first_tail;
+            for (int l = 0; l < kMaxLevels; l++) ls.lv[l] = lv[l < L ? l : L - 1];
+            q.launch(mg_tail_kernel, dim3(1), dim3(kTailThreads), ls);
+        }
+        for (int l = last - 1; l >= 0; l--) {
+            if (l == L - 1) continue;
             const Level& v = lv[l];
             const dim3 g(grid_of((size_t)v.H * v.W));
             q.launch(mg_prolong_kernel, g, b, v.mask, v.H, v.W, v.z, lv[l + 1].z, lv[l + 1].W);
