@@ -91,23 +91,51 @@ void follow(int8_t* img, int step, int x, int y, bool hole, Border& b) {
     }
 }
 
-// Visit every pixel of the filled border exactly once: fn(row, col).
-template <class F>
-void for_each_filled(Border& b, uint32_t* stamp, uint32_t id, int W, F fn) {
+// The filled border = its pixels + the even-odd interior spans [xa, xb) between sorted crossing pairs of a row.  Spans of
+// one contour are pairwise disjoint, so only the border pixels need the stamp image (a border can visit a pixel twice,
+// and border pixels may lie inside a span).
+struct FillStats { double ssum, csum; size_t cnt; };
+FillStats filled_stats(Border& b, uint32_t* __restrict stamp, uint32_t id, int W, const double* __restrict score, const uint8_t* __restrict seg) {
+    FillStats st = {0., 0., 0};
+    for (uint32_t p : b.pix) {
+        const size_t o = (size_t)(p >> 16) * W + (p & 0xffff);
+        if (stamp[o] != id) { stamp[o] = id; st.ssum += score[o]; st.csum += seg[o]; st.cnt++; }
+    }
     std::sort(b.cross.begin(), b.cross.end());
     const size_t nc = b.cross.size();
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    uint64_t c = 0, k = 0;
     for (size_t i = 0; i + 1 < nc; i += 2) {              // crossings pair up within a row (closed curve)
-        const uint32_t a = b.cross[i], c = b.cross[i + 1];
-        const int y = (int)(a >> 16), xa = (int)(a & 0xffff), xb = (int)(c & 0xffff);
-        uint32_t* srow = stamp + (size_t)y * W;
-        for (int x = xa; x < xb; x++)
-            if (srow[x] != id) { srow[x] = id; fn(y, x); }
+        const uint32_t a = b.cross[i], e = b.cross[i + 1];
+        const size_t base = (size_t)(a >> 16) * W;
+        const int xa = (int)(a & 0xffff), xb = (int)(e & 0xffff);
+        const uint32_t* __restrict sr = stamp + base;
+        const double* __restrict sc = score + base;
+        const uint8_t* __restrict sg = seg + base;
+        int x = xa;
+        for (; x + 4 <= xb; x += 4) {
+            const bool n0 = sr[x] != id, n1 = sr[x + 1] != id, n2 = sr[x + 2] != id, n3 = sr[x + 3] != id;
+            s0 += n0 ? sc[x] : 0.; s1 += n1 ? sc[x + 1] : 0.; s2 += n2 ? sc[x + 2] : 0.; s3 += n3 ? sc[x + 3] : 0.;
+            c += (n0 ? sg[x] : 0) + (n1 ? sg[x + 1] : 0) + (n2 ? sg[x + 2] : 0) + (n3 ? sg[x + 3] : 0);
+            k += (int)n0 + (int)n1 + (int)n2 + (int)n3;
+        }
+        for (; x < xb; x++)
+            if (sr[x] != id) { s0 += sc[x]; c += sg[x]; k++; }
     }
-    for (uint32_t p : b.pix) {
-        const int y = (int)(p >> 16), x = (int)(p & 0xffff);
-        uint32_t& s = stamp[(size_t)y * W + x];
-        if (s != id) { s = id; fn(y, x); }
+    st.ssum += (s0 + s1) + (s2 + s3);
+    st.csum += (double)c;                                  // integer sum: exact
+    st.cnt += k;
+    return st;
+}
+
+void mark_filled(const Border& b, uint8_t* __restrict valid, int W) {        // b.cross is already sorted
+    const size_t nc = b.cross.size();
+    for (size_t i = 0; i + 1 < nc; i += 2) {
+        const uint32_t a = b.cross[i], e = b.cross[i + 1];
+        const int xa = (int)(a & 0xffff), xb = (int)(e & 0xffff);
+        if (xb > xa) memset(valid + (size_t)(a >> 16) * W + xa, 1, (size_t)(xb - xa));
     }
+    for (uint32_t p : b.pix) valid[(size_t)(p >> 16) * W + (p & 0xffff)] = 1;
 }
 
 }  // namespace
@@ -124,20 +152,27 @@ extern "C" int usc_remove_invalid_objects_host(uint8_t* alpha, const uint8_t* se
         build_score(H, W, center_y, center_x, score);
         if (score_cache && score_cache_valid) *score_cache_valid = 1;
     }
-    std::vector<uint8_t> seg_copy;
-    if (!seg) { seg_copy.assign(alpha, alpha + n); seg = seg_copy.data(); }   // consensus against the input itself
+    // Scratch that survives between calls on this thread: fresh 8 MB vectors cost more in page faults and zero fills than
+    // the tracing itself.  `stamp` is never cleared - ids keep counting up across calls (wrap-around: one clear).
+    struct Scratch { std::vector<int8_t> img; std::vector<uint32_t> stamp; std::vector<uint8_t> valid; uint32_t next_id = 0; };
+    static thread_local Scratch sc;
+    if (!seg) seg = alpha;              // consensus against the input itself: alpha is only written after the last object
 
     const int step = W + 2;
-    std::vector<int8_t> img((size_t)(H + 2) * step, 0);
+    const size_t padded = (size_t)(H + 2) * step;
+    if (sc.img.size() != padded) sc.img.assign(padded, 0);            // the border stays zero; the interior is rewritten below
     for (int y = 0; y < H; y++) {
-        const uint8_t* a = alpha + (size_t)y * W;
-        int8_t* d = img.data() + (size_t)(y + 1) * step + 1;
-        for (int x = 0; x < W; x++) d[x] = a[x] != 0;
+        const uint8_t* __restrict a = alpha + (size_t)y * W;
+        int8_t* __restrict d = sc.img.data() + (size_t)(y + 1) * step + 1;
+        for (int x = 0; x < W; x++) d[x] = (int8_t)(a[x] != 0);
     }
-    std::vector<uint32_t> stamp(n, 0);
-    std::vector<uint8_t> valid(n, 0);
-    Border b;
-    uint32_t id = 0;
+    if (sc.stamp.size() != n || sc.next_id > 0xf0000000u) { sc.stamp.assign(n, 0); sc.next_id = 0; }
+    sc.valid.assign(n, 0);
+    std::vector<int8_t>& img = sc.img;
+    std::vector<uint32_t>& stamp = sc.stamp;
+    std::vector<uint8_t>& valid = sc.valid;
+    static thread_local Border b;
+    uint32_t id = sc.next_id;
     const double denom = (double)H * (double)W;
     for (int y = 1; y <= H; y++) {
         int8_t* row = img.data() + (size_t)y * step;
@@ -162,23 +197,21 @@ extern "C" int usc_remove_invalid_objects_host(uint8_t* alpha, const uint8_t* se
                 follow(img.data(), step, x - (hole ? 1 : 0), y, hole, b);
                 ++id;
                 if (fabs(b.twice_area * 0.5) >= 100) {
-                    double ssum = 0, csum = 0; size_t cnt = 0;
-                    for_each_filled(b, stamp.data(), id, W, [&](int yy, int xx) {
-                        size_t o = (size_t)yy * W + xx;
-                        ssum += score[o]; csum += seg[o]; cnt++;
-                    });
-                    const double sal = ssum / denom;
-                    const double cons = (csum / (double)cnt) / 255.;
-                    if ((sal > saliency_thr && cons > consensus_thr) || sal > saliency_thr * 10) {
-                        ++id;
-                        for_each_filled(b, stamp.data(), id, W, [&](int yy, int xx) { valid[(size_t)yy * W + xx] = 1; });
-                    }
+                    const FillStats fs = filled_stats(b, stamp.data(), id, W, score, seg);
+                    const double sal = fs.ssum / denom;
+                    const double cons = (fs.csum / (double)fs.cnt) / 255.;
+                    if ((sal > saliency_thr && cons > consensus_thr) || sal > saliency_thr * 10) mark_filled(b, valid.data(), W);
                 }
                 p = row[x];
             }
             prev = p;
         }
     }
-    for (size_t i = 0; i < n; i++) if (!valid[i]) alpha[i] = 0;
+    sc.next_id = id;
+    {
+        uint8_t* __restrict ap = alpha;
+        const uint8_t* __restrict vp = valid.data();
+        for (size_t i = 0; i < n; i++) ap[i] &= (uint8_t)(0 - (vp[i] != 0));
+    }
     return USC_OK;
 }
