@@ -119,6 +119,18 @@ def cpu_baseline(cfg, pipe, clip_cpu_frames, bg_always, nframes):
     return nframes / dt, dt
 
 
+def pmc_traffic(H, W):
+    """Fabric bytes of the conv stack per forward from the committed rocprofv3 PMC passes (profiles/r01/pmc_conv_traffic.json,
+    produced by tools/dev/run_profiles.sh + summarize_profiles.py on this workload): FETCH_SIZE x 2 (gfx950 reports half the bytes of
+    16-B/lane streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE.  Counters cannot be collected inside this process; null for any
+    other frame size or when the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_conv_traffic.json")
+    if (H, W) != (1080, 1920) or not os.path.exists(path):
+        return None
+    z = json.load(open(path))
+    return int(2 * z["fetch_raw_bytes_per_forward"] + z["write_bytes_per_forward"])
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -220,7 +232,7 @@ def main():
                 # 2*M*N*K of the reference module (torch flop counter).
                 result["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel (all %d conv launches of one forward)" % pipe.net.num_layers,
                                       "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                                      "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(H, W),
                                       "alg_gflop_per_forward": round(gflop, 2), "ms_per_forward": round(t_net * 1e3, 3)}
                 result["roofline_pixel"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
                                             "unit": "GB/s", "frac": dom["frac_hbm_peak"], "traffic": None,

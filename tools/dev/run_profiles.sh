@@ -1,0 +1,18 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): rocprofv3 kernel-trace + two PMC passes of bench.py (default and --no-seg), outputs under
+# gpurun_out/prof_r01/.  Summaries are made afterwards with tools/dev/summarize_profiles.py and committed under profiles/r01/.
+set -e
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/prof_r01
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for mode in default no_seg; do
+  extra=""; [ $mode = no_seg ] && extra="--no-seg"
+  rocprofv3 --kernel-trace --stats -d $OUT/${mode}_trace -o t --output-format csv -- python3 $ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-kernel-table $extra > $OUT/${mode}_trace.json 2> $OUT/${mode}_trace.err
+  echo "trace $mode done"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${mode}_fetch -o t --output-format csv -- python3 $ROOT/bench.py --steps 16 --warmup 0 --no-cpu-baseline --no-kernel-table --sync-loop $extra > /dev/null 2> $OUT/${mode}_fetch.err
+  echo "fetch $mode done"
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${mode}_write -o t --output-format csv -- python3 $ROOT/bench.py --steps 16 --warmup 0 --no-cpu-baseline --no-kernel-table --sync-loop $extra > /dev/null 2> $OUT/${mode}_write.err
+  echo "write $mode done"
+done
+ls -R $OUT | head -40

@@ -17,7 +17,9 @@ OURS = ("conv_mfma_kernel", "splitk_reduce_kernel", "head_conv_kernel", "bgdiff_
 def short(name):
     for o in OURS:
         if o in name:
-            return o + ("<2>" if "ILi2E" in name or "<2>" in name else "<1>" if ("ILi1E" in name or "<1>" in name) and o == "conv_mfma_kernel" else "")
+            if o != "conv_mfma_kernel":
+                return o
+            return o + ("<2>" if ("ILi2E" in name or "<2>" in name or "<2," in name) else "<1>")
     return None
 
 
@@ -51,5 +53,12 @@ for k, (c, t) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
     print(f"| {k} | {c} | {t/c/1e3:.2f} | {100*t/tot:.1f}% | {fk:.0f} | {2*fk*1024/1e6:.2f} | {wk*1024/1e6:.2f} |")
 conv_f = sum(v[1] for k, v in fe.items() if k.startswith(("conv_mfma", "splitk", "head_conv")))
 conv_w = sum(v[1] for k, v in wr.items() if k.startswith(("conv_mfma", "splitk", "head_conv")))
-print(f"\nAll conv-stack launches (conv_mfma + splitk_reduce + head), per frame over {frames} profiled frames: "
-      f"FETCH_SIZE {conv_f/frames*1024/1e6:.1f} MB raw / {2*conv_f/frames*1024/1e6:.1f} MB x2, WRITE_SIZE {conv_w/frames*1024/1e6:.1f} MB.")
+heads = fe.get("head_conv_kernel", [0, 0.0])[0]            # one head launch per matting forward
+if frames <= 0:
+    frames = heads
+print(f"\nAll conv-stack launches (conv_mfma + splitk_reduce + head) divided by the {frames} forwards of the PMC run: "
+      f"FETCH_SIZE {conv_f/frames*1024/1e6:.1f} MB raw / {2*conv_f/frames*1024/1e6:.1f} MB x2, WRITE_SIZE {conv_w/frames*1024/1e6:.1f} MB per forward.")
+import json
+json.dump({"forwards": frames, "fetch_raw_bytes_per_forward": conv_f / frames * 1024, "write_bytes_per_forward": conv_w / frames * 1024,
+           "note": "conv_mfma + splitk_reduce + head_conv launches; FETCH_SIZE raw (x2 for 16-B/lane streaming reads per MI355X_MICROARCH.md)"},
+          open(sys.argv[6], "w")) if len(sys.argv) > 6 else None

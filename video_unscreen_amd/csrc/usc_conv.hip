@@ -45,8 +45,16 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = d.OH * d.OW;
-    const int m0 = blockIdx.x * BM;
-    const int nb0 = blockIdx.y * (32 * NT);
+    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so with the natural
+    // order the N tiles of one pixel tile, and the pixel tiles one image row apart that share its 3x3 halo, all sit on
+    // different L2s and every one of them fetches the same activations from the fabric again.  The 1-D grid is re-labelled
+    // (bijectively, any size) so that XCD k owns the k-th contiguous run of (pixel tile, N tile) pairs, N tile fastest.
+    const int nblk = d.Cout / (32 * NT);
+    const int nwg = (int)gridDim.x, xcd = (int)blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
+    const int mtile = wgid / nblk;
+    const int m0 = mtile * BM;
+    const int nb0 = (wgid - mtile * nblk) * (32 * NT);
     const int Ktot = d.ntaps * d.Cin;
     // blockIdx.z = phase * ksplit + k-slice.  Phases: the four (py, px) outputs of a transposed conv, each with
     // its own tap table and weight block.  K slices: contiguous chunk ranges whose partial sums go to a slab.
@@ -422,7 +430,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     }
     p.d.ksplit = S;
     p.d.nphase = nphase;
-    p.grid = dim3(mblocks, nblocks, nphase * S);
+    p.grid = dim3(mblocks * nblocks, 1, nphase * S);          // 1-D over (pixel tile, N tile): the kernel re-labels it per XCD
     if (d.in_relu)
         p.fn = nt2 ? (void*)conv_mfma_kernel<2, true> : (void*)conv_mfma_kernel<1, true>;
     else
