@@ -140,10 +140,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # Rehearsal knobs (tests/test_tools_gpu.py exercises the N > 1 code path on a one-GPU box): ranks may share a device and
+    # talk over gloo.  The driver's runs use neither: one rank per GPU, backend "nccl" (= RCCL over xGMI).
+    backend = os.environ.get("USC_BENCH_BACKEND", "nccl")
+    if os.environ.get("USC_BENCH_SHARE_GPU"):
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     if rank == 0:

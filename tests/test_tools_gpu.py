@@ -52,3 +52,19 @@ def test_bg_step_tool_end_to_end(tmp_path, oracle_lib):
                         torch.from_numpy(read_img(str(dst / f"bg_{t:06d}.jpg"))).cuda(), bga)
         a = read_img(str(dst / f"alphamask_{t:06d}.jpg"))[..., 0].astype(int)
         assert np.abs(a - out["alpha"].cpu().numpy().astype(int)).mean() < 1.0
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py launched exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), with the
+    two ranks sharing this box's single GPU and gloo instead of RCCL: exercises the broadcast of weights / background, the
+    frame sharding, the barrier-bracketed timing, the MAX over ranks and the single JSON line."""
+    env = dict(os.environ, USC_BENCH_BACKEND="gloo", USC_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-kernel-table"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                         # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["value"] > 0 and abs(out["value"] - 2 * 6 / (out["ms_per_step"] * 6 / 1e3)) < 1e-2 * out["value"]
