@@ -179,6 +179,9 @@ int usc_im2col_nhwc_f32(const float* in, int IH, int IW, int cpitch, int cuse, i
                         int OH, int OW, int Kpad, usc_stream_t stream);
 int usc_upsample_nc_nhwc_f32(const float* src, int sh, int sw, int C, float* dst, int dh, int dw, int ld, int c0,
                              usc_stream_t stream);
+/* nn.AdaptiveAvgPool2d(s) on channels [c0, c0 + C) of an (H, W, ld) NHWC float32 tensor -> dense (s, s, C)
+ * (binseg/human_parse.py:92-96, deeplab/_deeplab.py:166); windows summed in a fixed order. */
+int usc_adaptive_avgpool_nhwc_f32(const float* src, int H, int W, int ld, int c0, int C, float* dst, int s, usc_stream_t stream);
 size_t usc_segagent_post_ws_bytes(int th, int tw);
 int usc_segagent_post(const float* logits, int ncrops, int lh, int lw, int cbuf, const int* locs_host, int crop_h, int crop_w,
                       int th, int tw, int H, int W, uint8_t* out, double* score_out, void* ws, size_t ws_bytes,
@@ -290,7 +293,14 @@ typedef struct usc_conv_desc {
     size_t slab_bytes;
     int out_ld, out_c0;            /* 0 / 0: `out` is a dense [pixel][Cout] tensor; otherwise `out` has out_ld channels per pixel
                                       and this layer writes channels [out_c0, out_c0 + Cout) (concat buffers) */
+    int batch;                     /* 0 / 1: one image.  > 1: `batch` images stacked along y in every tensor; OH and OHf count the
+                                      rows of all of them, IH is per image.  The K split is chosen per image, so a batched layer
+                                      gives bit for bit what `batch` single-image launches give. */
+    int pad0;
 } usc_conv_desc;
+
+/* sizeof(usc_conv_desc) as the library was built: bindings check their struct definition against it. */
+size_t usc_conv_desc_bytes(void);
 
 /* Enqueue `n` layers in order on `stream` (one kernel launch each, no host synchronisation). */
 int usc_conv_sequence_f32(const usc_conv_desc* descs, int n, usc_stream_t stream);

@@ -83,3 +83,23 @@ def test_humanseg_agent_vs_oracle_chain(nv, oracle_lib, H, W):
     mask_dev, lg = agent.forward_device(dev(frame), return_logits=True)
     want2 = oracle_lib.humanseg_post(lg.cpu().numpy()[..., :20].transpose(2, 0, 1), H, W)
     assert np.array_equal(mask_dev.cpu().numpy(), want2)
+
+
+def test_humanseg_batched_forward_is_bit_identical(nv):
+    """Two / three frames through one batched network forward: logits and masks equal the single-frame results bit for bit
+    (the K split of every layer is decided per image)."""
+    from video_unscreen_amd.binseg import HumanSegAgent
+    from video_unscreen_amd.synth import SyntheticClip
+    agent = HumanSegAgent(model_path=None)
+    clip = SyntheticClip(270, 480, 3, config_id=2, device="cuda")
+    frames = [clip.frame(t)["frame"] for t in range(3)]
+    single = []
+    for f in frames:
+        m, lg = agent.forward_device(f, return_logits=True)
+        single.append((m.clone(), lg.clone()))                  # the logits buffer is reused by the next forward
+    for n in (2, 3):
+        masks = agent.forward_device_batch(frames[:n])
+        net = agent._batch_nets[n]
+        for b in range(n):
+            assert torch.equal(net.image(net.logits32, b), single[b][1]), (n, b)
+            assert torch.equal(masks[b], single[b][0])

@@ -63,6 +63,7 @@ _SIGNATURES = {
     "usc_im2col_nhwc_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int,
                                       C.c_int, C.c_int, _vp]),
     "usc_upsample_nc_nhwc_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "usc_adaptive_avgpool_nhwc_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "usc_segagent_post_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "usc_segagent_post": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     _vp, _vp, _vp, C.c_size_t, _vp]),
@@ -82,6 +83,7 @@ _SIGNATURES = {
                                     C.c_size_t, _vp]),
     "usc_upsample_ac_nhwc_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "usc_seg_last_error": (C.c_char_p, []),
+    "usc_conv_desc_bytes": (C.c_size_t, []),
     "usc_conv_sequence_f32": (C.c_int, [_vp, C.c_int, _vp]),
     "usc_conv_last_error": (C.c_char_p, []),
     "usc_conv_graph_create": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
@@ -449,6 +451,17 @@ def upsample_nc(src, dst, c0=0):
     dh, dw, ld = dst.shape
     _check(load().usc_upsample_nc_nhwc_f32(src.data_ptr(), sh, sw, Cc, dst.data_ptr(), dh, dw, ld, int(c0), _stream()),
            "usc_upsample_nc_nhwc_f32")
+    return dst
+
+
+def adaptive_avgpool(src, c0, Cn, dst):
+    """nn.AdaptiveAvgPool2d(s) of channels [c0, c0 + Cn) of src (H, W, ld) f32 NHWC -> dst (s, s, Cn)."""
+    H, W, ld = src.shape
+    s, s2, cd = dst.shape
+    if s != s2 or cd != Cn:
+        raise NativeError("adaptive_avgpool: dst must be (s, s, Cn)")
+    _check(load().usc_adaptive_avgpool_nhwc_f32(src.data_ptr(), H, W, ld, int(c0), int(Cn), dst.data_ptr(), s, _stream()),
+           "usc_adaptive_avgpool_nhwc_f32")
     return dst
 
 

@@ -27,6 +27,7 @@ class HumanSegAgent():
             sd = strip_module_prefix(torch.load(model_path, map_location="cpu"))   # DataParallel keys: module.*
         self.state_dict = sd
         self.net = HipSchpNet(sd, INPUT_SIZE[0], INPUT_SIZE[1], device=self.device)
+        self._batch_nets = {}
         # kept for signature compatibility; the reference's forward() does not use them either (agent_human.py:277-312)
         self.crop_h, self.crop_w, self.flip = crop_h, crop_w, flip
         self.input_long_side, self.stride_ratio, self.division = input_long_side, stride_ratio, 1
@@ -42,6 +43,28 @@ class HumanSegAgent():
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         mask = nv.humanseg_post(logits, NUM_CLASSES, H, W, INPUT_SIZE[0], INPUT_SIZE[1], out=out, ws=self._ws)
         return (mask, logits) if return_logits else mask
+
+    def forward_device_batch(self, imgs, outs=None):
+        """Several frames through ONE network forward (frames are independent for this agent).  Every mask is bit for bit
+        what forward_device gives for that frame; the win is half (a third, ...) of the kernel launches per frame."""
+        n = len(imgs)
+        if n == 1:
+            return [self.forward_device(imgs[0], out=None if outs is None else outs[0])]
+        if n not in self._batch_nets:
+            self._batch_nets[n] = HipSchpNet(self.state_dict, INPUT_SIZE[0], INPUT_SIZE[1], device=self.device, batch=n)
+        net = self._batch_nets[n]
+        for b, img in enumerate(imgs):
+            nv.humanseg_pre(img, INPUT_SIZE[0], INPUT_SIZE[1], out=net.image(net.x4, b))
+        logits = net.forward(None)
+        need = nv.load().usc_humanseg_post_ws_bytes(NUM_CLASSES, INPUT_SIZE[0], INPUT_SIZE[1])
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        masks = []
+        for b, img in enumerate(imgs):
+            H, W, _ = img.shape
+            masks.append(nv.humanseg_post(net.image(logits, b), NUM_CLASSES, H, W, INPUT_SIZE[0], INPUT_SIZE[1],
+                                          out=None if outs is None else outs[b], ws=self._ws))
+        return masks
 
     def forward(self, img):
         """img (h, w, 3) uint8 BGR -> (h, w) uint8, 255 = person (reference agent_human.py:262-312)."""

@@ -218,8 +218,10 @@ class HipSchpNet(ConvGraphNet):
     """Every convolution on the f32-MFMA kernel (csrc/usc_conv.hip), NHWC buffers; pooling / bilinear glue between
     conv segments stays on torch ops (a handful of tiny tensors)."""
 
-    def __init__(self, state_dict, H=473, W=473, device="cuda:0"):
-        super().__init__(device, slab_floats=64 * 1024 * 1024)
+    def __init__(self, state_dict, H=473, W=473, device="cuda:0", batch=1):
+        """batch > 1: `batch` frames per forward, stacked along y in x4 / logits32 - same bits per frame as batch 1, half the
+        launches per frame (the 30 x 30 layers of this net are launch-bound)."""
+        super().__init__(device, slab_floats=64 * 1024 * 1024, batch=batch)
         self.H, self.W = H, W
         self.plan = SchpPlan(state_dict)
         self._build()
@@ -258,19 +260,20 @@ class HipSchpNet(ConvGraphNet):
                     t, h, w = self._conv(blk["c3"], y, h2, w2, y.shape[2], res1=idt)
             feats.append((t, h, w))
         (x2, h2, w2), (x3, h3, w3), (x4, h4, w4), (_, h5, w5) = feats
-        x5_view = self.nchw(cat5)[:, 2048:]                            # (1, 2048, h5, w5) strided view, no copy
         # PSP: adaptive pools (tiny) -> 1x1 conv + ABN -> bilinear (align_corners) into channels [512 i, 512 (i+1))
         pools = [self._buf(s, s, 2048) for s in PSP_SIZES]
 
         def pool_all():
             for s, pb in zip(PSP_SIZES, pools):
-                self.nchw(pb).copy_(F.adaptive_avg_pool2d(x5_view, s))
+                for b in range(self.batch):
+                    nv.adaptive_avgpool(self.image(cat5, b), 2048, 2048, self.image(pb, b))
         self._glue(pool_all)
         stage_out = [self._conv(c, pb, s, s, 2048)[0] for c, pb, s in zip(p.psp, pools, PSP_SIZES)]
 
         def assemble5():
             for i, so in enumerate(stage_out):
-                nv.upsample_ac(so, cat5, 512 * i)
+                for b in range(self.batch):
+                    nv.upsample_ac(self.image(so, b), self.image(cat5, b), 512 * i)
         self._glue(assemble5)
         ctx, _, _ = self._conv(p.psp_bottleneck, cat5, h5, w5, 4096)
         d1, _, _ = self._conv(p.dec1, ctx, h5, w5, 512)
@@ -282,9 +285,10 @@ class HipSchpNet(ConvGraphNet):
         e3, _, _ = self._conv(p.edge[2], x4, h4, w4, 1024)
 
         def assemble_dec():
-            nv.upsample_ac(d1, cat_dec, 0)
-            nv.upsample_ac(e2, cat_fuse, 512)
-            nv.upsample_ac(e3, cat_fuse, 768)
+            for b in range(self.batch):
+                nv.upsample_ac(self.image(d1, b), self.image(cat_dec, b), 0)
+                nv.upsample_ac(self.image(e2, b), self.image(cat_fuse, b), 512)
+                nv.upsample_ac(self.image(e3, b), self.image(cat_fuse, b), 768)
         self._glue(assemble_dec)
         # decoder.conv3: 304 input channels in the reference = 256 + 48; here 256 + 64 with zero weights for the pad
         w3a = self.plan.dec3a.w

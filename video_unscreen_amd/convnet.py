@@ -15,12 +15,15 @@ def _out_size(n, k, stride, pad, dil):
 class ConvGraphNet:
     ACTS = {"none": 0, "relu": 1, "leaky": 2, "leaky01": 3}
 
-    def __init__(self, device="cuda:0", slab_floats=64 * 1024 * 1024):
+    def __init__(self, device="cuda:0", slab_floats=64 * 1024 * 1024, batch=1):
+        """batch > 1: every buffer holds `batch` images stacked along y ((batch * h, w, c)); layers carry `batch` to the kernel."""
         from . import _native as nv
         from .vmatting.net_hip import ConvDesc, conv_taps, pack_k_major
         self.nv, self.ConvDesc, self.conv_taps, self.pack = nv, ConvDesc, conv_taps, pack_k_major
-        nv.load()
+        if C.sizeof(ConvDesc) != nv.load().usc_conv_desc_bytes():
+            raise nv.NativeError("ConvDesc (vmatting/net_hip.py) does not match usc_conv_desc of the built library: rebuild it")
         self.device = torch.device(device)
+        self.batch = batch
         self._keep = []
         self.slab = torch.empty(slab_floats, dtype=torch.float32, device=self.device)     # split-K partial sums
         self._segments = []            # list of ("conv", graph handle, ctypes array) | ("glue", callable, None)
@@ -28,7 +31,7 @@ class ConvGraphNet:
 
     # ---- buffers / descriptors
     def _buf(self, h, w, c):
-        t = torch.empty((h, w, c), dtype=torch.float32, device=self.device)
+        t = torch.empty((self.batch * h, w, c), dtype=torch.float32, device=self.device)
         self._keep.append(t)
         return t
 
@@ -37,10 +40,15 @@ class ConvGraphNet:
         self._keep.append(t)
         return t
 
-    @staticmethod
-    def nchw(buf):
-        """(H, W, C) NHWC buffer viewed as a channels-last (1, C, H, W) tensor (no copy)."""
-        return buf.permute(2, 0, 1).unsqueeze(0)
+    def nchw(self, buf):
+        """(batch * H, W, C) NHWC buffer viewed as a channels-last (batch, C, H, W) tensor (no copy)."""
+        bh, w, c = buf.shape
+        return buf.view(self.batch, bh // self.batch, w, c).permute(0, 3, 1, 2)
+
+    def image(self, buf, b):
+        """Image b of a stacked buffer (a contiguous slice)."""
+        h = buf.shape[0] // self.batch
+        return buf[b * h:(b + 1) * h]
 
     def _conv(self, c, x, IH, IW, cin_buf, out=None, res1=None, act=None, cout_pad=None, out_ld=0, out_c0=0, bias_buf=None,
               res2=None, in_relu=False, wpk_buf=None):
@@ -70,7 +78,9 @@ class ConvGraphNet:
         d.res1 = res1.data_ptr() if res1 is not None else None
         d.res2 = res2.data_ptr() if res2 is not None else None
         d.in_relu = 1 if in_relu else 0
-        d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = IH, IW, cin_buf, OH, OW, OH, OW, co
+        B = self.batch
+        d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = IH, IW, cin_buf, B * OH, OW, B * OH, OW, co
+        d.batch = B
         d.in_stride, d.out_stride = c.stride, 1
         d.act = self.ACTS[act or c.act]
         d.ntaps, d.kind, d.nphase = len(taps), 0, 1

@@ -96,8 +96,11 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
             const int Y = oy * d.out_stride + out_py, X = ox * d.out_stride + out_px;
             opix = Y * d.OWf + X;
             rpb = ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (X >> d.res1_shift)) * d.Cout * 4;
-            const int iy0 = oy * d.in_stride, ix0 = ox * d.in_stride;
-            vb = (iy0 * d.IW + ix0) * d.Cin * 4;
+            // batch: images are stacked along y on both sides (OH, OHf count all of them); only the input window is per image
+            int img = 0, oyl = oy;
+            if (d.batch > 1) { const int ohi = d.OH / d.batch; img = oy / ohi; oyl = oy - img * ohi; }
+            const int iy0 = oyl * d.in_stride, ix0 = ox * d.in_stride;
+            vb = ((img * d.IH + iy0) * d.IW + ix0) * d.Cin * 4;
 #pragma unroll
             for (int t = 0; t < 16; t++) {
                 if (t < d.ntaps) {
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
         vmask[j] = (unsigned)s_vmask[(tid >> 3) + 32 * j];
     }
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(d.in), 0, d.IH * d.IW * d.Cin * 4, 0x00020000);
+        const_cast<float*>(d.in), 0, (d.batch > 1 ? d.batch : 1) * d.IH * d.IW * d.Cin * 4, 0x00020000);
     const int wbytes = nch_all * 8 * d.Cout * 16;
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpk), 0, wbytes, 0x00020000);
     const int bkq = tid >> 5, bn = tid & 31;
@@ -405,17 +408,23 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     if ((d.Cin & (d.Cin - 1)) && d.Cin % 32) return conv_fail(USC_E_UNSUPPORTED, "usc_conv: Cin must be a power of two or a multiple of 32");
     if (d.out_ld && (d.out_ld < d.Cout + d.out_c0 || d.out_c0 < 0 || d.out_ld % 4 || d.out_c0 % 4))
         return conv_fail(USC_E_ARG, "usc_conv: out_ld / out_c0 must satisfy out_c0 + Cout <= out_ld, both multiples of 4");
-    if ((long long)d.IH * d.IW * d.Cin * 4 >= 0x7fff0000ll || (long long)d.OHf * d.OWf * (d.out_ld > d.Cout ? d.out_ld : d.Cout) * 4 >= 0x7fff0000ll)
+    const int nbatch = d.batch > 1 ? d.batch : 1;
+    if (nbatch > 1 && (d.OH % nbatch || d.nphase > 1 || d.kind == USC_CONV_HEAD))
+        return conv_fail(USC_E_ARG, "usc_conv: batch needs OH = batch * per-image rows and a plain (single-phase) layer");
+    if ((long long)nbatch * d.IH * d.IW * d.Cin * 4 >= 0x7fff0000ll || (long long)d.OHf * d.OWf * (d.out_ld > d.Cout ? d.out_ld : d.Cout) * 4 >= 0x7fff0000ll)
         return conv_fail(USC_E_UNSUPPORTED, "usc_conv: tensor >= 2 GiB");
     const int nphase = d.nphase > 1 ? d.nphase : 1;
     if (nphase != 1 && nphase != 4) return conv_fail(USC_E_ARG, "usc_conv: nphase must be 1 or 4");
     if (nphase * d.ntaps > 16) return conv_fail(USC_E_ARG, "usc_conv: more than 16 taps");
     const int mblocks = (int)((M + BM - 1) / BM);
     // two 32-column tiles per workgroup only while that still leaves >= 2 workgroups per CU
-    const bool nt2 = (d.Cout % 64 == 0) && ((long long)mblocks * (d.Cout / 64) * nphase >= 512);
+    // (tile shape and K split are decided per image, so that a batched layer sums K in exactly the order the single-image
+    // layer does)
+    const long long mblocks_img = (M / nbatch + BM - 1) / BM;
+    const bool nt2 = (d.Cout % 64 == 0) && (mblocks_img * (d.Cout / 64) * nphase >= 512);
     const int nblocks = nt2 ? d.Cout / 64 : d.Cout / 32;
     // split K when the grid would leave most CUs idle (M = 510 ... 2040 layers)
-    const long long blocks = (long long)mblocks * nblocks * nphase;
+    const long long blocks = mblocks_img * nblocks * nphase;
     const int nch = (d.ntaps * d.Cin + KC - 1) / KC;
     int S = 1;
     static const int split_below = getenv("USC_SPLIT_BELOW") ? atoi(getenv("USC_SPLIT_BELOW")) : 384;      // tuning knobs
@@ -444,6 +453,8 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     }
     return USC_OK;
 }
+
+extern "C" size_t usc_conv_desc_bytes(void) { return sizeof(usc_conv_desc); }
 
 extern "C" int usc_conv_sequence_f32(const usc_conv_desc* descs, int n, usc_stream_t stream) {
     if (!descs || n < 0) return conv_fail(USC_E_ARG, "usc_conv_sequence_f32: bad argument");
