@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--sync-loop", action="store_true", help="use the synchronous step() instead of the pipelined run()")
     ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--seg-batch", type=int, default=4,
+                    help="frames per human-parsing forward in the pipelined loop (bit-identical masks, fewer launches per frame)")
     ap.add_argument("--no-seg", action="store_true",
                     help="stage-3 loop only (segmentation masks are inputs, as in the reference's bg_offline.py with its "
                          "stages 1-2 disabled); default: the human-parsing net runs on every frame (binseg + trimap + vmatting)")
@@ -176,7 +178,8 @@ def main():
     if not args.no_seg:
         from video_unscreen_amd.binseg import HumanSegAgent
         seg_agent = HumanSegAgent(model_path=None, cuda_device=local)       # synthetic SCHP weights, same on every rank
-    pipe = BgStepPipeline(cfg, H, W, device=dev, dtype=dtype, state_dict=sd, net_backend=args.net, seg_agent=seg_agent)
+    pipe = BgStepPipeline(cfg, H, W, device=dev, dtype=dtype, state_dict=sd, net_backend=args.net, seg_agent=seg_agent,
+                          seg_batch=1 if args.sync_loop else args.seg_batch)
 
     # this rank's contiguous frame range, generated straight into HBM (not timed)
     lo, hi = shard_range((K + Wm) * world, rank, world)
@@ -224,7 +227,8 @@ def main():
             "config": {"workload": ("bg_step: " + ("human-parsing segmentation (SCHP ResNet-101) + " if seg_agent is not None else "")
                                     + "stage-3 loop (bgdiff mask + object filter + trimap + matting UNet-18 + get_fg), "
                                     + f"{W}x{H}, {K} frames/GPU, frame-sharded x{world}"),
-                       "binseg": "HumanSegAgent per frame" if seg_agent is not None else "masks are inputs (--no-seg)",
+                       "binseg": (f"HumanSegAgent on every frame ({pipe.seg_batch} frames per network forward)" if seg_agent is not None
+                                  else "masks are inputs (--no-seg)"),
                        "net_input": [pipe.in_h, pipe.in_w], "loop": "sync" if args.sync_loop else "pipelined", "convs": args.net,
                        "weights": "keyed-deterministic synthetic (no checkpoint offline)"},
         }

@@ -239,6 +239,33 @@ def test_pipelined_run_equals_step(nv, cfg):
         assert torch.equal(f[same], f2[same])                       # foreground identical wherever alpha is
 
 
+def test_pipelined_run_with_batched_segmentation_is_identical(nv, cfg):
+    """run() with the human-parsing net segmenting 3 frames per forward (7 frames: groups of 3, 3, 1) gives exactly the
+    frames of the per-frame loop: masks, trimaps, alphas and foregrounds (the HIP convs have a fixed summation order and the
+    batched layers keep the per-image K split)."""
+    from video_unscreen_amd.binseg import HumanSegAgent
+    from video_unscreen_amd.pipeline import BgStepPipeline
+    from video_unscreen_amd.synth import SyntheticClip
+    H, W, n = 270, 480, 7
+    clip = SyntheticClip(H, W, n, config_id=2, device="cpu")
+    frames = [clip.frame(t) for t in range(n)]
+    bga = clip.bg_always.cuda()
+    ins = [(f["frame"].cuda(), f["seg"].cuda(), f["bg"].cuda(), bga) for f in frames]
+    agent = HumanSegAgent(model_path=None)
+    outs = []
+    for sb in (1, 3):
+        pipe = BgStepPipeline(cfg, H, W, seg_agent=agent, seg_batch=sb)
+        got = []
+        pipe.run(iter(ins), on_result=lambda k, o: got.append(tuple(o[key].clone() for key in ("seg", "trimap", "alpha", "fg"))))
+        torch.cuda.synchronize()
+        assert len(got) == n
+        outs.append(got)
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert 0.02 < float((outs[0][0][0] > 0).float().mean()) < 0.98          # the masks come from the network, not the inputs
+
+
 @pytest.mark.parametrize("H,W", [(1080, 1920), (270, 480), (33, 47), (2, 5)])
 def test_inrange_and_trimap_withbg_bit_exact(nv, oracle_lib, H, W):
     """is_pixel_inrange (fgfuncs.py:9-65) and generate_trimap_withbg (trimap/agent.py:63-101): green-mode path."""

@@ -58,10 +58,12 @@ class _Slot:
 
 class BgStepPipeline:
     def __init__(self, cfg, H, W, device="cuda:0", dtype=torch.float32, state_dict=None, net_backend="hip",
-                 seg_agent=None):
+                 seg_agent=None, seg_batch=1):
         """seg_agent: optional HumanSegAgent.  When given, the coarse segmentation mask of every frame is computed on
         the device (reference bg_offline.py:63 `segagent.forward(frame)`, the untracked branch of stage 1) instead of
-        being read from the caller; it runs in the front half, concurrently with the previous frame's matting net."""
+        being read from the caller; it runs in the front half, concurrently with the previous frame's matting net.
+        seg_batch: run() segments that many frames ahead per network forward (frames are independent for the
+        segmentation; the masks are bit-identical to per-frame forwards, the launches per frame drop)."""
         self.cfg = cfg
         self.H, self.W = H, W
         self.device = torch.device(device)
@@ -101,6 +103,8 @@ class BgStepPipeline:
             raise ValueError(f"unknown net_backend {net_backend!r}")
         self.slots = [_Slot(H, W, dev) for _ in range(3)]
         self.seg_agent = seg_agent
+        self.seg_batch = max(1, int(seg_batch))
+        self._seg_ring = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in range(2 * self.seg_batch)] if seg_agent is not None else []
         self.alpha_pre = None
 
     def cpu_net(self):
@@ -113,9 +117,11 @@ class BgStepPipeline:
         self.alpha_pre = None
 
     # ------------------------------------------------------------------ stages
-    def _front_device(self, slot, frame, seg, bg_i, bg_always):
-        if self.seg_agent is not None:
+    def _front_device(self, slot, frame, seg, bg_i, bg_always, seg_ready=False):
+        if self.seg_agent is not None and not seg_ready:
             seg = self.seg_agent.forward_device(frame, out=slot.seg)
+        elif seg_ready:
+            slot.seg = seg
         nv.bgdiff_mask(frame, bg_i, bg_always, seg, self.beta, self.thr, out_bg=slot.bg, out_alpha=slot.gate,
                        ws=self.ws_bgdiff)
         slot.host.copy_(slot.gate, non_blocking=True)
@@ -178,18 +184,38 @@ class BgStepPipeline:
         try:
             it = iter(inputs)
             exhausted = False
+            ahead = []                                      # inputs whose segmentation mask is already enqueued
+            ngroups = 0
+            batched = self.seg_agent is not None and self.seg_batch > 1
             while True:
-                while not exhausted and len(pending) < 2:
-                    try:
-                        frame, seg, bg_i, bg_always = next(it)
-                    except StopIteration:
-                        exhausted = True
-                        break
+                while (ahead or not exhausted) and len(pending) < 2:
+                    if not ahead:
+                        group = []
+                        while len(group) < (self.seg_batch if batched else 1):
+                            try:
+                                group.append(next(it))
+                            except StopIteration:
+                                exhausted = True
+                                break
+                        if not group:
+                            break
+                        if batched:
+                            # two alternating sets of mask buffers: a set is rewritten two groups later, when every frame
+                            # of its group has left the pipeline (at most 2 frames are pending)
+                            half = (ngroups % 2) * self.seg_batch
+                            ngroups += 1
+                            front.wait_stream(main)
+                            with torch.cuda.stream(front):
+                                masks = self.seg_agent.forward_device_batch([g[0] for g in group],
+                                                                            outs=self._seg_ring[half:half + len(group)])
+                            group = [(g[0], m, g[2], g[3]) for g, m in zip(group, masks)]
+                        ahead.extend(group)
+                    frame, seg, bg_i, bg_always = ahead.pop(0)
                     slot = self.slots[submitted % len(self.slots)]
                     slot.frame = frame
                     front.wait_stream(main)                 # inputs produced on the main stream
                     with torch.cuda.stream(front):
-                        self._front_device(slot, frame, seg, bg_i, bg_always)
+                        self._front_device(slot, frame, seg, bg_i, bg_always, seg_ready=batched)
                     work.put(slot)
                     pending.append(slot)
                     submitted += 1
