@@ -232,7 +232,7 @@ def main():
                        "net_input": [pipe.in_h, pipe.in_w], "loop": "sync" if args.sync_loop else "pipelined", "convs": args.net,
                        "weights": "keyed-deterministic synthetic (no checkpoint offline)"},
         }
-        if not args.no_kernel_table:
+        if not args.no_kernel_table:                         # (other ranks wait at the final barrier: not inside the timed region)
             rows, t_net = kernel_table(pipe, frames[Wm], H, W)
             dom = max(rows, key=lambda r: r["us"])
             scale = (pipe.in_h * pipe.in_w) / (544 * 960)
@@ -259,7 +259,7 @@ def main():
             result["net"] = {"bound": "mfma", "what": what, "ms": round(t_net * 1e3, 3),
                              "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed at N = 1 only
             clip_cpu = SyntheticClip(H, W, args.cpu_frames, config_id=2, device="cpu")
             cf = []
             for t in range(args.cpu_frames):

@@ -66,6 +66,31 @@ def test_argument_errors_are_reported(nv):
     assert rc == -1 and b"usc_trimap_u8" in lib.usc_last_error()
     rc = lib.usc_morph_u8(1, 2, 8, 8, 99, 1, 0, None, 0, None)
     assert rc == -2
+    # argument checks of the later entry points come before any launch, so they can be exercised without a GPU
+    assert lib.usc_resize_u8(None, 4, 4, 3, None, 8, 8, 1, None) == -1 and b"usc_resize_u8" in lib.usc_last_error()
+    assert lib.usc_resize_u8(1, 4, 4, 2, 2, 8, 8, 1, None) == -1                      # 2 channels
+    assert lib.usc_cvt_color_u8(1, 16, 99, 2, None, None) == -1 and b"conversion code" in lib.usc_last_error()
+    assert lib.usc_cvt_color_u8(1, 16, 3, 2, None, None) == -1 and b"lab_tables" in lib.usc_last_error().lower()
+    assert lib.usc_gmm_alpha_u8(None, 16, None, None, None, None) == -1
+    assert lib.usc_color_correct_u8(1, 2, 8, 8, 3, 960, 0.95, 4, 5, None, 6, 16, None) == -3 and b"workspace" in lib.usc_last_error()
+    assert lib.usc_regionfill_u8(1, 2, 8, 8, 3, 1e-7, 100, None, 4, 16, None) == -3
+    assert lib.usc_regionfill_u8(1, 2, 8, 8, 3, 0.0, 100, None, 4, 1 << 30, None) == -1                      # rtol must be > 0
+    assert lib.usc_segagent_post(1, 65, 129, 129, 32, 2, 513, 513, 541, 962, 1080, 1920, 3, None, 4, 1 << 30, None) == -2      # > 64 crops
+    assert lib.usc_upsample_nc_nhwc_f32(1, 4, 4, 6, 2, 8, 8, 8, 0, None) == -1                               # C % 4
+    assert lib.usc_pack_kn_f32(1, 8, 8, 1, 8, 40, 32, 2, None) == -1                                         # Kpad % 32
+    assert lib.usc_box_filter_u8(1, 8, 8, 1, 17, 2, None) == -1                                              # 16-bit column sums
+    assert lib.usc_stm_post(1, 4, 4, 3, 16, 16, 16, 16, 2, 3, None) == -1                                    # odd channel pitch
+    assert lib.usc_conv_desc_bytes() == 208
+    import ctypes as C
+    blob = (C.c_uint8 * lib.usc_lab_tables_bytes())()
+    lib.usc_lab_tables_host(blob)                                                                             # host function: runs here
+    gamma = np.frombuffer(blob, np.uint16, 256)
+    assert gamma[0] == 0 and gamma[255] == 2040 and np.all(np.diff(gamma.astype(int)) >= 0)
+    lut = np.empty(256, np.float32)
+    dp = C.POINTER(C.c_double)
+    one = (C.c_double * 1)
+    assert lib.usc_gmm_lut_host(one(100.0), one(10.0), one(1.0), 1, lut.ctypes.data) == 0
+    assert abs(float(lut[100]) - 1 / (10 * np.sqrt(2 * np.pi))) < 1e-8 and abs(float(lut.sum()) - 1) < 1e-4
 
 
 def _random_mask(H, W, seed, q, sigma):
