@@ -16,3 +16,6 @@ for mode in default no_seg; do
   echo "write $mode done"
 done
 ls -R $OUT | head -40
+# MFMA utilisation pass (SQ + GRBM counters, stage-3 loop only)
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/no_seg_mfma -o t --output-format csv -- python3 $ROOT/bench.py --steps 16 --warmup 0 --no-cpu-baseline --no-kernel-table --sync-loop --no-seg > /dev/null 2> $OUT/no_seg_mfma.err
+echo "mfma pass done"
