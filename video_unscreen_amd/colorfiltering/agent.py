@@ -35,6 +35,9 @@ class ColorFilteringAgent():
         self.random_state = random_state          # None = unseeded, as the reference (agent.py:101-110)
         self._luts = None
         self._ws = None
+        self._cnt2 = None
+        self._bg_cache = None
+        self.last_bg_color = None
         self.reset_gmms()
 
     def is_trained(self):
@@ -102,7 +105,9 @@ class ColorFilteringAgent():
             self._luts = torch.from_numpy(np.stack(tabs)).to(device)
         return self._luts
 
-    def get_alpha_by_gmm_device(self, img_hsv):
+    def get_alpha_by_gmm_device(self, img_hsv, want_confidence=True):
+        if not want_confidence:
+            return nv.gmm_alpha(img_hsv, self._device_luts(img_hsv.device)), None
         alpha, prob = nv.gmm_alpha(img_hsv, self._device_luts(img_hsv.device), want_prob=True)
         return alpha, float(torch.std(prob))
 
@@ -123,11 +128,17 @@ class ColorFilteringAgent():
         """Adaptive threshold, then close and open (agent.py:259-283)."""
         return to_host(self.postprocess_device(to_dev(np.array(alpha, copy=True)), to_dev(mask), thr_ratio))
 
-    def forward_device(self, img, mask, iters=1):
-        """img (H, W, 3), mask (H, W) uint8 CUDA -> (alpha CUDA (H, W), bg_img CUDA (H, W, 3), confidence)."""
+    def forward_device(self, img, mask, iters=1, want_confidence=False):
+        """img (H, W, 3), mask (H, W) uint8 CUDA -> (alpha CUDA (H, W), bg_img CUDA (H, W, 3), confidence).  The confidence
+        (std of the probability map, one more reduction and a host sync) is only computed on request; no caller of the
+        reference uses it (green.py:99 discards it)."""
         n = mask.numel()
-        n_ge129 = int(nv.count_ge(mask, 129).item())
-        n_ge128 = int(nv.count_ge(mask, 128).item())
+        if self._cnt2 is None or self._cnt2.device != mask.device:
+            self._cnt2 = torch.zeros(2, dtype=torch.int64, device=mask.device)
+        nv.count_ge(mask, 129, out=self._cnt2[0:1])
+        nv.count_ge(mask, 128, out=self._cnt2[1:2])
+        n_ge129, n_ge128 = self._cnt2.tolist()                      # one host round trip for both counts
+        self.last_bg_color = None                            # set below once a fitted background colour is returned
         if n_ge129 < max(self.fg_ncomp) * 5:                 # no foreground
             return mask, img, 1.0
         if n - n_ge128 < max(self.bg_ncomp) * 5:             # no background
@@ -137,7 +148,7 @@ class ColorFilteringAgent():
         img_hsv = nv.resize(nv.cvt_color(img, nv.BGR2HSV), th, tw, 1)
         mask = nv.resize(mask, th, tw, 1)
         if iters == 0:
-            alpha, confidence = self.get_alpha_by_gmm_device(img_hsv)
+            alpha, confidence = self.get_alpha_by_gmm_device(img_hsv, want_confidence)
             alpha = self.postprocess_device(alpha, mask)
         else:
             hsv_host = to_host(img_hsv)
@@ -147,18 +158,22 @@ class ColorFilteringAgent():
                 fg_prior = self.get_color_prior(hsv_host, mask_host < 128, self.color_prior_winsize // 5)
                 self.fit_bg_gmms(hsv_host, mask_host < 128, bg_prior)
                 self.fit_fg_gmms(hsv_host, mask_host > 128, fg_prior)
-                alpha, confidence = self.get_alpha_by_gmm_device(img_hsv)
+                alpha, confidence = self.get_alpha_by_gmm_device(img_hsv, want_confidence)
                 alpha = self.postprocess_device(alpha, mask)
                 mask = (alpha > 128).to(torch.uint8) * 255
                 nfg = int(nv.count_ge(mask, 129).item())
                 if nfg < max(self.fg_ncomp) * 5 or mask.numel() - nfg < max(self.bg_ncomp) * 5:
                     break
         alpha = nv.resize(alpha, ori_h, ori_w, 1)
-        bg_hsv = torch.tensor([[[int(np.mean(g.means_[0, 0])) for g in self.bg_gmms]]], dtype=torch.uint8, device=img.device)
-        bg_bgr = nv.cvt_color(bg_hsv, nv.HSV2BGR)
-        return alpha, bg_bgr.expand(ori_h, ori_w, 3).contiguous(), confidence
+        hsv = tuple(int(np.mean(g.means_[0, 0])) for g in self.bg_gmms)
+        if self._bg_cache is None or self._bg_cache[0] != (hsv, ori_h, ori_w, str(img.device)):
+            bg_hsv = torch.tensor([[list(hsv)]], dtype=torch.uint8, device=img.device)
+            bg_bgr = nv.cvt_color(bg_hsv, nv.HSV2BGR)
+            self._bg_cache = ((hsv, ori_h, ori_w, str(img.device)), bg_bgr.expand(ori_h, ori_w, 3).contiguous(), bg_bgr[0, 0].cpu().numpy())
+        self.last_bg_color = self._bg_cache[2]                      # host copy of the background colour (B, G, R)
+        return alpha, self._bg_cache[1].clone(), confidence
 
     def forward(self, img, mask, iters=1):
         """NumPy API of the reference (agent.py:285-354)."""
-        a, b, c = self.forward_device(to_dev(img), to_dev(mask), iters)
+        a, b, c = self.forward_device(to_dev(img), to_dev(mask), iters, want_confidence=True)
         return to_host(a), to_host(b), c

@@ -61,7 +61,8 @@ class GreenPipeline:
         else:
             segmask = self.segagent.forward_device(frame)
         out = {"segmask": segmask, "tracking": tracking}
-        if not self._exist_foreground(segmask):
+        # tracking: segmask is the previous alpha, whose exist_foreground() set the flag at the end of the last step
+        if not (tracking or self._exist_foreground(segmask)):
             alpha, fg, bgimg = torch.zeros_like(segmask), torch.zeros_like(frame), frame
             out.update(cf_iters=None)
         else:
@@ -70,7 +71,8 @@ class GreenPipeline:
             else:
                 cf_iters = 0
             alphacf, bgimg, _ = self.cfagent.forward_device(frame, segmask, iters=cf_iters)
-            bg_color = bgimg[0, 0].cpu().numpy()
+            # the fitted background colour is known on the host; only the agent's early-outs hand back an image of their own
+            bg_color = self.cfagent.last_bg_color if self.cfagent.last_bg_color is not None else bgimg[0, 0].cpu().numpy()
             # host stage: contour filter on the 1 byte / pixel mask
             self._host_a.copy_(alphacf)
             seg_host = None
@@ -80,7 +82,7 @@ class GreenPipeline:
             self.filter(self._host_a.numpy(), seg_host, self.center, cfg["objectremoval"]["saliency_thr"],
                         cfg["objectremoval"]["consensus_thr"])
             alphaor = self._host_a.to(self.device)
-            if int(nv.count_ge(alphaor, 1, out=self._cnt).item()) == 0:
+            if not self._host_a.numpy().any():
                 trimap = alphaor                                   # generate_trimap_withbg returns an empty mask as is
             else:
                 trimap = self.trimapagent.forward_device_withbg(alphaor, frame, bg_color)
