@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-seg", action="store_true",
                     help="stage-3 loop only (segmentation masks are inputs, as in the reference's bg_offline.py with its "
                          "stages 1-2 disabled); default: the human-parsing net runs on every frame (binseg + trimap + vmatting)")
+    ap.add_argument("--mode", default="bg_step", choices=["bg_step", "green", "bg_online"],
+                    help="bg_step (default, BASELINE.json configs[1] / [3]); green (configs[0]: SegAgent / colour filtering loop) and "
+                         "bg_online (configs[2]: STM tracking + inpainting loop) time the other frame loops the same way")
     ap.add_argument("--net", default="hip", choices=["hip", "miopen"],
                     help="conv stack: hand-written f32-MFMA kernels (default) or PyTorch-ROCm / MIOpen")
     return ap.parse_args()
@@ -133,6 +136,62 @@ def pmc_traffic(H, W):
     return int(2 * z["fetch_raw_bytes_per_forward"] + z["write_bytes_per_forward"])
 
 
+def other_mode(args, rank, world, dev):
+    """green / bg_online: one step = one frame of that mode's (sequential) loop on this rank's own synthetic clip."""
+    import copy
+    from video_unscreen_amd.synth import SyntheticClip
+    H, W, K, Wm = args.height, args.width, args.steps, args.warmup
+    root = os.path.dirname(os.path.abspath(__file__))
+    if args.mode == "green":
+        from video_unscreen_amd.pipeline_green import GreenPipeline
+        cfg = json.load(open(os.path.join(root, "configs", "green.json")))
+        for k in ("binseg", "vmatting"):
+            cfg[k]["model_path"] = "synthetic"
+        pipe = GreenPipeline(cfg, H, W, device=dev, cf_random_state=0)
+        clip = SyntheticClip(H, W, K + Wm, config_id=1, device=dev)
+        what = "green: SegAgent (DeepLabv3+, untracked frames) / tracking + GMM colour filtering + object filter + trimap_withbg + matting UNet-18 + color_correct + get_fg"
+    else:
+        from video_unscreen_amd.pipeline_bg import BgOnlinePipeline
+        cfg = json.load(open(os.path.join(root, "configs", "bg.json")))
+        for k in ("binseg", "vmatting", "stm"):
+            cfg[k]["model_path"] = "synthetic"
+        pipe = BgOnlinePipeline(cfg, H, W, device=dev)
+        clip = SyntheticClip(H, W, K + Wm, config_id=2, device=dev)
+        what = "bg_online: HumanSegAgent / STM tracking + object filter + trimap + matting UNet-18 + get_bg + Laplace inpainting + bg-difference gate + object filter + trimap + matting UNet-18 + get_fg"
+    clip.gen.manual_seed(20260000 + 7919 * rank)
+    frames = [clip.frame(t)["frame"] for t in range(K + Wm)]
+    for f in frames[:Wm]:
+        pipe.step(f)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tracked = 0
+    for f in frames[Wm:]:
+        tracked += int(pipe.step(f)["tracking"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"frames/sec end-to-end unscreen ({args.mode}, {W}x{H})", "value": round(world * K / dt, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{what}, {W}x{H}, {K} frames/GPU, one independent clip per GPU", "tracked_frames_rank0": tracked,
+                       "weights": "keyed-deterministic synthetic (no checkpoint offline)"},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -160,6 +219,8 @@ def main():
         ge.build_native()
     if world > 1:
         dist.barrier()
+    if args.mode != "bg_step":
+        return other_mode(args, rank, world, dev)
     from video_unscreen_amd import _native as nv
     from video_unscreen_amd.dist import broadcast_state, shard_range
     from video_unscreen_amd.pipeline import BgStepPipeline, default_config
