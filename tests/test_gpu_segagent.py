@@ -129,3 +129,16 @@ def test_segagent_vs_oracle_chain(nv, oracle_lib, H, W):
     mask_dev, lgd, locs_d = agent.forward_device(dev(frame), return_logits=True)
     want2 = oracle_lib.segagent_post(lgd.cpu().numpy(), locs_d, 513, 513, th, tw, H, W)
     assert np.array_equal(mask_dev.cpu().numpy(), want2)
+
+
+def test_segagent_crop_batching_is_bit_identical(nv):
+    """Crops through batched network forwards (4 per forward; the 18-crop case ends with a batch of 2) give the logits and
+    the mask of crop-by-crop execution bit for bit."""
+    from video_unscreen_amd.binseg import SegAgent
+    frame = dev(frame_of(256, 256))
+    a1 = SegAgent(model_path=None, input_long_side=962, crop_batch=1)
+    a4 = SegAgent(model_path=None, input_long_side=962, crop_batch=4)
+    m1, l1, locs1 = a1.forward_device(frame, return_logits=True)
+    m4, l4, locs4 = a4.forward_device(frame, return_logits=True)
+    assert len(locs1) == 18 and np.array_equal(locs1, locs4)
+    assert torch.equal(l1, l4) and torch.equal(m1, m4)

@@ -17,7 +17,7 @@ from .deeplab_net import HipDeepLabNet, deeplab_synthetic_state_dict
 class SegAgent():
 
     def __init__(self, model_path=None, input_long_side=912, crop_h=513, crop_w=513, stride_ratio=1 / 2., flip=True,
-                 cuda_device=0):
+                 cuda_device=0, crop_batch=4):
         self.cuda_device = cuda_device if cuda_device is not None and cuda_device >= 0 else 0
         self.device = device(self.cuda_device)
         if model_path is None or model_path == "synthetic":
@@ -30,9 +30,16 @@ class SegAgent():
         self.flip = flip
         self.input_long_side = input_long_side
         self.stride_ratio = stride_ratio
-        self.model = HipDeepLabNet(sd, crop_h, crop_w, device=self.device)
+        self.crop_batch = max(1, int(crop_batch))       # crops per network forward (results do not depend on it)
+        self._models = {}
+        self.model = self.model_for(1)
         self._logits = None
         self._ws = None
+
+    def model_for(self, batch):
+        if batch not in self._models:
+            self._models[batch] = HipDeepLabNet(self.state_dict, self.crop_h, self.crop_w, device=self.device, batch=batch)
+        return self._models[batch]
 
     def get_target_size(self, h, w):
         """reference agent.py:70-100."""
@@ -49,13 +56,16 @@ class SegAgent():
         H, W, _ = img.shape
         th, tw = self.get_target_size(H, W)
         locs = self.grid_crop_locations(th, tw)
-        net = self.model
         n = len(locs)
+        oh, ow = self.model.out_h, self.model.out_w
         if self._logits is None or self._logits.shape[0] != n:
-            self._logits = torch.empty((n, net.out_h, net.out_w, 32), dtype=torch.float32, device=self.device)
-        for i, loc in enumerate(locs):
-            nv.segagent_pre(img, th, tw, loc, out=net.x4)
-            self._logits[i].copy_(net.forward(None))
+            self._logits = torch.empty((n, oh, ow, 32), dtype=torch.float32, device=self.device)
+        for i0 in range(0, n, self.crop_batch):
+            nb = min(self.crop_batch, n - i0)
+            net = self.model_for(nb)
+            for b in range(nb):
+                nv.segagent_pre(img, th, tw, locs[i0 + b], out=net.image(net.x4, b))
+            self._logits[i0:i0 + nb].copy_(net.forward(None).view(nb, oh, ow, 32))
         need = nv.load().usc_segagent_post_ws_bytes(th, tw)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)

@@ -175,8 +175,9 @@ class DeepLabNetTorch:
 class HipDeepLabNet(ConvGraphNet):
     """One crop per call: x4 (H, W, 4) float32 NHWC (R, G, B, 0) -> logits32 (H/4, W/4, 32) buffer."""
 
-    def __init__(self, state_dict, H=513, W=513, device="cuda:0"):
-        super().__init__(device, slab_floats=64 * 1024 * 1024)
+    def __init__(self, state_dict, H=513, W=513, device="cuda:0", batch=1):
+        """batch > 1: that many crops per forward, stacked along y in x4 / logits32 (bit-identical to single-crop forwards)."""
+        super().__init__(device, slab_floats=64 * 1024 * 1024, batch=batch)
         self.H, self.W = H, W
         self.plan = DeepLabPlan(state_dict)
         self._build()
@@ -187,7 +188,7 @@ class HipDeepLabNet(ConvGraphNet):
         # ---- stem: 7x7/2 over (R, G, B) as a [pixels][160] patch matrix times a (160, 64) weight
         sh, sw = _out_size(H, 7, 2, 3, 1), _out_size(W, 7, 2, 3, 1)
         cols = self._buf(sh, sw, 160)
-        self._glue(lambda: nv.im2col(self.x4, 3, 7, 7, 2, 3, cols))
+        self._glue(lambda: [nv.im2col(self.image(self.x4, b), 3, 7, 7, 2, 3, self.image(cols, b)) for b in range(self.batch)])
         w7 = p.stem.w.permute(0, 2, 3, 1).reshape(64, 147)                 # k = (ky*7 + kx)*3 + c, as the patch matrix
         stem1x1 = FConv(F.pad(w7, (0, 13)).reshape(64, 160, 1, 1), p.stem.b, act="relu")
         t, h, w = self._conv(stem1x1, cols, sh, sw, 160)
@@ -213,16 +214,19 @@ class HipDeepLabNet(ConvGraphNet):
         for i, c in enumerate(p.aspp_d):
             self._conv(c, x5, h5, w5, 2048, out=cat, out_ld=1024, out_c0=256 * (i + 1))
         gap = self._buf(1, 1, 2048)
-        self._glue(lambda: nv.adaptive_avgpool(x5, 0, 2048, gap))
+        self._glue(lambda: [nv.adaptive_avgpool(self.image(x5, b), 0, 2048, self.image(gap, b)) for b in range(self.batch)])
         pool_feat, _, _ = self._conv(p.aspp_pool, gap, 1, 1, 2048)
         wp = p.aspp_proj.w                                                  # (256, 1280, 1, 1), BN folded
         dyn_bias, _, _ = self._conv(FConv(wp[:, 1024:].contiguous(), p.aspp_proj.b), pool_feat, 1, 1, 256)
-        y, _, _ = self._conv(FConv(wp[:, :1024].contiguous(), p.aspp_proj.b, act="relu"), cat, h5, w5, 1024, bias_buf=dyn_bias)
+        # per-crop bias: broadcast over the crop's pixels and added before the ReLU as the layer's first residual operand
+        bias_map = self._buf(h5, w5, 256)
+        self._glue(lambda: self.nchw(bias_map).copy_(self.nchw(dyn_bias).expand(self.batch, 256, h5, w5)))
+        y, _, _ = self._conv(FConv(wp[:, :1024].contiguous(), torch.zeros(256), act="relu"), cat, h5, w5, 1024, res1=bias_map)
         # ---- decoder: [low-level 48 (+16 zero) | ASPP upsampled 256] -> 3x3 -> 1x1
         cat_dec = self._buf(lh, lw, 320)
         self._conv(p.low, low, lh, lw, 256, out=cat_dec, cout_pad=64, out_ld=320, out_c0=0)
         aspp_out = y
-        self._glue(lambda: nv.upsample_nc(aspp_out, cat_dec, 64))
+        self._glue(lambda: [nv.upsample_nc(self.image(aspp_out, b), self.image(cat_dec, b), 64) for b in range(self.batch)])
         w0 = p.cls0.w                                                        # (256, 304, 3, 3): [0:48] low, [48:304] ASPP
         w320 = torch.cat([w0[:, :48], w0.new_zeros(256, 16, 3, 3), w0[:, 48:]], 1)
         y, _, _ = self._conv(FConv(w320, p.cls0.b, pad=1, act="relu"), cat_dec, lh, lw, 320)
