@@ -182,6 +182,9 @@ int usc_upsample_nc_nhwc_f32(const float* src, int sh, int sw, int C, float* dst
 /* nn.AdaptiveAvgPool2d(s) on channels [c0, c0 + C) of an (H, W, ld) NHWC float32 tensor -> dense (s, s, C)
  * (binseg/human_parse.py:92-96, deeplab/_deeplab.py:166); windows summed in a fixed order. */
 int usc_adaptive_avgpool_nhwc_f32(const float* src, int H, int W, int ld, int c0, int C, float* dst, int s, usc_stream_t stream);
+/* The same for `batch` images stacked along y in src ((batch*H, W, ld)) -> dst (batch*s, s, C); per image bit-identical. */
+int usc_adaptive_avgpool_nhwc_batch_f32(const float* src, int H, int W, int ld, int c0, int C, float* dst, int s, int batch,
+                                        usc_stream_t stream);
 size_t usc_segagent_post_ws_bytes(int th, int tw);
 int usc_segagent_post(const float* logits, int ncrops, int lh, int lw, int cbuf, const int* locs_host, int crop_h, int crop_w,
                       int th, int tw, int H, int W, uint8_t* out, double* score_out, void* ws, size_t ws_bytes,
@@ -241,6 +244,8 @@ int    usc_humanseg_post(const float* logits, int C, int Cbuf, int lh, int lw, i
                          uint8_t* out, void* ws, size_t ws_bytes, usc_stream_t stream);
 /* F.interpolate(bilinear, align_corners=True) of an NHWC float32 tensor (sh x sw x C) into channels [c0, c0 + C) of a
  * (dh x dw x ld) tensor: the glue between the conv segments of the parsing net (human_parse.py:108, 147-150, 186). */
+int    usc_upsample_ac_nhwc_batch_f32(const float* src, int sh, int sw, int C, float* dst, int dh, int dw, int ld, int c0, int batch,
+                                      usc_stream_t stream);    /* `batch` images stacked along y in src and dst */
 int    usc_upsample_ac_nhwc_f32(const float* src, int sh, int sw, int C, float* dst, int dh, int dw, int ld, int c0,
                                 usc_stream_t stream);
 const char* usc_seg_last_error(void);

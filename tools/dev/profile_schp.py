@@ -5,7 +5,8 @@ import torch
 from video_unscreen_amd import _native as nv
 from video_unscreen_amd.binseg.schp_net import HipSchpNet, schp_synthetic_state_dict
 from video_unscreen_amd.vmatting.net_hip import ConvDesc
-net = HipSchpNet(schp_synthetic_state_dict(0), 473, 473)
+B = int(os.environ.get('B', '1'))
+net = HipSchpNet(schp_synthetic_state_dict(0), 473, 473, batch=B)
 lib = nv.load(); st = torch.cuda.current_stream().cuda_stream
 net.x4.normal_(); net(); torch.cuda.synchronize()
 groups = collections.OrderedDict()
@@ -21,7 +22,7 @@ for kind, a, arr in net._segments:
         for _ in range(10): lib.usc_conv_sequence_f32(one, 1, st)
         e1.record(); e1.synchronize()
         t = e0.elapsed_time(e1) / 10 * 1e-3
-        M = d.OH * d.OW; fl = 2.0 * M * d.Cout * d.ntaps * d.Cin
+        M = d.OH * d.OW; fl = 2.0 * M * d.Cout * d.ntaps * d.Cin      # d.OH counts all images of the batch
         key = (M, d.Cin, d.Cout, d.ntaps, d.in_stride)
         g = groups.setdefault(key, [0, 0.0, 0.0]); g[0] += 1; g[1] += t; g[2] += fl
         tot_t += t; tot_f += fl; idx += 1

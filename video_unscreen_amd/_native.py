@@ -82,6 +82,8 @@ _SIGNATURES = {
     "usc_humanseg_post": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
                                     C.c_size_t, _vp]),
     "usc_upsample_ac_nhwc_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "usc_upsample_ac_nhwc_batch_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "usc_adaptive_avgpool_nhwc_batch_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "usc_seg_last_error": (C.c_char_p, []),
     "usc_conv_desc_bytes": (C.c_size_t, []),
     "usc_conv_sequence_f32": (C.c_int, [_vp, C.c_int, _vp]),
@@ -435,11 +437,12 @@ def count_ge(mask, thr=128, out=None):
     return out
 
 
-def upsample_ac(src, dst, c0=0):
-    """src (sh, sw, C) -> channels [c0, c0+C) of dst (dh, dw, ld), both contiguous float32 CUDA NHWC buffers."""
+def upsample_ac(src, dst, c0=0, batch=1):
+    """src (batch*sh, sw, C) -> channels [c0, c0+C) of dst (batch*dh, dw, ld), both contiguous float32 CUDA NHWC buffers."""
     sh, sw, Cn = src.shape
     dh, dw, ld = dst.shape
-    rc = load().usc_upsample_ac_nhwc_f32(src.data_ptr(), sh, sw, Cn, dst.data_ptr(), dh, dw, ld, int(c0), _stream())
+    rc = load().usc_upsample_ac_nhwc_batch_f32(src.data_ptr(), sh // batch, sw, Cn, dst.data_ptr(), dh // batch, dw, ld, int(c0), int(batch),
+                                               _stream())
     if rc != 0:
         raise NativeError(f"usc_upsample_ac_nhwc_f32 failed ({rc}): {load().usc_seg_last_error().decode()}")
     return dst
@@ -454,14 +457,14 @@ def upsample_nc(src, dst, c0=0):
     return dst
 
 
-def adaptive_avgpool(src, c0, Cn, dst):
-    """nn.AdaptiveAvgPool2d(s) of channels [c0, c0 + Cn) of src (H, W, ld) f32 NHWC -> dst (s, s, Cn)."""
-    H, W, ld = src.shape
-    s, s2, cd = dst.shape
-    if s != s2 or cd != Cn:
-        raise NativeError("adaptive_avgpool: dst must be (s, s, Cn)")
-    _check(load().usc_adaptive_avgpool_nhwc_f32(src.data_ptr(), H, W, ld, int(c0), int(Cn), dst.data_ptr(), s, _stream()),
-           "usc_adaptive_avgpool_nhwc_f32")
+def adaptive_avgpool(src, c0, Cn, dst, batch=1):
+    """nn.AdaptiveAvgPool2d(s) of channels [c0, c0 + Cn) of src (batch*H, W, ld) f32 NHWC -> dst (batch*s, s, Cn)."""
+    BH, W, ld = src.shape
+    bs, s, cd = dst.shape
+    if bs != batch * s or cd != Cn or BH % batch:
+        raise NativeError("adaptive_avgpool: dst must be (batch*s, s, Cn)")
+    _check(load().usc_adaptive_avgpool_nhwc_batch_f32(src.data_ptr(), BH // batch, W, ld, int(c0), int(Cn), dst.data_ptr(), s, int(batch),
+                                                      _stream()), "usc_adaptive_avgpool_nhwc_f32")
     return dst
 
 

@@ -214,7 +214,7 @@ class HipDeepLabNet(ConvGraphNet):
         for i, c in enumerate(p.aspp_d):
             self._conv(c, x5, h5, w5, 2048, out=cat, out_ld=1024, out_c0=256 * (i + 1))
         gap = self._buf(1, 1, 2048)
-        self._glue(lambda: [nv.adaptive_avgpool(self.image(x5, b), 0, 2048, self.image(gap, b)) for b in range(self.batch)])
+        self._glue(lambda: nv.adaptive_avgpool(x5, 0, 2048, gap, batch=self.batch))
         pool_feat, _, _ = self._conv(p.aspp_pool, gap, 1, 1, 2048)
         wp = p.aspp_proj.w                                                  # (256, 1280, 1, 1), BN folded
         dyn_bias, _, _ = self._conv(FConv(wp[:, 1024:].contiguous(), p.aspp_proj.b), pool_feat, 1, 1, 256)

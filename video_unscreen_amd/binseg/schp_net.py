@@ -265,15 +265,13 @@ class HipSchpNet(ConvGraphNet):
 
         def pool_all():
             for s, pb in zip(PSP_SIZES, pools):
-                for b in range(self.batch):
-                    nv.adaptive_avgpool(self.image(cat5, b), 2048, 2048, self.image(pb, b))
+                nv.adaptive_avgpool(cat5, 2048, 2048, pb, batch=self.batch)
         self._glue(pool_all)
         stage_out = [self._conv(c, pb, s, s, 2048)[0] for c, pb, s in zip(p.psp, pools, PSP_SIZES)]
 
         def assemble5():
             for i, so in enumerate(stage_out):
-                for b in range(self.batch):
-                    nv.upsample_ac(self.image(so, b), self.image(cat5, b), 512 * i)
+                nv.upsample_ac(so, cat5, 512 * i, batch=self.batch)
         self._glue(assemble5)
         ctx, _, _ = self._conv(p.psp_bottleneck, cat5, h5, w5, 4096)
         d1, _, _ = self._conv(p.dec1, ctx, h5, w5, 512)
@@ -285,10 +283,9 @@ class HipSchpNet(ConvGraphNet):
         e3, _, _ = self._conv(p.edge[2], x4, h4, w4, 1024)
 
         def assemble_dec():
-            for b in range(self.batch):
-                nv.upsample_ac(self.image(d1, b), self.image(cat_dec, b), 0)
-                nv.upsample_ac(self.image(e2, b), self.image(cat_fuse, b), 512)
-                nv.upsample_ac(self.image(e3, b), self.image(cat_fuse, b), 768)
+            nv.upsample_ac(d1, cat_dec, 0, batch=self.batch)
+            nv.upsample_ac(e2, cat_fuse, 512, batch=self.batch)
+            nv.upsample_ac(e3, cat_fuse, 768, batch=self.batch)
         self._glue(assemble_dec)
         # decoder.conv3: 304 input channels in the reference = 256 + 48; here 256 + 64 with zero weights for the pad
         w3a = self.plan.dec3a.w

@@ -179,11 +179,14 @@ __global__ __launch_bounds__(256) void seg_warp_argmax_kernel(const float* __res
 // F.interpolate(mode='bilinear', align_corners=True) on NHWC float32, 4 channels per lane, written into channels
 // [c0, c0 + C) of a destination with ld channels per pixel (human_parse.py:108, 147-150, 186: PSP priors, edge and
 // decoder features are upsampled straight into their concat buffers).
-__global__ __launch_bounds__(256) void upsample_ac_nhwc_kernel(const float* __restrict__ src, int sh, int sw, int C,
-                                                               float* __restrict__ dst, int dh, int dw, int ld, int c0,
-                                                               float rh, float rw) {
-    const int c4n = C / 4, n = dh * dw * c4n;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void upsample_ac_nhwc_kernel(const float* __restrict__ src0, int sh, int sw, int C,
+                                                               float* __restrict__ dst0, int dh, int dw, int ld, int c0,
+                                                               float rh, float rw, int batch) {
+    const int c4n = C / 4, per = dh * dw * c4n, n = per * batch;
+    for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const int img = i0 / per, i = i0 - img * per;            // images are stacked along y in src and dst
+        const float* __restrict__ src = src0 + (size_t)img * sh * sw * C;
+        float* __restrict__ dst = dst0 + (size_t)img * dh * dw * ld;
         const int c4 = i % c4n, p = i / c4n;
         const int y = p / dw, x = p - y * dw;
         const float h1r = rh * y, w1r = rw * x;
@@ -287,14 +290,20 @@ extern "C" int usc_humanseg_post(const float* logits, int C, int Cbuf, int lh, i
     return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "seg_warp_argmax_kernel launch failed");
 }
 
+extern "C" int usc_upsample_ac_nhwc_batch_f32(const float* src, int sh, int sw, int C, float* dst, int dh, int dw, int ld, int c0,
+                                              int batch, usc_stream_t stream) {
+    if (!src || !dst || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || C <= 0 || C % 4 || ld % 4 || c0 % 4 || c0 + C > ld || batch < 1)
+        return seg_fail(USC_E_ARG, "usc_upsample_ac_nhwc_f32: bad argument (C, ld, c0 must be multiples of 4, c0 + C <= ld)");
+    if ((long long)batch * dh * dw * (C / 4) >= (1ll << 31)) return seg_fail(USC_E_UNSUPPORTED, "usc_upsample_ac_nhwc_f32: too large");
+    const float rh = dh > 1 ? (float)(sh - 1) / (dh - 1) : 0.f, rw = dw > 1 ? (float)(sw - 1) / (dw - 1) : 0.f;
+    hipLaunchKernelGGL(upsample_ac_nhwc_kernel, dim3(grid_for((long long)batch * dh * dw * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                       src, sh, sw, C, dst, dh, dw, ld, c0, rh, rw, batch);
+    return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "upsample_ac_nhwc_kernel launch failed");
+}
+
 extern "C" int usc_upsample_ac_nhwc_f32(const float* src, int sh, int sw, int C, float* dst, int dh, int dw, int ld, int c0,
                                         usc_stream_t stream) {
-    if (!src || !dst || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || C <= 0 || C % 4 || ld % 4 || c0 % 4 || c0 + C > ld)
-        return seg_fail(USC_E_ARG, "usc_upsample_ac_nhwc_f32: bad argument (C, ld, c0 must be multiples of 4, c0 + C <= ld)");
-    const float rh = dh > 1 ? (float)(sh - 1) / (dh - 1) : 0.f, rw = dw > 1 ? (float)(sw - 1) / (dw - 1) : 0.f;
-    hipLaunchKernelGGL(upsample_ac_nhwc_kernel, dim3(grid_for((long long)dh * dw * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream,
-                       src, sh, sw, C, dst, dh, dw, ld, c0, rh, rw);
-    return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "upsample_ac_nhwc_kernel launch failed");
+    return usc_upsample_ac_nhwc_batch_f32(src, sh, sw, C, dst, dh, dw, ld, c0, 1, stream);
 }
 
 extern "C" int usc_warp_affine_u8(const uint8_t* src, int sh, int sw, int cn, const double* M2x3, uint8_t* dst, int dh, int dw,

@@ -221,29 +221,45 @@ extern "C" int usc_upsample_nc_nhwc_f32(const float* src, int sh, int sw, int C,
 
 // --------------------------------------------------------------------------------------------
 // nn.AdaptiveAvgPool2d(s) on NHWC f32 (human_parse.py:92-96 PSP stages, deeplab/_deeplab.py:166 image pooling): window
-// [floor(o*H/s), ceil((o+1)*H/s)), summed row by row in float32 (the order of torch's CPU kernel), one lane per
-// (output cell, channel) - no atomics, so the result does not depend on launch shape or batching.
+// [floor(o*H/s), ceil((o+1)*H/s)) in float32, no atomics: the result does not depend on launch shape or batching.
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const float* __restrict__ src, int H, int W, int ld, int c0, int C,
-                                                               float* __restrict__ dst, int s) {
-    const int n = s * s * C;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int c = i % C, cell = i / C;
-        const int oy = cell / s, ox = cell - oy * s;
-        const int y0 = (oy * H) / s, y1 = ((oy + 1) * H + s - 1) / s, x0 = (ox * W) / s, x1 = ((ox + 1) * W + s - 1) / s;
-        float acc = 0.f;
-        for (int y = y0; y < y1; y++)
+// A workgroup = one output cell x 32 channels x 8 row partitions: partition p sums rows y0 + p, y0 + p + 8, ... (each row left
+// to right), the 8 partial sums are combined in order 0..7 - fixed for any launch shape or batch.
+__global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const float* __restrict__ src0, int H, int W, int ld, int c0, int C,
+                                                               float* __restrict__ dst0, int s) {
+    __shared__ float part[8][32];
+    const int cl = threadIdx.x & 31, p = threadIdx.x >> 5;
+    const int cgroups = (C + 31) / 32;
+    const int cell = blockIdx.x / cgroups, c = (blockIdx.x - cell * cgroups) * 32 + cl;
+    const int img = blockIdx.y;                                  // images stacked along y in src, cells stacked in dst
+    const float* __restrict__ src = src0 + (size_t)img * H * W * ld;
+    const int oy = cell / s, ox = cell - oy * s;
+    const int y0 = (oy * H) / s, y1 = ((oy + 1) * H + s - 1) / s, x0 = (ox * W) / s, x1 = ((ox + 1) * W + s - 1) / s;
+    float acc = 0.f;
+    if (c < C)
+        for (int y = y0 + p; y < y1; y += 8)
             for (int x = x0; x < x1; x++) acc += src[((size_t)y * W + x) * ld + c0 + c];
-        dst[i] = acc / (float)((y1 - y0) * (x1 - x0));
+    part[p][cl] = acc;
+    __syncthreads();
+    if (p == 0 && c < C) {
+        float t = part[0][cl];
+#pragma unroll
+        for (int k = 1; k < 8; k++) t += part[k][cl];
+        dst0[((size_t)img * s * s + cell) * C + c] = t / (float)((y1 - y0) * (x1 - x0));
     }
 }
 
-extern "C" int usc_adaptive_avgpool_nhwc_f32(const float* src, int H, int W, int ld, int c0, int C, float* dst, int s, usc_stream_t stream) {
-    if (!src || !dst || H <= 0 || W <= 0 || C <= 0 || c0 < 0 || c0 + C > ld || s <= 0 || s > H || s > W)
+extern "C" int usc_adaptive_avgpool_nhwc_batch_f32(const float* src, int H, int W, int ld, int c0, int C, float* dst, int s, int batch,
+                                                   usc_stream_t stream) {
+    if (!src || !dst || H <= 0 || W <= 0 || C <= 0 || c0 < 0 || c0 + C > ld || s <= 0 || s > H || s > W || batch < 1 || batch > 65535)
         return fail(USC_E_ARG, "usc_adaptive_avgpool_nhwc_f32: bad argument");
-    hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(grid_for((size_t)s * s * C, 256)), dim3(256), 0, (hipStream_t)stream, src, H, W, ld, c0, C,
+    hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(s * s * ((C + 31) / 32), batch), dim3(256), 0, (hipStream_t)stream, src, H, W, ld, c0, C,
                        dst, s);
     return check_launch("adaptive_avgpool_kernel");
+}
+
+extern "C" int usc_adaptive_avgpool_nhwc_f32(const float* src, int H, int W, int ld, int c0, int C, float* dst, int s, usc_stream_t stream) {
+    return usc_adaptive_avgpool_nhwc_batch_f32(src, H, W, ld, c0, C, dst, s, 1, stream);
 }
 
 // --------------------------------------------------------------------------------------------
