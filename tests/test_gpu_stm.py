@@ -169,3 +169,27 @@ def test_stm_agent_vs_oracle_chain(nv, oracle_lib, H, W):
     for t in (1, 2):
         want = oracle_lib.stm_post(dbg[t - 1]["p2"].cpu().numpy(), in_h, in_w, H, W)
         assert np.array_equal(masks_d[t].cpu().numpy(), want)
+
+
+def test_stm_agent_memory_policies(nv):
+    """Longer clips: the reference's update rule (bank frozen after t = 1, agent.py:166) and the repaired rule with a small
+    capacity (oldest entry dropped, slots compacted): memory sizes per step, determinism, and the compaction keeping the
+    right entries (the 6-frame result's first 4 masks equal the 4-frame result's)."""
+    from video_unscreen_amd.stm import STMAgent
+    from video_unscreen_amd.synth import SyntheticClip
+    H, W = 135, 240
+    clip = SyntheticClip(H, W, 6, config_id=2, device="cuda")
+    fr = [clip.frame(t) for t in range(6)]
+    frames, mask0 = [f["frame"] for f in fr], fr[0]["seg"]
+    quirk = STMAgent(model_path=None, memory_step=2, memory_capacity=10, input_long_side=240)
+    masks, dbg = quirk.forward_device(frames, mask0, return_debug=True)
+    assert [d["T"] for d in dbg] == [1, 2, 2, 2, 2]
+    fixed = STMAgent(model_path=None, memory_step=1, memory_capacity=3, input_long_side=240, fix_memory_step=True)
+    m6, d6 = fixed.forward_device(frames, mask0, return_debug=True)
+    assert [d["T"] for d in d6] == [1, 2, 3, 3, 3]
+    m6b, _ = fixed.forward_device(frames, mask0, return_debug=True)
+    assert all(torch.equal(a, b) for a, b in zip(m6, m6b))
+    m4, _ = fixed.forward_device(frames[:4], mask0, return_debug=True)
+    assert all(torch.equal(a, b) for a, b in zip(m6[:4], m4))
+    with pytest.raises(RuntimeError):                          # memory_step = 1 with the reference's rule: its NameError
+        STMAgent(model_path=None, memory_step=1, memory_capacity=3, input_long_side=240).forward_device(frames[:3], mask0)
