@@ -217,6 +217,15 @@ size_t usc_regionfill_ws_bytes(int H, int W);
 int usc_regionfill_u8(const uint8_t* img, const uint8_t* mask, int H, int W, uint8_t* out, double rtol, int max_iters,
                       int* iters_out, void* ws, size_t ws_bytes, usc_stream_t stream);
 
+/* remove_invalid_objects on the device (unscreen/utils/maskprocess.py:77-152) - no border following, no host round trip:
+ * connected-component labels + per-crack shoelace terms + containment-tree sums (csrc/usc_objects.hip).  alpha is modified
+ * in place; seg may be NULL (consensus against alpha itself); score = the device float64 score map of
+ * usc_score_map_f64 (maskprocess.py:155-189; ws8 = 8 bytes of device scratch), cached by the caller per geometry. */
+int usc_score_map_f64(int H, int W, double center_y, double center_x, double* out, void* ws8, usc_stream_t stream);
+size_t usc_remove_invalid_objects_ws_bytes(int H, int W);
+int usc_remove_invalid_objects_u8(uint8_t* alpha, const uint8_t* seg, int H, int W, const double* score, double saliency_thr,
+                                  double consensus_thr, void* ws, size_t ws_bytes, usc_stream_t stream);
+
 /* unscreen/utils/maskprocess.py:56-60 exist_foreground: *out_count (device, 8 bytes) = #(mask >= thr). */
 int usc_count_ge_u8(const uint8_t* mask, size_t n, int thr, unsigned long long* out_count, usc_stream_t stream);
 

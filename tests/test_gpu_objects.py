@@ -1,0 +1,143 @@
+"""GPU tests of remove_invalid_objects on the device (label-based, csrc/usc_objects.hip) against the oracle's border follower
+(reference unscreen/utils/maskprocess.py:77-152 semantics): the output mask must be identical."""
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nv():
+    assert torch.cuda.is_available()
+    from video_unscreen_amd import _native
+    _native.load()
+    return _native
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _cfg(thr):
+    return {"objectremoval": {"score_map_center": {"landscape": [0.5, 0.5], "portrait": [0.6, 0.5]}, "saliency_thr": thr,
+                              "consensus_thr": 0.5}}
+
+
+def _check(nv, oracle_lib, flt, alpha, seg, thr):
+    H, W = alpha.shape
+    cfg = _cfg(thr)
+    center = cfg["objectremoval"]["score_map_center"]["landscape" if W > H else "portrait"]
+    want = oracle_lib.remove_invalid_objects(cfg, alpha.copy(), None if seg is None else seg.copy())
+    got = flt(dev(alpha), None if seg is None else dev(seg), center, thr, 0.5).cpu().numpy()
+    assert np.array_equal(got, want), f"{(H, W)} thr {thr}: {(got != want).sum()} px differ"
+    return want
+
+
+def test_score_map_bit_exact(nv, oracle_lib):
+    flt = nv.DeviceObjectFilter()
+    for (H, W, c) in [(1080, 1920, (0.5, 0.5)), (1920, 1080, (0.6, 0.5)), (33, 47, (0.5, 0.5)), (64, 64, (0.3, 0.8)), (2, 3, (0.5, 0.5))]:
+        got = flt.score_map(H, W, c, torch.device("cuda")).cpu().numpy()
+        assert np.array_equal(got, oracle_lib.score_map(H, W, c))              # float64, same operations
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_masks(nv, oracle_lib, seed):
+    rng = np.random.default_rng(seed)
+    flt = nv.DeviceObjectFilter()
+    for _ in range(12):
+        H, W = int(rng.integers(20, 200)), int(rng.integers(20, 260))
+        sig = float(rng.choice([0.7, 1.2, 2.0, 3.0, 5.0]))
+        x = ndi.gaussian_filter(rng.random((H, W)), sig)
+        alpha = ((x > np.quantile(x, rng.uniform(0.2, 0.8))) * rng.integers(1, 256, (H, W))).astype(np.uint8)
+        if rng.random() < 0.3:
+            alpha[int(rng.integers(0, H)), :] = 200
+        if rng.random() < 0.3:
+            alpha[:, int(rng.integers(0, W))] = 77
+        seg = ((ndi.gaussian_filter(rng.random((H, W)), 3) > 0.5) * 255).astype(np.uint8)
+        thr = float(rng.choice([1e-5, 0.005, 0.02, 0.05]))
+        _check(nv, oracle_lib, flt, alpha, seg if rng.random() < 0.7 else None, thr)
+
+
+def test_structured_masks(nv, oracle_lib):
+    flt = nv.DeviceObjectFilter()
+    cases = []
+    a = np.zeros((64, 80), np.uint8)
+    a[2:62, 2:78] = 255; a[6:58, 6:74] = 0; a[10:54, 10:70] = 255; a[14:50, 14:66] = 0; a[20:44, 20:60] = 255; a[26:38, 30:50] = 0
+    a[30:34, 36:44] = 255
+    cases.append(a)                                                       # nested rings with an island
+    b = np.zeros((64, 80), np.uint8); b[::2, ::2] = 255; b[1::2, 1::2] = 255; cases.append(b)       # checkerboard (one 8-connected net)
+    c = np.zeros((64, 80), np.uint8)
+    for i in range(50):
+        c[5 + i, 10 + i] = 255
+    cases.append(c)                                                       # diagonal line
+    d = np.zeros((64, 80), np.uint8); d[10:50, 10:70] = 255
+    for i in range(30):
+        d[12 + i, 15 + i] = 0
+    cases.append(d)                                                       # diagonal slit: single-pixel holes
+    e = np.zeros((64, 80), np.uint8); e[20:40, 20:60] = 255; e[25:35, 25:55] = 0; e[34, 40] = 0; e[35, 41] = 0; cases.append(e)
+    f = np.full((64, 80), 255, np.uint8); f[10:20, 10:30] = 0; f[40:60, 50:70] = 0; f[45:55, 55:65] = 255; cases.append(f)
+    g = np.zeros((64, 80), np.uint8); g[0:30, 0:40] = 255; g[0:10, 0:10] = 0; g[63, :] = 255; g[:, 79] = 255; cases.append(g)
+    h = np.zeros((64, 80), np.uint8); h[30:34, 5:75] = 255; h[10:54, 38:42] = 255; cases.append(h)
+    j = np.zeros((100, 140), np.uint8)                                    # areas around the contourArea < 100 threshold
+    for n, (y, x) in zip((9, 10, 11, 12, 13), ((5, 5), (5, 30), (5, 60), (5, 90), (5, 115))):
+        j[y:y + n, x:x + n] = 255
+    yy, xx = np.mgrid[0:100, 0:140]
+    for r, (cy, cx) in zip((5.2, 5.7, 6.0, 6.3, 6.8), ((50, 15), (50, 40), (50, 70), (50, 100), (50, 125))):
+        j[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 255
+    cases.append(j)
+    cases += [np.zeros((9, 13), np.uint8), np.full((9, 13), 255, np.uint8), np.full((1, 7), 9, np.uint8), np.eye(12, dtype=np.uint8) * 5]
+    rng = np.random.default_rng(3)
+    for al in cases:
+        H, W = al.shape
+        for thr in (1e-5, 0.002, 0.02):
+            _check(nv, oracle_lib, flt, al, None, thr)
+            _check(nv, oracle_lib, flt, al, ((ndi.gaussian_filter(rng.random((H, W)), 2) > 0.5) * 255).astype(np.uint8), thr)
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920), (1920, 1080), (540, 960)])
+def test_clip_masks_full_size(nv, oracle_lib, H, W):
+    from video_unscreen_amd.synth import SyntheticClip
+    flt = nv.DeviceObjectFilter()
+    clip = SyntheticClip(H, W, 2, config_id=2, device="cpu")
+    rng = np.random.default_rng(H)
+    for t in range(2):
+        f = clip.frame(t)
+        alpha = f["seg"].numpy().copy()
+        noise = (rng.random((H, W)) < 0.002)                              # speckle: hundreds of tiny objects
+        alpha[ndi.binary_dilation(noise, iterations=int(rng.integers(1, 4)))] = 255
+        alpha[ndi.binary_dilation(rng.random((H, W)) < 0.0005, iterations=2)] = 0            # and holes
+        for thr in (1e-5, 0.005):
+            want = _check(nv, oracle_lib, flt, alpha, f["seg"].numpy(), thr)
+        assert 0.01 < (want > 0).mean() < 0.9
+
+
+def test_pipeline_device_filter_equals_host_filter(nv, cfg):
+    """BgStepPipeline with the label-based device filter (no host synchronisation in the loop) and with the border-following
+    host stage produce the same frames, in the synchronous and in the pipelined form."""
+    from video_unscreen_amd.pipeline import BgStepPipeline
+    from video_unscreen_amd.synth import SyntheticClip
+    H, W, n = 270, 480, 5
+    clip = SyntheticClip(H, W, n, config_id=2, device="cpu")
+    frames = [clip.frame(t) for t in range(n)]
+    bga = clip.bg_always.cuda()
+    ins = [(f["frame"].cuda(), f["seg"].cuda(), f["bg"].cuda(), bga) for f in frames]
+    res = {}
+    for mode in ("host", "device"):
+        pipe = BgStepPipeline(cfg, H, W, object_filter=mode)
+        res[mode, "step"] = []
+        for i in ins:
+            o = pipe.step(*i)                               # ONE step per frame: the loop carries alpha_pre
+            res[mode, "step"].append(tuple(o[k].clone() for k in ("alphaor", "trimap", "alpha", "fg")))
+        pipe = BgStepPipeline(cfg, H, W, object_filter=mode)
+        got = []
+        pipe.run(iter(ins), on_result=lambda k, o: got.append(tuple(o[key].clone() for key in ("alphaor", "trimap", "alpha", "fg"))))
+        torch.cuda.synchronize()
+        res[mode, "run"] = got
+    ref = res["host", "step"]
+    for key, got in res.items():
+        assert len(got) == n
+        for a, b in zip(ref, got):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), key

@@ -230,13 +230,8 @@ def test_pipelined_run_equals_step(nv, cfg):
     torch.cuda.synchronize()
     assert len(got) == n
     for (a, f, t), (a2, f2, t2) in zip(ref, got):
-        assert torch.equal(t, t2)                                   # index mask: bit-exact
-        # MIOpen's conv kernels accumulate with atomics: the network output moves by ~1e-7 from run to run
-        # (measured: tools/dev/debug_determinism.py), so a *255 truncation may flip in either loop form.
-        da = (a.int() - a2.int()).abs()
-        assert int(da.max()) <= 1 and float((da > 0).float().mean()) < 1e-3
-        same = (da == 0).unsqueeze(-1).expand_as(f)
-        assert torch.equal(f[same], f2[same])                       # foreground identical wherever alpha is
+        # every kernel of the path has a fixed summation order (no atomics in the convolutions): the two loop forms agree exactly
+        assert torch.equal(t, t2) and torch.equal(a, a2) and torch.equal(f, f2)
 
 
 def test_pipelined_run_with_batched_segmentation_is_identical(nv, cfg):

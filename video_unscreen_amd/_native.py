@@ -74,6 +74,9 @@ _SIGNATURES = {
     "usc_stm_mask_from_prob": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "usc_regionfill_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "usc_regionfill_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_double, C.c_int, C.POINTER(C.c_int), _vp, C.c_size_t, _vp]),
+    "usc_score_map_f64": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, _vp, _vp, _vp]),
+    "usc_remove_invalid_objects_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "usc_remove_invalid_objects_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp, C.c_size_t, _vp]),
     "usc_remove_invalid_objects_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                   C.c_double, _vp, C.POINTER(C.c_int)]),
     "usc_humanseg_affine": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -610,6 +613,38 @@ def humanseg_post(logits, C_classes, H, W, in_h=473, in_w=473, out=None, ws=None
     if rc != 0:
         raise NativeError(f"usc_humanseg_post failed ({rc}): {load().usc_seg_last_error().decode()}")
     return out
+
+
+# ---------------------------------------------------------------- object filter on the device
+class DeviceObjectFilter:
+    """remove_invalid_objects without leaving the GPU: per-geometry cached score map + workspace."""
+
+    def __init__(self):
+        self._score = {}
+        self._ws = None
+
+    def score_map(self, H, W, center, device):
+        key = (H, W, float(center[0]), float(center[1]), str(device))
+        if key not in self._score:
+            out = torch.empty((H, W), dtype=torch.float64, device=device)
+            ws8 = torch.zeros(8, dtype=torch.uint8, device=device)
+            _check(load().usc_score_map_f64(H, W, float(center[0]), float(center[1]), out.data_ptr(), ws8.data_ptr(), _stream()),
+                   "usc_score_map_f64")
+            self._score[key] = out
+        return self._score[key]
+
+    def __call__(self, alpha, seg, center, saliency_thr, consensus_thr):
+        """alpha (H, W) uint8 CUDA, modified in place and returned; seg (H, W) uint8 CUDA or None."""
+        H, W = alpha.shape
+        pa = _dev_u8(alpha, "remove_invalid_objects.alpha")
+        ps = _dev_u8(seg, "remove_invalid_objects.seg", (H, W)) if seg is not None else None
+        score = self.score_map(H, W, center, alpha.device)
+        need = load().usc_remove_invalid_objects_ws_bytes(H, W)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != alpha.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=alpha.device)
+        _check(load().usc_remove_invalid_objects_u8(pa, ps, H, W, score.data_ptr(), float(saliency_thr), float(consensus_thr),
+                                                    self._ws.data_ptr(), self._ws.numel(), _stream()), "usc_remove_invalid_objects_u8")
+        return alpha
 
 
 # ---------------------------------------------------------------- host stage

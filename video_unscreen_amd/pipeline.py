@@ -58,12 +58,15 @@ class _Slot:
 
 class BgStepPipeline:
     def __init__(self, cfg, H, W, device="cuda:0", dtype=torch.float32, state_dict=None, net_backend="hip",
-                 seg_agent=None, seg_batch=1):
+                 seg_agent=None, seg_batch=1, object_filter="device"):
         """seg_agent: optional HumanSegAgent.  When given, the coarse segmentation mask of every frame is computed on
         the device (reference bg_offline.py:63 `segagent.forward(frame)`, the untracked branch of stage 1) instead of
         being read from the caller; it runs in the front half, concurrently with the previous frame's matting net.
         seg_batch: run() segments that many frames ahead per network forward (frames are independent for the
-        segmentation; the masks are bit-identical to per-frame forwards, the launches per frame drop)."""
+        segmentation; the masks are bit-identical to per-frame forwards, the launches per frame drop).
+        object_filter: "device" (default) = remove_invalid_objects from connected-component labels on the GPU, the frame never
+        leaves HBM and the loop has no host synchronisation; "host" = the border-following C++ stage on a worker thread
+        (1 byte / pixel down and up), kept as the second implementation the first is tested against."""
         self.cfg = cfg
         self.H, self.W = H, W
         self.device = torch.device(device)
@@ -83,7 +86,11 @@ class BgStepPipeline:
         self.center = centers["landscape"] if W > H else centers["portrait"]
         self.sal_thr = cfg["objectremoval"]["saliency_thr"]
         self.cons_thr = cfg["objectremoval"]["consensus_thr"]
+        if object_filter not in ("device", "host"):
+            raise ValueError(f"unknown object_filter {object_filter!r}")
+        self.object_filter = object_filter
         self.filter = nv.ObjectFilter()
+        self.dfilter = nv.DeviceObjectFilter()
         dev = self.device
         self.ws_bgdiff = torch.empty(nv.load().usc_bgdiff_ws_bytes(H, W), dtype=torch.uint8, device=dev)
         self.ws_trimap = torch.empty(nv.load().usc_trimap_ws_bytes(H, W, self.long_side), dtype=torch.uint8, device=dev)
@@ -124,8 +131,15 @@ class BgStepPipeline:
             slot.seg = seg
         nv.bgdiff_mask(frame, bg_i, bg_always, seg, self.beta, self.thr, out_bg=slot.bg, out_alpha=slot.gate,
                        ws=self.ws_bgdiff)
-        slot.host.copy_(slot.gate, non_blocking=True)
-        slot.copied.record()
+        if self.object_filter == "host":
+            slot.host.copy_(slot.gate, non_blocking=True)
+            slot.copied.record()
+
+    def _front_filter_device(self, slot):
+        slot.alphaor.copy_(slot.gate)                      # the gate itself stays: it is alpha_pre of the first frame
+        self.dfilter(slot.alphaor, None, self.center, self.sal_thr, self.cons_thr)
+        nv.trimap(slot.alphaor, self.long_side, self.ksize, self.iters, out=slot.trimap, ws=self.ws_trimap)
+        slot.ready.record()
 
     def _front_host(self, slot):
         slot.copied.synchronize()
@@ -150,7 +164,10 @@ class BgStepPipeline:
         """One frame, all stages in order on the current stream (one host sync for the object filter)."""
         slot = self.slots[0]
         self._front_device(slot, frame, seg, bg_i, bg_always)
-        self._front_host(slot)
+        if self.object_filter == "device":
+            self._front_filter_device(slot)
+        else:
+            self._front_host(slot)
         return self._back(slot, frame, want_float=want_float)
 
     # ------------------------------------------------------------------ pipelined form
@@ -176,8 +193,10 @@ class BgStepPipeline:
                         err.append(e)
                     done.put(slot)
 
+        on_device = self.object_filter == "device"
         th = threading.Thread(target=worker, daemon=True)
-        th.start()
+        if not on_device:
+            th.start()
         n = 0
         pending = []
         submitted = 0
@@ -216,7 +235,12 @@ class BgStepPipeline:
                     front.wait_stream(main)                 # inputs produced on the main stream
                     with torch.cuda.stream(front):
                         self._front_device(slot, frame, seg, bg_i, bg_always, seg_ready=batched)
-                    work.put(slot)
+                        if on_device:
+                            self._front_filter_device(slot)
+                    if on_device:
+                        done.put(slot)
+                    else:
+                        work.put(slot)
                     pending.append(slot)
                     submitted += 1
                 if not pending:
@@ -232,6 +256,7 @@ class BgStepPipeline:
                     on_result(n, out)
                 n += 1
         finally:
-            work.put(None)
-            th.join()
+            if not on_device:
+                work.put(None)
+                th.join()
         return n

@@ -3,10 +3,10 @@
 Per frame:
     segmask   = STMAgent([prev frame, frame], binarised alpha_pre)[-1]  (tracking)  |  HumanSegAgent(frame)      bg.py:49-56
     exist_foreground(segmask)                                                                                    :60
-    alphaor   = remove_invalid_objects(segmask)  (host) -> trimap -> matting net            (pass 1)             :67-70
+    alphaor   = remove_invalid_objects(segmask) -> trimap -> matting net            (pass 1)             :67-70
     bg        = get_bg(alpha, frame);  hole = dilate3x3x2(alpha > 128);  bgimg = regionfill(bg, hole) per channel :71-81
     alphabg   = dilate4x4x2(gray(|frame - bgimg|) > thr);  alpha_ensm = alpha * (alphabg // 255)                  :85-92
-    alphaor   = remove_invalid_objects(alpha_ensm) (host) -> trimap -> matting net          (pass 2)             :93-95
+    alphaor   = remove_invalid_objects(alpha_ensm) -> trimap -> matting net          (pass 2)             :93-95
     bgimg[alpha == 0] = frame[alpha == 0];  fg = get_fg(frame, alpha, bgimg)                                      :99-100
     alpha_pre = alpha;  tracking = exist_foreground(alpha)                                                        :103-104
 """
@@ -31,9 +31,8 @@ class BgOnlinePipeline:
         self.vmatagent = vmatagent if vmatagent is not None else VMattingAgent(**dict(cfg["vmatting"], cuda_device=idx))
         centers = cfg["objectremoval"]["score_map_center"]
         self.center = centers["landscape"] if W > H else centers["portrait"]
-        self.filter = nv.ObjectFilter()
+        self.filter = nv.DeviceObjectFilter()
         self.fill_rtol = fill_rtol
-        self._host = torch.empty((H, W), dtype=torch.uint8).pin_memory()
         self._cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._ws_fill = torch.empty(nv.load().usc_regionfill_ws_bytes(H, W), dtype=torch.uint8, device=self.device)
         self._ws_diff = torch.empty(nv.load().usc_bgdiff_ws_bytes(H, W), dtype=torch.uint8, device=self.device)
@@ -49,10 +48,8 @@ class BgOnlinePipeline:
         return int(nv.count_ge(mask, 128, out=self._cnt).item()) > self.cfg["fg_exist_thr"] * self.H * self.W
 
     def _object_filter(self, mask):
-        self._host.copy_(mask)
-        self.filter(self._host.numpy(), None, self.center, self.cfg["objectremoval"]["saliency_thr"],
-                    self.cfg["objectremoval"]["consensus_thr"])
-        return self._host.to(self.device)
+        return self.filter(mask.clone(), None, self.center, self.cfg["objectremoval"]["saliency_thr"],
+                           self.cfg["objectremoval"]["consensus_thr"])
 
     def step(self, frame):
         """frame (H, W, 3) uint8 BGR CUDA -> dict(segmask, alpha, fg, bg, + the intermediates of every stage)."""

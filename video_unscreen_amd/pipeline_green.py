@@ -5,7 +5,7 @@ Per frame (every image stays in HBM; host work only where the reference's algori
     segmask   = alpha_pre (tracking)  |  SegAgent (DeepLabv3+ over 12-18 crops)      green.py:74-80
     exist_foreground(segmask)                                                          :82
     alphacf, bg = ColorFilteringAgent(frame, segmask, iters in {0, train_iters})       :88-100   (EM fit on the host)
-    alphaor   = remove_invalid_objects(alphacf[, segmask])   (host stage)              :106-109
+    alphaor   = remove_invalid_objects(alphacf[, segmask])   (device, label based)     :106-109
     trimap    = generate_trimap_withbg(alphaor, frame, bg_color)                       :114
     alpha     = matting net                                                            :115
     alpha     = color_correct(frame, alpha, bg_color)                                  :120
@@ -34,9 +34,7 @@ class GreenPipeline:
         self.cfagent = ColorFilteringAgent(**cfg["colorfiltering"], random_state=cf_random_state)
         centers = cfg["objectremoval"]["score_map_center"]
         self.center = centers["landscape"] if W > H else centers["portrait"]
-        self.filter = nv.ObjectFilter()
-        self._host_a = torch.empty((H, W), dtype=torch.uint8).pin_memory()
-        self._host_s = torch.empty((H, W), dtype=torch.uint8).pin_memory()
+        self.filter = nv.DeviceObjectFilter()
         self._cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.reset()
 
@@ -73,16 +71,10 @@ class GreenPipeline:
             alphacf, bgimg, _ = self.cfagent.forward_device(frame, segmask, iters=cf_iters)
             # the fitted background colour is known on the host; only the agent's early-outs hand back an image of their own
             bg_color = self.cfagent.last_bg_color if self.cfagent.last_bg_color is not None else bgimg[0, 0].cpu().numpy()
-            # host stage: contour filter on the 1 byte / pixel mask
-            self._host_a.copy_(alphacf)
-            seg_host = None
-            if not tracking:
-                self._host_s.copy_(segmask)
-                seg_host = self._host_s.numpy()
-            self.filter(self._host_a.numpy(), seg_host, self.center, cfg["objectremoval"]["saliency_thr"],
-                        cfg["objectremoval"]["consensus_thr"])
-            alphaor = self._host_a.to(self.device)
-            if not self._host_a.numpy().any():
+            # object filter on the device (labels, no border following): consensus against segmask unless tracking
+            alphaor = self.filter(alphacf.clone(), None if tracking else segmask, self.center, cfg["objectremoval"]["saliency_thr"],
+                                  cfg["objectremoval"]["consensus_thr"])
+            if int(nv.count_ge(alphaor, 1, out=self._cnt).item()) == 0:
                 trimap = alphaor                                   # generate_trimap_withbg returns an empty mask as is
             else:
                 trimap = self.trimapagent.forward_device_withbg(alphaor, frame, bg_color)

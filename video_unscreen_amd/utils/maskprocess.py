@@ -5,7 +5,7 @@ import numpy as np
 from .. import _native as nv
 from ._dev import to_dev, to_host
 
-_object_filter = nv.ObjectFilter()
+_object_filter = nv.DeviceObjectFilter()
 
 
 def dilate_mask(mask, kernelsize=5, iters=10):
@@ -39,9 +39,12 @@ def remove_invalid_objects(cfg, alpha, segmask=None, saliency_thr=0.001, consens
                            score_map=None, score_map_center=(3. / 5, 1. / 2)):
     """Contour-based object filter (reference maskprocess.py:77-152).  Like the reference, the thresholds come
     from cfg (the keyword values are ignored, :113-114), the centre from build_score_map (:119, :181-189), and
-    `alpha` is modified in place and returned.  Host stage: see csrc/usc_host_objects.cpp."""
+    `alpha` is modified in place and returned.  Runs on the device from connected-component labels (csrc/usc_objects.hip)."""
     h, w = alpha.shape
     centers = cfg['objectremoval']['score_map_center']
     center = centers['landscape'] if w > h else centers['portrait']
-    return _object_filter(alpha, segmask, center, cfg['objectremoval']['saliency_thr'],
-                          cfg['objectremoval']['consensus_thr'])
+    d = to_dev(alpha)
+    _object_filter(d, to_dev(segmask) if segmask is not None else None, center, cfg['objectremoval']['saliency_thr'],
+                   cfg['objectremoval']['consensus_thr'])
+    alpha[...] = to_host(d)
+    return alpha
