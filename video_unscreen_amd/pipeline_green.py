@@ -74,10 +74,9 @@ class GreenPipeline:
             # object filter on the device (labels, no border following): consensus against segmask unless tracking
             alphaor = self.filter(alphacf.clone(), None if tracking else segmask, self.center, cfg["objectremoval"]["saliency_thr"],
                                   cfg["objectremoval"]["consensus_thr"])
-            if int(nv.count_ge(alphaor, 1, out=self._cnt).item()) == 0:
-                trimap = alphaor                                   # generate_trimap_withbg returns an empty mask as is
-            else:
-                trimap = self.trimapagent.forward_device_withbg(alphaor, frame, bg_color)
+            # (an empty mask comes back as an all-zero trimap - what generate_trimap_withbg's early return hands on - without
+            # asking the host: the kernels decide on device counters)
+            trimap = self.trimapagent.forward_device_withbg(alphaor, frame, bg_color)
             alpha_mat = self.vmatagent.forward_device(frame, self.alpha_pre, trimap)
             alpha = nv.color_correct(frame, alpha_mat, bg_color)
             fg, bgimg = nv.get_fg(frame, alpha, bgimg.contiguous(), paste_thr=128, want_bg=True)
