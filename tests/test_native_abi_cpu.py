@@ -93,6 +93,22 @@ def test_argument_errors_are_reported(nv):
     assert abs(float(lut[100]) - 1 / (10 * np.sqrt(2 * np.pi))) < 1e-8 and abs(float(lut.sum()) - 1) < 1e-4
 
 
+_HOST_FILTER = None
+
+
+def remove_invalid_objects(cfg, alpha, segmask=None):
+    """The border-following host stage of the library (usc_remove_invalid_objects_host) - it runs without a GPU; the NumPy util
+    of the package goes through the device filter, which tests/test_gpu_objects.py checks against the same oracle."""
+    global _HOST_FILTER
+    from video_unscreen_amd import _native
+    if _HOST_FILTER is None:
+        _HOST_FILTER = _native.ObjectFilter()
+    h, w = alpha.shape
+    centers = cfg['objectremoval']['score_map_center']
+    return _HOST_FILTER(alpha, segmask, centers['landscape'] if w > h else centers['portrait'],
+                        cfg['objectremoval']['saliency_thr'], cfg['objectremoval']['consensus_thr'])
+
+
 def _random_mask(H, W, seed, q, sigma):
     rng = np.random.default_rng(seed)
     x = ndi.gaussian_filter(rng.random((H, W)), sigma)
@@ -107,13 +123,11 @@ def test_host_object_filter_equals_oracle(nv, oracle_lib, cfg, seed):
         m = ((m > 0) * np.random.default_rng(seed).integers(1, 256, m.shape)).astype(np.uint8)
     seg = None if seed % 2 == 0 else _random_mask(H, W, seed + 1000, 0.5, 3)
     want = oracle_lib.remove_invalid_objects(cfg, m.copy(), seg)
-    from video_unscreen_amd.utils import remove_invalid_objects
     got = remove_invalid_objects(cfg, m.copy(), seg)
     assert np.array_equal(got, want)
 
 
 def test_host_object_filter_edge_cases(nv, oracle_lib, cfg):
-    from video_unscreen_amd.utils import remove_invalid_objects
     for m in (np.zeros((40, 50), np.uint8), np.full((40, 50), 255, np.uint8)):
         assert np.array_equal(remove_invalid_objects(cfg, m.copy()), oracle_lib.remove_invalid_objects(cfg, m.copy()))
     m = np.zeros((60, 60), np.uint8)
