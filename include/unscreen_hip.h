@@ -226,6 +226,15 @@ size_t usc_remove_invalid_objects_ws_bytes(int H, int W);
 int usc_remove_invalid_objects_u8(uint8_t* alpha, const uint8_t* seg, int H, int W, const double* score, double saliency_thr,
                                   double consensus_thr, void* ws, size_t ws_bytes, usc_stream_t stream);
 
+/* Overall background of a clip (tools/unscreen/bg_offline.py:99-130; the stage is switched off with `if 0:` in the reference).
+ * usc_bg_accumulate_f32: one frame into the float32 accumulators raw (H*W*3) and cont (H*W; the reference keeps three equal
+ *   channels): raw += frame * (1 - mask // 255), cont += (mask < 250); mask = the frame's segmentation mask after dilate 3x3 x2.
+ *   Sums of integers: exact in float32, so per-rank partial sums can be all-reduced (the one collective on a data path).
+ * usc_bg_finalize_u8: mask_always = cont <= 10 (255 / 0), bg_always = uint8(clip(raw / max(cont, 1))) zeroed where always masked.
+ *   The reference then inpaints dilate3x3x2(mask_always) with cv2.inpaint(TELEA); this build fills it with usc_regionfill_u8. */
+int usc_bg_accumulate_f32(const uint8_t* frame, const uint8_t* mask_dilated, int H, int W, float* raw, float* cont, usc_stream_t stream);
+int usc_bg_finalize_u8(const float* raw, const float* cont, int H, int W, uint8_t* bg_always, uint8_t* mask_always, usc_stream_t stream);
+
 /* unscreen/utils/maskprocess.py:56-60 exist_foreground: *out_count (device, 8 bytes) = #(mask >= thr). */
 int usc_count_ge_u8(const uint8_t* mask, size_t n, int thr, unsigned long long* out_count, usc_stream_t stream);
 

@@ -536,3 +536,25 @@ def remove_invalid_objects(cfg, alpha, segmask=None, return_stats=False):
 
 def version():
     return lib().orc_version().decode()
+
+
+def overall_bg_accumulate(frame, segmask, raw, cont):
+    """One frame of tools/unscreen/bg_offline.py:111-117 (stage 2, disabled with `if 0:` in the reference): frames and masks already
+    have the destination size; src_mask = dilate3x3x2(mask); raw += float32(frame * float32(1 - mask // 255)); cont += (mask < 250).
+    raw / cont: float64 (H, W, 3) accumulators, updated in place."""
+    m = morph(np.ascontiguousarray(segmask), 3, 2, "dilate")
+    keep = (np.ones_like(m) - m // 255).astype(np.float32)
+    raw += (frame * keep[..., None]).astype(np.float32)
+    cont += (m < 250).astype(np.float32)[..., None]
+
+
+def overall_bg_finalize(raw, cont):
+    """bg_offline.py:118-127 up to the inpainting: mask_always = cont <= 10; bg_always = uint8(clip(raw / max(cont, 1))) with the
+    always-masked pixels zeroed; the hole mask = dilate3x3x2(gray(mask_always)).  Returns (bg_always uint8 (H, W, 3), hole uint8)."""
+    mask_always = ((cont <= 10) * 255).astype(np.uint8)
+    c = cont.copy()
+    c[cont == 0] = 1
+    bg_always = np.clip(raw / c, 0, 255).astype(np.uint8)
+    bg_always[mask_always == 255] = 0
+    hole = morph(bgr2gray(mask_always), 3, 2, "dilate")
+    return bg_always, hole

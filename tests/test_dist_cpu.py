@@ -81,3 +81,63 @@ def test_broadcast_and_shards_world2():
         single.append(float(net(torch.rand(1, 7, 32, 32, generator=g)).sum()))
     assert res[0][4] + res[1][4] == single
     assert res[0][5] == [[0.0, 3.0, 1.0], [1.0, 2.0, 1.0]]
+
+
+def _clip_for_bg(n=14, H=24, W=44):
+    rng = np.random.default_rng(5)
+    back = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    frames, masks = [], []
+    for t in range(n):
+        m = np.zeros((H, W), np.uint8)
+        m[4:16, 3 + 2 * t:13 + 2 * t] = 255
+        m[20:, :6] = 255                                   # never seen: the always-masked hole
+        f = back.copy()
+        f[m > 0] = rng.integers(0, 256, (int((m > 0).sum()), 3), dtype=np.uint8)
+        frames.append(f)
+        masks.append(m)
+    return frames, masks
+
+
+def _bg_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from video_unscreen_amd.bgestimate import OverallBackground
+    frames, masks = _clip_for_bg()
+    H, W = masks[0].shape
+    ob = OverallBackground(H, W, device="cpu")
+    lo, hi = shard_range(len(frames), rank, world)
+    raw, cont = ob.raw.numpy(), ob.cont.numpy()[..., None]            # views of the bucket; the oracle stands in for the kernel
+    for t in range(lo, hi):
+        oracle.overall_bg_accumulate(frames[t], masks[t], raw, cont)
+    ob.reduce()
+    q.put((rank, ob.raw.numpy().copy(), ob.cont.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overall_background_allreduce_world2():
+    """Stage 2 of bg_offline sharded by frames: per-rank partial sums + one all-reduce == the single-process accumulators."""
+    import oracle
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    frames, masks = _clip_for_bg()
+    H, W = masks[0].shape
+    raw = np.zeros((H, W, 3), np.float32)
+    cont = np.zeros((H, W, 1), np.float32)
+    for f, m in zip(frames, masks):
+        oracle.overall_bg_accumulate(f, m, raw, cont)
+    for _, r, c in res:
+        assert np.array_equal(r, raw) and np.array_equal(c, cont[..., 0])
+    bg_always, hole = oracle.overall_bg_finalize(raw, np.repeat(cont, 3, -1))
+    assert hole[20:, :6].all() and bg_always[hole == 0].any()

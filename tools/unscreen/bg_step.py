@@ -1,5 +1,9 @@
-"""bg_step / bg_offline mode on MI355X: the stage-3 loop of the reference's tools/unscreen/bg_offline.py:133-177
-(stages 1-2 are disabled in the reference), device-resident and optionally frame-sharded over GPUs.
+"""bg_step / bg_offline mode on MI355X: the stage-3 loop of the reference's tools/unscreen/bg_offline.py:133-177,
+device-resident and optionally frame-sharded over GPUs.  The reference ships with stages 1-2 switched off (`if 0:`) and
+reads their products from disk; `--stages 123` runs them here too (default "3" = the reference as shipped):
+  1  per frame segmask (HumanSegAgent, or STM while tracking) + one matting pass + per-frame background   bg_offline.py:51-97
+  2  overall background: masked mean over all frames, ONE all-reduce over the frame shards, hole filled  bg_offline.py:99-130
+  3  bg-difference ensemble mask -> object filter -> trimap -> matting -> foreground                  bg_offline.py:133-177
 
 Same CLI as the reference (--cfg, -vid/--video_id, --range a-b) plus --data_root (the reference hard-codes its
 dataset path, bg_offline.py:187).  Inputs, as in the reference: <data_root>/src_img/<vid>/*.jpg frames and, in
@@ -19,11 +23,14 @@ ROOT = osp.dirname(osp.dirname(osp.dirname(osp.abspath(__file__))))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
+from video_unscreen_amd.bgestimate import OverallBackground
 from video_unscreen_amd.dist import broadcast_state, shard_range
 from video_unscreen_amd.pipeline import BgStepPipeline
+from video_unscreen_amd.pipeline_bg import BgOnlinePipeline
 from video_unscreen_amd.utils.fileio import parallel_read_img, read_img, save_img, save_video
 
 
@@ -41,20 +48,70 @@ def main(cfg):
     os.makedirs(dst_img_dir, exist_ok=True)
 
     st = time.time()
+    stages = cfg["data"].get("stages", "3")
     frame_paths = sorted(glob(osp.join(src_img_dir, cfg["data"]["src_img_tmpl"])))
-    mask_paths = sorted(glob(osp.join(dst_img_dir, 'segmask_*.jpg')))
-    bg_paths = sorted(glob(osp.join(dst_img_dir, 'bg_*.jpg')))
     first = 0
     if cfg["data"]["range"]:
         a, b = cfg["data"]["range"]
         frame_paths, first = frame_paths[a:b], a
-    assert len(frame_paths) == len(mask_paths) == len(bg_paths), "frames, segmask_* and bg_* must pair up"
     lo, hi = shard_range(len(frame_paths), rank, world)          # this rank's contiguous range
     frames = parallel_read_img(frame_paths[lo:hi])
-    masks = parallel_read_img(mask_paths[lo:hi])
-    bgs = parallel_read_img(bg_paths[lo:hi])
     h, w = frames[0].shape[:2]
     print('{} frames. Reading Data Done! {:.2f}s'.format(len(frames), time.time() - st))
+    masks, bgs = [], []
+
+    if "1" in stages:
+        # every rank starts its range untracked, exactly like a --range run of the reference
+        print("get segmask using video segmentation")
+        st = time.time()
+        pipe1 = BgOnlinePipeline(cfg, h, w, device=dev)          # HumanSegAgent + STMAgent, as bg_offline.py:13,44-45
+        for i, f in enumerate(frames):
+            fid = first + lo + i
+            fd = torch.from_numpy(f).to(dev)
+            out = pipe1.step(fd, passes=1)
+            seg = out["segmask"].cpu().numpy()
+            # without a foreground the reference appends no background and its stage 3 then refuses the unequal lists
+            # (bg_offline.py:68-71,140); here such a frame is its own background
+            bgimg = out["bgimg"].cpu().numpy() if "bgimg" in out else f
+            masks.append(seg[..., None].repeat(3, 2))
+            bgs.append(bgimg)
+            save_img(seg, osp.join(dst_img_dir, 'segmask_{:06d}.jpg'.format(fid)))
+            save_img(bgimg, osp.join(dst_img_dir, 'bg_{:06d}.jpg'.format(fid)))
+        del pipe1
+        print('stage 1: {} frames in {:.2f}s on rank {}'.format(len(frames), time.time() - st, rank))
+
+    def shard_of(pattern):
+        paths = sorted(glob(osp.join(dst_img_dir, pattern)))
+        assert len(paths) >= first + len(frame_paths), "frames and {} must pair up".format(pattern)
+        if len(paths) != len(frame_paths):
+            paths = paths[first:first + len(frame_paths)]
+        return parallel_read_img(paths[lo:hi])
+
+    if world > 1:
+        dist.barrier()
+    if "2" in stages:
+        print("calculate overall bg image according to video segmentation and temporal constraints")
+        st = time.time()
+        if not masks:
+            masks = shard_of('segmask_*.jpg')
+        acc = OverallBackground(h, w, device=dev)
+        for f, m in zip(frames, masks):
+            acc.add(torch.from_numpy(f).to(dev), torch.from_numpy(np.ascontiguousarray(m[..., 0])).to(dev))
+        acc.reduce()                                   # RCCL all-reduce of one (h*w*4) float32 bucket
+        if rank == 0:
+            save_img(acc.finalize()["bg"].cpu().numpy(), osp.join(dst_img_dir, 'always_bg.jpg'))
+        del acc
+        print('stage 2: {:.2f}s on rank {}'.format(time.time() - st, rank))
+        if world > 1:
+            dist.barrier()
+    if "3" not in stages:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if not masks:
+        masks = shard_of('segmask_*.jpg')
+    if not bgs:
+        bgs = shard_of('bg_*.jpg')
 
     st = time.time()
     # rank 0 owns the checkpoint and the overall background; RCCL broadcast to the others
@@ -94,12 +151,13 @@ if __name__ == '__main__':
     parser.add_argument('--cfg', type=str, default='./configs/bg.json')
     parser.add_argument('-vid', '--video_id', type=str, default="1")
     parser.add_argument('--range', type=str, default=None, help="eg. 400-700")
+    parser.add_argument('--stages', type=str, default="3", help='which of the stages 1, 2, 3 to run, e.g. "123"')
     parser.add_argument('--data_root', type=str, default=os.environ.get("UNSCREEN_DATA_ROOT", "./data/greenmat"))
     args = parser.parse_args()
 
     cfg = json.load(open(args.cfg))
     cfg["data"] = {"range": [int(i) for i in args.range.split('-')] if args.range else None,
-                   "video_id": args.video_id,
+                   "video_id": args.video_id, "stages": args.stages,
                    "src_img_dir": osp.join(args.data_root, 'src_img', args.video_id),
                    "src_img_tmpl": '*.jpg',
                    "dst_img_dir": osp.join(args.data_root, 'test_img', args.video_id),

@@ -77,6 +77,8 @@ _SIGNATURES = {
     "usc_score_map_f64": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, _vp, _vp, _vp]),
     "usc_remove_invalid_objects_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "usc_remove_invalid_objects_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp, C.c_size_t, _vp]),
+    "usc_bg_accumulate_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "usc_bg_finalize_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "usc_remove_invalid_objects_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                   C.c_double, _vp, C.POINTER(C.c_int)]),
     "usc_humanseg_affine": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -580,6 +582,22 @@ def regionfill(img, mask, rtol=1e-7, max_iters=20000, out=None, ws=None, want_it
                                     _dev_u8(out, "regionfill.out", (H, W, 3)), float(rtol), int(max_iters), C.byref(it), ws.data_ptr(),
                                     ws.numel(), _stream()), "usc_regionfill_u8")
     return (out, it.value) if want_iters else out
+
+
+def bg_accumulate(frame, mask_dilated, raw, cont):
+    """raw (H, W, 3) / cont (H, W) float32 CUDA accumulators += one frame outside its (dilated) mask (bg_offline.py:111-117)."""
+    H, W, _ = frame.shape
+    _check(load().usc_bg_accumulate_f32(_dev_u8(frame, "bg_accumulate.frame", (H, W, 3)), _dev_u8(mask_dilated, "bg_accumulate.mask", (H, W)),
+                                        H, W, raw.data_ptr(), cont.data_ptr(), _stream()), "usc_bg_accumulate_f32")
+
+
+def bg_finalize(raw, cont):
+    """-> (bg_always (H, W, 3) uint8, mask_always (H, W) uint8 255 / 0)  (bg_offline.py:118-123)."""
+    H, W = cont.shape
+    bg = torch.empty((H, W, 3), dtype=torch.uint8, device=cont.device)
+    ma = torch.empty((H, W), dtype=torch.uint8, device=cont.device)
+    _check(load().usc_bg_finalize_u8(raw.data_ptr(), cont.data_ptr(), H, W, bg.data_ptr(), ma.data_ptr(), _stream()), "usc_bg_finalize_u8")
+    return bg, ma
 
 
 def humanseg_affine(w, h, in_w=473, in_h=473, inv=False):

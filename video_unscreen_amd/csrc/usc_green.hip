@@ -409,3 +409,51 @@ extern "C" int usc_box_filter_u8(const uint8_t* src, int H, int W, int cn, int k
                        div_scale, div_delta, dst);
     return check_launch("box_filter_kernel");
 }
+
+// --------------------------------------------------------------------------------------------
+// overall background of a clip (tools/unscreen/bg_offline.py:99-130, stage 2 - disabled with `if 0:` in the reference)
+// --------------------------------------------------------------------------------------------
+// raw += float32(frame * float32(1 - mask // 255)) ; cont += (mask < 250)        (bg_offline.py:111-117; mask already dilated)
+__global__ __launch_bounds__(256) void bg_accumulate_kernel(const uint8_t* __restrict__ frame, const uint8_t* __restrict__ mask, size_t n,
+                                                            float* __restrict__ raw, float* __restrict__ cont) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = mask[i];
+        const float keep = (float)(1 - m / 255);
+#pragma unroll
+        for (int c = 0; c < 3; c++) raw[3 * i + c] += (float)frame[3 * i + c] * keep;
+        cont[i] += m < 250 ? 1.f : 0.f;
+    }
+}
+
+extern "C" int usc_bg_accumulate_f32(const uint8_t* frame, const uint8_t* mask_dilated, int H, int W, float* raw, float* cont,
+                                     usc_stream_t stream) {
+    if (!frame || !mask_dilated || !raw || !cont || H <= 0 || W <= 0) return fail(USC_E_ARG, "usc_bg_accumulate_f32: bad argument");
+    const size_t n = (size_t)H * W;
+    hipLaunchKernelGGL(bg_accumulate_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, frame, mask_dilated, n, raw, cont);
+    return check_launch("bg_accumulate_kernel");
+}
+
+// mask_always = cont <= 10 ; bg_always = uint8(clip(raw / max(cont, 1), 0, 255)), zero where always masked   (bg_offline.py:118-123)
+__global__ __launch_bounds__(256) void bg_finalize_kernel(const float* __restrict__ raw, const float* __restrict__ cont, size_t n,
+                                                          uint8_t* __restrict__ bg_always, uint8_t* __restrict__ mask_always) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double c = (double)cont[i];
+        const bool always = c <= 10.;
+        const double d = c == 0. ? 1. : c;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            double v = (double)raw[3 * i + ch] / d;
+            v = v < 0. ? 0. : (v > 255. ? 255. : v);
+            bg_always[3 * i + ch] = always ? 0 : (uint8_t)(int)v;
+        }
+        mask_always[i] = always ? 255 : 0;
+    }
+}
+
+extern "C" int usc_bg_finalize_u8(const float* raw, const float* cont, int H, int W, uint8_t* bg_always, uint8_t* mask_always,
+                                  usc_stream_t stream) {
+    if (!raw || !cont || !bg_always || !mask_always || H <= 0 || W <= 0) return fail(USC_E_ARG, "usc_bg_finalize_u8: bad argument");
+    const size_t n = (size_t)H * W;
+    hipLaunchKernelGGL(bg_finalize_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, raw, cont, n, bg_always, mask_always);
+    return check_launch("bg_finalize_kernel");
+}

@@ -51,8 +51,10 @@ class BgOnlinePipeline:
         return self.filter(mask.clone(), None, self.center, self.cfg["objectremoval"]["saliency_thr"],
                            self.cfg["objectremoval"]["consensus_thr"])
 
-    def step(self, frame):
-        """frame (H, W, 3) uint8 BGR CUDA -> dict(segmask, alpha, fg, bg, + the intermediates of every stage)."""
+    def step(self, frame, passes=2):
+        """frame (H, W, 3) uint8 BGR CUDA -> dict(segmask, alpha, fg, bg, + the intermediates of every stage).
+        passes=1 stops after the per-frame background: stage 1 of tools/unscreen/bg_offline.py:51-97 (segmask, one matting
+        pass, bgimg; alpha_pre / tracking follow the pass-1 alpha) - no bg difference, second pass or foreground."""
         cfg = self.cfg
         tracking = self.tracking_flag
         if tracking:
@@ -70,6 +72,12 @@ class BgOnlinePipeline:
             bg = nv.get_bg(alpha1, frame)
             hole = nv.morph((alpha1 > 128).to(torch.uint8) * 255, 3, 2, nv.DILATE)
             bgimg, self.fill_iters = nv.regionfill(bg, hole, rtol=self.fill_rtol, ws=self._ws_fill, want_iters=True)
+            if passes == 1:
+                self.alpha_pre = alpha1
+                self.tracking_flag = self._exist_foreground(alpha1)
+                self.prev_frame = frame
+                out.update(alphaor1=alphaor1, trimap1=trimap1, alpha1=alpha1, alpha=alpha1, bg_holes=bg, hole=hole, bgimg=bgimg)
+                return out
             _, alpha_ensm = nv.bgdiff_mask(frame, bgimg, None, alpha1, 1.0, cfg["bg_mask"]["thr"], ws=self._ws_diff)
             alphaor2 = self._object_filter(alpha_ensm)
             trimap2 = self.trimapagent.forward_device(alphaor2)
