@@ -317,9 +317,11 @@ typedef struct usc_conv_desc {
     int out_ld, out_c0;            /* 0 / 0: `out` is a dense [pixel][Cout] tensor; otherwise `out` has out_ld channels per pixel
                                       and this layer writes channels [out_c0, out_c0 + Cout) (concat buffers) */
     int batch;                     /* 0 / 1: one image.  > 1: `batch` images stacked along y in every tensor; OH and OHf count the
-                                      rows of all of them, IH is per image.  The K split is chosen per image, so a batched layer
-                                      gives bit for bit what `batch` single-image launches give. */
-    int pad0;
+                                      rows of all of them, IH is per image. */
+    int plan_batch;                /* 0 / 1 or the batch the tile shape and the K partition are planned for (independent of `batch`).
+                                      Layers of the same plan_batch give bit for bit the same per-image results at any `batch`:
+                                      a pipeline that runs a batch-4 network and, for single frames, a batch-1 network gives
+                                      both plan_batch = 4. */
 } usc_conv_desc;
 
 /* sizeof(usc_conv_desc) as the library was built: bindings check their struct definition against it. */

@@ -85,12 +85,14 @@ def test_humanseg_agent_vs_oracle_chain(nv, oracle_lib, H, W):
     assert np.array_equal(mask_dev.cpu().numpy(), want2)
 
 
-def test_humanseg_batched_forward_is_bit_identical(nv):
+@pytest.mark.parametrize("plan", [1, 4])
+def test_humanseg_batched_forward_is_bit_identical(nv, plan):
     """Two / three frames through one batched network forward: logits and masks equal the single-frame results bit for bit
-    (the K split of every layer is decided per image)."""
+    (tile shape and K partition of every layer depend on the per-image shape and the agent's plan_batch, not on the batch)."""
     from video_unscreen_amd.binseg import HumanSegAgent
     from video_unscreen_amd.synth import SyntheticClip
     agent = HumanSegAgent(model_path=None)
+    agent.set_plan_batch(plan)
     clip = SyntheticClip(270, 480, 3, config_id=2, device="cuda")
     frames = [clip.frame(t)["frame"] for t in range(3)]
     single = []
@@ -99,7 +101,7 @@ def test_humanseg_batched_forward_is_bit_identical(nv):
         single.append((m.clone(), lg.clone()))                  # the logits buffer is reused by the next forward
     for n in (2, 3):
         masks = agent.forward_device_batch(frames[:n])
-        net = agent._batch_nets[n]
+        net = agent.model_for(n)
         for b in range(n):
             assert torch.equal(net.image(net.logits32, b), single[b][1]), (n, b)
             assert torch.equal(masks[b], single[b][0])

@@ -27,7 +27,7 @@ for i, d in enumerate(net._descs):
     e1.record(); e1.synchronize()
     t = e0.elapsed_time(e1) / 20 * 1e-3
     M = d.OH * d.OW
-    fl = 2.0 * M * d.Cout * d.ntaps * d.Cin
+    fl = 2.0 * M * d.Cout * d.ntaps * d.Cin * max(d.nphase, 1)
     tot_t += t; tot_f += fl
     mb = (M + 127) // 128
     print(f"{i:3d} M={M:7d} Cin={d.Cin:4d} Cout={d.Cout:4d} taps={d.ntaps:2d} s={d.in_stride} os={d.out_stride} "

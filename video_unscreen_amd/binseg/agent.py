@@ -17,7 +17,7 @@ from .deeplab_net import HipDeepLabNet, deeplab_synthetic_state_dict
 class SegAgent():
 
     def __init__(self, model_path=None, input_long_side=912, crop_h=513, crop_w=513, stride_ratio=1 / 2., flip=True,
-                 cuda_device=0, crop_batch=4):
+                 cuda_device=0, crop_batch=4, plan_batch=4):
         self.cuda_device = cuda_device if cuda_device is not None and cuda_device >= 0 else 0
         self.device = device(self.cuda_device)
         if model_path is None or model_path == "synthetic":
@@ -31,6 +31,7 @@ class SegAgent():
         self.input_long_side = input_long_side
         self.stride_ratio = stride_ratio
         self.crop_batch = max(1, int(crop_batch))       # crops per network forward (results do not depend on it)
+        self.plan_batch = max(1, int(plan_batch))       # batch the conv kernels plan their K partitions for (results do)
         self._models = {}
         self.model = self.model_for(1)
         self._logits = None
@@ -38,7 +39,8 @@ class SegAgent():
 
     def model_for(self, batch):
         if batch not in self._models:
-            self._models[batch] = HipDeepLabNet(self.state_dict, self.crop_h, self.crop_w, device=self.device, batch=batch)
+            self._models[batch] = HipDeepLabNet(self.state_dict, self.crop_h, self.crop_w, device=self.device, batch=batch,
+                                                 plan_batch=self.plan_batch)   # one K partition for full and tail groups
         return self._models[batch]
 
     def get_target_size(self, h, w):

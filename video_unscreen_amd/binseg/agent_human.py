@@ -26,12 +26,29 @@ class HumanSegAgent():
         else:
             sd = strip_module_prefix(torch.load(model_path, map_location="cpu"))   # DataParallel keys: module.*
         self.state_dict = sd
-        self.net = HipSchpNet(sd, INPUT_SIZE[0], INPUT_SIZE[1], device=self.device)
-        self._batch_nets = {}
+        self.plan_batch = 1
+        self._nets = {}                       # batch -> network, all planned for self.plan_batch
         # kept for signature compatibility; the reference's forward() does not use them either (agent_human.py:277-312)
         self.crop_h, self.crop_w, self.flip = crop_h, crop_w, flip
         self.input_long_side, self.stride_ratio, self.division = input_long_side, stride_ratio, 1
         self._ws = None
+
+    def set_plan_batch(self, n):
+        """Plan the conv kernels' tiles / K partitions for `n` frames per forward (what the caller will mostly run).  All
+        networks of one plan give bit-identical masks per frame whatever the batch they are run at."""
+        n = max(1, int(n))
+        if n != self.plan_batch:
+            self.plan_batch, self._nets = n, {}
+
+    def model_for(self, batch):
+        if batch not in self._nets:
+            self._nets[batch] = HipSchpNet(self.state_dict, INPUT_SIZE[0], INPUT_SIZE[1], device=self.device, batch=batch,
+                                           plan_batch=self.plan_batch)
+        return self._nets[batch]
+
+    @property
+    def net(self):
+        return self.model_for(1)
 
     def forward_device(self, img, out=None, return_logits=False):
         """img: (H, W, 3) uint8 BGR CUDA tensor -> (H, W) uint8 mask {0, 255} on the device."""
@@ -50,9 +67,7 @@ class HumanSegAgent():
         n = len(imgs)
         if n == 1:
             return [self.forward_device(imgs[0], out=None if outs is None else outs[0])]
-        if n not in self._batch_nets:
-            self._batch_nets[n] = HipSchpNet(self.state_dict, INPUT_SIZE[0], INPUT_SIZE[1], device=self.device, batch=n)
-        net = self._batch_nets[n]
+        net = self.model_for(n)
         for b, img in enumerate(imgs):
             nv.humanseg_pre(img, INPUT_SIZE[0], INPUT_SIZE[1], out=net.image(net.x4, b))
         logits = net.forward(None)

@@ -175,9 +175,9 @@ class DeepLabNetTorch:
 class HipDeepLabNet(ConvGraphNet):
     """One crop per call: x4 (H, W, 4) float32 NHWC (R, G, B, 0) -> logits32 (H/4, W/4, 32) buffer."""
 
-    def __init__(self, state_dict, H=513, W=513, device="cuda:0", batch=1):
+    def __init__(self, state_dict, H=513, W=513, device="cuda:0", batch=1, plan_batch=1):
         """batch > 1: that many crops per forward, stacked along y in x4 / logits32 (bit-identical to single-crop forwards)."""
-        super().__init__(device, slab_floats=64 * 1024 * 1024, batch=batch)
+        super().__init__(device, slab_floats=64 * 1024 * 1024, batch=batch, plan_batch=plan_batch)
         self.H, self.W = H, W
         self.plan = DeepLabPlan(state_dict)
         self._build()

@@ -218,10 +218,10 @@ class HipSchpNet(ConvGraphNet):
     """Every convolution on the f32-MFMA kernel (csrc/usc_conv.hip), NHWC buffers; pooling / bilinear glue between
     conv segments stays on torch ops (a handful of tiny tensors)."""
 
-    def __init__(self, state_dict, H=473, W=473, device="cuda:0", batch=1):
+    def __init__(self, state_dict, H=473, W=473, device="cuda:0", batch=1, plan_batch=1):
         """batch > 1: `batch` frames per forward, stacked along y in x4 / logits32 - same bits per frame as batch 1, half the
         launches per frame (the 30 x 30 layers of this net are launch-bound)."""
-        super().__init__(device, slab_floats=64 * 1024 * 1024, batch=batch)
+        super().__init__(device, slab_floats=64 * 1024 * 1024, batch=batch, plan_batch=plan_batch)
         self.H, self.W = H, W
         self.plan = SchpPlan(state_dict)
         self._build()

@@ -15,8 +15,10 @@ def _out_size(n, k, stride, pad, dil):
 class ConvGraphNet:
     ACTS = {"none": 0, "relu": 1, "leaky": 2, "leaky01": 3}
 
-    def __init__(self, device="cuda:0", slab_floats=64 * 1024 * 1024, batch=1):
-        """batch > 1: every buffer holds `batch` images stacked along y ((batch * h, w, c)); layers carry `batch` to the kernel."""
+    def __init__(self, device="cuda:0", slab_floats=64 * 1024 * 1024, batch=1, plan_batch=1):
+        """batch > 1: every buffer holds `batch` images stacked along y ((batch * h, w, c)); layers carry `batch` to the kernel.
+        plan_batch: the batch the kernel plans its tiles / K partition for; networks built with the same
+        plan_batch give bit-identical per-image results whatever their batch."""
         from . import _native as nv
         from .vmatting.net_hip import ConvDesc, conv_taps, pack_k_major
         self.nv, self.ConvDesc, self.conv_taps, self.pack = nv, ConvDesc, conv_taps, pack_k_major
@@ -24,6 +26,7 @@ class ConvGraphNet:
             raise nv.NativeError("ConvDesc (vmatting/net_hip.py) does not match usc_conv_desc of the built library: rebuild it")
         self.device = torch.device(device)
         self.batch = batch
+        self.plan_batch = max(1, int(plan_batch))
         self._keep = []
         self.slab = torch.empty(slab_floats, dtype=torch.float32, device=self.device)     # split-K partial sums
         self._segments = []            # list of ("conv", graph handle, ctypes array) | ("glue", callable, None)
@@ -81,6 +84,7 @@ class ConvGraphNet:
         B = self.batch
         d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = IH, IW, cin_buf, B * OH, OW, B * OH, OW, co
         d.batch = B
+        d.plan_batch = self.plan_batch
         d.in_stride, d.out_stride = c.stride, 1
         d.act = self.ACTS[act or c.act]
         d.ntaps, d.kind, d.nphase = len(taps), 0, 1

@@ -1,20 +1,26 @@
 // usc_conv.hip - fused NHWC float32 convolution on the f32-input matrix cores (v_mfma_f32_32x32x2_f32).
 //
-// The matting network (reference unscreen/vmatting/model.py:435-568) is ~50 small convolutions on a
-// 544 x 960 frame: dense contractions with M = output pixels (510 ... 522,240), N = Cout (32 ... 512),
-// K = taps * Cin (72 ... 4608).  One implicit-GEMM kernel serves every shape:
-//   * taps are a list of (dy, dx) offsets with an input stride, so 3x3 s1/s2, 1x1, the 2x2-s2 form of
+// The networks of the path (matting UNet, human-parsing ResNet-101, DeepLabv3+, STM) are hundreds of small convolutions:
+// dense contractions with M = output pixels (510 ... 522,240), N = Cout (32 ... 2048), K = taps * Cin (72 ... 36,864).
+// One implicit-GEMM kernel serves every shape:
+//   * taps are a list of (dy, dx) offsets with an input stride, so 3x3 s1/s2 (any dilation), 1x1, the 2x2-s2 form of
 //     avg-pool + 1x1, and the four 2x2 output phases of ConvTranspose2d(k4, s2, p1) are the same code;
-//   * a workgroup of 4 waves owns 128 output pixels x (32 | 64) channels; every K step stages a
-//     [128 px][32 k] slice of the im2col matrix and a [32 k][N] slice of the packed weights in LDS
-//     (double buffered, one barrier per step) and each wave issues 16 x NT back-to-back MFMAs on its 32 rows;
-//   * LDS images are padded / packed so every ds_read_b128 of a fragment is conflict-free
-//     (A: 36-float row pitch; B: [k/4][n][4] so consecutive lanes read consecutive 16-byte words);
+//   * a workgroup owns 128 output pixels x (32 | 64) channels; each of its waves owns 32 of those pixels.  A wave only ever
+//     multiplies ITS OWN 32 pixel rows, so LDS is a layout transposer for A (coalesced 128-byte pixel rows -> the MFMA's
+//     one-row-per-lane operand), not a sharing medium: every wave stages its rows in a private 4.6 KB LDS image (LDS
+//     executes one wave's instructions in order: no barrier between its ds_write and ds_read) and reads its weight
+//     fragments straight from global memory - the packed layout [k/4][n][4] IS the B-operand layout, a fragment load is two
+//     contiguous 512-byte runs that all waves of the layer share through L1 / L2.  No __syncthreads in the K loop: waves
+//     drift freely, 4 (3 for the 64-column tile) per SIMD;
+//   * K parallelism for the many layers with only one or two tiles per CU: a workgroup may hold KW groups of 4 waves that
+//     split the K range of the same tile (partial sums meet in LDS, added in slice order), and / or the grid splits K into
+//     S slices whose partial sums go through a slab and splitk_reduce_kernel;
+//   * A is padded in LDS (36-float row pitch) so every ds_read_b128 / ds_write_b128 of a fragment is conflict-free;
 //   * the epilogue fuses bias, residual (optionally from a half-resolution tensor = nearest x2 upsample),
-//     ReLU / LeakyReLU(0.2), a per-channel affine (the shortcut branches' BN-after-ReLU) and a second residual,
-//     so no elementwise pass ever touches HBM again.
-// f32 MFMA is an exact k-ordered fmaf chain; accumulation order is fixed, so results are run-to-run identical
-// (the MIOpen kernels this replaces accumulate with atomics).
+//     ReLU / LeakyReLU, a per-channel affine (the shortcut branches' BN-after-ReLU), a second residual and a channel
+//     slice of a wider output tensor (concat buffers), so no elementwise pass ever touches HBM again.
+// f32 MFMA is an exact k-ordered fmaf chain; the K partition and the order partial sums are added in depend only on the
+// layer's shape (and the caller's plan_batch), so results are run-to-run and batch-to-batch identical.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -34,49 +40,38 @@ namespace {
 constexpr int BM = 128;        // output pixels per workgroup
 constexpr int KC = 32;         // K slice per step
 constexpr int APITCH = 36;     // floats per A row in LDS (32 + 4 pad: b128 reads hit 64 distinct banks)
-constexpr int THREADS = 256;
 
-template <int NT, bool IN_RELU>
-__global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
-    __shared__ __attribute__((aligned(16))) float As[2][BM * APITCH];
-    __shared__ __attribute__((aligned(16))) float Bs[2][8 * 32 * NT * 4];
+template <int NT, int KW, bool IN_RELU>
+__global__ __launch_bounds__(256 * KW) void conv_mfma_kernel(usc_conv_desc d) {
+    __shared__ __attribute__((aligned(16))) float As[4 * KW][32 * APITCH];
     __shared__ int s_toff[16];
     __shared__ int s_outpix[BM], s_res1pix[BM], s_vbase[BM], s_vmask[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rg = wave & 3, kg = wave >> 2;                     // row group (32 pixels) and K group of this wave
     const int M = d.OH * d.OW;
-    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so with the natural
-    // order the N tiles of one pixel tile, and the pixel tiles one image row apart that share its 3x3 halo, all sit on
-    // different L2s and every one of them fetches the same activations from the fabric again.  The 1-D grid is re-labelled
-    // (bijectively, any size) so that XCD k owns the k-th contiguous run of (pixel tile, N tile) pairs, N tile fastest.
     const int nblk = d.Cout / (32 * NT);
-    const int nwg = (int)gridDim.x, xcd = (int)blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int nwg = (int)gridDim.x, xcd = (int)blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;      // XCD-aware order, see above
     const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
     const int mtile = wgid / nblk;
     const int m0 = mtile * BM;
     const int nb0 = (wgid - mtile * nblk) * (32 * NT);
     const int Ktot = d.ntaps * d.Cin;
-    // blockIdx.z = phase * ksplit + k-slice.  Phases: the four (py, px) outputs of a transposed conv, each with
-    // its own tap table and weight block.  K slices: contiguous chunk ranges whose partial sums go to a slab.
     const int S = d.ksplit;
     const int ph = blockIdx.z / S, ks = blockIdx.z - ph * S;
     const int nch_all = (Ktot + KC - 1) / KC;
-    const int c_begin = (int)((long long)ks * nch_all / S), c_end = (int)((long long)(ks + 1) * nch_all / S);
+    const int b_begin = (int)((long long)ks * nch_all / S), b_end = (int)((long long)(ks + 1) * nch_all / S);
+    // this wave's slice of the block's chunk range
+    const int c_begin = b_begin + (int)((long long)kg * (b_end - b_begin) / KW);
+    const int c_end = b_begin + (int)((long long)(kg + 1) * (b_end - b_begin) / KW);
     const float* __restrict__ wpk = d.wpk + (size_t)ph * d.wphase_stride;
     const int out_py = d.nphase > 1 ? (ph >> 1) : d.out_py, out_px = d.nphase > 1 ? (ph & 1) : d.out_px;
 
-
-    // ---- per-tile tables, one output pixel per thread (tid < 128), everything that does not change from K step
-    // to K step: byte offset of the pixel's row in the output / residual tensors, byte offset of its (0,0) tap in
-    // the input, and a 16-bit mask of the taps that fall inside the image.  Tap offsets are read from the kernel
-    // arguments (scalar registers), so the only long-latency operation here is one integer division.
-    // Invalid rows / taps get offsets beyond their buffer: buffer loads then return 0 and buffer stores are dropped
-    // by the hardware range check - no branches anywhere downstream.
     constexpr int INVALID = 0x7fff0000;
     uint32_t dyw[4], dxw[4];
     __builtin_memcpy(dyw, d.dy, 16);
     __builtin_memcpy(dxw, d.dx, 16);
-    if (d.nphase > 1) {                                          // 4 phases x 4 taps: phase p owns bytes [4p, 4p+4)
+    if (d.nphase > 1) {
         dyw[0] = ph == 0 ? dyw[0] : ph == 1 ? dyw[1] : ph == 2 ? dyw[2] : dyw[3];
         dxw[0] = ph == 0 ? dxw[0] : ph == 1 ? dxw[1] : ph == 2 ? dxw[2] : dxw[3];
     }
@@ -96,7 +91,6 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
             const int Y = oy * d.out_stride + out_py, X = ox * d.out_stride + out_px;
             opix = Y * d.OWf + X;
             rpb = ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (X >> d.res1_shift)) * d.Cout * 4;
-            // batch: images are stacked along y on both sides (OH, OHf count all of them); only the input window is per image
             int img = 0, oyl = oy;
             if (d.batch > 1) { const int ohi = d.OH / d.batch; img = oy / ohi; oyl = oy - img * ohi; }
             const int iy0 = oyl * d.in_stride, ix0 = ox * d.in_stride;
@@ -117,60 +111,53 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
     }
     __syncthreads();
 
-    // ---- staging assignment: thread -> (4 pixels 32 apart, one float4 of the 32-wide K slice)
-    const int q = tid & 7;
+    // ---- staging assignment: lane -> (4 of this wave's rows, 8 apart; one float4 of the 32-wide K slice)
+    const int q = lane & 7;
     const bool cin_pow2 = (d.Cin & (d.Cin - 1)) == 0;
     const int log2cin = 31 - __builtin_clz(d.Cin);
     int vbase[4];
     unsigned vmask[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        vbase[j] = s_vbase[(tid >> 3) + 32 * j];
-        vmask[j] = (unsigned)s_vmask[(tid >> 3) + 32 * j];
+        vbase[j] = s_vbase[32 * rg + (lane >> 3) + 8 * j];
+        vmask[j] = (unsigned)s_vmask[32 * rg + (lane >> 3) + 8 * j];
     }
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(d.in), 0, (d.batch > 1 ? d.batch : 1) * d.IH * d.IW * d.Cin * 4, 0x00020000);
     const int wbytes = nch_all * 8 * d.Cout * 16;
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpk), 0, wbytes, 0x00020000);
-    const int bkq = tid >> 5, bn = tid & 31;
-    const int wbase = (bkq * d.Cout + nb0 + bn) * 16;          // bytes; + 32*16 per extra N tile, + 8*Cout*16 per chunk
-    const int wstep = 8 * d.Cout * 16;
+    // B fragment of MFMA group g (4 MFMAs = k rows 8g .. 8g+7), N tile j: float4 at ((8c + 2g + h) * Cout + nb0 + 32j + n) * 16 bytes
+    const int wbase = ((lane >> 5) * d.Cout + nb0 + (lane & 31)) * 16;
+    const int wstep = 8 * d.Cout * 16, wg2 = 2 * d.Cout * 16;
+    float* const Aw = As[wave];
 
-    // Two register sets: chunk c+2 is requested while chunk c is multiplied, so a global load has two MFMA
-    // phases (~2 x 1024 cycles) to land before its ds_write.
-    float4 ra0[4], rb0[NT], ra1[4], rb1[NT];
-    // Loads are unconditional: a chunk index past this block's K range (c >= c_end) gets out-of-range offsets and
-    // comes back as zeros, so the main loop has no branches and hipcc can count vmcnt exactly.
-    auto load_chunk = [&](int c, float4 (&ra)[4], float4 (&rb)[NT]) {
+    float4 ra0[4], ra1[4], bf[4 * NT];
+    auto load_a = [&](int c, float4 (&ra)[4]) {
         const bool live = c < c_end;
         const int k0 = c * KC + 4 * q;
-        // tap of this thread's float4: a shift when Cin is a power of two (a 32-wide K slice may then span several
-        // taps, Cin = 4 / 8 / 16); otherwise Cin is a multiple of 32 and the whole slice lies in one tap
-        const int tap = cin_pow2 ? (k0 >> log2cin) : (c * KC) / d.Cin;      // >= ntaps in the zero-padded K tail: mask bit is 0
+        const int tap = cin_pow2 ? (k0 >> log2cin) : (c * KC) / d.Cin;
         const int koff = s_toff[tap & 15] + ((k0 - tap * d.Cin) << 2);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const bool ok = live && ((vmask[j] >> tap) & 1u);
-            const int off = ok ? vbase[j] + koff : 0x7ffffff0;
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? vbase[j] + koff : 0x7ffffff0, 0, 0);
             ra[j] = *reinterpret_cast<const float4*>(&v);
         }
+    };
+    auto load_b = [&](int c, int g) {                      // the fragments of MFMA group g of chunk c
 #pragma unroll
         for (int j = 0; j < NT; j++) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, live ? wbase + c * wstep + j * 512 : 0x7ffffff0, 0, 0);
-            rb[j] = *reinterpret_cast<const float4*>(&v);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, c < c_end ? wbase + c * wstep + g * wg2 + j * 512 : 0x7ffffff0, 0, 0);
+            bf[g * NT + j] = *reinterpret_cast<const float4*>(&v);
         }
     };
-    auto store_chunk = [&](int buf, const float4 (&ra)[4], const float4 (&rb)[NT]) {
+    auto stage = [&](const float4 (&ra)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float4 a = ra[j];
-            if (IN_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }   // conv(relu(x))
-            *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * j) * APITCH + 4 * q]) = a;
+            if (IN_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+            *reinterpret_cast<float4*>(&Aw[((lane >> 3) + 8 * j) * APITCH + 4 * q]) = a;
         }
-#pragma unroll
-        for (int j = 0; j < NT; j++)
-            *reinterpret_cast<float4*>(&Bs[buf][(bkq * (32 * NT) + bn + 32 * j) * 4]) = rb[j];
     };
 
     f32x16 acc[NT];
@@ -179,53 +166,52 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
 
-    const int arow = (32 * wave + (lane & 31)) * APITCH + 4 * (lane >> 5);
-    auto compute = [&](int buf) {
+    const int arow = (lane & 31) * APITCH + 4 * (lane >> 5);
+    // One K step: the staged chunk's fragments -> registers; request chunk + 2 of A; per MFMA group multiply and then
+    // re-request that group's weight fragments for chunk + 1 into the registers just consumed (a rolling window: one
+    // register set, almost a full step of latency cover); late in the run put A chunk + 1 (requested one step ago) into
+    // the LDS image the fragments have left.
+    auto step = [&](int c, float4 (&ra_next)[4], float4 (&ra_far)[4]) {
+        float4 a[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) a[g] = *reinterpret_cast<const float4*>(&Aw[arow + g * 8]);
+        load_a(c + 2, ra_far);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const float4 a = *reinterpret_cast<const float4*>(&As[buf][arow + g * 8]);
+            if (g == 3) stage(ra_next);
 #pragma unroll
             for (int j = 0; j < NT; j++) {
-                const float4 b = *reinterpret_cast<const float4*>(&Bs[buf][((g * 2 + (lane >> 5)) * (32 * NT) + j * 32 + (lane & 31)) * 4]);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[j], 0, 0, 0);
+                const float4 b = bf[g * NT + j];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, b.x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, b.y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, b.z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, b.w, acc[j], 0, 0, 0);
             }
+            load_b(c + 1, g);
         }
     };
 
-    load_chunk(c_begin, ra0, rb0);
-    load_chunk(c_begin + 1, ra1, rb1);
-    store_chunk(0, ra0, rb0);
-    __syncthreads();
+    load_a(c_begin, ra0);
+#pragma unroll
+    for (int g = 0; g < 4; g++) load_b(c_begin, g);
+    load_a(c_begin + 1, ra1);
+    stage(ra0);
     int c = c_begin;
     for (; c + 1 < c_end; c += 2) {
-        load_chunk(c + 2, ra0, rb0);
-        compute(0);
-        store_chunk(1, ra1, rb1);
-        __syncthreads();
-        load_chunk(c + 3, ra1, rb1);
-        compute(1);
-        store_chunk(0, ra0, rb0);
-        __syncthreads();
+        step(c, ra1, ra0);
+        step(c + 1, ra0, ra1);
     }
-    if (c < c_end) compute(0);          // odd chunk count: the last chunk is already staged in buffer 0
+    if (c < c_end) step(c, ra1, ra0);          // odd count: the trailing requests are out of range (zeros, no traffic)
 
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): a lane
-    // holds ONE channel of 16 rows, which would mean 16 scattered dword stores per tile.  Each wave therefore bounces its
-    // 32 x 32 tile through its own rows of LDS buffer 1 (free since the last barrier; only this wave touches them) and
-    // re-reads it row-major, 4 channels per lane: every global access of the epilogue is then 16 bytes per lane and a
-    // wave instruction covers eight 128-byte rows.  Offsets are 32-bit and go through buffer instructions: rows past the
-    // end of the image carry an out-of-range offset and are dropped (stores) / read as zero (residuals).
-    float* const T = &As[1][(32 * wave) * APITCH];
+    // ---- epilogue: as above, through this wave's own LDS image (free now); K groups > 0 only deposit their partial tile
+    float* const T = Aw;
     const int out_ld = d.out_ld > 0 ? d.out_ld : d.Cout;
     const int out_bytes = d.OHf * d.OWf * d.Cout * 4;
-    const int erow = lane >> 3, ec4 = (lane & 7) * 4;            // this lane's row (per pass of 8 rows) and first channel
-    int ops[4], oos[4], rps[4];                                   // dense [pixel][Cout] offset, output offset, residual offset
+    const int erow = lane >> 3, ec4 = (lane & 7) * 4;
+    int ops[4], oos[4], rps[4];
 #pragma unroll
     for (int ps = 0; ps < 4; ps++) {
-        const int p = 32 * wave + ps * 8 + erow;
+        const int p = 32 * rg + ps * 8 + erow;
         const int opix = s_outpix[p];
         ops[ps] = opix < 0 ? INVALID : opix * d.Cout * 4;
         oos[ps] = opix < 0 ? INVALID : (opix * out_ld + d.out_c0) * 4;
@@ -241,26 +227,33 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
         const_cast<float*>(d.res2), 0, (has_r2 && S == 1) ? out_bytes : 0, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NT; j++) {
+        if (KW > 1 && j > 0) __syncthreads();                     // the previous tile has been read by K group 0
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float a = acc[j][r];
-            T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * APITCH + (lane & 31)] = a;
-        }
+        for (int r = 0; r < 16; r++) T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * APITCH + (lane & 31)] = acc[j][r];
+        if (KW > 1) __syncthreads();
+        if (kg != 0) continue;
         const int n = nb0 + j * 32 + ec4;
         const int nb4 = n * 4;
-        if (S > 1) {                 // partial sums only; splitk_reduce_kernel finishes the layer
+        float4 tv[4];
 #pragma unroll
-            for (int ps = 0; ps < 4; ps++) {
-                const float4 v = *reinterpret_cast<const float4*>(&T[(ps * 8 + erow) * APITCH + ec4]);
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), out_rsrc, ops[ps] + nb4, 0, 0);
+        for (int ps = 0; ps < 4; ps++) {
+            float4 t = *reinterpret_cast<const float4*>(&T[(ps * 8 + erow) * APITCH + ec4]);
+#pragma unroll
+            for (int k = 1; k < KW; k++) {                        // slice order: ((p0 + p1) + p2) + p3
+                const float4 u = *reinterpret_cast<const float4*>(&As[4 * k + rg][(ps * 8 + erow) * APITCH + ec4]);
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
             }
+            tv[ps] = t;
+        }
+        if (S > 1) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++)
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&tv[ps]), out_rsrc, ops[ps] + nb4, 0, 0);
             continue;
         }
         float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bias;
         if (d.bias) bias = *reinterpret_cast<const float4*>(d.bias + n);
         if (has_aff) { sc = *reinterpret_cast<const float4*>(d.scale + n); sh = *reinterpret_cast<const float4*>(d.shift + n); }
-        // residual loads of all four passes are issued before their first use (one wait); a zero-sized descriptor
-        // (no residual) turns them into zeros without touching memory
         u32x4 r1v[4], r2v[4];
 #pragma unroll
         for (int ps = 0; ps < 4; ps++) {
@@ -269,7 +262,7 @@ __global__ __launch_bounds__(THREADS) void conv_mfma_kernel(usc_conv_desc d) {
         }
 #pragma unroll
         for (int ps = 0; ps < 4; ps++) {
-            const float4 t = *reinterpret_cast<const float4*>(&T[(ps * 8 + erow) * APITCH + ec4]);
+            const float4 t = tv[ps];
             const float4 r1 = *reinterpret_cast<const float4*>(&r1v[ps]), r2 = *reinterpret_cast<const float4*>(&r2v[ps]);
             float v[4] = {t.x + bias.x, t.y + bias.y, t.z + bias.z, t.w + bias.w};
             const float a1[4] = {r1.x, r1.y, r1.z, r1.w}, a2[4] = {r2.x, r2.y, r2.z, r2.w};
@@ -395,7 +388,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     const long long M = (long long)d.OH * d.OW;
     p.d = d;
     p.reduce = false;
-    p.block = dim3(THREADS);
+    p.block = dim3(256);
     if (d.kind == USC_CONV_HEAD) {
         if (d.Cout != 1 || d.Cin != 32 || d.ntaps != 9 || d.in_stride != 1 || d.IH != d.OH || d.IW != d.OW)
             return conv_fail(USC_E_UNSUPPORTED, "usc_conv: the head kernel is Conv2d(32, 1, 3, padding=1)");
@@ -417,33 +410,48 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     if (nphase != 1 && nphase != 4) return conv_fail(USC_E_ARG, "usc_conv: nphase must be 1 or 4");
     if (nphase * d.ntaps > 16) return conv_fail(USC_E_ARG, "usc_conv: more than 16 taps");
     const int mblocks = (int)((M + BM - 1) / BM);
-    // two 32-column tiles per workgroup only while that still leaves >= 2 workgroups per CU
-    // (tile shape and K split are decided per image, so that a batched layer sums K in exactly the order the single-image
-    // layer does)
-    const long long mblocks_img = (M / nbatch + BM - 1) / BM;
-    const bool nt2 = (d.Cout % 64 == 0) && (mblocks_img * (d.Cout / 64) * nphase >= 512);
+    // Tile shape and K partition are planned for `plan_batch` images of this layer's per-image size, whatever `batch` is:
+    // a batched layer then sums K in exactly the order the single-image layer of the same plan does.
+    // Two 32-column tiles per workgroup only while that still leaves >= 2 workgroups per CU.
+    const int plan_batch = d.plan_batch > 1 ? d.plan_batch : 1;
+    const long long mblocks_plan = (M / nbatch * plan_batch + BM - 1) / BM;
+    static const int nt2_min = getenv("USC_NT2_MIN") ? atoi(getenv("USC_NT2_MIN")) : 512;
+    const bool nt2 = (d.Cout % 64 == 0) && (mblocks_plan * (d.Cout / 64) * nphase >= nt2_min);
     const int nblocks = nt2 ? d.Cout / 64 : d.Cout / 32;
-    // split K when the grid would leave most CUs idle (M = 510 ... 2040 layers)
-    const long long blocks = mblocks_img * nblocks * nphase;
+    const long long blocks = mblocks_plan * nblocks * nphase;
     const int nch = (d.ntaps * d.Cin + KC - 1) / KC;
-    int S = 1;
-    static const int split_below = getenv("USC_SPLIT_BELOW") ? atoi(getenv("USC_SPLIT_BELOW")) : 384;      // tuning knobs
-    static const int split_target = getenv("USC_SPLIT_TARGET") ? atoi(getenv("USC_SPLIT_TARGET")) : 768;
-    if (d.slab && blocks < split_below) {
-        S = (int)((split_target + blocks - 1) / blocks);
-        if (S > nch / 6) S = nch / 6;          // a slice needs >= 6 K steps to amortise its prologue / epilogue / reduce
-        if (S > 16) S = 16;
-        const size_t need = (size_t)S * d.OHf * d.OWf * d.Cout * sizeof(float);
-        if (need > d.slab_bytes) S = (int)(d.slab_bytes / ((size_t)d.OHf * d.OWf * d.Cout * sizeof(float)));
-        if (S < 1) S = 1;
+    // Parallelism over K for layers with few tiles: F slices in all, wanted so that every SIMD holds ~4 waves.  The
+    // grid-level split (S, through the slab) only as far as needed to put a workgroup on every CU, the rest as K groups
+    // inside the workgroup (KW: no slab traffic, partial sums meet in LDS).
+    static const int kw_target = getenv("USC_KW_TARGET") ? atoi(getenv("USC_KW_TARGET")) : 768;           // tuning knobs
+    static const int f_target = getenv("USC_F_TARGET") ? atoi(getenv("USC_F_TARGET")) : 1024;
+    static const int wg_min = getenv("USC_WG_MIN") ? atoi(getenv("USC_WG_MIN")) : 256;
+    static const int min_steps = getenv("USC_MIN_STEPS") ? atoi(getenv("USC_MIN_STEPS")) : 9;
+    int KW = 1, S = 1;
+    if (blocks < kw_target) {
+        int F = (int)((f_target + blocks - 1) / blocks);
+        if (F > nch / min_steps) F = nch / min_steps;
+        if (F < 1) F = 1;
+        if (d.slab && blocks < wg_min) {
+            S = (int)((wg_min + blocks - 1) / blocks);
+            if (S > F) S = F;
+            if (S > 16) S = 16;
+            const size_t plane = (size_t)d.OHf * d.OWf * d.Cout * sizeof(float);
+            if ((size_t)S * plane > d.slab_bytes) S = (int)(d.slab_bytes / plane);
+            if (S < 1) S = 1;
+        }
+        KW = F / S;
+        KW = KW >= 4 ? 4 : KW >= 2 ? 2 : 1;
+        if (nt2 && KW > 2) KW = 2;          // 16 waves of the 64-column tile would not fit the register file
     }
     p.d.ksplit = S;
     p.d.nphase = nphase;
     p.grid = dim3(mblocks * nblocks, 1, nphase * S);          // 1-D over (pixel tile, N tile): the kernel re-labels it per XCD
-    if (d.in_relu)
-        p.fn = nt2 ? (void*)conv_mfma_kernel<2, true> : (void*)conv_mfma_kernel<1, true>;
-    else
-        p.fn = nt2 ? (void*)conv_mfma_kernel<2, false> : (void*)conv_mfma_kernel<1, false>;
+    p.block = dim3(256 * KW);
+#define USC_PICK(NTV, KWV) (d.in_relu ? (void*)conv_mfma_kernel<NTV, KWV, true> : (void*)conv_mfma_kernel<NTV, KWV, false>)
+    p.fn = nt2 ? (KW >= 2 ? USC_PICK(2, 2) : USC_PICK(2, 1))
+               : (KW == 4 ? USC_PICK(1, 4) : KW == 2 ? USC_PICK(1, 2) : USC_PICK(1, 1));
+#undef USC_PICK
     if (S > 1) {
         const long long items = (long long)d.OHf * d.OWf * (d.Cout / 4);
         int rb = (int)((items + 255) / 256);

@@ -114,6 +114,8 @@ class BgStepPipeline:
         self.slots = [_Slot(H, W, dev) for _ in range(3)]
         self.seg_agent = seg_agent
         self.seg_batch = max(1, int(seg_batch))
+        if seg_agent is not None and hasattr(seg_agent, "set_plan_batch"):
+            seg_agent.set_plan_batch(self.seg_batch)       # step() and run() then segment a frame to the same bits
         self._seg_ring = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in range(2 * self.seg_batch)] if seg_agent is not None else []
         self.alpha_pre = None
 

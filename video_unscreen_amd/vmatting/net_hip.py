@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ("dy", C.c_byte * 16), ("dx", C.c_byte * 16),
                 ("nphase", C.c_int), ("wphase_stride", C.c_int), ("ksplit", C.c_int), ("in_relu", C.c_int),
                 ("slab", C.c_void_p), ("slab_bytes", C.c_size_t), ("out_ld", C.c_int), ("out_c0", C.c_int),
-                ("batch", C.c_int), ("pad0", C.c_int)]
+                ("batch", C.c_int), ("plan_batch", C.c_int)]
 
 
 def d_out_elems(OH, OW, out_stride, OHf, OWf, Cout):
