@@ -333,7 +333,9 @@ const char* usc_conv_last_error(void);
 
 /* The same layer list as a pre-instantiated hipGraph (one node per launch; edges follow the buffers each layer
  * reads, so independent branches run concurrently).  The descriptors are copied; the buffers they point to must
- * stay valid until usc_conv_graph_destroy.  One handle may be in flight on one stream at a time. */
+ * stay valid until usc_conv_graph_destroy.  A handle is instantiated once per stream it is launched on (at that stream's
+ * first launch); launches of one handle must come from one host thread at a time, and - its layers sharing their
+ * activation buffers - must not overlap on the device (launch it on one stream, or order the streams). */
 int  usc_conv_graph_create(const usc_conv_desc* descs, int n, void** handle);
 int  usc_conv_graph_launch(void* handle, usc_stream_t stream);
 void usc_conv_graph_destroy(void* handle);

@@ -236,8 +236,8 @@ def test_pipelined_run_equals_step(nv, cfg):
 
 def test_pipelined_run_with_batched_segmentation_is_identical(nv, cfg):
     """run() with the human-parsing net segmenting 3 frames per forward (7 frames: groups of 3, 3, 1) gives exactly the
-    frames of the per-frame loop: masks, trimaps, alphas and foregrounds (the HIP convs have a fixed summation order and the
-    batched layers keep the per-image K split)."""
+    frames of the per-frame loop step(): masks, trimaps, alphas and foregrounds (the HIP convs have a fixed summation order and
+    the batched layers keep the K partition of the pipeline's plan, whatever the batch)."""
     from video_unscreen_amd.binseg import HumanSegAgent
     from video_unscreen_amd.pipeline import BgStepPipeline
     from video_unscreen_amd.synth import SyntheticClip
@@ -247,11 +247,17 @@ def test_pipelined_run_with_batched_segmentation_is_identical(nv, cfg):
     bga = clip.bg_always.cuda()
     ins = [(f["frame"].cuda(), f["seg"].cuda(), f["bg"].cuda(), bga) for f in frames]
     agent = HumanSegAgent(model_path=None)
+    keys = ("seg", "trimap", "alpha", "fg")
     outs = []
-    for sb in (1, 3):
-        pipe = BgStepPipeline(cfg, H, W, seg_agent=agent, seg_batch=sb)
+    for mode in ("step", "run"):
+        pipe = BgStepPipeline(cfg, H, W, seg_agent=agent, seg_batch=3)       # both plan the conv K partitions for 3 frames
         got = []
-        pipe.run(iter(ins), on_result=lambda k, o: got.append(tuple(o[key].clone() for key in ("seg", "trimap", "alpha", "fg"))))
+        if mode == "run":
+            pipe.run(iter(ins), on_result=lambda k, o: got.append(tuple(o[key].clone() for key in keys)))
+        else:
+            for i in ins:
+                o = pipe.step(*i)
+                got.append(tuple(o[key].clone() for key in keys))
         torch.cuda.synchronize()
         assert len(got) == n
         outs.append(got)

@@ -7,4 +7,4 @@ run() {  # name, env...
   env "$@" B=4 python tools/dev/profile_schp.py > $out/schp_$name.txt 2>&1 || return 1
   echo "$name: $(grep 'whole forward' $out/unet_$name.txt) | $(tail -1 $out/schp_$name.txt)"
 }
-run base USC_MIN_STEPS=9 && run q4 USC_MIN_STEPS=9 USC_F_TARGET=256 USC_WG_MIN=64 USC_KW_TARGET=192 && run q3 USC_MIN_STEPS=9 USC_F_TARGET=384 USC_WG_MIN=64 USC_KW_TARGET=256 && run q2 USC_MIN_STEPS=9 USC_F_TARGET=512 USC_WG_MIN=128 USC_KW_TARGET=384 && run q4b USC_MIN_STEPS=9 USC_F_TARGET=256 USC_WG_MIN=32 USC_KW_TARGET=192
+run kw9 USC_KW_STEPS=9 PLAN=4 && run kw2 PLAN=4 && run kw4 USC_KW_STEPS=4 PLAN=4 && run ms6 USC_MIN_STEPS=6 PLAN=4 && run ms12 USC_MIN_STEPS=12 PLAN=4

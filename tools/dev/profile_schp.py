@@ -6,7 +6,7 @@ from video_unscreen_amd import _native as nv
 from video_unscreen_amd.binseg.schp_net import HipSchpNet, schp_synthetic_state_dict
 from video_unscreen_amd.vmatting.net_hip import ConvDesc
 B = int(os.environ.get('B', '1'))
-net = HipSchpNet(schp_synthetic_state_dict(0), 473, 473, batch=B)
+net = HipSchpNet(schp_synthetic_state_dict(0), 473, 473, batch=B, plan_batch=int(os.environ.get('PLAN', '1')))
 lib = nv.load(); st = torch.cuda.current_stream().cuda_stream
 net.x4.normal_(); net(); torch.cuda.synchronize()
 groups = collections.OrderedDict()

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <utility>
 #include <vector>
 
 #include "../../include/unscreen_hip.h"
@@ -428,7 +429,41 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     static const int wg_min = getenv("USC_WG_MIN") ? atoi(getenv("USC_WG_MIN")) : 256;
     static const int min_steps = getenv("USC_MIN_STEPS") ? atoi(getenv("USC_MIN_STEPS")) : 9;
     int KW = 1, S = 1;
-    if (blocks < kw_target) {
+    static const int use_model = getenv("USC_PLAN_MODEL") ? atoi(getenv("USC_PLAN_MODEL")) : 1;
+    if (use_model) {
+        // Cost model (microseconds) of one layer for every admissible (S, KW); all inputs are plan quantities.
+        //   a wave needs n = nch / (S KW) K steps; a step costs 1024 MFMA cycles (0.43 us) times the W waves that share the
+        //   SIMD, but never less than the ~1 us a lone wave needs per step (load latency it cannot hide on its own);
+        //   W = (workgroups on the busiest CU) x KW, in rounds when they exceed the CU's wave slots;
+        //   a grid split adds the reduce launch and the slab round trip.
+        static const double t_step = getenv("USC_T_STEP") ? atof(getenv("USC_T_STEP")) : 0.43;
+        static const double t_lone = getenv("USC_T_LONE") ? atof(getenv("USC_T_LONE")) : 1.5;
+        static const double t_fixed = getenv("USC_T_FIXED") ? atof(getenv("USC_T_FIXED")) : 3.0;
+        static const double t_reduce = getenv("USC_T_REDUCE") ? atof(getenv("USC_T_REDUCE")) : 8.0;
+        const double plane_mb = (double)(M / nbatch) * plan_batch * d.Cout * 4e-6 * nphase;
+        const int slots = nt2 ? 3 : 4;                               // waves per SIMD the register file admits
+        double best = 1e30;
+        for (int s = 1; s <= 16; s++) {
+            if (s > 1 && (!d.slab || (size_t)s * d.OHf * d.OWf * d.Cout * sizeof(float) > d.slab_bytes)) break;
+            for (int kw = 1; kw <= 4; kw *= 2) {
+                static const int kw_steps = getenv("USC_KW_STEPS") ? atoi(getenv("USC_KW_STEPS")) : 4;
+                if (kw > slots || (s > 1 && nch / (s * kw) < min_steps) || (kw > 1 && nch / (s * kw) < kw_steps)) continue;
+                const int n = (nch + s * kw - 1) / (s * kw);
+                const long long wgs = blocks * s;
+                const int per_cu = (int)((wgs + 255) / 256);          // workgroups on the busiest CU
+                const int fit = slots / kw;                           // workgroups a CU holds at once
+                double t = 0.;
+                for (int left = per_cu; left > 0; left -= fit) {
+                    const int W = (left < fit ? left : fit) * kw;
+                    const double per_step = t_step * W > t_lone ? t_step * W : t_lone;
+                    t += n * per_step + t_fixed;
+                }
+                if (s > 1) t += t_reduce + plane_mb * (s + 1.0) / 3.0;        // slab write + read at ~3 TB/s effective
+                t += 0.3 * (kw - 1);                                          // partial tiles meet in LDS
+                if (t < best - 1e-9) { best = t; S = s; KW = kw; }
+            }
+        }
+    } else if (blocks < kw_target) {
         int F = (int)((f_target + blocks - 1) / blocks);
         if (F > nch / min_steps) F = nch / min_steps;
         if (F < 1) F = 1;
@@ -484,7 +519,9 @@ extern "C" int usc_conv_sequence_f32(const usc_conv_desc* descs, int n, usc_stre
 // ramp / tail of the main chain, and one hipGraphLaunch replaces ~85 kernel launches per frame.
 struct ConvGraph {
     hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+    // One instantiation per stream the graph is launched on: an executable graph that has run on one stream is not
+    // launched on another (observed to fault on ROCm 7.2 when the first stream was the null stream).
+    std::vector<std::pair<hipStream_t, hipGraphExec_t>> execs;
     std::vector<LayerPlan> plans;          // kernel arguments must outlive the graph
 };
 
@@ -530,10 +567,6 @@ extern "C" int usc_conv_graph_create(const usc_conv_desc* descs, int n, void** h
             last[i] = rnode;
         }
     }
-    if (hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) {
-        (void)hipGraphDestroy(g->graph); delete g;
-        return conv_fail(USC_E_LAUNCH, "hipGraphInstantiate failed");
-    }
     *handle = g;
     return USC_OK;
 }
@@ -541,7 +574,15 @@ extern "C" int usc_conv_graph_create(const usc_conv_desc* descs, int n, void** h
 extern "C" int usc_conv_graph_launch(void* handle, usc_stream_t stream) {
     if (!handle) return conv_fail(USC_E_ARG, "usc_conv_graph_launch: null handle");
     ConvGraph* g = (ConvGraph*)handle;
-    hipError_t e = hipGraphLaunch(g->exec, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    hipGraphExec_t exec = nullptr;
+    for (auto& se : g->execs)
+        if (se.first == st) exec = se.second;
+    if (!exec) {
+        if (hipGraphInstantiate(&exec, g->graph, nullptr, nullptr, 0) != hipSuccess) return conv_fail(USC_E_LAUNCH, "hipGraphInstantiate failed");
+        g->execs.emplace_back(st, exec);
+    }
+    hipError_t e = hipGraphLaunch(exec, st);
     if (e != hipSuccess) return conv_fail(USC_E_LAUNCH, hipGetErrorString(e));
     return USC_OK;
 }
@@ -549,7 +590,7 @@ extern "C" int usc_conv_graph_launch(void* handle, usc_stream_t stream) {
 extern "C" void usc_conv_graph_destroy(void* handle) {
     if (!handle) return;
     ConvGraph* g = (ConvGraph*)handle;
-    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    for (auto& se : g->execs) (void)hipGraphExecDestroy(se.second);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;
 }

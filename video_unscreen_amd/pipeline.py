@@ -116,7 +116,7 @@ class BgStepPipeline:
         self.seg_batch = max(1, int(seg_batch))
         if seg_agent is not None and hasattr(seg_agent, "set_plan_batch"):
             seg_agent.set_plan_batch(self.seg_batch)       # step() and run() then segment a frame to the same bits
-        self._seg_ring = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in range(2 * self.seg_batch)] if seg_agent is not None else []
+        self._seg_ring = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in range(3 * self.seg_batch)] if seg_agent is not None else []
         self.alpha_pre = None
 
     def cpu_net(self):
@@ -216,34 +216,50 @@ class BgStepPipeline:
         submitted = 0
         try:
             it = iter(inputs)
-            exhausted = False
             ahead = []                                      # inputs whose segmentation mask is already enqueued
-            ngroups = 0
             batched = self.seg_agent is not None and self.seg_batch > 1
+            seg_stream = torch.cuda.Stream(self.device) if batched else None
+            state = {"exhausted": False, "ngroups": 0}
+
+            def launch_group():
+                """Fetch the next seg_batch inputs and enqueue their segmentation forward on the segmentation stream, where it
+                runs beside the stage-3 work of the group before it (two MFMA-bound streams fill each other's launch gaps
+                and tails).  Three alternating sets of mask buffers: a set is rewritten three groups later, when every
+                frame of its group has left the pipeline (the group in flight + the one ahead + at most 2 pending frames)."""
+                group = []
+                while not state["exhausted"] and len(group) < self.seg_batch:
+                    try:
+                        group.append(next(it))
+                    except StopIteration:
+                        state["exhausted"] = True
+                if not group:
+                    return []
+                first = (state["ngroups"] % 3) * self.seg_batch
+                state["ngroups"] += 1
+                seg_stream.wait_stream(main)                # frames produced on the main stream
+                with torch.cuda.stream(seg_stream):
+                    masks = self.seg_agent.forward_device_batch([g[0] for g in group], outs=self._seg_ring[first:first + len(group)])
+                    ev = torch.cuda.Event()
+                    ev.record(seg_stream)
+                return [(g[0], m, g[2], g[3], ev) for g, m in zip(group, masks)]
+
+            nxt = None
             while True:
-                while (ahead or not exhausted) and len(pending) < 2:
+                while (ahead or nxt or not state["exhausted"]) and len(pending) < 2:
                     if not ahead:
-                        group = []
-                        while len(group) < (self.seg_batch if batched else 1):
-                            try:
-                                group.append(next(it))
-                            except StopIteration:
-                                exhausted = True
-                                break
-                        if not group:
-                            break
                         if batched:
-                            # two alternating sets of mask buffers: a set is rewritten two groups later, when every frame
-                            # of its group has left the pipeline (at most 2 frames are pending)
-                            half = (ngroups % 2) * self.seg_batch
-                            ngroups += 1
-                            front.wait_stream(main)
-                            with torch.cuda.stream(front):
-                                masks = self.seg_agent.forward_device_batch([g[0] for g in group],
-                                                                            outs=self._seg_ring[half:half + len(group)])
-                            group = [(g[0], m, g[2], g[3]) for g, m in zip(group, masks)]
-                        ahead.extend(group)
-                    frame, seg, bg_i, bg_always = ahead.pop(0)
+                            ahead = nxt if nxt is not None else launch_group()
+                            nxt = launch_group()            # one group ahead
+                        else:
+                            try:
+                                ahead = [tuple(next(it)) + (None,)]
+                            except StopIteration:
+                                state["exhausted"] = True
+                        if not ahead:
+                            break
+                    frame, seg, bg_i, bg_always, seg_ev = ahead.pop(0)
+                    if seg_ev is not None:
+                        front.wait_event(seg_ev)
                     slot = self.slots[submitted % len(self.slots)]
                     slot.frame = frame
                     front.wait_stream(main)                 # inputs produced on the main stream
