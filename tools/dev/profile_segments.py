@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from video_unscreen_amd.binseg.schp_net import HipSchpNet, schp_synthetic_state_dict
 B = int(os.environ.get("B", "4"))
-net = HipSchpNet(schp_synthetic_state_dict(0), 473, 473, batch=B)
+net = HipSchpNet(schp_synthetic_state_dict(0), 473, 473, batch=B, plan_batch=B)
 net.x4.normal_(); net.run(); torch.cuda.synchronize()
 lib = net.nv.load(); st = torch.cuda.current_stream().cuda_stream
 tot = 0

@@ -6,6 +6,7 @@ of wide (16 B/lane) coalesced streaming reads; narrower access widths are uncali
 are listed for the read side and the one that applies is named per kernel."""
 import collections
 import csv
+import re
 import sys
 
 stats_f, fetch_f, write_f, frames, title = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
@@ -15,11 +16,14 @@ OURS = ("conv_mfma_kernel", "splitk_reduce_kernel", "head_conv_kernel", "bgdiff_
 
 
 def short(name):
+    """conv_mfma_kernel<NT, KW, IN_RELU> -> conv_mfma_kernel<NT>: the 32- and the 64-column tile (K groups and the input ReLU
+    do not change the traffic pattern)."""
     for o in OURS:
         if o in name:
             if o != "conv_mfma_kernel":
                 return o
-            return o + ("<2>" if ("ILi2E" in name or "<2>" in name or "<2," in name) else "<1>")
+            m = re.search(r"conv_mfma_kernel<(\d)", name) or re.search(r"conv_mfma_kernelILi(\d)E", name)
+            return o + "<%s>" % (m.group(1) if m else "?")
     return None
 
 

@@ -374,6 +374,11 @@ static int conv_fail(int code, const char* msg) {
     return code;
 }
 
+// Tuning hook: force (tile width, grid K split, K groups) for every layer planned from this thread (0 = let the planner
+// decide).  Used by tools/dev/tune_convs.py to time all admissible plans of a layer shape on the device.
+static thread_local int g_force_nt = 0, g_force_s = 0, g_force_kw = 0;
+extern "C" void usc_conv_force_plan(int nt, int ksplit, int kgroups) { g_force_nt = nt; g_force_s = ksplit; g_force_kw = kgroups; }
+
 // One layer = one main launch (+ one reduce launch when K is split).
 struct LayerPlan {
     usc_conv_desc d;
@@ -417,36 +422,46 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     const int plan_batch = d.plan_batch > 1 ? d.plan_batch : 1;
     const long long mblocks_plan = (M / nbatch * plan_batch + BM - 1) / BM;
     static const int nt2_min = getenv("USC_NT2_MIN") ? atoi(getenv("USC_NT2_MIN")) : 512;
-    const bool nt2 = (d.Cout % 64 == 0) && (mblocks_plan * (d.Cout / 64) * nphase >= nt2_min);
+    bool nt2 = (d.Cout % 64 == 0) && (mblocks_plan * (d.Cout / 64) * nphase >= nt2_min);
+    const int m_plan = (int)(M / nbatch * plan_batch);
+    if (g_force_nt) nt2 = g_force_nt == 2 && d.Cout % 64 == 0;
     const int nblocks = nt2 ? d.Cout / 64 : d.Cout / 32;
     const long long blocks = mblocks_plan * nblocks * nphase;
     const int nch = (d.ntaps * d.Cin + KC - 1) / KC;
-    // Parallelism over K for layers with few tiles: F slices in all, wanted so that every SIMD holds ~4 waves.  The
-    // grid-level split (S, through the slab) only as far as needed to put a workgroup on every CU, the rest as K groups
-    // inside the workgroup (KW: no slab traffic, partial sums meet in LDS).
-    static const int kw_target = getenv("USC_KW_TARGET") ? atoi(getenv("USC_KW_TARGET")) : 768;           // tuning knobs
-    static const int f_target = getenv("USC_F_TARGET") ? atoi(getenv("USC_F_TARGET")) : 1024;
-    static const int wg_min = getenv("USC_WG_MIN") ? atoi(getenv("USC_WG_MIN")) : 256;
-    static const int min_steps = getenv("USC_MIN_STEPS") ? atoi(getenv("USC_MIN_STEPS")) : 9;
+    // Parallelism over K for layers with few tiles: the grid may split K into S slices (partial sums through the slab and
+    // splitk_reduce_kernel) and a workgroup may hold KW groups of 4 waves that split its K range (partial sums meet in
+    // LDS, no slab traffic).  Chosen by a cost model; tools/dev/tune_convs.py times every admissible plan of every layer
+    // shape of the path's networks on the device: the model's plans are within ~4 % of the best measured ones in total.
+    static const int min_steps = getenv("USC_MIN_STEPS") ? atoi(getenv("USC_MIN_STEPS")) : 9;           // tuning knobs
+    static const int kw_steps = getenv("USC_KW_STEPS") ? atoi(getenv("USC_KW_STEPS")) : 4;
     int KW = 1, S = 1;
-    static const int use_model = getenv("USC_PLAN_MODEL") ? atoi(getenv("USC_PLAN_MODEL")) : 1;
-    if (use_model) {
+    // slab capacity is checked for the planned batch (or the actual one if larger): the same S at every batch <= plan_batch
+    const size_t plane_actual = (size_t)d.OHf * d.OWf * d.Cout * sizeof(float);
+    const size_t plane_plan = (size_t)d.OHf / nbatch * plan_batch * d.OWf * d.Cout * sizeof(float);
+    const size_t plane_bytes = plane_actual > plane_plan ? plane_actual : plane_plan;
+    if (g_force_s || g_force_kw) {
+        S = g_force_s ? g_force_s : 1;
+        KW = g_force_kw ? g_force_kw : 1;
+        if (S > 1 && (!d.slab || (size_t)S * plane_bytes > d.slab_bytes)) S = 1;
+        if (S * KW > nch) { S = 1; KW = 1; }
+        if (KW != 1 && KW != 2 && KW != 4) KW = 1;
+        if (nt2 && KW > 2) KW = 2;          // 16 waves of the 64-column tile would not fit the register file
+    } else {
         // Cost model (microseconds) of one layer for every admissible (S, KW); all inputs are plan quantities.
         //   a wave needs n = nch / (S KW) K steps; a step costs 1024 MFMA cycles (0.43 us) times the W waves that share the
-        //   SIMD, but never less than the ~1 us a lone wave needs per step (load latency it cannot hide on its own);
+        //   SIMD, but never less than the ~1.5 us a lone wave needs per step (load latency it cannot hide on its own);
         //   W = (workgroups on the busiest CU) x KW, in rounds when they exceed the CU's wave slots;
         //   a grid split adds the reduce launch and the slab round trip.
         static const double t_step = getenv("USC_T_STEP") ? atof(getenv("USC_T_STEP")) : 0.43;
         static const double t_lone = getenv("USC_T_LONE") ? atof(getenv("USC_T_LONE")) : 1.5;
         static const double t_fixed = getenv("USC_T_FIXED") ? atof(getenv("USC_T_FIXED")) : 3.0;
         static const double t_reduce = getenv("USC_T_REDUCE") ? atof(getenv("USC_T_REDUCE")) : 8.0;
-        const double plane_mb = (double)(M / nbatch) * plan_batch * d.Cout * 4e-6 * nphase;
+        const double plane_mb = (double)m_plan * d.Cout * 4e-6 * nphase;
         const int slots = nt2 ? 3 : 4;                               // waves per SIMD the register file admits
         double best = 1e30;
         for (int s = 1; s <= 16; s++) {
-            if (s > 1 && (!d.slab || (size_t)s * d.OHf * d.OWf * d.Cout * sizeof(float) > d.slab_bytes)) break;
+            if (s > 1 && (!d.slab || (size_t)s * plane_bytes > d.slab_bytes)) break;
             for (int kw = 1; kw <= 4; kw *= 2) {
-                static const int kw_steps = getenv("USC_KW_STEPS") ? atoi(getenv("USC_KW_STEPS")) : 4;
                 if (kw > slots || (s > 1 && nch / (s * kw) < min_steps) || (kw > 1 && nch / (s * kw) < kw_steps)) continue;
                 const int n = (nch + s * kw - 1) / (s * kw);
                 const long long wgs = blocks * s;
@@ -463,21 +478,6 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
                 if (t < best - 1e-9) { best = t; S = s; KW = kw; }
             }
         }
-    } else if (blocks < kw_target) {
-        int F = (int)((f_target + blocks - 1) / blocks);
-        if (F > nch / min_steps) F = nch / min_steps;
-        if (F < 1) F = 1;
-        if (d.slab && blocks < wg_min) {
-            S = (int)((wg_min + blocks - 1) / blocks);
-            if (S > F) S = F;
-            if (S > 16) S = 16;
-            const size_t plane = (size_t)d.OHf * d.OWf * d.Cout * sizeof(float);
-            if ((size_t)S * plane > d.slab_bytes) S = (int)(d.slab_bytes / plane);
-            if (S < 1) S = 1;
-        }
-        KW = F / S;
-        KW = KW >= 4 ? 4 : KW >= 2 ? 2 : 1;
-        if (nt2 && KW > 2) KW = 2;          // 16 waves of the 64-column tile would not fit the register file
     }
     p.d.ksplit = S;
     p.d.nphase = nphase;
