@@ -68,6 +68,23 @@ __global__ __launch_bounds__(256 * KW) void conv_mfma_kernel(usc_conv_desc d) {
     const float* __restrict__ wpk = d.wpk + (size_t)ph * d.wphase_stride;
     const int out_py = d.nphase > 1 ? (ph >> 1) : d.out_py, out_px = d.nphase > 1 ? (ph & 1) : d.out_px;
 
+    const int wbytes = nch_all * 8 * d.Cout * 16;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpk), 0, wbytes, 0x00020000);
+    // B fragment of MFMA group g (4 MFMAs = k rows 8g .. 8g+7), N tile j: float4 at ((8c + 2g + h) * Cout + nb0 + 32j + n) * 16 bytes
+    const int wbase = ((lane >> 5) * d.Cout + nb0 + (lane & 31)) * 16;
+    const int wstep = 8 * d.Cout * 16, wg2 = 2 * d.Cout * 16;
+    // The weight fragments of the first K step do not depend on the per-pixel tables: request them before anything else.
+    float4 bf[4 * NT];
+    auto load_b = [&](int c, int g) {                      // the fragments of MFMA group g of chunk c
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, c < c_end ? wbase + c * wstep + g * wg2 + j * 512 : 0x7ffffff0, 0, 0);
+            bf[g * NT + j] = *reinterpret_cast<const float4*>(&v);
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < 4; g++) load_b(c_begin, g);
+
     constexpr int INVALID = 0x7fff0000;
     uint32_t dyw[4], dxw[4];
     __builtin_memcpy(dyw, d.dy, 16);
@@ -125,14 +142,9 @@ __global__ __launch_bounds__(256 * KW) void conv_mfma_kernel(usc_conv_desc d) {
     }
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(d.in), 0, (d.batch > 1 ? d.batch : 1) * d.IH * d.IW * d.Cin * 4, 0x00020000);
-    const int wbytes = nch_all * 8 * d.Cout * 16;
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpk), 0, wbytes, 0x00020000);
-    // B fragment of MFMA group g (4 MFMAs = k rows 8g .. 8g+7), N tile j: float4 at ((8c + 2g + h) * Cout + nb0 + 32j + n) * 16 bytes
-    const int wbase = ((lane >> 5) * d.Cout + nb0 + (lane & 31)) * 16;
-    const int wstep = 8 * d.Cout * 16, wg2 = 2 * d.Cout * 16;
     float* const Aw = As[wave];
 
-    float4 ra0[4], ra1[4], bf[4 * NT];
+    float4 ra0[4], ra1[4];
     auto load_a = [&](int c, float4 (&ra)[4]) {
         const bool live = c < c_end;
         const int k0 = c * KC + 4 * q;
@@ -143,13 +155,6 @@ __global__ __launch_bounds__(256 * KW) void conv_mfma_kernel(usc_conv_desc d) {
             const bool ok = live && ((vmask[j] >> tap) & 1u);
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? vbase[j] + koff : 0x7ffffff0, 0, 0);
             ra[j] = *reinterpret_cast<const float4*>(&v);
-        }
-    };
-    auto load_b = [&](int c, int g) {                      // the fragments of MFMA group g of chunk c
-#pragma unroll
-        for (int j = 0; j < NT; j++) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, c < c_end ? wbase + c * wstep + g * wg2 + j * 512 : 0x7ffffff0, 0, 0);
-            bf[g * NT + j] = *reinterpret_cast<const float4*>(&v);
         }
     };
     auto stage = [&](const float4 (&ra)[4]) {
@@ -193,8 +198,6 @@ __global__ __launch_bounds__(256 * KW) void conv_mfma_kernel(usc_conv_desc d) {
     };
 
     load_a(c_begin, ra0);
-#pragma unroll
-    for (int g = 0; g < 4; g++) load_b(c_begin, g);
     load_a(c_begin + 1, ra1);
     stage(ra0);
     int c = c_begin;
@@ -228,13 +231,23 @@ __global__ __launch_bounds__(256 * KW) void conv_mfma_kernel(usc_conv_desc d) {
         const_cast<float*>(d.res2), 0, (has_r2 && S == 1) ? out_bytes : 0, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NT; j++) {
+        const int n = nb0 + j * 32 + ec4;
+        const int nb4 = n * 4;
+        // residuals of all four passes are requested before the accumulators go through LDS (one wait, hidden behind the
+        // transposition); a zero-sized descriptor (no residual, split layer) turns them into zeros without touching memory
+        u32x4 r1v[4], r2v[4];
+        if (kg == 0) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++) {
+                r1v[ps] = __builtin_amdgcn_raw_buffer_load_b128(r1_rsrc, rps[ps] + nb4, 0, 0);
+                r2v[ps] = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, ops[ps] + nb4, 0, 0);
+            }
+        }
         if (KW > 1 && j > 0) __syncthreads();                     // the previous tile has been read by K group 0
 #pragma unroll
         for (int r = 0; r < 16; r++) T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * APITCH + (lane & 31)] = acc[j][r];
         if (KW > 1) __syncthreads();
         if (kg != 0) continue;
-        const int n = nb0 + j * 32 + ec4;
-        const int nb4 = n * 4;
         float4 tv[4];
 #pragma unroll
         for (int ps = 0; ps < 4; ps++) {
@@ -255,12 +268,6 @@ __global__ __launch_bounds__(256 * KW) void conv_mfma_kernel(usc_conv_desc d) {
         float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bias;
         if (d.bias) bias = *reinterpret_cast<const float4*>(d.bias + n);
         if (has_aff) { sc = *reinterpret_cast<const float4*>(d.scale + n); sh = *reinterpret_cast<const float4*>(d.shift + n); }
-        u32x4 r1v[4], r2v[4];
-#pragma unroll
-        for (int ps = 0; ps < 4; ps++) {
-            r1v[ps] = __builtin_amdgcn_raw_buffer_load_b128(r1_rsrc, rps[ps] + nb4, 0, 0);
-            r2v[ps] = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, ops[ps] + nb4, 0, 0);
-        }
 #pragma unroll
         for (int ps = 0; ps < 4; ps++) {
             const float4 t = tv[ps];
