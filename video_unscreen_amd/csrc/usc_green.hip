@@ -216,7 +216,10 @@ struct CcStats {
     unsigned int dmin_bits, dmax_bits;    // dist >= 0: float order == unsigned order of the bit patterns
     unsigned long long count;
     double sums[kSqrtLevels];
+    int levels;                           // number of sqrt passes the reference's while loop would run
 };
+constexpr int kCcBlocks = 256;            // blocks of the two reduction kernels = rows of the partial-sum table
+struct CcPartial { double sums[kSqrtLevels]; unsigned long long count; };
 
 __device__ __forceinline__ int torch_nearest_idx(int o, int in, int out, float scale) {
     if (out == in) return o;
@@ -258,14 +261,20 @@ __global__ __launch_bounds__(256) void cc_dist_kernel(const uint8_t* __restrict_
         dmax = fmaxf(dmax, __shfl_down(dmax, off, kWave));
     }
     (void)any;
-    if ((threadIdx.x & (kWave - 1)) == 0 && dmin != INFINITY) {
-        atomicMin(&st->dmin_bits, __float_as_uint(dmin));
-        atomicMax(&st->dmax_bits, __float_as_uint(dmax));
+    __shared__ float s_min[4], s_max[4];
+    if ((threadIdx.x & (kWave - 1)) == 0) { s_min[threadIdx.x >> 6] = dmin; s_max[threadIdx.x >> 6] = dmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {                       // one pair of atomics per block (min / max: order independent)
+        for (int w = 1; w < 4; w++) { dmin = fminf(dmin, s_min[w]); dmax = fmaxf(dmax, s_max[w]); }
+        if (dmin != INFINITY) {
+            atomicMin(&st->dmin_bits, __float_as_uint(dmin));
+            atomicMax(&st->dmax_bits, __float_as_uint(dmax));
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void cc_sums_kernel(float* __restrict__ dist, const uint8_t* __restrict__ alpha_r, uint32_t n,
-                                                      CcStats* __restrict__ st) {
+                                                      const CcStats* __restrict__ st, CcPartial* __restrict__ part) {
     const float dmin = __uint_as_float(st->dmin_bits), range = __uint_as_float(st->dmax_bits) - dmin;
     double sums[kSqrtLevels];
 #pragma unroll
@@ -280,34 +289,58 @@ __global__ __launch_bounds__(256) void cc_sums_kernel(float* __restrict__ dist, 
             for (int k = 0; k < kSqrtLevels; k++) { sums[k] += (double)d; d = sqrtf(d); }
         }
     }
+    // fixed-order reduction (lanes, then the block's 4 waves): the table row of this block, no atomics - the level count
+    // below is then the same from run to run
+    __shared__ double s_sum[4][kSqrtLevels];
+    __shared__ unsigned long long s_cnt[4];
     cnt = wave_sum_u64(cnt);
 #pragma unroll
     for (int k = 0; k < kSqrtLevels; k++) {
         double v = sums[k];
 #pragma unroll
         for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-        sums[k] = v;
+        if ((threadIdx.x & (kWave - 1)) == 0) s_sum[threadIdx.x >> 6][k] = v;
     }
-    if ((threadIdx.x & (kWave - 1)) == 0 && cnt) {
-        atomicAdd(&st->count, cnt);
-#pragma unroll
-        for (int k = 0; k < kSqrtLevels; k++) atomicAdd(&st->sums[k], sums[k]);
+    if ((threadIdx.x & (kWave - 1)) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x < kSqrtLevels) part[blockIdx.x].sums[threadIdx.x] = ((s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x]) + s_sum[2][threadIdx.x]) + s_sum[3][threadIdx.x];
+    if (threadIdx.x == 0) part[blockIdx.x].count = ((s_cnt[0] + s_cnt[1]) + s_cnt[2]) + s_cnt[3];
+}
+
+// One block: sum the table rows in row order and run the reference's `while mean(...) < mean_exp: dist = sqrt(dist)` on the sums.
+__global__ __launch_bounds__(64) void cc_levels_kernel(const CcPartial* __restrict__ part, int rows, float mean_exp, CcStats* __restrict__ st,
+                                                       int* __restrict__ n_sqrt_out) {
+    __shared__ double s_tot[kSqrtLevels];
+    __shared__ unsigned long long s_count;
+    if (threadIdx.x < kSqrtLevels) {
+        double v = 0.;
+        for (int r = 0; r < rows; r++) v += part[r].sums[threadIdx.x];
+        s_tot[threadIdx.x] = v;
+        st->sums[threadIdx.x] = v;
+    }
+    if (threadIdx.x == kSqrtLevels) {
+        unsigned long long c = 0;
+        for (int r = 0; r < rows; r++) c += part[r].count;
+        s_count = c;
+        st->count = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int levels = 0;
+        const double c = (double)s_count;
+        for (; levels < kSqrtLevels; levels++) {
+            const float mean = (float)(s_tot[levels] / c);         // count 0 -> nan -> the loop condition is false
+            if (!(mean < mean_exp)) break;
+        }
+        st->levels = levels;
+        if (n_sqrt_out) *n_sqrt_out = levels;
     }
 }
 
 __global__ __launch_bounds__(256) void cc_apply_kernel(const uint8_t* __restrict__ alpha, int H, int W, const float* __restrict__ dist,
                                                        const uint8_t* __restrict__ alpha_r, int th, int tw, float sy_scale, float sx_scale,
-                                                       const CcStats* __restrict__ st, float mean_exp, uint8_t* __restrict__ out,
-                                                       int* __restrict__ n_sqrt_out) {
-    int levels = 0;
-    {
-        const double c = (double)st->count;
-        for (; levels < kSqrtLevels; levels++) {
-            const float mean = (float)(st->sums[levels] / c);      // count 0 -> nan -> the loop condition is false
-            if (!(mean < mean_exp)) break;
-        }
-    }
-    if (n_sqrt_out && blockIdx.x == 0 && threadIdx.x == 0) *n_sqrt_out = levels;
+                                                       const CcStats* __restrict__ st, uint8_t* __restrict__ out) {
+    const int levels = st->levels;
     const uint32_t n = (uint32_t)H * (uint32_t)W;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int y = (int)(i / (uint32_t)W), x = (int)(i - (uint32_t)y * (uint32_t)W);
@@ -327,7 +360,7 @@ extern "C" size_t usc_color_correct_ws_bytes(int H, int W, int long_side) {
     int th, tw;
     usc_get_target_size(H, W, long_side, 1, &th, &tw);
     const size_t n = (size_t)th * tw;
-    return 256 + align256(n * sizeof(float)) + align256(n);
+    return 256 + align256(n * sizeof(float)) + align256(n) + align256(kCcBlocks * sizeof(CcPartial));
 }
 
 extern "C" int usc_color_correct_u8(const uint8_t* img, const uint8_t* alpha, int H, int W, const uint8_t* bg_color_host, int long_side,
@@ -346,12 +379,12 @@ extern "C" int usc_color_correct_u8(const uint8_t* img, const uint8_t* alpha, in
     CcStats* stats = reinterpret_cast<CcStats*>(base);
     float* dist = reinterpret_cast<float*>(base + 256);
     uint8_t* alpha_r = base + 256 + align256(n * sizeof(float));
+    CcPartial* part = reinterpret_cast<CcPartial*>(alpha_r + align256(n));
     static_assert(sizeof(CcStats) <= 256, "CcStats fits the header");
 
-    LabTables host_tab;                     // the background colour is one host pixel: convert it here
-    fill_lab_tables(&host_tab);
-    int bL, bA, bB;
-    bgr2lab_u8(&host_tab, bg_color_host[0], bg_color_host[1], bg_color_host[2], bL, bA, bB);
+    static const LabTables* const host_tab = [] { LabTables* t = new LabTables; fill_lab_tables(t); return t; }();   // built once
+    int bL, bA, bB;                         // the background colour is one host pixel: convert it here
+    bgr2lab_u8(host_tab, bg_color_host[0], bg_color_host[1], bg_color_host[2], bL, bA, bB);
     const float ba = (float)bA / 255.f, bb = (float)bB / 255.f;
 
     CcStats init;
@@ -364,9 +397,10 @@ extern "C" int usc_color_correct_u8(const uint8_t* img, const uint8_t* alpha, in
     const ResizeGeom rg = resize_geom(H, W, th, tw);
     hipLaunchKernelGGL(cc_dist_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, img, alpha, H, W, th, tw, rg.mode, rg.scale_y, rg.scale_x,
                        reinterpret_cast<const LabTables*>(lab_tables), ba, bb, dist, alpha_r, stats);
-    hipLaunchKernelGGL(cc_sums_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, dist, alpha_r, (uint32_t)n, stats);
+    hipLaunchKernelGGL(cc_sums_kernel, dim3(kCcBlocks), dim3(256), 0, st, dist, alpha_r, (uint32_t)n, stats, part);
+    hipLaunchKernelGGL(cc_levels_kernel, dim3(1), dim3(64), 0, st, part, kCcBlocks, (float)mean_exp, stats, n_sqrt_out);
     hipLaunchKernelGGL(cc_apply_kernel, dim3(grid_for((size_t)H * W, 256)), dim3(256), 0, st, alpha, H, W, dist, alpha_r, th, tw,
-                       (float)th / (float)H, (float)tw / (float)W, stats, (float)mean_exp, out, n_sqrt_out);
+                       (float)th / (float)H, (float)tw / (float)W, stats, out);
     return check_launch("color_correct kernels");
 }
 
