@@ -182,7 +182,13 @@ __global__ __launch_bounds__(256) void cf_stats_kernel(const uint8_t* __restrict
     }
     sum = wave_sum_u64(sum);
     cnt = wave_sum_u64(cnt);
-    if ((threadIdx.x & (kWave - 1)) == 0 && cnt) { atomicAdd(&stats[0], sum); atomicAdd(&stats[1], cnt); }
+    __shared__ unsigned long long s_sum[4], s_cnt[4];
+    if ((threadIdx.x & (kWave - 1)) == 0) { s_sum[threadIdx.x >> 6] = sum; s_cnt[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {                       // one pair of (integer, order-independent) atomics per block
+        for (int w = 1; w < 4; w++) { sum += s_sum[w]; cnt += s_cnt[w]; }
+        if (cnt) { atomicAdd(&stats[0], sum); atomicAdd(&stats[1], cnt); }
+    }
 }
 
 __global__ __launch_bounds__(256) void cf_apply_kernel(uint8_t* __restrict__ alpha, size_t n, const unsigned long long* __restrict__ stats,
@@ -201,7 +207,7 @@ extern "C" int usc_cf_threshold_u8(uint8_t* alpha, const uint8_t* mask, size_t n
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* stats = reinterpret_cast<unsigned long long*>(ws);
     if (hipMemsetAsync(stats, 0, 16, st) != hipSuccess) return fail(USC_E_LAUNCH, "usc_cf_threshold_u8: memset failed");
-    hipLaunchKernelGGL(cf_stats_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, alpha, mask, n, stats);
+    hipLaunchKernelGGL(cf_stats_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, st, alpha, mask, n, stats);      // 8 px per lane: ~1000 blocks
     hipLaunchKernelGGL(cf_apply_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, alpha, n, stats, thr_ratio);
     return check_launch("cf_threshold kernels");
 }
