@@ -189,7 +189,10 @@ class BgStepPipeline:
 
     def _run(self, inputs, on_result):
         main = torch.cuda.current_stream(self.device)
-        front = torch.cuda.Stream(self.device)
+        # the pipeline's side streams live as long as it does: the conv graphs are instantiated once per stream they run on
+        if getattr(self, "_front_stream", None) is None:
+            self._front_stream = torch.cuda.Stream(self.device)
+        front = self._front_stream
         work = queue.Queue()
         done = queue.Queue()
         err = []
@@ -218,7 +221,9 @@ class BgStepPipeline:
             it = iter(inputs)
             ahead = []                                      # inputs whose segmentation mask is already enqueued
             batched = self.seg_agent is not None and self.seg_batch > 1
-            seg_stream = torch.cuda.Stream(self.device) if batched else None
+            if batched and getattr(self, "_seg_stream", None) is None:
+                self._seg_stream = torch.cuda.Stream(self.device)
+            seg_stream = self._seg_stream if batched else None
             state = {"exhausted": False, "ngroups": 0}
 
             def launch_group():
