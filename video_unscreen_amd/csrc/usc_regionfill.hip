@@ -281,6 +281,85 @@ __global__ __launch_bounds__(kThreads) void mg_jacobi_kernel(const uint8_t* __re
     mg_jacobi_cells(mask, H, W, s, zin, r, zout, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
+// Two sweeps from zero in one pass: z1 = omega / (s n) r is pointwise, so the second sweep evaluates it on the fly for the
+// cell and its neighbours - the same operations in the same order as two mg_jacobi_cells calls, one launch less per level.
+__device__ __forceinline__ void mg_jacobi2_cells(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ r,
+                                                 double* __restrict__ zout, uint32_t start, uint32_t stride) {
+    const uint32_t n = (uint32_t)H * (uint32_t)W;
+    for (uint32_t i = start; i < n; i += stride) {
+        if (!mask[i]) continue;
+        const int y = (int)(i / (uint32_t)W), x = (int)(i - (uint32_t)y * (uint32_t)W);
+        const Nbr nb = neighbours(y, x, H, W);
+        const double w = kOmega / (s * (double)nb.n);
+        uint8_t mk[4];
+        double z1n[4][3];
+        const int dy[4] = {-1, 1, 0, 0}, dx[4] = {0, 0, -1, 1};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            mk[k] = mask[nb.idx[k]];
+            // the neighbour's own in-image neighbour count
+            const int yy = y + dy[k], xx = x + dx[k];
+            const int nn = (yy > 0) + (yy < H - 1) + (xx > 0) + (xx < W - 1);
+            const double wn = kOmega / (s * (double)nn);
+#pragma unroll
+            for (int c = 0; c < 3; c++) z1n[k][c] = wn * r[3 * (size_t)nb.idx[k] + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double z1 = w * r[3 * (size_t)i + c];
+            double a = (double)nb.n * z1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) a -= (nb.in[k] && mk[k]) ? z1n[k][c] : 0.;
+            zout[3 * (size_t)i + c] = z1 + w * (r[3 * (size_t)i + c] - s * a);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void mg_jacobi2_kernel(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ r,
+                                                              double* __restrict__ zout) {
+    mg_jacobi2_cells(mask, H, W, s, r, zout, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// Coarse correction + one sweep in one pass: z' = z + z_c(parent) is pointwise, evaluated on the fly for the cell and its
+// neighbours (same operations, same order as adding the correction in place and then sweeping).  Reads z and z_c, writes zout.
+__device__ __forceinline__ void mg_prolong_jacobi_cells(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ z,
+                                                        const double* __restrict__ zc, int Wc, const double* __restrict__ r,
+                                                        double* __restrict__ zout, uint32_t start, uint32_t stride) {
+    const uint32_t n = (uint32_t)H * (uint32_t)W;
+    for (uint32_t i = start; i < n; i += stride) {
+        if (!mask[i]) continue;
+        const int y = (int)(i / (uint32_t)W), x = (int)(i - (uint32_t)y * (uint32_t)W);
+        const Nbr nb = neighbours(y, x, H, W);
+        const double w = kOmega / (s * (double)nb.n);
+        const int dy[4] = {-1, 1, 0, 0}, dx[4] = {0, 0, -1, 1};
+        uint8_t mk[4];
+        double zn[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            mk[k] = mask[nb.idx[k]];
+            const int yy = nb.in[k] ? y + dy[k] : 0, xx = nb.in[k] ? x + dx[k] : 0;
+            const size_t I = (size_t)(yy >> 1) * Wc + (xx >> 1);
+#pragma unroll
+            for (int c = 0; c < 3; c++) zn[k][c] = z[3 * (size_t)nb.idx[k] + c] + zc[3 * I + c];
+        }
+        const size_t I0 = (size_t)(y >> 1) * Wc + (x >> 1);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double zi = z[3 * (size_t)i + c] + zc[3 * I0 + c];
+            double a = (double)nb.n * zi;
+#pragma unroll
+            for (int k = 0; k < 4; k++) a -= (nb.in[k] && mk[k]) ? zn[k][c] : 0.;
+            zout[3 * (size_t)i + c] = zi + w * (r[3 * (size_t)i + c] - s * a);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void mg_prolong_jacobi_kernel(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ z,
+                                                                     const double* __restrict__ zc, int Wc, const double* __restrict__ r,
+                                                                     double* __restrict__ zout) {
+    mg_prolong_jacobi_cells(mask, H, W, s, z, zc, Wc, r, zout, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
 // r_c(I) = sum over the children i of I inside the fine mask of (r_f - s_f A' z_f)(i)
 __device__ __forceinline__ void mg_restrict_cells(const uint8_t* __restrict__ mf, int Hf, int Wf, double sf, const double* __restrict__ zf,
                                                   const double* __restrict__ rf, const uint8_t* __restrict__ mc, int Hc, int Wc,
@@ -312,24 +391,6 @@ __global__ __launch_bounds__(kThreads) void mg_restrict_kernel(const uint8_t* __
     mg_restrict_cells(mf, Hf, Wf, sf, zf, rf, mc, Hc, Wc, rc, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
-// z_f(i) += z_c(parent(i)) inside the fine mask
-__device__ __forceinline__ void mg_prolong_cells(const uint8_t* __restrict__ mf, int Hf, int Wf, double* __restrict__ zf,
-                                                 const double* __restrict__ zc, int Wc, uint32_t start, uint32_t stride) {
-    const uint32_t n = (uint32_t)Hf * (uint32_t)Wf;
-    for (uint32_t i = start; i < n; i += stride) {
-        if (!mf[i]) continue;
-        const int y = (int)(i / (uint32_t)Wf), x = (int)(i - (uint32_t)y * (uint32_t)Wf);
-        const size_t I = (size_t)(y >> 1) * Wc + (x >> 1);
-#pragma unroll
-        for (int c = 0; c < 3; c++) zf[3 * (size_t)i + c] += zc[3 * I + c];
-    }
-}
-
-__global__ __launch_bounds__(kThreads) void mg_prolong_kernel(const uint8_t* __restrict__ mf, int Hf, int Wf, double* __restrict__ zf,
-                                                              const double* __restrict__ zc, int Wc) {
-    mg_prolong_cells(mf, Hf, Wf, zf, zc, Wc, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
-}
-
 // The coarse end of the V-cycle (levels first_tail .. L-1, a few thousand cells at most) inside ONE workgroup: the same
 // sweeps in the same order as the per-level kernels, separated by workgroup barriers instead of kernel boundaries
 // (every cell's arithmetic is identical, so the result does not depend on which path ran).
@@ -347,9 +408,7 @@ __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls) {
                 __syncthreads();
             }
         } else {
-            mg_jacobi_cells(v.mask, v.H, v.W, v.s, nullptr, v.r, v.zt, t, nt);
-            __syncthreads();
-            mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, t, nt);
+            mg_jacobi2_cells(v.mask, v.H, v.W, v.s, v.r, v.z, t, nt);
             __syncthreads();
             const Level& c = ls.lv[l + 1];
             mg_restrict_cells(v.mask, v.H, v.W, v.s, v.z, v.r, c.mask, c.H, c.W, c.r, t, nt);
@@ -358,9 +417,7 @@ __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls) {
     }
     for (int l = ls.L - 2; l >= ls.first_tail; l--) {
         const Level& v = ls.lv[l];
-        mg_prolong_cells(v.mask, v.H, v.W, v.z, ls.lv[l + 1].z, ls.lv[l + 1].W, t, nt);
-        __syncthreads();
-        mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.z, v.r, v.zt, t, nt);
+        mg_prolong_jacobi_cells(v.mask, v.H, v.W, v.s, v.z, ls.lv[l + 1].z, ls.lv[l + 1].W, v.r, v.zt, t, nt);
         __syncthreads();
         mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, t, nt);
         __syncthreads();
@@ -470,8 +527,7 @@ struct Solver {
                     q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.zt, v.r, v.z);
                 }
             } else {
-                q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, (const double*)nullptr, v.r, v.zt);
-                q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.zt, v.r, v.z);
+                q.launch(mg_jacobi2_kernel, g, b, v.mask, v.H, v.W, v.s, v.r, v.z);             // two sweeps from zero
                 const Level& c = lv[l + 1];
                 q.launch(mg_restrict_kernel, dim3(grid_of((size_t)c.H * c.W)), b, v.mask, v.H, v.W, v.s, v.z, v.r, c.mask, c.H, c.W, c.r);
             }
@@ -486,8 +542,7 @@ struct Solver {
             if (l == L - 1) continue;
             const Level& v = lv[l];
             const dim3 g(grid_of((size_t)v.H * v.W));
-            q.launch(mg_prolong_kernel, g, b, v.mask, v.H, v.W, v.z, lv[l + 1].z, lv[l + 1].W);
-            q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.z, v.r, v.zt);
+            q.launch(mg_prolong_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.z, lv[l + 1].z, lv[l + 1].W, v.r, v.zt);   // correction + sweep
             q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.zt, v.r, v.z);
         }
     }
