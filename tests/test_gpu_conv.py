@@ -176,3 +176,43 @@ def test_full_network_matches_torch_plan_and_golden(hipnet, H, W):
     # deterministic: same input twice -> bit-identical (no atomics in the accumulation)
     again = net(x8).cpu()
     assert torch.equal(again, got)
+
+
+@pytest.mark.parametrize("in_relu", [False, True])
+def test_conv_every_plan_gives_the_same_layer(hipnet, in_relu):
+    """All kernel variants on one layer: tile width (32 / 64 columns) x grid K split x K groups per workgroup, forced through
+    the tuning hook.  Every plan must give the reference result (the K partition only changes the summation order), with the
+    fused epilogue (bias, residual, ReLU) applied exactly once whether it runs in the conv kernel or in the split-K reduce."""
+    from video_unscreen_amd import _native as nv
+    lib = nv.load()
+    g = torch.Generator().manual_seed(99)
+    cin, cout, h, w = 64, 128, 21, 37               # M = 777: a ragged last tile; K = 576: 18 steps
+    x = torch.randn(1, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / 24.
+    b = torch.randn(cout, generator=g)
+    r1 = torch.randn(1, cout, h, w, generator=g)
+    xin = F.relu(x) if in_relu else x
+    want = F.relu(F.conv2d(xin.double(), wt.double(), b.double(), padding=1) + r1.double()).float()
+    L = _Layer(hipnet)
+    taps, wk = hipnet.conv_taps(wt, 1)
+    xd, r1d = nhwc(x).cuda(), nhwc(r1).cuda()
+    slab = torch.empty(8 * h * w * cout, device="cuda")
+    results = {}
+    try:
+        for nt in (1, 2):
+            for s in (1, 2, 3, 6):
+                for kw in (1, 2, 4):
+                    lib.usc_conv_force_plan(nt, s, kw)
+                    out = torch.full((h, w, cout), float("nan"), device="cuda")
+                    d = L.desc(xd, out, taps, wk, b, h, w, cin, h, w, cout, res1=r1d, act=1)          # USC_ACT_RELU
+                    d.in_relu = 1 if in_relu else 0
+                    d.slab, d.slab_bytes = slab.data_ptr(), slab.numel() * 4
+                    L.run([d])
+                    assert rel_err(out.cpu(), nhwc(want)) < 2e-5, (nt, s, kw)
+                    results[(nt, s, kw)] = out.clone()
+    finally:
+        lib.usc_conv_force_plan(0, 0, 0)
+    # the tile width does not touch the summation order: bit-identical for the same (S, KW)
+    for s in (1, 2, 3, 6):
+        for kw in (1, 2):
+            assert torch.equal(results[(1, s, kw)], results[(2, s, kw)]), (s, kw)
