@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--seg-batch", type=int, default=4,
                     help="frames per human-parsing forward in the pipelined loop (bit-identical masks, fewer launches per frame)")
+    ap.add_argument("--object-filter", default="auto", choices=["auto", "device", "host"],
+                    help="remove_invalid_objects: device = label-based HIP kernels, host = the border-following C++ twin on a worker "
+                         "thread; auto = host inside the pipelined run() (frees 0.5 ms of GPU time per frame), device in step()")
     ap.add_argument("--no-seg", action="store_true",
                     help="stage-3 loop only (segmentation masks are inputs, as in the reference's bg_offline.py with its "
                          "stages 1-2 disabled); default: the human-parsing net runs on every frame (binseg + trimap + vmatting)")
@@ -240,7 +243,7 @@ def main():
         from video_unscreen_amd.binseg import HumanSegAgent
         seg_agent = HumanSegAgent(model_path=None, cuda_device=local)       # synthetic SCHP weights, same on every rank
     pipe = BgStepPipeline(cfg, H, W, device=dev, dtype=dtype, state_dict=sd, net_backend=args.net, seg_agent=seg_agent,
-                          seg_batch=1 if args.sync_loop else args.seg_batch)
+                          seg_batch=1 if args.sync_loop else args.seg_batch, object_filter=args.object_filter)
 
     # this rank's contiguous frame range, generated straight into HBM (not timed)
     lo, hi = shard_range((K + Wm) * world, rank, world)
@@ -291,8 +294,24 @@ def main():
                        "binseg": (f"HumanSegAgent on every frame ({pipe.seg_batch} frames per network forward)" if seg_agent is not None
                                   else "masks are inputs (--no-seg)"),
                        "net_input": [pipe.in_h, pipe.in_w], "loop": "sync" if args.sync_loop else "pipelined", "convs": args.net,
+                       "object_filter": ("device (label-based HIP kernels)" if (args.object_filter == "device" or args.sync_loop) else
+                                         "host worker thread (border-following C++ in libunscreen_hip.so, same masks as the device "
+                                         "kernels; --object-filter device keeps the whole frame on the GPU)"),
                        "weights": "keyed-deterministic synthetic (no checkpoint offline)"},
         }
+        if world == 1 and not args.sync_loop and args.object_filter != "device":
+            # the same timed loop with every stage on the GPU, for the record (not `value`)
+            chosen, pipe.object_filter, pipe._filter_choice = pipe._filter_choice, "device", "device"
+            pipe.reset()
+            run(frames[:Wm])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run(frames[Wm:Wm + K])
+            torch.cuda.synchronize()
+            result["all_device"] = {"value": round(K / (time.perf_counter() - t1), 2), "unit": "frames/s",
+                                    "note": "same loop with remove_invalid_objects on the GPU too (usc_objects.hip)"}
+            pipe._filter_choice = chosen
+            pipe.object_filter = "device" if chosen == "auto" else chosen
         if not args.no_kernel_table:                         # (other ranks wait at the final barrier: not inside the timed region)
             rows, t_net = kernel_table(pipe, frames[Wm], H, W)
             dom = max(rows, key=lambda r: r["us"])
