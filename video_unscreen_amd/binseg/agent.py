@@ -2,9 +2,10 @@
 
 forward(img) = resize / reflect-pad to the target, normalise, overlapping 513 x 513 crops (+ mirrored copies),
 DeepLabv3+/ResNet-50 per crop, softmax, float64 merge, inverse pad-resize, argmax.  Pre- and post-processing are HIP
-kernels (csrc/usc_segagent.hip); every convolution runs on the f32-MFMA kernel (deeplab_net.HipDeepLabNet), one crop
-after the other through one set of activation buffers - a crop already fills the chip (>= 136 workgroups per layer,
-split-K below that), so batching the crops would only multiply the activation memory by 12.
+kernels (csrc/usc_segagent.hip); every convolution runs on the f32-MFMA kernel (deeplab_net.HipDeepLabNet), `crop_batch`
+crops per network forward (4: 3.4 ms per crop at 1080p against 5.2 ms one by one).  The conv kernels plan their K
+partitions for `plan_batch` crops whatever the size of a forward, so the result does not depend on `crop_batch` (full and
+tail groups, or crop-by-crop execution, give the same bits).
 """
 import numpy as np
 import torch
