@@ -324,9 +324,10 @@ typedef struct usc_conv_desc {
                                       both plan_batch = 4. */
 } usc_conv_desc;
 
-/* Tuning hook (tools/dev/tune_convs.py): force the tile width (1 | 2 x 32 columns), the grid K split and the K groups per
- * workgroup of every layer planned from the calling thread; 0 = the library's own plan (measured table, else cost model). */
-void usc_conv_force_plan(int nt, int ksplit, int kgroups);
+/* Tuning hook (tools/dev/tune_convs.py): force the tile width (1 | 2 x 32 columns), the row groups per workgroup (4 | 2 | 1
+ * x 32 pixels), the grid K split and the K groups per workgroup of every layer planned from the calling thread; 0 = the
+ * library's own plan (cost model). */
+void usc_conv_force_plan(int nt, int rowgroups, int ksplit, int kgroups);
 
 /* sizeof(usc_conv_desc) as the library was built: bindings check their struct definition against it. */
 size_t usc_conv_desc_bytes(void);

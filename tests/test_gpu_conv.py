@@ -180,8 +180,8 @@ def test_full_network_matches_torch_plan_and_golden(hipnet, H, W):
 
 @pytest.mark.parametrize("in_relu", [False, True])
 def test_conv_every_plan_gives_the_same_layer(hipnet, in_relu):
-    """All kernel variants on one layer: tile width (32 / 64 columns) x grid K split x K groups per workgroup, forced through
-    the tuning hook.  Every plan must give the reference result (the K partition only changes the summation order), with the
+    """All kernel variants on one layer: tile width (32 / 64 columns) x pixels per workgroup (128 / 64 / 32) x grid K split x
+    K groups per workgroup, forced through the tuning hook.  Every plan must give the reference result (the K partition only changes the summation order), with the
     fused epilogue (bias, residual, ReLU) applied exactly once whether it runs in the conv kernel or in the split-K reduce."""
     from video_unscreen_amd import _native as nv
     lib = nv.load()
@@ -199,20 +199,24 @@ def test_conv_every_plan_gives_the_same_layer(hipnet, in_relu):
     slab = torch.empty(8 * h * w * cout, device="cuda")
     results = {}
     try:
-        for nt in (1, 2):
+        for nt, rg in ((1, 4), (2, 4), (1, 2), (1, 1)):
             for s in (1, 2, 3, 6):
-                for kw in (1, 2, 4):
-                    lib.usc_conv_force_plan(nt, s, kw)
+                for kw in (1, 2, 4, 8, 16):
+                    if (nt == 2 and kw > 2) or (rg == 4 and kw > 4) or (rg < 4 and not 4 <= rg * kw <= 16) or s * kw > 18:
+                        continue                                   # not a kernel variant / more slices than K steps
+                    lib.usc_conv_force_plan(nt, rg, s, kw)
                     out = torch.full((h, w, cout), float("nan"), device="cuda")
                     d = L.desc(xd, out, taps, wk, b, h, w, cin, h, w, cout, res1=r1d, act=1)          # USC_ACT_RELU
                     d.in_relu = 1 if in_relu else 0
                     d.slab, d.slab_bytes = slab.data_ptr(), slab.numel() * 4
                     L.run([d])
-                    assert rel_err(out.cpu(), nhwc(want)) < 2e-5, (nt, s, kw)
-                    results[(nt, s, kw)] = out.clone()
+                    assert rel_err(out.cpu(), nhwc(want)) < 2e-5, (nt, rg, s, kw)
+                    results[(nt, rg, s, kw)] = out.clone()
     finally:
-        lib.usc_conv_force_plan(0, 0, 0)
-    # the tile width does not touch the summation order: bit-identical for the same (S, KW)
-    for s in (1, 2, 3, 6):
-        for kw in (1, 2):
-            assert torch.equal(results[(1, s, kw)], results[(2, s, kw)]), (s, kw)
+        lib.usc_conv_force_plan(0, 0, 0, 0)
+    # neither the tile width nor the pixels per workgroup touch the summation order: bit-identical for the same (S, KW)
+    for (nt, rg, s_, kw), out in results.items():
+        base = results.get((1, 4, s_, kw))
+        if base is not None:
+            assert torch.equal(out, base), (nt, rg, s_, kw)
+    assert len(results) >= 30

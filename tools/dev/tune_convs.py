@@ -73,30 +73,32 @@ for name, net, descs in nets():
             continue
         seen += 1
         nch = (d.ntaps * d.Cin + 31) // 32
-        lib.usc_conv_force_plan(0, 0, 0)
+        lib.usc_conv_force_plan(0, 0, 0, 0)
         base = time_layer(d)
-        best = (base, 0, 0, 0)
+        best = (base, 0, 0, 0, 0)
         rows = []
-        for nt in ((1, 2) if d.Cout % 64 == 0 else (1,)):
+        for nt, rg in (((1, 4), (2, 4), (1, 2), (1, 1)) if d.Cout % 64 == 0 else ((1, 4), (1, 2), (1, 1))):
             for s in (1, 2, 3, 4, 6, 8, 12, 16):
-                for kw in ((1, 2) if nt == 2 else (1, 2, 4)):
+                for kw in (1, 2, 4, 8, 16):
+                    if (nt == 2 and kw > 2) or (rg == 4 and kw > 4) or (rg < 4 and not 4 <= rg * kw <= 16):
+                        continue
                     if s * kw > 1 and nch // (s * kw) < 2:
                         continue
-                    lib.usc_conv_force_plan(nt, s, kw)
+                    lib.usc_conv_force_plan(nt, rg, s, kw)
                     t = time_layer(d)
                     if t is None:
                         continue
-                    rows.append((nt, s, kw, round(t, 2)))
+                    rows.append((nt, rg, s, kw, round(t, 2)))
                     if t < best[0]:
-                        best = (t, nt, s, kw)
-        lib.usc_conv_force_plan(0, 0, 0)
+                        best = (t, nt, rg, s, kw)
+        lib.usc_conv_force_plan(0, 0, 0, 0)
         # keep the planner's own choice unless a measured plan wins by > 3 % (timer noise)
         if best[1] and best[0] < 0.97 * base:
             table[key] = best[1:]
         else:
             table[key] = None
         log.append({"net": name, "key": key, "planner_us": round(base, 2), "best_us": round(best[0], 2), "best": best[1:], "all": rows})
-        print(f"{name:20s} {key} planner {base:7.1f} us  best {best[0]:7.1f} us  nt/S/KW={best[1:]}", flush=True)
+        print(f"{name:20s} {key} planner {base:7.1f} us  best {best[0]:7.1f} us  nt/RG/S/KW={best[1:]}", flush=True)
     print(f"{name}: {seen} new shapes", flush=True)
     del net
     torch.cuda.empty_cache()

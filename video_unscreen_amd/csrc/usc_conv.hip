@@ -38,18 +38,20 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BM = 128;        // output pixels per workgroup
 constexpr int KC = 32;         // K slice per step
 constexpr int APITCH = 36;     // floats per A row in LDS (32 + 4 pad: b128 reads hit 64 distinct banks)
 
-template <int NT, int KW, bool IN_RELU>
-__global__ __launch_bounds__(256 * KW) void conv_mfma_kernel(usc_conv_desc d) {
-    __shared__ __attribute__((aligned(16))) float As[4 * KW][32 * APITCH];
+// NT: 32-column tiles per wave (1 | 2).  RG: row groups = waves side by side on 32 pixels each (4 | 2 | 1: a workgroup owns
+// 128 | 64 | 32 pixels).  KW: K groups (RG x KW waves in all, <= 16).  IN_RELU: the layer computes conv(relu(x)).
+template <int NT, int RG, int KW, bool IN_RELU>
+__global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d) {
+    constexpr int BM = 32 * RG;                                  // output pixels per workgroup
+    __shared__ __attribute__((aligned(16))) float As[RG * KW][32 * APITCH];
     __shared__ int s_toff[16];
     __shared__ int s_outpix[BM], s_res1pix[BM], s_vbase[BM], s_vmask[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rg = wave & 3, kg = wave >> 2;                     // row group (32 pixels) and K group of this wave
+    const int rg = wave % RG, kg = wave / RG;                    // row group (32 pixels) and K group of this wave
     const int M = d.OH * d.OW;
     const int nblk = d.Cout / (32 * NT);
     const int nwg = (int)gridDim.x, xcd = (int)blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;      // XCD-aware order, see above
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256 * KW) void conv_mfma_kernel(usc_conv_desc d) {
             float4 t = *reinterpret_cast<const float4*>(&T[(ps * 8 + erow) * APITCH + ec4]);
 #pragma unroll
             for (int k = 1; k < KW; k++) {                        // slice order: ((p0 + p1) + p2) + p3
-                const float4 u = *reinterpret_cast<const float4*>(&As[4 * k + rg][(ps * 8 + erow) * APITCH + ec4]);
+                const float4 u = *reinterpret_cast<const float4*>(&As[RG * k + rg][(ps * 8 + erow) * APITCH + ec4]);
                 t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
             }
             tv[ps] = t;
@@ -381,10 +383,12 @@ static int conv_fail(int code, const char* msg) {
     return code;
 }
 
-// Tuning hook: force (tile width, grid K split, K groups) for every layer planned from this thread (0 = let the planner
-// decide).  Used by tools/dev/tune_convs.py to time all admissible plans of a layer shape on the device.
-static thread_local int g_force_nt = 0, g_force_s = 0, g_force_kw = 0;
-extern "C" void usc_conv_force_plan(int nt, int ksplit, int kgroups) { g_force_nt = nt; g_force_s = ksplit; g_force_kw = kgroups; }
+// Tuning hook: force (tile width, row groups, grid K split, K groups) for every layer planned from this thread (0 = let the
+// planner decide).  Used by tools/dev/tune_convs.py to time all admissible plans of a layer shape on the device.
+static thread_local int g_force_nt = 0, g_force_rg = 0, g_force_s = 0, g_force_kw = 0;
+extern "C" void usc_conv_force_plan(int nt, int rowgroups, int ksplit, int kgroups) {
+    g_force_nt = nt; g_force_rg = rowgroups; g_force_s = ksplit; g_force_kw = kgroups;
+}
 
 // One layer = one main launch (+ one reduce launch when K is split).
 struct LayerPlan {
@@ -422,77 +426,92 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     const int nphase = d.nphase > 1 ? d.nphase : 1;
     if (nphase != 1 && nphase != 4) return conv_fail(USC_E_ARG, "usc_conv: nphase must be 1 or 4");
     if (nphase * d.ntaps > 16) return conv_fail(USC_E_ARG, "usc_conv: more than 16 taps");
-    const int mblocks = (int)((M + BM - 1) / BM);
     // Tile shape and K partition are planned for `plan_batch` images of this layer's per-image size, whatever `batch` is:
     // a batched layer then sums K in exactly the order the single-image layer of the same plan does.
-    // Two 32-column tiles per workgroup only while that still leaves >= 2 workgroups per CU.
+    // Two 32-column tiles per wave only while that still leaves >= 2 workgroups per CU.
     const int plan_batch = d.plan_batch > 1 ? d.plan_batch : 1;
-    const long long mblocks_plan = (M / nbatch * plan_batch + BM - 1) / BM;
+    const long long m_plan = M / nbatch * plan_batch;
     static const int nt2_min = getenv("USC_NT2_MIN") ? atoi(getenv("USC_NT2_MIN")) : 512;
-    bool nt2 = (d.Cout % 64 == 0) && (mblocks_plan * (d.Cout / 64) * nphase >= nt2_min);
-    const int m_plan = (int)(M / nbatch * plan_batch);
+    bool nt2 = (d.Cout % 64 == 0) && ((m_plan + 127) / 128 * (d.Cout / 64) * nphase >= nt2_min);
     if (g_force_nt) nt2 = g_force_nt == 2 && d.Cout % 64 == 0;
     const int nblocks = nt2 ? d.Cout / 64 : d.Cout / 32;
-    const long long blocks = mblocks_plan * nblocks * nphase;
     const int nch = (d.ntaps * d.Cin + KC - 1) / KC;
-    // Parallelism over K for layers with few tiles: the grid may split K into S slices (partial sums through the slab and
-    // splitk_reduce_kernel) and a workgroup may hold KW groups of 4 waves that split its K range (partial sums meet in
-    // LDS, no slab traffic).  Chosen by a cost model; tools/dev/tune_convs.py times every admissible plan of every layer
-    // shape of the path's networks on the device: the model's plans are within ~4 % of the best measured ones in total.
+    // Parallelism for layers with few pixels: a workgroup's RG row groups cover 128 | 64 | 32 pixels, a workgroup may hold
+    // KW groups of RG waves that split its K range (partial sums meet in LDS, no HBM traffic), and the grid may split K into
+    // S slices (partial sums through the slab and splitk_reduce_kernel).  Chosen by a cost model; tools/dev/tune_convs.py
+    // times every admissible plan of every layer shape of the path's networks on the device.
     static const int min_steps = getenv("USC_MIN_STEPS") ? atoi(getenv("USC_MIN_STEPS")) : 9;           // tuning knobs
     static const int kw_steps = getenv("USC_KW_STEPS") ? atoi(getenv("USC_KW_STEPS")) : 4;
-    int KW = 1, S = 1;
+    static const int rg_min = getenv("USC_RG_MIN") ? atoi(getenv("USC_RG_MIN")) : 1;                    // 4: 128-pixel workgroups only
+    int RG = 4, KW = 1, S = 1;
     // slab capacity is checked for the planned batch (or the actual one if larger): the same S at every batch <= plan_batch
     const size_t plane_actual = (size_t)d.OHf * d.OWf * d.Cout * sizeof(float);
     const size_t plane_plan = (size_t)d.OHf / nbatch * plan_batch * d.OWf * d.Cout * sizeof(float);
     const size_t plane_bytes = plane_actual > plane_plan ? plane_actual : plane_plan;
-    if (g_force_s || g_force_kw) {
+    // kernel variants that exist: 64-column tiles with 4 row groups and KW <= 2 (register file); 32-column tiles with
+    // RG x KW <= 16 waves, and at least 4 waves unless RG = 4
+    auto exists = [&](int rg, int kw) {
+        if (nt2) return rg == 4 && kw <= 2;
+        if (rg == 4) return kw <= 4;
+        return rg * kw >= 4 && rg * kw <= 16;
+    };
+    if (g_force_s || g_force_kw || g_force_rg) {
         S = g_force_s ? g_force_s : 1;
         KW = g_force_kw ? g_force_kw : 1;
+        RG = g_force_rg ? g_force_rg : 4;
         if (S > 1 && (!d.slab || (size_t)S * plane_bytes > d.slab_bytes)) S = 1;
         if (S * KW > nch) { S = 1; KW = 1; }
-        if (KW != 1 && KW != 2 && KW != 4) KW = 1;
-        if (nt2 && KW > 2) KW = 2;          // 16 waves of the 64-column tile would not fit the register file
+        if (RG != 1 && RG != 2 && RG != 4) RG = 4;
+        if (!exists(RG, KW)) { RG = 4; KW = nt2 ? (KW >= 2 ? 2 : 1) : (KW >= 4 ? 4 : KW >= 2 ? 2 : 1); }
     } else {
-        // Cost model (microseconds) of one layer for every admissible (S, KW); all inputs are plan quantities.
+        // Cost model (microseconds) of one layer for every admissible (RG, S, KW); all inputs are plan quantities.
         //   a wave needs n = nch / (S KW) K steps; a step costs 1024 MFMA cycles (0.43 us) times the W waves that share the
         //   SIMD, but never less than the ~1.5 us a lone wave needs per step (load latency it cannot hide on its own);
-        //   W = (workgroups on the busiest CU) x KW, in rounds when they exceed the CU's wave slots;
-        //   a grid split adds the reduce launch and the slab round trip.
+        //   a workgroup puts RG KW / 4 waves on each SIMD; W = that x the workgroups on the busiest CU, in rounds when they
+        //   exceed the CU's wave slots; a grid split adds the reduce launch and the slab round trip.
         static const double t_step = getenv("USC_T_STEP") ? atof(getenv("USC_T_STEP")) : 0.43;
         static const double t_lone = getenv("USC_T_LONE") ? atof(getenv("USC_T_LONE")) : 1.5;
         static const double t_fixed = getenv("USC_T_FIXED") ? atof(getenv("USC_T_FIXED")) : 3.0;
         static const double t_reduce = getenv("USC_T_REDUCE") ? atof(getenv("USC_T_REDUCE")) : 8.0;
         const double plane_mb = (double)m_plan * d.Cout * 4e-6 * nphase;
-        const int slots = nt2 ? 3 : 4;                               // waves per SIMD the register file admits
+        const double slots = nt2 ? 3. : 4.;                          // waves per SIMD the register file admits
         double best = 1e30;
-        for (int s = 1; s <= 16; s++) {
-            if (s > 1 && (!d.slab || (size_t)s * plane_bytes > d.slab_bytes)) break;
-            for (int kw = 1; kw <= 4; kw *= 2) {
-                if (kw > slots || (s > 1 && nch / (s * kw) < min_steps) || (kw > 1 && nch / (s * kw) < kw_steps)) continue;
-                const int n = (nch + s * kw - 1) / (s * kw);
-                const long long wgs = blocks * s;
-                const int per_cu = (int)((wgs + 255) / 256);          // workgroups on the busiest CU
-                const int fit = slots / kw;                           // workgroups a CU holds at once
-                double t = 0.;
-                for (int left = per_cu; left > 0; left -= fit) {
-                    const int W = (left < fit ? left : fit) * kw;
-                    const double per_step = t_step * W > t_lone ? t_step * W : t_lone;
-                    t += n * per_step + t_fixed;
+        for (int rg = 4; rg >= rg_min; rg >>= 1) {
+            const long long blocks = (m_plan + 32 * rg - 1) / (32 * rg) * nblocks * nphase;
+            for (int s = 1; s <= 16; s++) {
+                if (s > 1 && (!d.slab || (size_t)s * plane_bytes > d.slab_bytes)) break;
+                for (int kw = 1; kw <= 16; kw *= 2) {
+                    if (!exists(rg, kw)) continue;
+                    if ((s > 1 && nch / (s * kw) < min_steps) || (kw > 1 && nch / (s * kw) < kw_steps)) continue;
+                    const int n = (nch + s * kw - 1) / (s * kw);
+                    const double wps = rg * kw / 4.;                  // waves a workgroup puts on each SIMD
+                    const long long wgs = blocks * s;
+                    const int per_cu = (int)((wgs + 255) / 256);      // workgroups on the busiest CU
+                    int fit = (int)(slots / wps);                     // workgroups a CU holds at once
+                    if (fit < 1) fit = 1;
+                    double t = 0.;
+                    for (int left = per_cu; left > 0; left -= fit) {
+                        const double W = (left < fit ? left : fit) * wps;
+                        const double per_step = t_step * W > t_lone ? t_step * W : t_lone;
+                        t += n * per_step + t_fixed;
+                    }
+                    if (s > 1) t += t_reduce + plane_mb * (s + 1.0) / 3.0;    // slab write + read at ~3 TB/s effective
+                    t += 0.3 * (kw - 1) / (kw >= 8 ? 2. : 1.) + (rg < 4 ? 0.2 : 0.);   // partial tiles meet in LDS; weights fetched by more workgroups
+                    if (t < best - 1e-9) { best = t; RG = rg; S = s; KW = kw; }
                 }
-                if (s > 1) t += t_reduce + plane_mb * (s + 1.0) / 3.0;        // slab write + read at ~3 TB/s effective
-                t += 0.3 * (kw - 1);                                          // partial tiles meet in LDS
-                if (t < best - 1e-9) { best = t; S = s; KW = kw; }
             }
         }
     }
+    const int mblocks = (int)((M + 32 * RG - 1) / (32 * RG));
     p.d.ksplit = S;
     p.d.nphase = nphase;
     p.grid = dim3(mblocks * nblocks, 1, nphase * S);          // 1-D over (pixel tile, N tile): the kernel re-labels it per XCD
-    p.block = dim3(256 * KW);
-#define USC_PICK(NTV, KWV) (d.in_relu ? (void*)conv_mfma_kernel<NTV, KWV, true> : (void*)conv_mfma_kernel<NTV, KWV, false>)
-    p.fn = nt2 ? (KW >= 2 ? USC_PICK(2, 2) : USC_PICK(2, 1))
-               : (KW == 4 ? USC_PICK(1, 4) : KW == 2 ? USC_PICK(1, 2) : USC_PICK(1, 1));
+    p.block = dim3(64 * RG * KW);
+#define USC_PICK(NTV, RGV, KWV) (d.in_relu ? (void*)conv_mfma_kernel<NTV, RGV, KWV, true> : (void*)conv_mfma_kernel<NTV, RGV, KWV, false>)
+    if (nt2) p.fn = KW >= 2 ? USC_PICK(2, 4, 2) : USC_PICK(2, 4, 1);
+    else if (RG == 4) p.fn = KW == 4 ? USC_PICK(1, 4, 4) : KW == 2 ? USC_PICK(1, 4, 2) : USC_PICK(1, 4, 1);
+    else if (RG == 2) p.fn = KW == 8 ? USC_PICK(1, 2, 8) : KW == 4 ? USC_PICK(1, 2, 4) : USC_PICK(1, 2, 2);
+    else p.fn = KW == 16 ? USC_PICK(1, 1, 16) : KW == 8 ? USC_PICK(1, 1, 8) : USC_PICK(1, 1, 4);
 #undef USC_PICK
     if (S > 1) {
         const long long items = (long long)d.OHf * d.OWf * (d.Cout / 4);
