@@ -11,8 +11,8 @@ cc, kt, forwards, ms_unprofiled = sys.argv[1], sys.argv[2], int(sys.argv[3]), fl
 
 def short(name):
     if "conv_mfma_kernel" in name:
-        m = re.search(r"conv_mfma_kernel<(\d), (\d)", name)
-        return "conv_mfma_kernel<NT=%s, KW=%s>" % (m.group(1), m.group(2)) if m else "conv_mfma_kernel"
+        m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+)", name)
+        return "conv_mfma_kernel<NT=%s, RG=%s, KW=%s>" % m.groups() if m else "conv_mfma_kernel"
     for o in ("splitk_reduce_kernel", "head_conv_kernel"):
         if o in name:
             return o
