@@ -3,7 +3,7 @@ networks on the device (usc_conv_force_plan) and compare with the plan the libra
 
 Run on the GPU box:  python tools/dev/tune_convs.py gpurun_out/tune   -> gpurun_out/tune/tune_log.json + a summary line.
 A shape's key is (pixels per image x plan_batch, Cin, Cout, taps, input stride, phases): the quantities the planner sees.
-Round-1 result (profiles/r01/conv_plan_tuning.md): the model's plans cost 10.27 ms over the 115 shapes, the best measured
+Round-1 result (profiles/r01/conv_plan_tuning.md; first run, before the row groups): the model's plans cost 10.27 ms over 115 shapes, the best measured
 plans 9.82 ms (-4.4 %), and wiring the measured plans in did not move bench.py (272.2 -> 272.1 fps), so no table is kept."""
 import ctypes as C
 import json
