@@ -240,8 +240,6 @@ class HipSchpNet(ConvGraphNet):
         t, h, w = pooled, ph, pw
         feats = []
         nv = self.nv
-        cat5 = None
-        nlayers = len(p.layers)
         for li, blocks in enumerate(p.layers):
             for bi, blk in enumerate(blocks):
                 cin = t.shape[2]
@@ -251,29 +249,37 @@ class HipSchpNet(ConvGraphNet):
                     idt = t
                 y, _, _ = self._conv(blk["c1"], t, h, w, cin)
                 y, h2, w2 = self._conv(blk["c2"], y, h, w, y.shape[2])
-                last = li == nlayers - 1 and bi == len(blocks) - 1
-                if last:                       # x5 goes straight into channels [2048, 4096) of the PSP concat buffer
-                    cat5 = self._buf(h2, w2, 4096)
-                    self._conv(blk["c3"], y, h2, w2, y.shape[2], out=cat5, res1=idt, out_ld=4096, out_c0=2048)
-                    t, h, w = None, h2, w2
-                else:
-                    t, h, w = self._conv(blk["c3"], y, h2, w2, y.shape[2], res1=idt)
+                t, h, w = self._conv(blk["c3"], y, h2, w2, y.shape[2], res1=idt)
             feats.append((t, h, w))
-        (x2, h2, w2), (x3, h3, w3), (x4, h4, w4), (_, h5, w5) = feats
-        # PSP: adaptive pools (tiny) -> 1x1 conv + ABN -> bilinear (align_corners) into channels [512 i, 512 (i+1))
+        (x2, h2, w2), (x3, h3, w3), (x4, h4, w4), (x5, h5, w5) = feats
+        # PSP (human_parse.py:83-111): adaptive pools (s x s, s = 1, 2, 3, 6) -> 1x1 conv + ABN -> bilinear (align_corners) up,
+        # concatenated with x5 and fed to a 3x3 bottleneck with 4096 input channels.  Half of that layer's 34 GFLOP would
+        # multiply upsampled s x s maps: a 3x3 conv of an upsampled map is sum_taps shift_tap(up(p W_tap)) (the channel mixing
+        # of a tap commutes with the spatial upsampling), so each prior goes through ONE tiny 1x1 layer with the nine tap
+        # matrices side by side (512 -> 9 x 512) and usc_upsample_ac_taps_accum_f32 adds the nine upsampled results at the tap
+        # offsets into a map that the bottleneck over x5 alone (2048 input channels) takes as its residual.  Same sum, other
+        # order; 17 GFLOP and the 4096-channel concat buffer less per frame.
         pools = [self._buf(s, s, 2048) for s in PSP_SIZES]
 
         def pool_all():
             for s, pb in zip(PSP_SIZES, pools):
-                nv.adaptive_avgpool(cat5, 2048, 2048, pb, batch=self.batch)
+                nv.adaptive_avgpool(x5, 0, 2048, pb, batch=self.batch)
         self._glue(pool_all)
         stage_out = [self._conv(c, pb, s, s, 2048)[0] for c, pb, s in zip(p.psp, pools, PSP_SIZES)]
+        wb = p.psp_bottleneck.w                                          # (512, 4096, 3, 3), BN folded: priors first, x5 last
+        qs = []
+        for i, (so, s) in enumerate(zip(stage_out, PSP_SIZES)):
+            wi = wb[:, 512 * i:512 * (i + 1)]                            # (co, ci, 3, 3) -> rows tap * 512 + co
+            wq = wi.permute(2, 3, 0, 1).reshape(9 * 512, 512, 1, 1).contiguous()
+            qs.append(self._conv(FConv(wq, wq.new_zeros(9 * 512), act="none"), so, s, s, 512)[0])
+        prior_map = self._buf(h5, w5, 512)
 
-        def assemble5():
-            for i, so in enumerate(stage_out):
-                nv.upsample_ac(so, cat5, 512 * i, batch=self.batch)
-        self._glue(assemble5)
-        ctx, _, _ = self._conv(p.psp_bottleneck, cat5, h5, w5, 4096)
+        def priors():
+            for i, q in enumerate(qs):
+                nv.upsample_ac_taps_accum(q, prior_map, batch=self.batch, accumulate=i > 0)
+        self._glue(priors)
+        bott = FConv(wb[:, 2048:].contiguous(), p.psp_bottleneck.b, pad=1, act="leaky01")
+        ctx, _, _ = self._conv(bott, x5, h5, w5, 2048, res1=prior_map)
         d1, _, _ = self._conv(p.dec1, ctx, h5, w5, 512)
         cat_dec = self._buf(h2, w2, 320)
         cat_fuse = self._buf(h2, w2, 1024)

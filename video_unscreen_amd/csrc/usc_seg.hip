@@ -206,6 +206,45 @@ __global__ __launch_bounds__(256) void upsample_ac_nhwc_kernel(const float* __re
     }
 }
 
+// conv3x3(upsample(p)) without the convolution.  A 3x3 conv (padding 1) over a bilinearly upsampled low-resolution map p
+// (s x s x Cin, s <= 6: the PSP priors of human_parse.py:83-111) is linear in both steps and the 1x1 channel mixing of a tap
+// commutes with the spatial upsampling:  conv(up(p)) = sum_taps shift_tap(up(p W_tap)).  The caller computes Q = p [W_0 .. W_8]
+// (one tiny 1x1 layer with 9 C output channels) and this kernel adds, for every output pixel, the nine upsampled Q_tap sampled
+// at the tap's neighbour (zero outside the image = the conv's zero padding): 36 fused multiply-adds per element instead of
+// 9 Cin.  dst (+)= the sum; same align_corners arithmetic as upsample_ac_nhwc_kernel.
+__global__ __launch_bounds__(256) void upsample_ac_taps_kernel(const float* __restrict__ q0, int sh, int sw, int C,
+                                                               float* __restrict__ dst0, int dh, int dw, float rh, float rw, int batch,
+                                                               int accumulate) {
+    const int c4n = C / 4, per = dh * dw * c4n, n = per * batch;
+    for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const int img = i0 / per, i = i0 - img * per;
+        const float* __restrict__ q = q0 + (size_t)img * sh * sw * 9 * C;
+        float* __restrict__ dst = dst0 + (size_t)img * dh * dw * C;
+        const int c4 = i % c4n, p = i / c4n;
+        const int y = p / dw, x = p - y * dw;
+        float4 acc = accumulate ? reinterpret_cast<const float4*>(dst + (size_t)p * C)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy < 0 || yy >= dh || xx < 0 || xx >= dw) continue;
+            const float h1r = rh * yy, w1r = rw * xx;
+            const int h1 = (int)h1r, w1 = (int)w1r;
+            const int h1p = h1 < sh - 1 ? 1 : 0, w1p = w1 < sw - 1 ? 1 : 0;
+            const float h1l = h1r - h1, h0l = 1.f - h1l, w1l = w1r - w1, w0l = 1.f - w1l;
+            const float* base = q + (size_t)t * C;
+            const float4 v00 = reinterpret_cast<const float4*>(base + ((size_t)h1 * sw + w1) * 9 * C)[c4];
+            const float4 v01 = reinterpret_cast<const float4*>(base + ((size_t)h1 * sw + w1 + w1p) * 9 * C)[c4];
+            const float4 v10 = reinterpret_cast<const float4*>(base + ((size_t)(h1 + h1p) * sw + w1) * 9 * C)[c4];
+            const float4 v11 = reinterpret_cast<const float4*>(base + ((size_t)(h1 + h1p) * sw + w1 + w1p) * 9 * C)[c4];
+            acc.x += h0l * (w0l * v00.x + w1l * v01.x) + h1l * (w0l * v10.x + w1l * v11.x);
+            acc.y += h0l * (w0l * v00.y + w1l * v01.y) + h1l * (w0l * v10.y + w1l * v11.y);
+            acc.z += h0l * (w0l * v00.z + w1l * v01.z) + h1l * (w0l * v10.z + w1l * v11.z);
+            acc.w += h0l * (w0l * v00.w + w1l * v01.w) + h1l * (w0l * v10.w + w1l * v11.w);
+        }
+        reinterpret_cast<float4*>(dst + (size_t)p * C)[c4] = acc;
+    }
+}
+
 // cv2.warpAffine(img, M, (dw, dh), INTER_LINEAR, BORDER_CONSTANT 0) on uint8, 1 or 3 channels (imgprocess.py:55-64 shift_fg).
 __global__ __launch_bounds__(256) void warp_affine_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw, int cn, Affine A,
                                                              uint8_t* __restrict__ dst, int dh, int dw) {
@@ -299,6 +338,17 @@ extern "C" int usc_upsample_ac_nhwc_batch_f32(const float* src, int sh, int sw, 
     hipLaunchKernelGGL(upsample_ac_nhwc_kernel, dim3(grid_for((long long)batch * dh * dw * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream,
                        src, sh, sw, C, dst, dh, dw, ld, c0, rh, rw, batch);
     return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "upsample_ac_nhwc_kernel launch failed");
+}
+
+extern "C" int usc_upsample_ac_taps_accum_f32(const float* q, int sh, int sw, int C, float* dst, int dh, int dw, int batch, int accumulate,
+                                              usc_stream_t stream) {
+    if (!q || !dst || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || C <= 0 || C % 4 || batch < 1)
+        return seg_fail(USC_E_ARG, "usc_upsample_ac_taps_accum_f32: bad argument (C must be a multiple of 4)");
+    if ((long long)batch * dh * dw * (C / 4) >= (1ll << 31)) return seg_fail(USC_E_UNSUPPORTED, "usc_upsample_ac_taps_accum_f32: too large");
+    const float rh = dh > 1 ? (float)(sh - 1) / (dh - 1) : 0.f, rw = dw > 1 ? (float)(sw - 1) / (dw - 1) : 0.f;
+    hipLaunchKernelGGL(upsample_ac_taps_kernel, dim3(grid_for((long long)batch * dh * dw * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                       q, sh, sw, C, dst, dh, dw, rh, rw, batch, accumulate);
+    return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "upsample_ac_taps_kernel launch failed");
 }
 
 extern "C" int usc_upsample_ac_nhwc_f32(const float* src, int sh, int sw, int C, float* dst, int dh, int dw, int ld, int c0,
