@@ -351,7 +351,7 @@ const char* usc_conv_last_error(void);
  * activation buffers - must not overlap on the device (launch it on one stream, or order the streams). */
 int  usc_conv_graph_create(const usc_conv_desc* descs, int n, void** handle);
 int  usc_conv_graph_launch(void* handle, usc_stream_t stream);
-void usc_conv_graph_destroy(void* handle);
+void usc_conv_graph_destroy(void* handle);   /* retires the handle (the HIP graph objects are kept until the process ends) */
 
 #ifdef __cplusplus
 }

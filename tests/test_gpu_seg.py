@@ -101,7 +101,7 @@ def test_humanseg_batched_forward_is_bit_identical(nv, plan):
         single.append((m.clone(), lg.clone()))                  # the logits buffer is reused by the next forward
     for n in (2, 3):
         masks = agent.forward_device_batch(frames[:n])
-        net = agent.model_for(n)
+        net = agent.model_for(max(n, plan))                     # a short group rides in the planned-batch network
         for b in range(n):
             assert torch.equal(net.image(net.logits32, b), single[b][1]), (n, b)
             assert torch.equal(masks[b], single[b][0])

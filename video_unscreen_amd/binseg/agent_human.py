@@ -65,11 +65,14 @@ class HumanSegAgent():
         """Several frames through ONE network forward (frames are independent for this agent).  Every mask is bit for bit
         what forward_device gives for that frame; the win is half (a third, ...) of the kernel launches per frame."""
         n = len(imgs)
-        if n == 1:
+        if n == 1 and self.plan_batch == 1:
             return [self.forward_device(imgs[0], out=None if outs is None else outs[0])]
-        net = self.model_for(n)
-        for b, img in enumerate(imgs):
-            nv.humanseg_pre(img, INPUT_SIZE[0], INPUT_SIZE[1], out=net.image(net.x4, b))
+        # a short group (the tail of a clip) rides in the network the agent is planned for, its last frame repeated: no second
+        # network has to be built for it, and - per-image results not depending on the batch - its masks are the same bits
+        nb = max(n, self.plan_batch)
+        net = self.model_for(nb)
+        for b in range(nb):
+            nv.humanseg_pre(imgs[min(b, n - 1)], INPUT_SIZE[0], INPUT_SIZE[1], out=net.image(net.x4, b))
         logits = net.forward(None)
         need = nv.load().usc_humanseg_post_ws_bytes(NUM_CLASSES, INPUT_SIZE[0], INPUT_SIZE[1])
         if self._ws is None or self._ws.numel() < need:

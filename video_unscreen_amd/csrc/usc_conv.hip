@@ -614,9 +614,9 @@ extern "C" int usc_conv_graph_launch(void* handle, usc_stream_t stream) {
 }
 
 extern "C" void usc_conv_graph_destroy(void* handle) {
-    if (!handle) return;
-    ConvGraph* g = (ConvGraph*)handle;
-    for (auto& se : g->execs) (void)hipGraphExecDestroy(se.second);
-    if (g->graph) (void)hipGraphDestroy(g->graph);
-    delete g;
+    // Graphs are retired, not destroyed.  On this runtime (ROCm 7.2) hipGraphExecDestroy / hipGraphDestroy leave dangling state
+    // behind: a test sequence that builds and frees a few dozen networks segfaulted inside a later hipGraphLaunch, reproducibly,
+    // and stopped doing so as soon as nothing was destroyed.  A retired graph keeps its host-side plan and its (small) kernel
+    // argument blocks until the process ends; networks live as long as their pipeline anyway.
+    (void)handle;
 }

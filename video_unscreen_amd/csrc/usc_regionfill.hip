@@ -579,11 +579,8 @@ hipGraphExec_t iteration_graph(const Solver& s, void* ws) {
     q.launch(rf_publish_kernel, dim3(1), dim3(kThreads), s.part_rr, s.scal, 1);
     hipGraphExec_t exec = nullptr;
     if (!q.ok || hipGraphInstantiate(&exec, q.graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(q.graph); return nullptr; }
-    if (g_cache.size() >= 8) {                       // a handful of sizes at most; drop the oldest
-        (void)hipGraphExecDestroy(g_cache.front().exec);
-        (void)hipGraphDestroy(g_cache.front().graph);
-        g_cache.erase(g_cache.begin());
-    }
+    if (g_cache.size() >= 8) g_cache.erase(g_cache.begin());      // a handful of sizes at most; the oldest entry is dropped from the
+                                                                  // cache but its graph is not destroyed (see usc_conv_graph_destroy)
     g_cache.push_back(CachedGraph{ws, s.H, s.W, q.graph, exec, std::move(q.keep)});
     return exec;
 }
