@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--sync-loop", action="store_true", help="use the synchronous step() instead of the pipelined run()")
     ap.add_argument("--cpu-frames", type=int, default=2)
-    ap.add_argument("--seg-batch", type=int, default=4,
+    ap.add_argument("--seg-batch", type=int, default=8,
                     help="frames per human-parsing forward in the pipelined loop (bit-identical masks, fewer launches per frame)")
     ap.add_argument("--object-filter", default="auto", choices=["auto", "device", "host"],
                     help="remove_invalid_objects: device = label-based HIP kernels, host = the border-following C++ twin on a worker "
