@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--sync-loop", action="store_true", help="use the synchronous step() instead of the pipelined run()")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=5)
     ap.add_argument("--seg-batch", type=int, default=8,
                     help="frames per human-parsing forward in the pipelined loop (bit-identical masks, fewer launches per frame)")
     ap.add_argument("--object-filter", default="auto", choices=["auto", "device", "host"],
