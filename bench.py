@@ -42,8 +42,9 @@ def parse():
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--sync-loop", action="store_true", help="use the synchronous step() instead of the pipelined run()")
     ap.add_argument("--cpu-frames", type=int, default=5)
-    ap.add_argument("--seg-batch", type=int, default=8,
-                    help="frames per human-parsing forward in the pipelined loop (bit-identical masks, fewer launches per frame)")
+    ap.add_argument("--seg-batch", type=int, default=0,
+                    help="frames per human-parsing forward in the pipelined loop (bit-identical masks, fewer launches per frame); "
+                         "0 = the largest of 12, 8, 6, 4 that divides --steps (a short last group would ride in a full forward), else 8")
     ap.add_argument("--object-filter", default="auto", choices=["auto", "device", "host"],
                     help="remove_invalid_objects: device = label-based HIP kernels, host = the border-following C++ twin on a worker "
                          "thread; auto = host inside the pipelined run() (frees 0.5 ms of GPU time per frame), device in step()")
@@ -242,8 +243,9 @@ def main():
     if not args.no_seg:
         from video_unscreen_amd.binseg import HumanSegAgent
         seg_agent = HumanSegAgent(model_path=None, cuda_device=local)       # synthetic SCHP weights, same on every rank
+    seg_batch = args.seg_batch if args.seg_batch > 0 else next((b for b in (12, 8, 6, 4) if K % b == 0), 8)
     pipe = BgStepPipeline(cfg, H, W, device=dev, dtype=dtype, state_dict=sd, net_backend=args.net, seg_agent=seg_agent,
-                          seg_batch=1 if args.sync_loop else args.seg_batch, object_filter=args.object_filter)
+                          seg_batch=1 if args.sync_loop else seg_batch, object_filter=args.object_filter)
 
     # this rank's contiguous frame range, generated straight into HBM (not timed)
     lo, hi = shard_range((K + Wm) * world, rank, world)
