@@ -53,6 +53,7 @@ class _Slot:
         self.host = torch.empty((H, W), dtype=torch.uint8).pin_memory()
         self.ready = torch.cuda.Event()
         self.copied = torch.cuda.Event()
+        self.host_done = threading.Event()            # set by the host worker that filtered this slot
         self.frame = None
 
 
@@ -71,6 +72,7 @@ class BgStepPipeline:
         that is the faster choice (measured: 240 vs 225 frames/s at 1080p)."""
         self.cfg = cfg
         self.H, self.W = H, W
+        self._enqueue_lock = threading.Lock()
         self.device = torch.device(device)
         nv.load()
         self._sd = state_dict if state_dict is not None else synthetic_state_dict(0)
@@ -149,9 +151,10 @@ class BgStepPipeline:
     def _front_host(self, slot):
         slot.copied.synchronize()
         self.filter(slot.host.numpy(), None, self.center, self.sal_thr, self.cons_thr)
-        slot.alphaor.copy_(slot.host, non_blocking=True)
-        nv.trimap(slot.alphaor, self.long_side, self.ksize, self.iters, out=slot.trimap, ws=self.ws_trimap)
-        slot.ready.record()
+        with self._enqueue_lock:                           # the trimap kernels of two workers share one scratch buffer
+            slot.alphaor.copy_(slot.host, non_blocking=True)
+            nv.trimap(slot.alphaor, self.long_side, self.ksize, self.iters, out=slot.trimap, ws=self.ws_trimap)
+            slot.ready.record()
 
     def _back(self, slot, frame, want_float=False):
         alpha_pre = self.alpha_pre if self.alpha_pre is not None else slot.gate       # bg_offline.py:162-163
@@ -194,7 +197,6 @@ class BgStepPipeline:
             self._front_stream = torch.cuda.Stream(self.device)
         front = self._front_stream
         work = queue.Queue()
-        done = queue.Queue()
         err = []
 
         def worker():
@@ -208,11 +210,15 @@ class BgStepPipeline:
                         self._front_host(slot)
                     except Exception as e:      # surfaced to the main thread
                         err.append(e)
-                    done.put(slot)
+                    slot.host_done.set()
 
         on_device = self.object_filter == "device"
-        th = threading.Thread(target=worker, daemon=True)
-        if not on_device:
+        # two host workers: at most two frames are between the gate and the matting net, and at 3840x2160 the border following
+        # of one frame (5 ms on one core) is longer than the frame's GPU time; results are still consumed in frame order
+        workers = [] if on_device else [threading.Thread(target=worker, daemon=True) for _ in range(2)]
+        if workers:
+            self.filter(np.zeros((self.H, self.W), np.uint8), None, self.center, self.sal_thr, self.cons_thr)   # score map built once, here
+        for th in workers:
             th.start()
         n = 0
         pending = []
@@ -272,26 +278,26 @@ class BgStepPipeline:
                         self._front_device(slot, frame, seg, bg_i, bg_always, seg_ready=batched)
                         if on_device:
                             self._front_filter_device(slot)
-                    if on_device:
-                        done.put(slot)
-                    else:
+                    if not on_device:
+                        slot.host_done.clear()
                         work.put(slot)
                     pending.append(slot)
                     submitted += 1
                 if not pending:
                     break
-                slot = done.get()
+                slot = pending.pop(0)
+                if not on_device:
+                    slot.host_done.wait()
                 if err:
                     raise err[0]
-                assert slot is pending[0]
-                pending.pop(0)
                 main.wait_event(slot.ready)
                 out = self._back(slot, slot.frame)
                 if on_result is not None:
                     on_result(n, out)
                 n += 1
         finally:
-            if not on_device:
+            for th in workers:
                 work.put(None)
+            for th in workers:
                 th.join()
         return n
