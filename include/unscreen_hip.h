@@ -267,13 +267,14 @@ int    usc_upsample_ac_nhwc_batch_f32(const float* src, int sh, int sw, int C, f
 int    usc_upsample_ac_nhwc_f32(const float* src, int sh, int sw, int C, float* dst, int dh, int dw, int ld, int c0,
                                 usc_stream_t stream);
 
-/* conv3x3(padding 1) of a bilinearly (align_corners=True) upsampled low-resolution map without the convolution
- * (binseg/human_parse.py:83-111: the PSP priors are s x s maps, s = 1, 2, 3, 6, upsampled to the feature size and fed to a
- * 3x3 bottleneck).  The channel mixing of a tap commutes with the upsampling: conv(up(p)) = sum_taps shift_tap(up(p W_tap)).
+/* conv3x3(padding 1) of a bilinearly upsampled low-resolution map without the convolution (binseg/human_parse.py:83-111: the
+ * PSP priors are s x s maps, s = 1, 2, 3, 6, upsampled with align_corners=True to the feature size and fed to a 3x3 bottleneck;
+ * binseg/deeplab/_deeplab.py:51-55: the ASPP output, upsampled x4 with align_corners=False, is 256 of the 304 input channels of
+ * the decoder's 3x3 conv).  The channel mixing of a tap commutes with the upsampling: conv(up(p)) = sum_taps shift_tap(up(p W_tap)).
  * q = (batch*sh, sw, 9*C) holds p W_tap in channels [tap*C, (tap+1)*C), taps in (dy, dx) row-major order; dst (batch*dh, dw, C)
  * = (accumulate ? dst : 0) + sum over the 9 taps of up(q_tap) sampled at (y + dy, x + dx), zero outside the image. */
-int    usc_upsample_ac_taps_accum_f32(const float* q, int sh, int sw, int C, float* dst, int dh, int dw, int batch, int accumulate,
-                                      usc_stream_t stream);
+int    usc_upsample_taps_accum_f32(const float* q, int sh, int sw, int C, float* dst, int dh, int dw, int batch, int accumulate,
+                                   int align_corners, usc_stream_t stream);
 const char* usc_seg_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------

@@ -107,24 +107,25 @@ def test_humanseg_batched_forward_is_bit_identical(nv, plan):
             assert torch.equal(masks[b], single[b][0])
 
 
-@pytest.mark.parametrize("s,h,w,batch", [(1, 30, 30, 1), (2, 30, 30, 2), (3, 17, 23, 1), (6, 30, 30, 4)])
-def test_upsample_taps_accum_equals_conv_of_upsampled(nv, s, h, w, batch):
-    """usc_upsample_ac_taps_accum_f32: sum_taps shift_tap(up(p W_tap)) == conv3x3(up(p), padding 1) - the identity that takes the
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("s,h,w,batch", [(1, 30, 30, 1), (2, 30, 30, 2), (3, 17, 23, 1), (6, 30, 30, 4), (9, 33, 35, 2)])
+def test_upsample_taps_accum_equals_conv_of_upsampled(nv, s, h, w, batch, align):
+    """usc_upsample_taps_accum_f32: sum_taps shift_tap(up(p W_tap)) == conv3x3(up(p), padding 1) - the identity that takes the
     PSP priors out of the parsing net's 4096-channel bottleneck (human_parse.py:83-111)."""
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(100 + s)
     cin, cout = 8, 12
     p = torch.randn(batch, cin, s, s, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g)
-    want = F.conv2d(F.interpolate(p.double(), size=(h, w), mode="bilinear", align_corners=True), wt.double(), padding=1).float()
+    want = F.conv2d(F.interpolate(p.double(), size=(h, w), mode="bilinear", align_corners=align), wt.double(), padding=1).float()
     # q = p [W_0 .. W_8]: channels tap * cout + co, taps in (ky, kx) row-major order
     wq = wt.permute(2, 3, 0, 1).reshape(9 * cout, cin)
     q = torch.einsum("bchw,oc->bhwo", p.double(), wq.double()).float().reshape(batch * s, s, 9 * cout).contiguous().cuda()
     dst = torch.full((batch * h, w, cout), float("nan"), device="cuda")
-    nv.upsample_ac_taps_accum(q, dst, batch=batch)
+    nv.upsample_taps_accum(q, dst, batch=batch, align_corners=align)
     got = dst.view(batch, h, w, cout).permute(0, 3, 1, 2).cpu()
     assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
     base = torch.randn(batch * h, w, cout, generator=g).cuda()
     acc = base.clone()
-    nv.upsample_ac_taps_accum(q, acc, batch=batch, accumulate=True)
+    nv.upsample_taps_accum(q, acc, batch=batch, accumulate=True, align_corners=align)
     assert float((acc - (base + dst)).abs().max()) < 1e-5 * float(want.abs().max())

@@ -77,7 +77,7 @@ _SIGNATURES = {
     "usc_score_map_f64": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, _vp, _vp, _vp]),
     "usc_remove_invalid_objects_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "usc_remove_invalid_objects_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp, C.c_size_t, _vp]),
-    "usc_upsample_ac_taps_accum_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "usc_upsample_taps_accum_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "usc_conv_force_plan": (None, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "usc_bg_accumulate_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "usc_bg_finalize_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
@@ -455,17 +455,17 @@ def upsample_ac(src, dst, c0=0, batch=1):
     return dst
 
 
-def upsample_ac_taps_accum(q, dst, batch=1, accumulate=False):
-    """dst (batch*dh, dw, C) (+)= sum over the 9 taps of the align_corners upsampling of q (batch*sh, sw, 9*C) channels
+def upsample_taps_accum(q, dst, batch=1, accumulate=False, align_corners=True):
+    """dst (batch*dh, dw, C) (+)= sum over the 9 taps of the bilinear upsampling of q (batch*sh, sw, 9*C) channels
     [tap*C, (tap+1)*C) sampled at the tap's neighbour: conv3x3(upsample(p)) from q = p [W_0 .. W_8]."""
     sh, sw, c9 = q.shape
     dh, dw, Cn = dst.shape
     if c9 != 9 * Cn or sh % batch or dh % batch:
-        raise NativeError("upsample_ac_taps_accum: q must be (batch*sh, sw, 9*C) for dst (batch*dh, dw, C)")
-    rc = load().usc_upsample_ac_taps_accum_f32(q.data_ptr(), sh // batch, sw, Cn, dst.data_ptr(), dh // batch, dw, int(batch),
-                                               1 if accumulate else 0, _stream())
+        raise NativeError("upsample_taps_accum: q must be (batch*sh, sw, 9*C) for dst (batch*dh, dw, C)")
+    rc = load().usc_upsample_taps_accum_f32(q.data_ptr(), sh // batch, sw, Cn, dst.data_ptr(), dh // batch, dw, int(batch),
+                                            1 if accumulate else 0, 1 if align_corners else 0, _stream())
     if rc != 0:
-        raise NativeError(f"usc_upsample_ac_taps_accum_f32 failed ({rc}): {load().usc_seg_last_error().decode()}")
+        raise NativeError(f"usc_upsample_taps_accum_f32 failed ({rc}): {load().usc_seg_last_error().decode()}")
     return dst
 
 

@@ -256,7 +256,7 @@ class HipSchpNet(ConvGraphNet):
         # concatenated with x5 and fed to a 3x3 bottleneck with 4096 input channels.  Half of that layer's 34 GFLOP would
         # multiply upsampled s x s maps: a 3x3 conv of an upsampled map is sum_taps shift_tap(up(p W_tap)) (the channel mixing
         # of a tap commutes with the spatial upsampling), so each prior goes through ONE tiny 1x1 layer with the nine tap
-        # matrices side by side (512 -> 9 x 512) and usc_upsample_ac_taps_accum_f32 adds the nine upsampled results at the tap
+        # matrices side by side (512 -> 9 x 512) and usc_upsample_taps_accum_f32 adds the nine upsampled results at the tap
         # offsets into a map that the bottleneck over x5 alone (2048 input channels) takes as its residual.  Same sum, other
         # order; 17 GFLOP and the 4096-channel concat buffer less per frame.
         pools = [self._buf(s, s, 2048) for s in PSP_SIZES]
@@ -276,7 +276,7 @@ class HipSchpNet(ConvGraphNet):
 
         def priors():
             for i, q in enumerate(qs):
-                nv.upsample_ac_taps_accum(q, prior_map, batch=self.batch, accumulate=i > 0)
+                nv.upsample_taps_accum(q, prior_map, batch=self.batch, accumulate=i > 0)
         self._glue(priors)
         bott = FConv(wb[:, 2048:].contiguous(), p.psp_bottleneck.b, pad=1, act="leaky01")
         ctx, _, _ = self._conv(bott, x5, h5, w5, 2048, res1=prior_map)

@@ -211,10 +211,12 @@ __global__ __launch_bounds__(256) void upsample_ac_nhwc_kernel(const float* __re
 // commutes with the spatial upsampling:  conv(up(p)) = sum_taps shift_tap(up(p W_tap)).  The caller computes Q = p [W_0 .. W_8]
 // (one tiny 1x1 layer with 9 C output channels) and this kernel adds, for every output pixel, the nine upsampled Q_tap sampled
 // at the tap's neighbour (zero outside the image = the conv's zero padding): 36 fused multiply-adds per element instead of
-// 9 Cin.  dst (+)= the sum; same align_corners arithmetic as upsample_ac_nhwc_kernel.
-__global__ __launch_bounds__(256) void upsample_ac_taps_kernel(const float* __restrict__ q0, int sh, int sw, int C,
-                                                               float* __restrict__ dst0, int dh, int dw, float rh, float rw, int batch,
-                                                               int accumulate) {
+// 9 Cin.  dst (+)= the sum; the interpolation arithmetic is that of upsample_ac_nhwc_kernel (align_corners=True) or of
+// upsample_nc_nhwc_kernel (align_corners=False: the DeepLabv3+ decoder, deeplab/_deeplab.py:51-55).
+template <bool ALIGN>
+__global__ __launch_bounds__(256) void upsample_taps_kernel(const float* __restrict__ q0, int sh, int sw, int C,
+                                                            float* __restrict__ dst0, int dh, int dw, float rh, float rw, int batch,
+                                                            int accumulate) {
     const int c4n = C / 4, per = dh * dw * c4n, n = per * batch;
     for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += gridDim.x * blockDim.x) {
         const int img = i0 / per, i = i0 - img * per;
@@ -227,7 +229,13 @@ __global__ __launch_bounds__(256) void upsample_ac_taps_kernel(const float* __re
         for (int t = 0; t < 9; t++) {
             const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
             if (yy < 0 || yy >= dh || xx < 0 || xx >= dw) continue;
-            const float h1r = rh * yy, w1r = rw * xx;
+            float h1r, w1r;
+            if (ALIGN) { h1r = rh * yy; w1r = rw * xx; }
+            else {                                          // ATen area_pixel_compute_source_index, align_corners=False
+                h1r = rh * ((float)yy + 0.5f) - 0.5f; w1r = rw * ((float)xx + 0.5f) - 0.5f;
+                if (h1r < 0.f) h1r = 0.f;
+                if (w1r < 0.f) w1r = 0.f;
+            }
             const int h1 = (int)h1r, w1 = (int)w1r;
             const int h1p = h1 < sh - 1 ? 1 : 0, w1p = w1 < sw - 1 ? 1 : 0;
             const float h1l = h1r - h1, h0l = 1.f - h1l, w1l = w1r - w1, w0l = 1.f - w1l;
@@ -340,15 +348,20 @@ extern "C" int usc_upsample_ac_nhwc_batch_f32(const float* src, int sh, int sw, 
     return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "upsample_ac_nhwc_kernel launch failed");
 }
 
-extern "C" int usc_upsample_ac_taps_accum_f32(const float* q, int sh, int sw, int C, float* dst, int dh, int dw, int batch, int accumulate,
-                                              usc_stream_t stream) {
+extern "C" int usc_upsample_taps_accum_f32(const float* q, int sh, int sw, int C, float* dst, int dh, int dw, int batch, int accumulate,
+                                           int align_corners, usc_stream_t stream) {
     if (!q || !dst || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || C <= 0 || C % 4 || batch < 1)
-        return seg_fail(USC_E_ARG, "usc_upsample_ac_taps_accum_f32: bad argument (C must be a multiple of 4)");
-    if ((long long)batch * dh * dw * (C / 4) >= (1ll << 31)) return seg_fail(USC_E_UNSUPPORTED, "usc_upsample_ac_taps_accum_f32: too large");
-    const float rh = dh > 1 ? (float)(sh - 1) / (dh - 1) : 0.f, rw = dw > 1 ? (float)(sw - 1) / (dw - 1) : 0.f;
-    hipLaunchKernelGGL(upsample_ac_taps_kernel, dim3(grid_for((long long)batch * dh * dw * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream,
-                       q, sh, sw, C, dst, dh, dw, rh, rw, batch, accumulate);
-    return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "upsample_ac_taps_kernel launch failed");
+        return seg_fail(USC_E_ARG, "usc_upsample_taps_accum_f32: bad argument (C must be a multiple of 4)");
+    if ((long long)batch * dh * dw * (C / 4) >= (1ll << 31)) return seg_fail(USC_E_UNSUPPORTED, "usc_upsample_taps_accum_f32: too large");
+    const dim3 grid(grid_for((long long)batch * dh * dw * (C / 4), 256));
+    if (align_corners) {
+        const float rh = dh > 1 ? (float)(sh - 1) / (dh - 1) : 0.f, rw = dw > 1 ? (float)(sw - 1) / (dw - 1) : 0.f;
+        hipLaunchKernelGGL(upsample_taps_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, q, sh, sw, C, dst, dh, dw, rh, rw, batch, accumulate);
+    } else {
+        hipLaunchKernelGGL(upsample_taps_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, q, sh, sw, C, dst, dh, dw,
+                           (float)sh / (float)dh, (float)sw / (float)dw, batch, accumulate);
+    }
+    return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "upsample_taps_kernel launch failed");
 }
 
 extern "C" int usc_upsample_ac_nhwc_f32(const float* src, int sh, int sw, int C, float* dst, int dh, int dw, int ld, int c0,
