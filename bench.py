@@ -5,11 +5,14 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A "step" is one frame through the whole per-frame path (difference mask -> host object filter -> trimap ->
-matting pre / network / post -> foreground), inputs already resident in HBM.  With N ranks the clip is sharded
-into contiguous frame ranges (no data-path collective: frames only couple through alpha_pre inside a shard,
-exactly like the reference's --range runs); weights and the overall background are broadcast from rank 0 over
-RCCL before the timed region.  Rank 0 prints ONE JSON line.
+A "step" is one frame through the whole per-frame path (segmentation -> difference mask -> object filter -> trimap ->
+matting pre / network / post -> foreground).  `value` is SURVEY.md section 8d's end-to-end rate: every frame (and its
+per-frame background) starts in pinned host memory and its alpha + foreground end in pinned host memory, uploads and
+downloads on copy streams beside the compute (video_unscreen_amd/hostio.py); the same loop with inputs resident in HBM
+and no download is reported beside it as `device_resident`.  With N ranks the clip is sharded into contiguous frame
+ranges (no data-path collective: frames only couple through alpha_pre inside a shard, exactly like the reference's
+--range runs); weights and the overall background are broadcast from rank 0 over RCCL before the timed region.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -37,7 +40,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--dtype", default="float32", choices=["float32", "float16", "bfloat16"])
+    ap.add_argument("--device-resident", action="store_true",
+                    help="time the loop with inputs already in HBM and outputs left there (round 1's figure) as `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--sync-loop", action="store_true", help="use the synchronous step() instead of the pipelined run()")
@@ -105,8 +109,9 @@ def kernel_table(pipe, sample, H, W):
     add("get_fg", lambda: nv.get_fg(frame, alpha, slot.bg, paste_thr=1, out_fg=out["fg"]), 10 * N)
     cnt = torch.empty(1, dtype=torch.int64, device=frame.device)
     add("count_ge", lambda: nv.count_ge(alpha, 128, out=cnt), N)
-    t_net = time_kernel(lambda: pipe.net(pipe.x7), iters=20, warm=3)
-    return rows, t_net
+    t_graph = time_kernel(lambda: pipe.net(pipe.x7), iters=20, warm=3)
+    t_net = time_kernel(lambda: pipe.net.forward_serial(), iters=20, warm=3) if hasattr(pipe.net, "forward_serial") else t_graph
+    return rows, t_net, t_graph
 
 
 def cpu_baseline(cfg, pipe, clip_cpu_frames, bg_always, nframes):
@@ -129,12 +134,13 @@ def cpu_baseline(cfg, pipe, clip_cpu_frames, bg_always, nframes):
 
 
 def pmc_traffic(H, W):
-    """Fabric bytes of the conv stack per forward from the committed rocprofv3 PMC passes (profiles/r01/pmc_conv_traffic.json,
+    """Fabric bytes of the conv stack per forward from the committed rocprofv3 PMC passes (profiles/r02/pmc_conv_traffic.json, else r01's,
     produced by tools/dev/run_profiles.sh + summarize_profiles.py on this workload): FETCH_SIZE x 2 (gfx950 reports half the bytes of
     16-B/lane streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE.  Counters cannot be collected inside this process; null for any
     other frame size or when the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_conv_traffic.json")
-    if (H, W) != (1080, 1920) or not os.path.exists(path):
+    root = os.path.dirname(os.path.abspath(__file__))
+    path = next((q for q in (os.path.join(root, "profiles", r, "pmc_conv_traffic.json") for r in ("r02", "r01")) if os.path.exists(q)), None)
+    if (H, W) != (1080, 1920) or path is None:
         return None
     z = json.load(open(path))
     return int(2 * z["fetch_raw_bytes_per_forward"] + z["write_bytes_per_forward"])
@@ -233,7 +239,6 @@ def main():
 
     H, W, K, Wm = args.height, args.width, args.steps, args.warmup
     cfg = default_config()
-    dtype = getattr(torch, args.dtype)
 
     # weights + overall background: rank 0 owns them, everyone else receives them over RCCL / xGMI
     clip = SyntheticClip(H, W, (K + Wm) * world, config_id=2, device=dev)
@@ -244,38 +249,67 @@ def main():
         from video_unscreen_amd.binseg import HumanSegAgent
         seg_agent = HumanSegAgent(model_path=None, cuda_device=local)       # synthetic SCHP weights, same on every rank
     seg_batch = args.seg_batch if args.seg_batch > 0 else next((b for b in (12, 8, 6, 4) if K % b == 0), 8)
-    pipe = BgStepPipeline(cfg, H, W, device=dev, dtype=dtype, state_dict=sd, net_backend=args.net, seg_agent=seg_agent,
+    pipe = BgStepPipeline(cfg, H, W, device=dev, state_dict=sd, net_backend=args.net, seg_agent=seg_agent,
                           seg_batch=1 if args.sync_loop else seg_batch, object_filter=args.object_filter)
 
-    # this rank's contiguous frame range, generated straight into HBM (not timed)
+    # this rank's contiguous frame range (not timed).  Host boundary (default): each frame + its per-frame background (+ its
+    # mask with --no-seg) sit in pinned host memory, and pinned host buffers receive alpha + fg.
+    from video_unscreen_amd.hostio import HostFrameIO
     lo, hi = shard_range((K + Wm) * world, rank, world)
     clip.gen.manual_seed(20260002 + 7919 * rank)
-    frames = []
+    host_io = not args.device_resident
+    frames, frames_h = [], []
     for t in range(lo, hi):
         f = clip.frame(t)
-        frames.append((f["frame"], f["seg"], f["bg"], bg_always))
+        if host_io:
+            frames_h.append((f["frame"].cpu().pin_memory(), f["seg"].cpu().pin_memory() if seg_agent is None else None,
+                             f["bg"].cpu().pin_memory()))
+        if not host_io or (rank == 0 and t - lo < Wm + K):
+            frames.append((f["frame"], f["seg"], f["bg"], bg_always))
+    alpha_h = fg_h = io = None
+    if host_io:
+        alpha_h = torch.empty((K, H, W), dtype=torch.uint8).pin_memory()
+        fg_h = torch.empty((K, H, W, 3), dtype=torch.uint8).pin_memory()
+        io = HostFrameIO(pipe)
     torch.cuda.synchronize()
 
-    def run(inputs):
+    def run(inputs):                                         # inputs resident in HBM, outputs stay there
         if args.sync_loop:
             for i in inputs:
                 pipe.step(*i)
         else:
             pipe.run(iter(inputs))
 
-    pipe.reset()
-    run(frames[:Wm])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(frames[Wm:Wm + K])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    def run_host(first, n):                                  # pinned host -> pinned host
+        if args.sync_loop:
+            for j in range(n):
+                fh, sh, bh = frames_h[first + j]
+                out = pipe.step(fh.to(dev, non_blocking=True), sh.to(dev, non_blocking=True) if sh is not None else None,
+                                bh.to(dev, non_blocking=True), bg_always)
+                alpha_h[j].copy_(out["alpha"], non_blocking=True)
+                fg_h[j].copy_(out["fg"], non_blocking=True)
+        else:
+            pipe.run(io.inputs(frames_h[first:first + n], bg_always), on_result=io.collect(alpha_h, fg_h))
+
+    def timed(fn_warm, fn):
+        pipe.reset()
+        fn_warm()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    if host_io:
+        dt = timed(lambda: run_host(0, Wm), lambda: run_host(Wm, K))
+    else:
+        dt = timed(lambda: run(frames[:Wm]), lambda: run(frames[Wm:Wm + K]))
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -288,11 +322,13 @@ def main():
             "metric": "frames/sec end-to-end unscreen (bg_step, 1080p)" if (H, W) == (1080, 1920) else f"frames/sec end-to-end unscreen (bg_step, {W}x{H})",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"float32": "f32", "float16": "f16", "bfloat16": "bf16"}[args.dtype],
-            "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("bg_step: " + ("human-parsing segmentation (SCHP ResNet-101) + " if seg_agent is not None else "")
                                     + "stage-3 loop (bgdiff mask + object filter + trimap + matting UNet-18 + get_fg), "
                                     + f"{W}x{H}, {K} frames/GPU, frame-sharded x{world}"),
+                       "boundary": ("pinned host -> pinned host: frame + per-frame background" + (" + mask" if seg_agent is None else "")
+                                    + " uploaded, alpha + fg downloaded per frame inside the timed region (SURVEY.md 8d)") if host_io
+                                   else "device resident: inputs in HBM when the timed region starts, outputs left in HBM",
                        "binseg": (f"HumanSegAgent on every frame ({pipe.seg_batch} frames per network forward)" if seg_agent is not None
                                   else "masks are inputs (--no-seg)"),
                        "net_input": [pipe.in_h, pipe.in_w], "loop": "sync" if args.sync_loop else "pipelined", "convs": args.net,
@@ -301,33 +337,44 @@ def main():
                                          "kernels; --object-filter device keeps the whole frame on the GPU)"),
                        "weights": "keyed-deterministic synthetic (no checkpoint offline)"},
         }
+        if host_io:
+            nb = H * W
+            result["pcie_bytes_per_frame"] = {"up": 6 * nb + (nb if seg_agent is None else 0), "down": 4 * nb}
+        if world == 1 and host_io:
+            # the same loop with inputs resident in HBM and outputs left there (round 1's figure), for the record (not `value`)
+            t1 = timed(lambda: run(frames[:Wm]), lambda: run(frames[Wm:Wm + K]))
+            result["device_resident"] = {"value": round(K / t1, 2), "unit": "frames/s",
+                                         "note": "same loop, frames already in HBM, alpha / fg not copied out"}
         if world == 1 and not args.sync_loop and args.object_filter != "device":
             # the same timed loop with every stage on the GPU, for the record (not `value`)
             chosen, pipe.object_filter, pipe._filter_choice = pipe._filter_choice, "device", "device"
-            pipe.reset()
-            run(frames[:Wm])
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            run(frames[Wm:Wm + K])
-            torch.cuda.synchronize()
-            result["all_device"] = {"value": round(K / (time.perf_counter() - t1), 2), "unit": "frames/s",
-                                    "note": "same loop with remove_invalid_objects on the GPU too (usc_objects.hip)"}
+            if host_io:
+                t1 = timed(lambda: run_host(0, Wm), lambda: run_host(Wm, K))
+            else:
+                t1 = timed(lambda: run(frames[:Wm]), lambda: run(frames[Wm:Wm + K]))
+            result["all_device"] = {"value": round(K / t1, 2), "unit": "frames/s",
+                                    "note": "same loop and boundary as `value` with remove_invalid_objects on the GPU too (usc_objects.hip)"}
             pipe._filter_choice = chosen
             pipe.object_filter = "device" if chosen == "auto" else chosen
         if not args.no_kernel_table:                         # (other ranks wait at the final barrier: not inside the timed region)
-            rows, t_net = kernel_table(pipe, frames[Wm], H, W)
+            rows, t_net, t_graph = kernel_table(pipe, frames[Wm], H, W)
             dom = max(rows, key=lambda r: r["us"])
             scale = (pipe.in_h * pipe.in_w) / (544 * 960)
             gflop = UNET_GFLOP_544x960 * scale
             tf = gflop / t_net / 1e3
             if args.net == "hip":
-                # dominant kernel of the frame: conv_mfma_kernel (usc_conv.hip), ~95 % of GPU time.  One "launch" here
-                # is one network forward = one hipGraph of num_layers conv launches; flops are the algorithmic
-                # 2*M*N*K of the reference module (torch flop counter).
+                # dominant kernel of the frame: conv_mfma_kernel (usc_conv.hip).  One "launch" here is one network forward =
+                # num_layers conv launches; flops are the algorithmic 2*M*N*K of the reference module (torch flop counter,
+                # SURVEY.md section 6).  Time: HIP events around forwards whose layers are launched one after the other on ONE
+                # stream (usc_conv_sequence_f32) with nothing beside them - the quantity profiles/r02/unet_layer_table.md
+                # (rocprofv3 kernel trace of the same launches, tools/dev/layer_table.py) sums per layer.  The product launches
+                # the same layers as a hipGraph whose independent branches overlap: ms_per_forward_graph.
                 result["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel (all %d conv launches of one forward)" % pipe.net.num_layers,
                                       "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(H, W),
-                                      "alg_gflop_per_forward": round(gflop, 2), "ms_per_forward": round(t_net * 1e3, 3)}
+                                      "alg_gflop_per_forward": round(gflop, 2), "ms_per_forward": round(t_net * 1e3, 3),
+                                      "ms_per_forward_graph": round(t_graph * 1e3, 3),
+                                      "timing": "serial single-stream launches, HIP events; see profiles/r02/unet_layer_table.md"}
                 result["roofline_pixel"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
                                             "unit": "GB/s", "frac": dom["frac_hbm_peak"], "traffic": None,
                                             "alg_bytes_per_launch": dom["alg_bytes"], "us_per_launch": dom["us"]}
@@ -338,9 +385,9 @@ def main():
             result["kernels"] = rows
             what = ("matting UNet-18, hand-written f32 MFMA implicit-GEMM convs (usc_conv.hip), %d fused launches" % pipe.net.num_layers
                     if args.net == "hip" else "matting UNet-18 via PyTorch-ROCm (MIOpen)")
-            result["net"] = {"bound": "mfma", "what": what, "ms": round(t_net * 1e3, 3),
-                             "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+            result["net"] = {"bound": "mfma", "what": what, "ms": round(t_graph * 1e3, 3),
+                             "achieved": round(gflop / t_graph / 1e3, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(gflop / t_graph / 1e3 / MFMA_F32_PEAK_TFLOPS, 4)}
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed at N = 1 only
             clip_cpu = SyntheticClip(H, W, args.cpu_frames, config_id=2, device="cpu")
             cf = []

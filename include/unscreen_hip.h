@@ -338,6 +338,12 @@ typedef struct usc_conv_desc {
  * library's own plan (cost model). */
 void usc_conv_force_plan(int nt, int rowgroups, int ksplit, int kgroups);
 
+/* The launch plan the library chooses for one layer (no device work): tile width in 32-column units, row groups and K groups
+ * per workgroup, grid K split, workgroups and threads of the main launch, launches per layer (2 when the grid splits K).
+ * Used by the profiling tools to label kernel traces (tools/dev/layer_table.py). */
+typedef struct usc_conv_plan_info { int nt, rowgroups, ksplit, kgroups, workgroups, threads, launches; } usc_conv_plan_info;
+int usc_conv_plan_query(const usc_conv_desc* desc, usc_conv_plan_info* out);
+
 /* sizeof(usc_conv_desc) as the library was built: bindings check their struct definition against it. */
 size_t usc_conv_desc_bytes(void);
 
@@ -352,7 +358,8 @@ const char* usc_conv_last_error(void);
  * activation buffers - must not overlap on the device (launch it on one stream, or order the streams). */
 int  usc_conv_graph_create(const usc_conv_desc* descs, int n, void** handle);
 int  usc_conv_graph_launch(void* handle, usc_stream_t stream);
-void usc_conv_graph_destroy(void* handle);   /* retires the handle (the HIP graph objects are kept until the process ends) */
+void usc_conv_graph_destroy(void* handle);   /* the one entry of this group that blocks: waits for the device to drain (a launch
+                                              * of the graph may still be queued), then destroys the graph, its execs and plans */
 
 #ifdef __cplusplus
 }

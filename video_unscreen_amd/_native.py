@@ -93,6 +93,7 @@ _SIGNATURES = {
     "usc_adaptive_avgpool_nhwc_batch_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "usc_seg_last_error": (C.c_char_p, []),
     "usc_conv_desc_bytes": (C.c_size_t, []),
+    "usc_conv_plan_query": (C.c_int, [_vp, _vp]),
     "usc_conv_sequence_f32": (C.c_int, [_vp, C.c_int, _vp]),
     "usc_conv_last_error": (C.c_char_p, []),
     "usc_conv_graph_create": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
@@ -123,6 +124,25 @@ def load():
 
 class NativeError(RuntimeError):
     pass
+
+
+class ConvPlanInfo(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("nt", "rowgroups", "ksplit", "kgroups", "workgroups", "threads", "launches")]
+
+
+def conv_plans(desc_array, n):
+    """The library's launch plan of each of the n layers of a ctypes array of usc_conv_desc (usc_conv_plan_query)."""
+    out = []
+    size = load().usc_conv_desc_bytes()
+    base = C.addressof(desc_array)
+    for i in range(n):
+        info = ConvPlanInfo()
+        rc = load().usc_conv_plan_query(base + i * size, C.byref(info))
+        if rc != 0:
+            raise NativeError(f"usc_conv_plan_query failed ({rc}): {load().usc_conv_last_error().decode()}")
+        out.append({"plan": f"{info.nt},{info.rowgroups},{info.ksplit},{info.kgroups}", "workgroups": info.workgroups,
+                    "threads": info.threads, "launches": info.launches})
+    return out
 
 
 def _check(rc, what):

@@ -125,10 +125,20 @@ class ConvGraphNet:
     def n_layers(self):
         return sum(len(arr) for kind, _, arr in self._segments if kind == "conv")
 
+    def close(self):
+        """Destroy the conv graphs (usc_conv_graph_destroy drains the device first: a launch may still be queued) and only then
+        let go of the buffers whose addresses are baked into the graph nodes."""
+        segs, self._segments = getattr(self, "_segments", []), []
+        for kind, a, _ in segs:
+            if kind == "conv" and a:
+                self.nv.load().usc_conv_graph_destroy(a)
+        self._keep = []
+
     def __del__(self):
+        import sys
+        if sys.is_finalizing():            # the HIP runtime may already be gone: the process frees everything anyway
+            return
         try:
-            for kind, a, _ in getattr(self, "_segments", []):
-                if kind == "conv" and a:
-                    self.nv.load().usc_conv_graph_destroy(a)
+            self.close()
         except Exception:
             pass

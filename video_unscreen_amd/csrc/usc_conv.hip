@@ -397,6 +397,7 @@ struct LayerPlan {
     dim3 grid, block;
     bool reduce;
     dim3 rgrid;
+    int nt = 0, rg = 0, kw = 0;            // for usc_conv_plan_query
 };
 
 static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
@@ -507,6 +508,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     p.d.nphase = nphase;
     p.grid = dim3(mblocks * nblocks, 1, nphase * S);          // 1-D over (pixel tile, N tile): the kernel re-labels it per XCD
     p.block = dim3(64 * RG * KW);
+    p.nt = nt2 ? 2 : 1; p.rg = nt2 ? 4 : RG; p.kw = KW;
 #define USC_PICK(NTV, RGV, KWV) (d.in_relu ? (void*)conv_mfma_kernel<NTV, RGV, KWV, true> : (void*)conv_mfma_kernel<NTV, RGV, KWV, false>)
     if (nt2) p.fn = KW >= 2 ? USC_PICK(2, 4, 2) : USC_PICK(2, 4, 1);
     else if (RG == 4) p.fn = KW == 4 ? USC_PICK(1, 4, 4) : KW == 2 ? USC_PICK(1, 4, 2) : USC_PICK(1, 4, 1);
@@ -524,6 +526,18 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
 }
 
 extern "C" size_t usc_conv_desc_bytes(void) { return sizeof(usc_conv_desc); }
+
+extern "C" int usc_conv_plan_query(const usc_conv_desc* desc, usc_conv_plan_info* out) {
+    if (!desc || !out) return conv_fail(USC_E_ARG, "usc_conv_plan_query: bad argument");
+    LayerPlan p;
+    int rc = plan_layer(*desc, p);
+    if (rc) return rc;
+    out->nt = p.nt; out->rowgroups = p.rg; out->kgroups = p.kw; out->ksplit = p.d.kind == USC_CONV_HEAD ? 1 : p.d.ksplit;
+    out->workgroups = (int)(p.grid.x * p.grid.y * p.grid.z);
+    out->threads = (int)p.block.x;
+    out->launches = p.reduce ? 2 : 1;
+    return USC_OK;
+}
 
 extern "C" int usc_conv_sequence_f32(const usc_conv_desc* descs, int n, usc_stream_t stream) {
     if (!descs || n < 0) return conv_fail(USC_E_ARG, "usc_conv_sequence_f32: bad argument");
@@ -549,11 +563,13 @@ struct ConvGraph {
     // launched on another (observed to fault on ROCm 7.2 when the first stream was the null stream).
     std::vector<std::pair<hipStream_t, hipGraphExec_t>> execs;
     std::vector<LayerPlan> plans;          // kernel arguments must outlive the graph
+    int device = -1;                       // the device the graph was created (and is launched) on
 };
 
 extern "C" int usc_conv_graph_create(const usc_conv_desc* descs, int n, void** handle) {
     if (!descs || n <= 0 || !handle) return conv_fail(USC_E_ARG, "usc_conv_graph_create: bad argument");
     ConvGraph* g = new ConvGraph();
+    (void)hipGetDevice(&g->device);
     g->plans.resize(n);
     for (int i = 0; i < n; i++) {
         int rc = plan_layer(descs[i], g->plans[i]);
@@ -614,9 +630,18 @@ extern "C" int usc_conv_graph_launch(void* handle, usc_stream_t stream) {
 }
 
 extern "C" void usc_conv_graph_destroy(void* handle) {
-    // Graphs are retired, not destroyed.  On this runtime (ROCm 7.2) hipGraphExecDestroy / hipGraphDestroy leave dangling state
-    // behind: a test sequence that builds and frees a few dozen networks segfaulted inside a later hipGraphLaunch, reproducibly,
-    // and stopped doing so as soon as nothing was destroyed.  A retired graph keeps its host-side plan and its (small) kernel
-    // argument blocks until the process ends; networks live as long as their pipeline anyway.
-    (void)handle;
+    // An executable graph must not be destroyed while one of its launches is still queued or running: the runtime frees the
+    // exec's kernel-argument blocks and its internal branch streams at once, and a later hipGraphLaunch on the same stream
+    // then walks freed command objects (round 1 saw exactly that as a host segfault: ConvGraphNet.__del__ destroyed graphs
+    // at garbage-collection time with launches in flight).  So: drain every stream the graph was launched on, then destroy.
+    if (!handle) return;
+    ConvGraph* g = (ConvGraph*)handle;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (g->device >= 0 && g->device != cur) (void)hipSetDevice(g->device);
+    if (!g->execs.empty()) (void)hipDeviceSynchronize();
+    for (auto& se : g->execs) (void)hipGraphExecDestroy(se.second);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    if (g->device >= 0 && g->device != cur && cur >= 0) (void)hipSetDevice(cur);
+    delete g;
 }

@@ -1,0 +1,88 @@
+"""Host boundary of the frame loops: decoded frames in pinned host memory go in, alpha + foreground
+come back in pinned host memory - what the reference's loop does around every agent (`.cuda()` up, `.cpu().numpy()` down:
+vmatting/agent.py:154-161, binseg/agent_human.py:295-303) and what its tools do around the loop (frame_list in RAM,
+bg_offline.py:36; cv2.imwrite of alpha and fg, :169,175).
+
+Uploads run on their own HIP stream a bounded number of frames ahead of the compute streams, downloads on a third stream
+behind them; PCIe is full duplex, so at 1080p (14.5 MB up, 8.3 MB down per frame) both directions hide behind the 3 ms of
+GPU work per frame.  Nothing here touches pixels: it is plumbing around BgStepPipeline.run()."""
+import torch
+
+
+_BUSY = object()          # staging slot handed to the pipeline, result not collected yet
+
+
+def pinned_like(shape, dtype=torch.uint8):
+    return torch.empty(shape, dtype=dtype).pin_memory()
+
+
+class HostFrameIO:
+    """Ring of device staging slots + copy streams around a pipeline's run().
+
+        io = HostFrameIO(pipe, depth)
+        pipe.run(io.inputs(host_frames, bg_always_dev), on_result=io.collect(alpha_host, fg_host))
+        io.drain()
+
+    host_frames yields (frame, seg | None, bg_i) pinned uint8 CPU tensors ((H, W, 3), (H, W) | None, (H, W, 3));
+    alpha_host[i] / fg_host[i] are pinned CPU tensors that receive frame i's outputs.  depth must exceed the number of
+    frames the pipeline holds in flight (run() looks two segmentation groups + two frames ahead)."""
+
+    def __init__(self, pipe, depth=None):
+        self.pipe = pipe
+        dev = pipe.device
+        H, W = pipe.H, pipe.W
+        self.depth = depth if depth is not None else 2 * pipe.seg_batch + 6
+        u8 = dict(dtype=torch.uint8, device=dev)
+        self.frames = [torch.empty((H, W, 3), **u8) for _ in range(self.depth)]
+        self.bgs = [torch.empty((H, W, 3), **u8) for _ in range(self.depth)]
+        self.segs = [torch.empty((H, W), **u8) for _ in range(self.depth)]
+        self.done = [None] * self.depth              # event: the frame staged in this slot has left the pipeline
+        self.up = torch.cuda.Stream(dev)
+        self.down = torch.cuda.Stream(dev)
+        self._n_in = 0
+        self._last_down = None
+
+    def inputs(self, host_frames, bg_always):
+        """Generator for BgStepPipeline.run(): uploads each host frame into the next staging slot on the upload stream and
+        yields (frame, seg, bg_i, bg_always, uploaded_event) device tensors."""
+        for frame_h, seg_h, bg_h in host_frames:
+            i = self._n_in % self.depth
+            self._n_in += 1
+            if self.done[i] is _BUSY:
+                raise RuntimeError("HostFrameIO: depth %d is smaller than the number of frames the pipeline holds in flight" % self.depth)
+            if self.done[i] is not None:
+                self.up.wait_event(self.done[i])     # the slot's previous frame has been consumed
+            self.done[i] = _BUSY
+            with torch.cuda.stream(self.up):
+                self.frames[i].copy_(frame_h, non_blocking=True)
+                self.bgs[i].copy_(bg_h, non_blocking=True)
+                if seg_h is not None:
+                    self.segs[i].copy_(seg_h, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.up)
+            yield (self.frames[i], self.segs[i] if seg_h is not None else None, self.bgs[i], bg_always, ev)
+
+    def collect(self, alpha_host, fg_host):
+        """on_result callback for run(): copies frame n's alpha and fg to alpha_host[n] / fg_host[n] on the download stream
+        and marks the frame's staging slot free.  The pipeline's outputs live in its own ring of four, whose reuse waits for
+        these copies."""
+        main = torch.cuda.current_stream(self.pipe.device)
+        base = self._n_in                            # inputs() of this run has not started yet: slots continue from here
+
+        def on_result(n, out):
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.done[(base + n) % self.depth] = ev  # frames are consumed in order: the slot input n was staged in
+            self.down.wait_event(ev)
+            with torch.cuda.stream(self.down):
+                alpha_host[n].copy_(out["alpha"], non_blocking=True)
+                fg_host[n].copy_(out["fg"], non_blocking=True)
+                dn = torch.cuda.Event()
+                dn.record(self.down)
+            self.pipe.note_output_consumed(out, dn)
+            self._last_down = dn
+        return on_result
+
+    def drain(self):
+        self.up.synchronize()
+        self.down.synchronize()

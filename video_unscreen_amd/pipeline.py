@@ -119,6 +119,11 @@ class BgStepPipeline:
         if seg_agent is not None and hasattr(seg_agent, "set_plan_batch"):
             seg_agent.set_plan_batch(self.seg_batch)       # step() and run() then segment a frame to the same bits
         self._seg_ring = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in range(3 * self.seg_batch)] if seg_agent is not None else []
+        # outputs live in a ring of 4 (alpha of frame t is alpha_pre of frame t + 1; a consumer on another stream - the
+        # download stream of hostio.HostFrameIO - may still be reading frame t - 1): no allocation inside the frame loop
+        self._out_ring = [{"alpha": torch.empty((H, W), dtype=torch.uint8, device=dev),
+                           "fg": torch.empty((H, W, 3), dtype=torch.uint8, device=dev), "consumed": None} for _ in range(4)]
+        self._out_i = 0
         self.alpha_pre = None
 
     def cpu_net(self):
@@ -160,12 +165,22 @@ class BgStepPipeline:
         alpha_pre = self.alpha_pre if self.alpha_pre is not None else slot.gate       # bg_offline.py:162-163
         nv.vmat_pre(frame, alpha_pre, slot.trimap, self.in_h, self.in_w, layout=self._layout, out=self.x7)
         pred = self.net(self.x7)
-        res = nv.vmat_post(pred.view(self.in_h, self.in_w), slot.trimap, want_float=want_float)
+        ring = self._out_ring[self._out_i % len(self._out_ring)]
+        self._out_i += 1
+        if ring["consumed"] is not None:                   # a reader on another stream (note_output_consumed) has finished
+            torch.cuda.current_stream(self.device).wait_event(ring["consumed"])
+            ring["consumed"] = None
+        res = nv.vmat_post(pred.view(self.in_h, self.in_w), slot.trimap, out_u8=ring["alpha"], want_float=want_float)
         alpha, alpha_f = (res if want_float else (res, None))
-        fg = nv.get_fg(frame, alpha, slot.bg, paste_thr=1)
+        fg = nv.get_fg(frame, alpha, slot.bg, paste_thr=1, out_fg=ring["fg"])
         self.alpha_pre = alpha
         return {"alpha": alpha, "alpha_f32": alpha_f, "fg": fg, "trimap": slot.trimap, "bg": slot.bg,
-                "gate": slot.gate, "alphaor": slot.alphaor, "pred": pred, "seg": slot.seg}
+                "gate": slot.gate, "alphaor": slot.alphaor, "pred": pred, "seg": slot.seg, "_ring": ring}
+
+    def note_output_consumed(self, out, event):
+        """A consumer that reads out["alpha"] / out["fg"] on another stream hands back the event that ends its reads; the
+        ring entry is not rewritten (three frames later) before that event."""
+        out["_ring"]["consumed"] = event
 
     # ------------------------------------------------------------------ synchronous form
     def step(self, frame, seg, bg_i, bg_always, want_float=False):
@@ -180,8 +195,10 @@ class BgStepPipeline:
 
     # ------------------------------------------------------------------ pipelined form
     def run(self, inputs, on_result=None):
-        """inputs: iterable of (frame, seg, bg_i, bg_always) CUDA tensors.  Calls on_result(index, dict) per frame
-        (the dict's tensors are only valid until two more frames have been submitted).  Returns the frame count."""
+        """inputs: iterable of (frame, seg, bg_i, bg_always[, ready_event]) CUDA tensors; ready_event (optional): the
+        event after which the tensors may be read - inputs staged on a copy stream (hostio.HostFrameIO); without it they
+        are taken to be produced on the current stream.  Calls on_result(index, dict) per frame (the dict's tensors are
+        only valid until two more frames have been submitted).  Returns the frame count."""
         chosen = self.object_filter
         if self._filter_choice == "auto":
             self.object_filter = "host"
@@ -247,12 +264,17 @@ class BgStepPipeline:
                     return []
                 first = (state["ngroups"] % 3) * self.seg_batch
                 state["ngroups"] += 1
-                seg_stream.wait_stream(main)                # frames produced on the main stream
+                group = [tuple(g) if len(g) == 5 else tuple(g) + (None,) for g in group]
+                if any(g[4] is None for g in group):
+                    seg_stream.wait_stream(main)            # frames produced on the main stream
+                for g in group:
+                    if g[4] is not None:
+                        seg_stream.wait_event(g[4])         # frames staged on a copy stream
                 with torch.cuda.stream(seg_stream):
                     masks = self.seg_agent.forward_device_batch([g[0] for g in group], outs=self._seg_ring[first:first + len(group)])
                     ev = torch.cuda.Event()
                     ev.record(seg_stream)
-                return [(g[0], m, g[2], g[3], ev) for g, m in zip(group, masks)]
+                return [(g[0], m, g[2], g[3], ev, g[4]) for g, m in zip(group, masks)]
 
             nxt = None
             while True:
@@ -263,17 +285,21 @@ class BgStepPipeline:
                             nxt = launch_group()            # one group ahead
                         else:
                             try:
-                                ahead = [tuple(next(it)) + (None,)]
+                                g = tuple(next(it))
+                                ahead = [g[:4] + (None, g[4] if len(g) == 5 else None)]
                             except StopIteration:
                                 state["exhausted"] = True
                         if not ahead:
                             break
-                    frame, seg, bg_i, bg_always, seg_ev = ahead.pop(0)
+                    frame, seg, bg_i, bg_always, seg_ev, up_ev = ahead.pop(0)
                     if seg_ev is not None:
                         front.wait_event(seg_ev)
                     slot = self.slots[submitted % len(self.slots)]
                     slot.frame = frame
-                    front.wait_stream(main)                 # inputs produced on the main stream
+                    if up_ev is not None:
+                        front.wait_event(up_ev)             # inputs staged on a copy stream
+                    else:
+                        front.wait_stream(main)             # inputs produced on the main stream
                     with torch.cuda.stream(front):
                         self._front_device(slot, frame, seg, bg_i, bg_always, seg_ready=batched)
                         if on_device:

@@ -15,8 +15,9 @@ Mirrors the *function* of the reference network
 * tensors are kept channels-last (NHWC) so the pixel kernels' 7-channel packed
   output feeds the first conv without a transpose.
 
-The conv contractions themselves run through PyTorch-ROCm (MIOpen / MFMA); all
-arithmetic is f32 unless ``dtype`` says otherwise.
+``MattingNet`` below evaluates the folded plan with torch ops: on the CPU it is the network's f32 oracle for the
+tests, on the GPU (``net_backend="miopen"``) a comparison baseline.  The product path is ``net_hip.HipMattingNet``:
+the same plan on the hand-written f32-MFMA kernel of csrc/usc_conv.hip.
 """
 from __future__ import annotations
 

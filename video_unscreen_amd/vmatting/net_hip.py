@@ -2,7 +2,7 @@
 
 Same folded plan as net.py (reference unscreen/vmatting/model.py:435-568, spectral norm and conv->BN folded at
 load), but instead of ~230 PyTorch / MIOpen kernel launches per frame the whole forward is ONE C call that
-enqueues 65 fused layers: every bias, residual add, ReLU / LeakyReLU, shortcut BN and nearest-x2 upsample lives
+enqueues 54 fused layers: every bias, residual add, ReLU / LeakyReLU, shortcut BN and nearest-x2 upsample lives
 in a conv epilogue, ConvTranspose2d(k4, s2, p1) runs as its four 2x2 output phases, AvgPool2d(2)+1x1 as one
 2x2-stride-2 conv.  All tensors are NHWC float32 buffers allocated once per frame size.
 """
@@ -83,11 +83,19 @@ class HipMattingNet:
             if rc != 0:
                 raise nv.NativeError(f"usc_conv_graph_create failed ({rc}): {nv.load().usc_conv_last_error().decode()}")
 
+    def close(self):
+        """Destroy the graph (usc_conv_graph_destroy drains the device first), then release the buffers its nodes point to."""
+        if getattr(self, "_graph", None) is not None and self._graph:
+            nv.load().usc_conv_graph_destroy(self._graph)
+            self._graph = C.c_void_p()
+        self._keep = []
+
     def __del__(self):
+        import sys
+        if sys.is_finalizing():            # the HIP runtime may already be gone: the process frees everything anyway
+            return
         try:
-            if getattr(self, "_graph", None) is not None and self._graph:
-                nv.load().usc_conv_graph_destroy(self._graph)
-                self._graph = C.c_void_p()
+            self.close()
         except Exception:
             pass
 
@@ -231,3 +239,11 @@ class HipMattingNet:
         return self.pred
 
     __call__ = forward
+
+    def forward_serial(self):
+        """The same layers launched one after the other on the current stream (no graph, no branch overlap): what the per-layer
+        profile table and bench.py's roofline time."""
+        rc = nv.load().usc_conv_sequence_f32(self._arr, len(self._descs), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise nv.NativeError(f"conv launch failed ({rc}): {nv.load().usc_conv_last_error().decode()}")
+        return self.pred
