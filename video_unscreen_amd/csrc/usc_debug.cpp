@@ -1,0 +1,31 @@
+// Diagnostic aid (off unless USC_SEGV_BACKTRACE is set when the library loads): on SIGSEGV print the native call stack to
+// stderr, then hand over to the handler that was installed before (Python's faulthandler under pytest).  Used to find which
+// runtime call a crash sits in when the only evidence is a Python-level trace ending in a ctypes call.
+#include <execinfo.h>
+#include <signal.h>
+#include <stdlib.h>
+#include <unistd.h>
+
+namespace {
+struct sigaction g_prev;
+
+void on_segv(int, siginfo_t*, void*) {
+    void* frames[96];
+    const int n = backtrace(frames, 96);
+    static const char msg[] = "\n[usc] SIGSEGV - native backtrace of the faulting thread:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    sigaction(SIGSEGV, &g_prev, nullptr);          // returning re-executes the faulting instruction under the previous handler
+}
+
+__attribute__((constructor)) void usc_install_segv_backtrace() {
+    if (!getenv("USC_SEGV_BACKTRACE")) return;
+    void* warm[2];
+    (void)backtrace(warm, 2);                      // loads libgcc now, not inside the handler
+    struct sigaction sa;
+    sa.sa_sigaction = on_segv;
+    sigemptyset(&sa.sa_mask);
+    sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+    sigaction(SIGSEGV, &sa, &g_prev);
+}
+}  // namespace
