@@ -534,6 +534,46 @@ def remove_invalid_objects(cfg, alpha, segmask=None, return_stats=False):
     return alpha
 
 
+def find_contours(image):
+    """cv2.findContours(image, RETR_LIST, CHAIN_APPROX_SIMPLE) of maskprocess.py:123: a list of (n, 2) int32 (x, y) arrays in the
+    order the raster scan meets the borders (every border pixel is kept; dropping collinear ones changes neither area nor fill)."""
+    image, p = _u8(image)
+    h, w = image.shape
+    cap = 8 * h * w + 64
+    pts = np.empty((cap, 2), np.int32)
+    lens = np.empty(h * w + 1, np.int32)
+    ip = C.POINTER(C.c_int)
+    fn = lib().orc_find_contours
+    fn.argtypes = [u8p, C.c_int, C.c_int, ip, C.c_longlong, ip, C.c_int]
+    n = fn(p, h, w, pts.ctypes.data_as(ip), cap, lens.ctypes.data_as(ip), lens.size)
+    if n < 0:
+        raise RuntimeError("orc_find_contours: capacity exceeded")
+    out, o = [], 0
+    for i in range(n):
+        out.append(pts[o:o + lens[i]].copy())
+        o += lens[i]
+    return out
+
+
+def contour_area(pts):
+    """cv2.contourArea (maskprocess.py:133)."""
+    pts = np.ascontiguousarray(pts, np.int32)
+    fn = lib().orc_contour_area
+    fn.restype = C.c_double
+    fn.argtypes = [C.POINTER(C.c_int), C.c_int]
+    return fn(pts.ctypes.data_as(C.POINTER(C.c_int)), len(pts))
+
+
+def draw_contour_filled(img, pts, value=255):
+    """cv2.drawContours(img, [contour], 0, value, cv2.FILLED) in place on a one-channel uint8 image (maskprocess.py:137,148)."""
+    assert img.dtype == np.uint8 and img.ndim == 2 and img.flags.c_contiguous
+    pts = np.ascontiguousarray(pts, np.int32)
+    fn = lib().orc_draw_contour_filled
+    fn.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, u8p, C.c_int]
+    fn(pts.ctypes.data_as(C.POINTER(C.c_int)), len(pts), img.shape[0], img.shape[1], img.ctypes.data_as(u8p), int(value))
+    return img
+
+
 def version():
     return lib().orc_version().decode()
 

@@ -911,6 +911,60 @@ ORC_API int orc_remove_invalid_objects(uint8_t* alpha, const uint8_t* segmask, i
     return count;
 }
 
+/* The three OpenCV contour calls of maskprocess.py:123-149 as separate entry points (same border follower, area and fill as
+ * orc_remove_invalid_objects above), so that the reference's own Python can be run against them (tests/golden/cv2_shim.py).
+ * orc_find_contours: image != 0 is object; every contour's points (x, y pairs, every visited border pixel) are appended to
+ * pts (capacity max_pts points), lens[i] = number of points of contour i, in the order the raster scan meets them.
+ * Returns the number of contours, or -1 when a capacity is exceeded. */
+ORC_API int orc_find_contours(const uint8_t* image, int H, int W, int* pts, long long max_pts, int* lens, int max_contours)
+{
+    int step = W + 2;
+    int8_t* img = (int8_t*)calloc((size_t)(H + 2) * step, 1);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) img[(size_t)(y + 1) * step + x + 1] = image[(size_t)y * W + x] != 0;
+    orc_chain ch = {0, 0, 0};
+    int count = 0;
+    long long used = 0;
+    for (int y = 1; y <= H && count >= 0; y++) {
+        int prev = 0;
+        for (int x = 1; x <= W; x++) {
+            int p = img[(size_t)y * step + x];
+            if (p != prev) {
+                int is_hole = 0, start = 0;
+                if (prev == 0 && p == 1) start = 1;
+                else if (p == 0 && prev >= 1) { is_hole = 1; start = 1; }
+                if (start) {
+                    orc_follow(img, step, x - is_hole, y, is_hole, &ch);
+                    if (count >= max_contours || used + (long long)ch.n > max_pts) { count = -1; break; }
+                    for (size_t i = 0; i < ch.n; i++) { pts[2 * (used + i)] = ch.p[i].x - 1; pts[2 * (used + i) + 1] = ch.p[i].y - 1; }
+                    lens[count++] = (int)ch.n;
+                    used += (long long)ch.n;
+                    p = img[(size_t)y * step + x];
+                }
+            }
+            prev = p;
+        }
+    }
+    free(ch.p); free(img);
+    return count;
+}
+
+ORC_API double orc_contour_area(const int* pts, int n)
+{
+    orc_chain c = {(orc_pt*)pts, (size_t)n, (size_t)n};
+    return orc_chain_area(&c);
+}
+
+/* cv2.drawContours(img, [contour], 0, value, cv2.FILLED) on a one-channel image. */
+ORC_API void orc_draw_contour_filled(const int* pts, int n, int H, int W, uint8_t* img, int value)
+{
+    orc_chain c = {(orc_pt*)pts, (size_t)n, (size_t)n};
+    uint8_t* obj = (uint8_t*)calloc((size_t)H * W, 1);
+    orc_fill(&c, H, W, obj);
+    for (size_t i = 0; i < (size_t)H * W; i++) if (obj[i]) img[i] = (uint8_t)value;
+    free(obj);
+}
+
 /* ------------------------------------------------------------------------------------------
  * HumanSegAgent pre / post processing (unscreen/binseg/agent_human.py:262-312)
  * ---------------------------------------------------------------------------------------- */

@@ -1,0 +1,234 @@
+"""Orchestration goldens: the reference's OWN Python run in the build container against a module
+named `cv2` that is backed by the C oracle (tests/golden/cv2_shim.py).  Output: tests/golden/orchestration.npz (data only).
+
+What runs, unmodified, from /root/reference (loaded by file path into a stand-in `unscreen` package that holds only these files -
+the real package imports mmcv / matplotlib / cv2 on import):
+    unscreen/utils/imgprocess.py, maskprocess.py, fgfuncs.py      get_target_size, pad_resize, inv_pad_resize, imnormalize,
+                                                                    color_correct, dilate_mask, erode_mask, exist_foreground,
+                                                                    remove_invalid_objects, is_pixel_inrange, get_fg, get_bg
+    unscreen/trimap/agent.py                                        TrimapAgent.forward / generate_trimap / generate_trimap_withbg
+    unscreen/vmatting/agent.py + model.py                           VMattingAgent(model_path, cuda_device=-1): preprocess, the
+                                                                    reference UNet on the CPU, postprocess, forward
+    tools/unscreen/bg_offline.py:145-176                            the stage-3 frame loop: the `for fid in ...` statement is lifted
+                                                                    out of main() with ast and executed as it stands (save_img
+                                                                    collects what it is handed)
+NumPy >= 1.24 dropped the aliases np.float / np.bool / np.int the reference uses: they are restored for this process.
+
+This pins the reference's order of operations, thresholds, dtype promotions, truncations and in-place behaviour.  It does not pin
+OpenCV's arithmetic inside a call (the shim is the oracle's restatement).  Usage: python tests/golden/gen_orchestration.py"""
+import ast
+import importlib.util
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+REF = "/root/reference"
+
+CFG = {
+    "fg_exist_thr": 0.001,
+    "bg_mask": {"thr": 25, "fusion_weight": 0.1},
+    "objectremoval": {"score_map_center": {"landscape": [0.5, 0.5], "portrait": [0.6, 0.5]},
+                      "saliency_thr": 0.00001, "consensus_thr": 0.5},
+    "trimap": {"input_long_side": 144, "kernelsize": 3, "iters": 2, "color_winsize": [10, 100, 180]},
+    "vmatting": {"model_path": "synthetic", "input_long_side": 192},
+}
+
+
+def load_reference():
+    """Stand-in package `unscreen` holding the reference's hot-path files, with `cv2` = the oracle-backed shim."""
+    import cv2_shim
+    np.float, np.bool, np.int = float, bool, int
+    sys.modules["cv2"] = cv2_shim
+
+    def pkg(name):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+        return m
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+
+    pkg("unscreen")
+    utils = pkg("unscreen.utils")
+    for sub in ("imgprocess", "maskprocess", "fgfuncs"):          # `from .x import *` of utils/__init__.py for these three
+        m = load(f"unscreen.utils.{sub}", f"unscreen/utils/{sub}.py")
+        for k, v in vars(m).items():
+            if not k.startswith("_"):
+                setattr(utils, k, v)
+    pkg("unscreen.trimap")
+    tri = load("unscreen.trimap.agent", "unscreen/trimap/agent.py")
+    pkg("unscreen.vmatting")
+    load("unscreen.vmatting.model", "unscreen/vmatting/model.py")
+    vm = load("unscreen.vmatting.agent", "unscreen/vmatting/agent.py")
+    return utils, tri.TrimapAgent, vm.VMattingAgent, cv2_shim
+
+
+def blobs(rng, h, w, n, rmax):
+    """Random ellipse blobs + speckle: objects of every size class around the area-100 rule, some nested holes."""
+    yy, xx = np.mgrid[:h, :w]
+    m = np.zeros((h, w), bool)
+    for _ in range(n):
+        cy, cx = rng.uniform(0, h), rng.uniform(0, w)
+        ry, rx = rng.uniform(1.5, rmax), rng.uniform(1.5, rmax)
+        e = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2
+        m |= e <= 1
+        if rng.random() < 0.4:
+            m &= ~(e <= 0.25)
+    m ^= rng.random((h, w)) < 0.01
+    return np.where(m, 255, 0).astype(np.uint8)
+
+
+def main():
+    from video_unscreen_amd.synth import SyntheticClip
+    from video_unscreen_amd.vmatting.net import synthetic_state_dict
+    utils, TrimapAgent, VMattingAgent, shim = load_reference()
+    out = {"cfg_json": np.frombuffer(json.dumps(CFG).encode(), np.uint8)}
+    rng = np.random.default_rng(20260006)
+
+    # ---- 1. TrimapAgent.generate_trimap: default parameters (long side 960: up-scaling by non-integer ratios) and the golden config
+    for name, (h, w), kw in (("a", (54, 96), {}), ("b", (96, 54), {}), ("c", (64, 96), dict(input_long_side=144, iters=2)),
+                             ("d", (270, 480), dict(input_long_side=240))):
+        mask = blobs(rng, h, w, 6, min(h, w) / 3)
+        mask[mask > 0] = rng.integers(100, 256, int((mask > 0).sum()), dtype=np.uint8)       # grey masks: the >127 / <128 rules matter
+        agent = TrimapAgent(**kw)
+        m_in = mask.copy()
+        tri = agent.forward(m_in)
+        assert np.array_equal(m_in, mask), "generate_trimap must not modify its argument"
+        out[f"tri_{name}_mask"], out[f"tri_{name}_out"] = mask, tri
+        out[f"tri_{name}_params"] = np.array([agent.input_long_side, agent.kernelsize, agent.iters], np.int64)
+    # ---- 1b. generate_trimap_withbg, both branches of the 0.1 ratio test + the empty mask (returns its argument)
+    agent = TrimapAgent(input_long_side=144, iters=2)
+    for name, greenish in (("lo", 0.02), ("hi", 0.5)):
+        h, w = 64, 96
+        bg_color = np.array([60, 200, 60], np.uint8)
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        mask = blobs(rng, h, w, 4, 20)
+        near = (rng.random((h, w)) < greenish)
+        img[near] = np.clip(bg_color.astype(int) + rng.integers(-3, 4, (int(near.sum()), 3)), 0, 255).astype(np.uint8)
+        tri = agent.forward(mask.copy(), img.copy(), bg_color.copy())
+        out[f"triwb_{name}_mask"], out[f"triwb_{name}_img"], out[f"triwb_{name}_bg"], out[f"triwb_{name}_out"] = mask, img, bg_color, tri
+        inr = utils.is_pixel_inrange(img.copy(), bg_color.copy(), agent.color_winsize)
+        out[f"triwb_{name}_inrange"] = inr.astype(np.uint8)
+    empty = np.zeros((20, 30), np.uint8)
+    assert agent.forward(empty, np.zeros((20, 30, 3), np.uint8), np.array([60, 200, 60], np.uint8)) is empty
+    # is_pixel_inrange with a background IMAGE (the torch branch)
+    img = rng.integers(0, 256, (40, 60, 3), dtype=np.uint8)
+    bgimg = np.clip(img.astype(int) + rng.integers(-40, 41, img.shape), 0, 255).astype(np.uint8)
+    out["inr_img"], out["inr_bgimg"] = img, bgimg
+    out["inr_out"] = utils.is_pixel_inrange(img.copy(), bgimg.copy(), (20, 20, 120)).astype(np.uint8)
+
+    # ---- 2. dilate_mask / erode_mask
+    m = blobs(rng, 50, 70, 5, 12)
+    out["morph_mask"] = m
+    for k, it in ((3, 5), (4, 2), (5, 1)):
+        out[f"morph_dil_{k}_{it}"] = utils.dilate_mask(m.copy(), k, it)
+        out[f"morph_ero_{k}_{it}"] = utils.erode_mask(m.copy(), k, it)
+
+    # ---- 3. remove_invalid_objects, with and without a segmentation mask; in place on its argument
+    for name, (h, w) in (("land", (96, 144)), ("port", (144, 96))):
+        alpha = blobs(rng, h, w, 9, 22)
+        seg = blobs(rng, h, w, 3, 40)
+        cfg_hi = json.loads(json.dumps(CFG))
+        cfg_hi["objectremoval"]["saliency_thr"] = 0.002                # objects on both sides of the saliency threshold
+        for tag, c, s in (("plain", CFG, None), ("seg", cfg_hi, seg)):
+            a = alpha.copy()
+            r = utils.remove_invalid_objects(c, a) if s is None else utils.remove_invalid_objects(c, a, s.copy())
+            assert r is a, "remove_invalid_objects returns its (modified) argument"
+            out[f"rio_{name}_{tag}_out"] = r
+        out[f"rio_{name}_alpha"], out[f"rio_{name}_seg"], out[f"rio_{name}_thr_seg"] = alpha, seg, np.float64(0.002)
+    out["ef"] = np.array([utils.exist_foreground(out["rio_land_alpha"], t) for t in (0.001, 0.2, 0.9)])
+
+    # ---- 4. get_fg / get_bg / color_correct
+    h, w = 48, 64
+    img, bg = rng.integers(0, 256, (h, w, 3), dtype=np.uint8), rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    alpha = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    alpha[:10] = 0
+    alpha[-10:] = 255
+    out["fg_img"], out["fg_bg"], out["fg_alpha"] = img, bg, alpha
+    out["fg_out"] = utils.get_fg(img.copy(), alpha.copy(), bg.copy())
+    out["bg_out"] = utils.get_bg(alpha.copy(), bg.copy())
+    green = np.array([60, 200, 60], np.uint8)
+    gimg = np.clip(green.astype(int) + rng.integers(-60, 61, (h, w, 3)), 0, 255).astype(np.uint8)
+    out["cc_img"], out["cc_alpha"], out["cc_bg"] = gimg, alpha, green
+    out["cc_out"] = utils.color_correct(gimg.copy(), alpha.copy(), green.copy(), target_long_side=96)
+
+    # ---- 5. VMattingAgent on the CPU: preprocess tensors, postprocess, forward (the reference UNet itself)
+    with tempfile.TemporaryDirectory() as td:
+        ck = os.path.join(td, "unet18_synth.pth")
+        torch.save({"state_dict": synthetic_state_dict(0)}, ck)
+        vmat = VMattingAgent(ck, input_long_side=CFG["vmatting"]["input_long_side"], cuda_device=-1)
+    H, W, n = 64, 96, 3
+    clip = SyntheticClip(H, W, n, config_id=2, device="cpu")
+    frames = [clip.frame(t) for t in range(n)]
+    f0 = frames[0]["frame"].numpy()
+    tri0 = TrimapAgent(**{k: CFG["trimap"][k] for k in ("input_long_side", "kernelsize", "iters")}).forward(frames[0]["seg"].numpy().copy())
+    ap0 = frames[0]["seg"].numpy()
+    it, at, tt, ot = vmat.preprocess(f0.copy(), ap0.copy(), tri0.copy())
+    out["vm_frame"], out["vm_alpha_pre"], out["vm_trimap"] = f0, ap0, tri0
+    out["vm_pre_x7"] = torch.cat([it, at, tt], 1)[0].numpy()             # (7, in_h, in_w) float32
+    assert np.array_equal(ot, tri0)
+    pred = torch.rand(it.shape[2], it.shape[3], generator=torch.Generator().manual_seed(5)).numpy()
+    out["vm_post_pred"], out["vm_post_out"] = pred, vmat.postprocess(pred.copy(), tri0)
+
+    # ---- 6. the stage-3 frame loop of tools/unscreen/bg_offline.py, statement for statement
+    tree = ast.parse(open(os.path.join(REF, "tools/unscreen/bg_offline.py")).read())
+    main_fn = [x for x in tree.body if isinstance(x, ast.FunctionDef) and x.name == "main"][0]
+    loops = [x for x in ast.walk(main_fn) if isinstance(x, ast.For) and isinstance(x.target, ast.Name) and x.target.id == "fid"]
+    loop = [x for x in loops if any(isinstance(y, ast.Call) and getattr(y.func, "id", "") == "get_fg" for y in ast.walk(x))][0]
+    assert 140 <= loop.lineno <= 150 and 170 <= loop.end_lineno <= 180, (loop.lineno, loop.end_lineno)
+    saved = {}
+    trace = {"alphaor": [], "trimap": []}
+
+    def rio(cfg, alpha):
+        r = utils.remove_invalid_objects(cfg, alpha)
+        trace["alphaor"].append(r.copy())
+        return r
+
+    class TrimapTrace:
+        def __init__(self, agent):
+            self.agent = agent
+
+        def forward(self, mask):
+            t = self.agent.forward(mask)
+            trace["trimap"].append(t.copy())
+            return t
+
+    ns = {"np": np, "cv2": shim, "osp": os.path, "tqdm": types.SimpleNamespace(tqdm=lambda x: x), "cfg": CFG, "numframes": n,
+          "frame_list": [f["frame"].numpy() for f in frames],
+          "mask_list": [np.repeat(f["seg"].numpy()[..., None], 3, 2) for f in frames],       # masks come back from JPEGs as 3 channels
+          "bg_list": [f["bg"].numpy() for f in frames], "bgimg_always": clip.bg_always.numpy(),
+          "dst_img_dir": "", "alpha_pre": None, "dilate_mask": utils.dilate_mask, "remove_invalid_objects": rio, "get_fg": utils.get_fg,
+          "trimapagent": TrimapTrace(TrimapAgent(**CFG["trimap"])), "vmatagent": vmat,
+          "save_img": lambda img, path: saved.__setitem__(os.path.basename(path), img.copy())}
+    exec(compile(ast.Module(body=[loop], type_ignores=[]), "bg_offline.py", "exec"), ns)
+    out["loop_frames"] = np.stack(ns["frame_list"])
+    out["loop_seg"] = np.stack([f["seg"].numpy() for f in frames])
+    out["loop_bg"] = np.stack(ns["bg_list"])
+    out["loop_bg_always"] = ns["bgimg_always"]
+    out["loop_alphaor"] = np.stack(trace["alphaor"])
+    out["loop_trimap"] = np.stack(trace["trimap"])
+    out["loop_alpha"] = np.stack([saved[f"alphamask_{i:06d}.jpg"] for i in range(n)])
+    out["loop_fg"] = np.stack([saved[f"fg_{i:06d}.jpg"] for i in range(n)])
+    used = sorted({c[0] for c in shim.calls})
+    out["cv2_calls_reached"] = np.frombuffer(",".join(used).encode(), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "orchestration.npz"), **out)
+    print("orchestration.npz:", len(out), "arrays; cv2 entry points reached:", used)
+    print("loop alpha: nonzero", [int((a > 0).sum()) for a in out["loop_alpha"]], "unknown px", [int((t == 128).sum()) for t in out["loop_trimap"]])
+
+
+if __name__ == "__main__":
+    main()

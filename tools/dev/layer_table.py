@@ -81,12 +81,12 @@ def table(layers_json, trace_csv):
         k += l["launches"]
         tot_us += us
         tot_gf += l["gflop"]
-        tf = l["gflop"] / us * 1e-3 if us > 0 else 0.0
+        tf = l["gflop"] / us * 1e3 if us > 0 else 0.0
         what = "head (N = 1, HBM-bound)" if l["kind"] == 1 else l["plan"]
         print(f"| {l['i']} | {l['M']} | {l['Cin']} | {l['Cout']} | {l['taps']} | {what} | {l['workgroups']} | {l['gflop']:.3f} | {us:.1f} | {tf:.1f} | {tf / PEAK:.3f} |")
     print(f"\n**Sum over the {len(layers)} layers: {tot_us / 1e3:.3f} ms of kernel time per forward, {tot_gf:.2f} GFLOP executed** "
-          f"-> {tot_gf / tot_us * 1e-3:.1f} TFLOP/s executed; against the reference module's 132.75 GFLOP: "
-          f"**{132.75 / tot_us * 1e-3:.1f} TFLOP/s = {132.75 / tot_us * 1e-3 / PEAK:.3f} of the f32-MFMA peak**.")
+          f"-> {tot_gf / tot_us * 1e3:.1f} TFLOP/s executed; against the reference module's 132.75 GFLOP: "
+          f"**{132.75 / tot_us * 1e3:.1f} TFLOP/s = {132.75 / tot_us * 1e3 / PEAK:.3f} of the f32-MFMA peak**.")
     print(f"\nHIP events around the same serial launches in the same (traced) process: {meta['hip_event_ms_per_forward']:.3f} ms per forward "
           "(kernel time + the gaps between consecutive launches on the stream).")
 

@@ -613,8 +613,11 @@ extern "C" int usc_conv_graph_create(const usc_conv_desc* descs, int n, void** h
     return USC_OK;
 }
 
+extern "C" void usc_debug_arm_segv_backtrace(void);      // usc_debug.cpp (no-op unless USC_SEGV_BACKTRACE is set)
+
 extern "C" int usc_conv_graph_launch(void* handle, usc_stream_t stream) {
     if (!handle) return conv_fail(USC_E_ARG, "usc_conv_graph_launch: null handle");
+    usc_debug_arm_segv_backtrace();
     ConvGraph* g = (ConvGraph*)handle;
     hipStream_t st = (hipStream_t)stream;
     hipGraphExec_t exec = nullptr;

@@ -18,8 +18,16 @@ void on_segv(int, siginfo_t*, void*) {
     sigaction(SIGSEGV, &g_prev, nullptr);          // returning re-executes the faulting instruction under the previous handler
 }
 
-__attribute__((constructor)) void usc_install_segv_backtrace() {
-    if (!getenv("USC_SEGV_BACKTRACE")) return;
+}  // namespace
+
+// (Re-)arm the handler: called when the library loads and again in front of the graph launches, because runtimes loaded later
+// (HSA, Python's faulthandler) install their own handlers on top.
+extern "C" void usc_debug_arm_segv_backtrace(void) {
+    static const bool on = getenv("USC_SEGV_BACKTRACE") != nullptr;
+    if (!on) return;
+    struct sigaction cur;
+    sigaction(SIGSEGV, nullptr, &cur);
+    if ((cur.sa_flags & SA_SIGINFO) && cur.sa_sigaction == on_segv) return;
     void* warm[2];
     (void)backtrace(warm, 2);                      // loads libgcc now, not inside the handler
     struct sigaction sa;
@@ -28,4 +36,7 @@ __attribute__((constructor)) void usc_install_segv_backtrace() {
     sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
     sigaction(SIGSEGV, &sa, &g_prev);
 }
+
+namespace {
+__attribute__((constructor)) void usc_arm_at_load() { usc_debug_arm_segv_backtrace(); }
 }  // namespace
