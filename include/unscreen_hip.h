@@ -144,8 +144,11 @@ int usc_composite_fgbg_u8(const uint8_t* fg, const uint8_t* alpha, int fh, int f
 #define USC_CVT_HSV2BGR  1
 #define USC_CVT_BGR2GRAY 2
 #define USC_CVT_BGR2LAB  3
+#define USC_CVT_LAB2BGR  4         /* cv2.COLOR_LAB2BGR, harmonization/agent.py:73; `lab_tables` = device copy of the usc_lab_inv_tables_host() blob */
 size_t usc_lab_tables_bytes(void);
 void usc_lab_tables_host(void* blob);
+size_t usc_lab_inv_tables_bytes(void);
+void usc_lab_inv_tables_host(void* blob);
 int usc_cvt_color_u8(const uint8_t* src, size_t n, int code, uint8_t* dst, const void* lab_tables, usc_stream_t stream);
 int usc_gmm_lut_host(const double* means, const double* stds, const double* weights, int K, float* lut256);
 int usc_gmm_alpha_u8(const uint8_t* hsv, size_t n, const float* luts, uint8_t* alpha, float* prob_out, usc_stream_t stream);

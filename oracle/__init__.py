@@ -61,7 +61,7 @@ def lib():
         _lib.orc_cf_threshold.argtypes = [u8p, u8p, C.c_size_t, C.c_double]
         _lib.orc_color_correct.argtypes = [u8p, u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_double, u8p, C.POINTER(C.c_int)]
         _lib.orc_box_filter_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
-        for name in ("orc_bgr2gray_u8", "orc_bgr2hsv_u8", "orc_hsv2bgr_u8", "orc_bgr2lab_u8"):
+        for name in ("orc_bgr2gray_u8", "orc_bgr2hsv_u8", "orc_hsv2bgr_u8", "orc_bgr2lab_u8", "orc_lab2bgr_u8"):
             getattr(_lib, name).argtypes = [u8p, u8p, C.c_size_t]
     return _lib
 
@@ -185,6 +185,14 @@ def bgr2lab(img):
     img, p = _u8(img)
     out = np.empty_like(img)
     lib().orc_bgr2lab_u8(p, out.ctypes.data_as(u8p), img.size // 3)
+    return out
+
+
+def lab2bgr(img):
+    """cv2.cvtColor(img, cv2.COLOR_LAB2BGR) on uint8 (harmonization/agent.py:73)."""
+    img, p = _u8(img)
+    out = np.empty_like(img)
+    lib().orc_lab2bgr_u8(p, out.ctypes.data_as(u8p), img.size // 3)
     return out
 
 

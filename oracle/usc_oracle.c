@@ -1231,6 +1231,74 @@ ORC_API void orc_bgr2lab_u8(const uint8_t* src, uint8_t* dst, size_t n)
     for (size_t i = 0; i < n; i++) orc_bgr2lab_px(src + 3 * i, dst + 3 * i);
 }
 
+/* cv2.COLOR_LAB2BGR on uint8 (unscreen/harmonization/agent.py:73 foreground_toning).  OpenCV 4's Lab2RGB_b runs its integer
+ * path (Lab2RGBinteger, color_lab.cpp; enableBitExactness): BASE = 2^14,
+ *   (y, ify) = LabToYF_b[L]: L <= 20: y = round(L*BASE*180 / (17*29^3)), ify = round(BASE*(16/116 + L*5/(3*17*29)));
+ *                            else fy = L*100*BASE/(255*116) + 16*BASE/116 (float), ify = round(fy), y = round(fy^3 / BASE^2)
+ *   adiv = ((5*a*53687 + 128) >> 13) - 128*BASE/500 ; bdiv = ((b*41943 + 16) >> 9) - 128*BASE/200 + 1
+ *   x = abToXZ(ify + adiv), z = abToXZ(ify - bdiv): v <= 3390: v*108/841 - BASE*16/116*108/841 (C integer division),
+ *                                                     else v*v/BASE*v/BASE
+ *   (r, g, b) = descale(C . (x, y, z), 14) with C = round(4096 * XYZ2sRGB_D65 * white), clamped to [0, 4095], through the
+ *   4096-entry inverse sRGB gamma table round(255 * invgamma(i / 4096)).
+ * PARITY UNPINNED: restated from the published source; the float table entries use libm (OpenCV: its softfloat). */
+static uint16_t orc_lab_yf_b[512], orc_lab_invgamma_b[4096];
+static int orc_lab_inv_coeffs[9], orc_lab_inv_ready = 0;
+ORC_API void orc_lab_inv_tables(uint16_t* yf512, uint16_t* invgamma4096, int* coeffs9)
+{
+    static const double m[9] = {3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311};
+    static const double white[3] = {0.950456, 1., 1.088754};
+    const int BASE = 1 << 14;
+    for (int i = 0; i < 256; i++) {
+        int y, ify;
+        if (i <= 20) {
+            y = orc_round_i((double)((float)(i * BASE * 20 * 9) / (float)(17 * 29 * 29 * 29)));
+            ify = orc_round_i((double)((float)BASE * (16.f / 116.f + (float)(i * 5) / (float)(3 * 17 * 29))));
+        } else {
+            float fy = (float)(i * 100 * BASE) / (float)(255 * 116) + (float)(16 * BASE) / 116.f;
+            ify = orc_round_i((double)fy);
+            y = orc_round_i((double)(fy * fy * fy / (float)((double)BASE * BASE)));
+        }
+        yf512[2 * i] = (uint16_t)y;
+        yf512[2 * i + 1] = (uint16_t)ify;
+    }
+    for (int i = 0; i < 4096; i++) {
+        float x = (1.f / 4096.f) * (float)i;
+        double xd = (double)x;
+        float v = (float)(xd <= 0.0031308 ? xd * 12.92 : pow(xd, 1. / 2.4) * 1.055 - 0.055);
+        invgamma4096[i] = (uint16_t)orc_round_i((double)(255.f * v));
+    }
+    for (int i = 0; i < 3; i++) {            /* rows of coeffs9: B, G, R (blueIdx = 0); column i scaled by the white point */
+        coeffs9[0 + i] = orc_round_i(4096. * m[6 + i] * white[i]);
+        coeffs9[3 + i] = orc_round_i(4096. * m[3 + i] * white[i]);
+        coeffs9[6 + i] = orc_round_i(4096. * m[0 + i] * white[i]);
+    }
+}
+static inline int orc_ab_to_xz(int v)
+{
+    const int BASE = 1 << 14;
+    if (v <= 3390) return v * 108 / 841 - BASE * 16 / 116 * 108 / 841;
+    return v * v / BASE * v / BASE;
+}
+static inline void orc_lab2bgr_px(const uint8_t* s, uint8_t* d)
+{
+    if (!orc_lab_inv_ready) { orc_lab_inv_tables(orc_lab_yf_b, orc_lab_invgamma_b, orc_lab_inv_coeffs); orc_lab_inv_ready = 1; }
+    const int BASE = 1 << 14;
+    int y = orc_lab_yf_b[2 * s[0]], ify = orc_lab_yf_b[2 * s[0] + 1];
+    int adiv = ((5 * s[1] * 53687 + (1 << 7)) >> 13) - 128 * BASE / 500;
+    int bdiv = ((s[2] * 41943 + (1 << 4)) >> 9) - 128 * BASE / 200 + 1;
+    int x = orc_ab_to_xz(ify + adiv), z = orc_ab_to_xz(ify - bdiv);
+    const int* C = orc_lab_inv_coeffs;
+    for (int c = 0; c < 3; c++) {
+        int v = orc_descale(C[3 * c] * x + C[3 * c + 1] * y + C[3 * c + 2] * z, 14);
+        v = v < 0 ? 0 : (v > 4095 ? 4095 : v);
+        d[c] = (uint8_t)orc_lab_invgamma_b[v];
+    }
+}
+ORC_API void orc_lab2bgr_u8(const uint8_t* src, uint8_t* dst, size_t n)
+{
+    for (size_t i = 0; i < n; i++) orc_lab2bgr_px(src + 3 * i, dst + 3 * i);
+}
+
 /* unscreen/colorfiltering/agent.py:201-230 get_prob_by_gmm for the 256 possible sample values: float32 throughout,
  * x = (s - mean)/std ; y = 1/(std*sqrt(2 pi)) * exp(-0.5 * x*x) ; prob = sum_k w_k * y_k (torch.mm; summed here in
  * component order without fma - the BLAS order is unspecified, agreement is to float rounding). */

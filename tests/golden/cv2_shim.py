@@ -15,7 +15,8 @@ import oracle
 INTER_NEAREST, INTER_LINEAR, INTER_CUBIC = 0, 1, 2
 BORDER_CONSTANT, BORDER_REFLECT = 0, 2
 COLOR_BGR2RGB, COLOR_BGR2GRAY, COLOR_RGB2GRAY = 4, 6, 7
-COLOR_BGR2HSV, COLOR_BGR2Lab, COLOR_HSV2BGR = 40, 44, 54
+COLOR_BGR2HSV, COLOR_BGR2Lab, COLOR_HSV2BGR, COLOR_Lab2BGR = 40, 44, 54, 56
+COLOR_BGR2LAB, COLOR_LAB2BGR = COLOR_BGR2Lab, COLOR_Lab2BGR
 MORPH_ELLIPSE = 2
 RETR_LIST, CHAIN_APPROX_SIMPLE, FILLED = 1, 2, -1
 calls = []          # (name, detail) log: lets the generator record which OpenCV entry points a reference function reached
@@ -60,8 +61,14 @@ def cvtColor(src, code, dst=None, dstCn=0):
         return oracle.bgr2gray(flat).reshape(shape[:-1])
     if code == COLOR_RGB2GRAY:
         return oracle.bgr2gray(np.ascontiguousarray(flat[..., ::-1])).reshape(shape[:-1])
-    fn = {COLOR_BGR2HSV: oracle.bgr2hsv, COLOR_HSV2BGR: oracle.hsv2bgr, COLOR_BGR2Lab: oracle.bgr2lab}[code]
+    fn = {COLOR_BGR2HSV: oracle.bgr2hsv, COLOR_HSV2BGR: oracle.hsv2bgr, COLOR_BGR2Lab: oracle.bgr2lab, COLOR_Lab2BGR: oracle.lab2bgr}[code]
     return fn(flat).reshape(shape)
+
+
+def boxFilter(src, ddepth, ksize, dst=None, anchor=None, normalize=True, borderType=None):
+    assert ddepth == -1 and ksize[0] == ksize[1] and normalize
+    _log("boxFilter", str(ksize))
+    return oracle.box_filter(np.ascontiguousarray(src), int(ksize[0]))
 
 
 def _scalar_like(a, b):

@@ -7,6 +7,8 @@ the real package imports mmcv / matplotlib / cv2 on import):
                                                                     color_correct, dilate_mask, erode_mask, exist_foreground,
                                                                     remove_invalid_objects, is_pixel_inrange, get_fg, get_bg
     unscreen/trimap/agent.py                                        TrimapAgent.forward / generate_trimap / generate_trimap_withbg
+    unscreen/harmonization/agent.py                                 HarmonizationAgent: get_means, foreground_toning, alpha_smoothing,
+                                                                    background_blurring
     unscreen/vmatting/agent.py + model.py                           VMattingAgent(model_path, cuda_device=-1): preprocess, the
                                                                     reference UNet on the CPU, postprocess, forward
     tools/unscreen/bg_offline.py:145-176                            the stage-3 frame loop: the `for fid in ...` statement is lifted
@@ -74,6 +76,9 @@ def load_reference():
     pkg("unscreen.vmatting")
     load("unscreen.vmatting.model", "unscreen/vmatting/model.py")
     vm = load("unscreen.vmatting.agent", "unscreen/vmatting/agent.py")
+    pkg("unscreen.harmonization")
+    global HarmonizationAgent
+    HarmonizationAgent = load("unscreen.harmonization.agent", "unscreen/harmonization/agent.py").HarmonizationAgent
     return utils, tri.TrimapAgent, vm.VMattingAgent, cv2_shim
 
 
@@ -165,6 +170,17 @@ def main():
     gimg = np.clip(green.astype(int) + rng.integers(-60, 61, (h, w, 3)), 0, 255).astype(np.uint8)
     out["cc_img"], out["cc_alpha"], out["cc_bg"] = gimg, alpha, green
     out["cc_out"] = utils.color_correct(gimg.copy(), alpha.copy(), green.copy(), target_long_side=96)
+
+    # ---- 4b. HarmonizationAgent (unscreen/harmonization/agent.py): means, Lab toning, box smoothing
+    ha = HarmonizationAgent()
+    hfg, hbg = rng.integers(0, 256, (60, 90, 3), dtype=np.uint8), rng.integers(40, 200, (60, 90, 3), dtype=np.uint8)
+    halpha = blobs(rng, 60, 90, 4, 25)
+    out["ha_fg"], out["ha_bg"], out["ha_alpha"] = hfg, hbg, halpha
+    out["ha_toned"] = ha.foreground_toning(hfg.copy(), hbg.copy(), halpha.copy())
+    out["ha_toned_strong"] = ha.foreground_toning(hfg.copy(), hbg.copy(), halpha.copy(), toning_ratio=(1.0, 1.0, 1.0), max_shift=40, min_shift=-40)
+    out["ha_means"] = ha.get_means(hbg.copy(), halpha > 0, target_long_side=45)
+    out["ha_alpha_smooth"] = ha.alpha_smoothing(halpha.copy(), target_long_side=120)
+    out["ha_bg_blur"] = ha.background_blurring(hbg.copy(), target_long_side=45)
 
     # ---- 5. VMattingAgent on the CPU: preprocess tensors, postprocess, forward (the reference UNet itself)
     with tempfile.TemporaryDirectory() as td:

@@ -44,6 +44,7 @@ def test_cvt_color_bit_exact(nv, oracle_lib):
     assert np.array_equal(host(nv.cvt_color(d, nv.HSV2BGR)), oracle_lib.hsv2bgr(img))
     assert np.array_equal(host(nv.cvt_color(d, nv.BGR2GRAY)), oracle_lib.bgr2gray(img))
     assert np.array_equal(host(nv.cvt_color(d, nv.BGR2LAB)), oracle_lib.bgr2lab(img))
+    assert np.array_equal(host(nv.cvt_color(d, nv.LAB2BGR)), oracle_lib.lab2bgr(img))      # all 2^24 (L, a, b) triples
     # known OpenCV values (8-bit Lab): white, black, pure green
     lab = host(nv.cvt_color(dev(np.array([[[255, 255, 255], [0, 0, 0], [0, 255, 0]]], np.uint8)), nv.BGR2LAB))
     assert lab.tolist() == [[[255, 128, 128], [0, 128, 128], [224, 42, 211]]]
@@ -165,8 +166,18 @@ def test_harmonization_agent(nv, oracle_lib):
     assert np.allclose(ha.get_means(bg), small.reshape(-1, 3).mean(axis=0), rtol=0, atol=1e-9)
     m = oracle_lib.resize_linear(alpha, th, tw) > 0
     assert np.allclose(ha.get_means(bg, alpha > 0), small[m].reshape(-1, 3).mean(axis=0), rtol=0, atol=1e-9)
-    with pytest.raises(NotImplementedError):
-        ha.foreground_toning(bg, bg, alpha)
+    # foreground_toning (agent.py:39-76) against the oracle chain: Lab, region means, clamped shifts in float64, clip, truncation, Lab -> BGR
+    fg = rng.integers(0, 256, (270, 480, 3), dtype=np.uint8)
+    for kw in ({}, dict(toning_ratio=(1.0, 1.0, 1.0), max_shift=40, min_shift=-40)):
+        ratio, hi, lo = kw.get("toning_ratio", (0.5, 0.05, 0.05)), kw.get("max_shift", 15), kw.get("min_shift", -30)
+        fl, bl = oracle_lib.bgr2lab(fg), oracle_lib.bgr2lab(bg)
+        fm = oracle_lib.resize_linear(fl, th, tw)[m].reshape(-1, 3).mean(axis=0)
+        bm = oracle_lib.resize_linear(bl, th, tw).reshape(-1, 3).mean(axis=0)
+        f = fl.astype(np.float64)
+        for i in range(3):
+            f[:, :, i] = f[:, :, i] + max(min(ratio[i] * (bm[i] - fm[i]), hi), lo)
+        want = oracle_lib.lab2bgr(np.clip(f, 0, 255).astype(np.uint8))
+        assert np.array_equal(ha.foreground_toning(fg, bg, alpha, **kw), want)
 
 
 GREEN_CFG = {

@@ -72,6 +72,60 @@ def test_get_fg_get_bg_color_correct(oracle_lib, z):
     assert np.array_equal(oracle_lib.color_correct(z["cc_img"], z["cc_alpha"], z["cc_bg"], target_long_side=96), z["cc_out"])
 
 
+def test_harmonization(oracle_lib, z):
+    """HarmonizationAgent (harmonization/agent.py:14-113) restated on the oracle's primitives."""
+    fg, bg, alpha = z["ha_fg"], z["ha_bg"], z["ha_alpha"]
+    h, w = alpha.shape
+
+    def means(img, mask, L):
+        th, tw = oracle_lib.get_target_size(h, w, L)
+        small = oracle_lib.resize_linear(img, th, tw)
+        if mask is None:
+            return small.reshape(-1, 3).mean(axis=0)
+        return small[oracle_lib.resize_linear(mask.astype(np.uint8) * 255, th, tw) > 0].reshape(-1, 3).mean(axis=0)
+
+    for key, ratio, hi, lo in (("ha_toned", (0.5, 0.05, 0.05), 15, -30), ("ha_toned_strong", (1.0, 1.0, 1.0), 40, -40)):
+        fl, bl = oracle_lib.bgr2lab(fg), oracle_lib.bgr2lab(bg)
+        fm, bm = means(fl, alpha > 0, 240), means(bl, None, 240)
+        f = fl.astype(np.float64)
+        for i in range(3):
+            f[:, :, i] = f[:, :, i] + max(min(ratio[i] * (bm[i] - fm[i]), hi), lo)
+        assert np.array_equal(oracle_lib.lab2bgr(np.clip(f, 0, 255).astype(np.uint8)), z[key]), key
+    assert np.allclose(means(bg, alpha > 0, 45), z["ha_means"], rtol=0, atol=1e-12)
+
+    def smooth(img, L):
+        th, tw = oracle_lib.get_target_size(h, w, L)
+        x = oracle_lib.resize_linear(img, th, tw)
+        for _ in range(3):
+            x = oracle_lib.box_filter(x, 3)
+        return oracle_lib.resize_linear(x, h, w)
+
+    assert np.array_equal(smooth(alpha, 120), z["ha_alpha_smooth"])
+    assert np.array_equal(smooth(bg, 45), z["ha_bg_blur"])
+
+
+def test_lab2bgr_against_float_formula(oracle_lib):
+    """The 8-bit integer Lab -> BGR path against the CIE formulas in float64 (independent restatement): within 2 levels."""
+    rng = np.random.default_rng(11)
+    lab = oracle_lib.bgr2lab(rng.integers(0, 256, (120, 160, 3), dtype=np.uint8))
+    got = oracle_lib.lab2bgr(lab).astype(int)
+    L = lab[..., 0].astype(float) * 100 / 255
+    a, b = lab[..., 1].astype(float) - 128, lab[..., 2].astype(float) - 128
+    fy = (L + 16) / 116
+    finv = lambda t: np.where(t > 6 / 29, t ** 3, (t - 16 / 116) / 7.787)
+    xyz = np.stack([finv(fy + a / 500) * 0.950456, np.where(L > 8, fy ** 3, L / 903.3), finv(fy - b / 200) * 1.088754], -1)
+    M = np.array([[3.240479, -1.53715, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]])
+    rgb = np.clip(xyz @ M.T, 0, 1)
+    g = np.where(rgb <= 0.0031308, rgb * 12.92, 1.055 * rgb ** (1 / 2.4) - 0.055)
+    want = np.clip(np.round(g * 255), 0, 255)[..., ::-1]
+    d = np.abs(got - want)
+    assert d.max() <= 2 and (d > 1).mean() < 1e-3, (d.max(), (d > 1).mean())
+    # grey axis: a = b = 128 maps back to equal B = G = R
+    grey = np.stack([np.arange(256), np.full(256, 128), np.full(256, 128)], -1).astype(np.uint8)[None]
+    out = oracle_lib.lab2bgr(grey)[0].astype(int)
+    assert np.abs(out - out[:, :1]).max() <= 1 and out[0].tolist() == [0, 0, 0] and out[255].min() >= 254
+
+
 def test_vmatting_pre_post(oracle_lib, z, gcfg):
     x7 = z["vm_pre_x7"]
     in_h, in_w = oracle_lib.vmat_input_size(*z["vm_trimap"].shape, gcfg["vmatting"]["input_long_side"])

@@ -49,6 +49,8 @@ _SIGNATURES = {
     "usc_composite_fgbg_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
     "usc_lab_tables_bytes": (C.c_size_t, []),
     "usc_lab_tables_host": (None, [_vp]),
+    "usc_lab_inv_tables_bytes": (C.c_size_t, []),
+    "usc_lab_inv_tables_host": (None, [_vp]),
     "usc_cvt_color_u8": (C.c_int, [_vp, C.c_size_t, C.c_int, _vp, _vp, _vp]),
     "usc_gmm_lut_host": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, _vp]),
     "usc_gmm_alpha_u8": (C.c_int, [_vp, C.c_size_t, _vp, _vp, _vp, _vp]),
@@ -368,8 +370,9 @@ def composite_fgbg(fg, alpha, bg, out=None):
 
 
 # ---------------------------------------------------------------- green mode
-BGR2HSV, HSV2BGR, BGR2GRAY, BGR2LAB = 0, 1, 2, 3
+BGR2HSV, HSV2BGR, BGR2GRAY, BGR2LAB, LAB2BGR = 0, 1, 2, 3, 4
 _lab_tables = {}
+_lab_inv_tables = {}
 
 
 def lab_tables(device):
@@ -382,13 +385,23 @@ def lab_tables(device):
     return _lab_tables[key]
 
 
+def lab_inv_tables(device):
+    """Device copy of the 8-bit Lab->BGR tables (L -> (y, f(y)), inverse sRGB gamma, XYZ->BGR coefficients)."""
+    key = str(device)
+    if key not in _lab_inv_tables:
+        blob = np.empty(load().usc_lab_inv_tables_bytes(), np.uint8)
+        load().usc_lab_inv_tables_host(blob.ctypes.data)
+        _lab_inv_tables[key] = torch.from_numpy(blob).to(device)
+    return _lab_inv_tables[key]
+
+
 def cvt_color(img, code, out=None):
-    """cv2.cvtColor on a (H, W, 3) uint8 CUDA tensor; code BGR2HSV / HSV2BGR / BGR2GRAY / BGR2LAB."""
+    """cv2.cvtColor on a (H, W, 3) uint8 CUDA tensor; code BGR2HSV / HSV2BGR / BGR2GRAY / BGR2LAB / LAB2BGR."""
     H, W, _ = img.shape
     pi = _dev_u8(img, "cvt_color.img", (H, W, 3))
     shape = (H, W) if code == BGR2GRAY else (H, W, 3)
     out = torch.empty(shape, dtype=torch.uint8, device=img.device) if out is None else out
-    tab = lab_tables(img.device).data_ptr() if code == BGR2LAB else None
+    tab = lab_tables(img.device).data_ptr() if code == BGR2LAB else lab_inv_tables(img.device).data_ptr() if code == LAB2BGR else None
     _check(load().usc_cvt_color_u8(pi, H * W, int(code), _dev_u8(out, "cvt_color.out", shape), tab, _stream()), "usc_cvt_color_u8")
     return out
 

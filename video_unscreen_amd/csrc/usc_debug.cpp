@@ -30,6 +30,13 @@ extern "C" void usc_debug_arm_segv_backtrace(void) {
     if ((cur.sa_flags & SA_SIGINFO) && cur.sa_sigaction == on_segv) return;
     void* warm[2];
     (void)backtrace(warm, 2);                      // loads libgcc now, not inside the handler
+    static char* alt = nullptr;                    // the handler runs on its own stack: a stack overflow is a SIGSEGV too
+    if (!alt) {
+        alt = (char*)malloc(1 << 18);
+        stack_t ss;
+        ss.ss_sp = alt; ss.ss_size = 1 << 18; ss.ss_flags = 0;
+        sigaltstack(&ss, nullptr);
+    }
     struct sigaction sa;
     sa.sa_sigaction = on_segv;
     sigemptyset(&sa.sa_mask);

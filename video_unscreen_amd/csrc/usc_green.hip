@@ -66,6 +66,77 @@ __host__ __device__ __forceinline__ void bgr2lab_u8(const T* t, int c0, int c1, 
     b = bb < 0 ? 0 : (bb > 255 ? 255 : bb);
 }
 
+// 8-bit Lab -> BGR (cv::Lab2RGB_b, integer path Lab2RGBinteger: BASE 2^14, inverse gamma table of 4096 entries); the
+// a / b -> x / z table of OpenCV is a closed form in integers and is evaluated on the fly.
+struct LabInvTables {
+    uint16_t yf[512];         // (y, ify) per L
+    uint16_t invgamma[4096];  // round(255 * sRGB inverse gamma(i / 4096))
+    int coeffs[9];            // round(4096 * XYZ2sRGB_D65 * white), rows B, G, R
+    int pad[3];
+};
+static_assert(sizeof(LabInvTables) == 1024 + 8192 + 48, "LabInvTables layout");
+
+void fill_lab_inv_tables(LabInvTables* t) {
+    static const double m[9] = {3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311};
+    static const double white[3] = {0.950456, 1., 1.088754};
+    const int BASE = 1 << 14;
+    for (int i = 0; i < 256; i++) {
+        int y, ify;
+        if (i <= 20) {
+            y = round_half_even((double)((float)(i * BASE * 20 * 9) / (float)(17 * 29 * 29 * 29)));
+            ify = round_half_even((double)((float)BASE * (16.f / 116.f + (float)(i * 5) / (float)(3 * 17 * 29))));
+        } else {
+            const float fy = (float)(i * 100 * BASE) / (float)(255 * 116) + (float)(16 * BASE) / 116.f;
+            ify = round_half_even((double)fy);
+            y = round_half_even((double)(fy * fy * fy / (float)((double)BASE * BASE)));
+        }
+        t->yf[2 * i] = (uint16_t)y;
+        t->yf[2 * i + 1] = (uint16_t)ify;
+    }
+    for (int i = 0; i < 4096; i++) {
+        const float x = (1.f / 4096.f) * (float)i;
+        const double xd = (double)x;
+        const float v = (float)(xd <= 0.0031308 ? xd * 12.92 : pow(xd, 1. / 2.4) * 1.055 - 0.055);
+        t->invgamma[i] = (uint16_t)round_half_even((double)(255.f * v));
+    }
+    for (int i = 0; i < 3; i++) {
+        t->coeffs[0 + i] = round_half_even(4096. * m[6 + i] * white[i]);
+        t->coeffs[3 + i] = round_half_even(4096. * m[3 + i] * white[i]);
+        t->coeffs[6 + i] = round_half_even(4096. * m[0 + i] * white[i]);
+    }
+    t->pad[0] = t->pad[1] = t->pad[2] = 0;
+}
+
+__host__ __device__ __forceinline__ int lab_ab_to_xz(int v) {
+    constexpr int BASE = 1 << 14;
+    if (v <= 3390) return v * 108 / 841 - BASE * 16 / 116 * 108 / 841;
+    return v * v / BASE * v / BASE;
+}
+
+template <typename T>
+__host__ __device__ __forceinline__ void lab2bgr_u8(const T* t, int L, int a, int b, int& o0, int& o1, int& o2) {
+    constexpr int BASE = 1 << 14;
+    const int y = t->yf[2 * L], ify = t->yf[2 * L + 1];
+    const int adiv = ((5 * a * 53687 + (1 << 7)) >> 13) - 128 * BASE / 500;
+    const int bdiv = ((b * 41943 + (1 << 4)) >> 9) - 128 * BASE / 200 + 1;
+    const int x = lab_ab_to_xz(ify + adiv), z = lab_ab_to_xz(ify - bdiv);
+    const int* C = t->coeffs;
+    int v[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        int w = (C[3 * c] * x + C[3 * c + 1] * y + C[3 * c + 2] * z + (1 << 13)) >> 14;
+        w = w < 0 ? 0 : (w > 4095 ? 4095 : w);
+        v[c] = t->invgamma[w];
+    }
+    o0 = v[0]; o1 = v[1]; o2 = v[2];
+}
+
+__device__ __forceinline__ void load_lab_inv_tables(LabInvTables* s, const LabInvTables* __restrict__ g) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s);
+    for (int i = threadIdx.x; i < (int)(sizeof(LabInvTables) / 4); i += blockDim.x) dst[i] = src[i];
+}
+
 __device__ __forceinline__ void load_lab_tables(LabTables* s, const LabTables* __restrict__ g) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
     uint32_t* dst = reinterpret_cast<uint32_t*>(s);
@@ -76,6 +147,8 @@ __device__ __forceinline__ void load_lab_tables(LabTables* s, const LabTables* _
 
 extern "C" size_t usc_lab_tables_bytes(void) { return sizeof(LabTables); }
 extern "C" void usc_lab_tables_host(void* blob) { fill_lab_tables(reinterpret_cast<LabTables*>(blob)); }
+extern "C" size_t usc_lab_inv_tables_bytes(void) { return sizeof(LabInvTables); }
+extern "C" void usc_lab_inv_tables_host(void* blob) { fill_lab_inv_tables(reinterpret_cast<LabInvTables*>(blob)); }
 
 // --------------------------------------------------------------------------------------------
 // cvtColor
@@ -85,8 +158,10 @@ __global__ __launch_bounds__(256) void cvt_color_kernel(const uint8_t* __restric
                                                         const LabTables* __restrict__ lab) {
     __shared__ int s_sdiv[256], s_hdiv[256];
     __shared__ LabTables s_lab;
+    __shared__ LabInvTables s_inv;
     if (CODE == USC_CVT_BGR2HSV) load_hsv_tables(s_sdiv, s_hdiv);
     if (CODE == USC_CVT_BGR2LAB) load_lab_tables(&s_lab, lab);
+    if (CODE == USC_CVT_LAB2BGR) load_lab_inv_tables(&s_inv, reinterpret_cast<const LabInvTables*>(lab));
     __syncthreads();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int c0 = src[3 * i], c1 = src[3 * i + 1], c2 = src[3 * i + 2];
@@ -94,6 +169,7 @@ __global__ __launch_bounds__(256) void cvt_color_kernel(const uint8_t* __restric
         if (CODE == USC_CVT_BGR2HSV) bgr2hsv_u8(c0, c1, c2, s_sdiv, s_hdiv, o0, o1, o2);
         else if (CODE == USC_CVT_HSV2BGR) hsv2bgr_u8(c0, c1, c2, o0, o1, o2);
         else if (CODE == USC_CVT_BGR2LAB) bgr2lab_u8(&s_lab, c0, c1, c2, o0, o1, o2);
+        else if (CODE == USC_CVT_LAB2BGR) lab2bgr_u8(&s_inv, c0, c1, c2, o0, o1, o2);
         else { o0 = gray_u8(c0, c1, c2); o1 = o2 = 0; }
         if (CODE == USC_CVT_BGR2GRAY) dst[i] = (uint8_t)o0;
         else { dst[3 * i] = (uint8_t)o0; dst[3 * i + 1] = (uint8_t)o1; dst[3 * i + 2] = (uint8_t)o2; }
@@ -113,6 +189,10 @@ extern "C" int usc_cvt_color_u8(const uint8_t* src, size_t n, int code, uint8_t*
         case USC_CVT_BGR2LAB:
             if (!lt) return fail(USC_E_ARG, "usc_cvt_color_u8: BGR2LAB needs the device copy of usc_lab_tables_host()");
             hipLaunchKernelGGL(cvt_color_kernel<USC_CVT_BGR2LAB>, g, b, 0, st, src, n, dst, lt);
+            break;
+        case USC_CVT_LAB2BGR:
+            if (!lt) return fail(USC_E_ARG, "usc_cvt_color_u8: LAB2BGR needs the device copy of usc_lab_inv_tables_host()");
+            hipLaunchKernelGGL(cvt_color_kernel<USC_CVT_LAB2BGR>, g, b, 0, st, src, n, dst, lt);
             break;
         default: return fail(USC_E_ARG, "usc_cvt_color_u8: unknown conversion code %d", code);
     }
