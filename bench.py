@@ -243,11 +243,15 @@ def main():
     # weights + overall background: rank 0 owns them, everyone else receives them over RCCL / xGMI
     clip = SyntheticClip(H, W, (K + Wm) * world, config_id=2, device=dev)
     sd = synthetic_state_dict(0) if rank == 0 else None
-    sd, bg_always = broadcast_state(sd, clip.bg_always if rank == 0 else torch.empty_like(clip.bg_always), dev, world)
+    extra = {}
+    if not args.no_seg:
+        from video_unscreen_amd.binseg.schp_net import schp_synthetic_state_dict
+        extra["schp"] = schp_synthetic_state_dict(0) if rank == 0 else None          # 267 MB: rank 0's, one bucket with the UNet's
+    sd, bg_always, extra = broadcast_state(sd, clip.bg_always if rank == 0 else torch.empty_like(clip.bg_always), dev, world, extra=extra)
     seg_agent = None
     if not args.no_seg:
         from video_unscreen_amd.binseg import HumanSegAgent
-        seg_agent = HumanSegAgent(model_path=None, cuda_device=local)       # synthetic SCHP weights, same on every rank
+        seg_agent = HumanSegAgent(model_path=None, cuda_device=local, state_dict=extra["schp"])
     seg_batch = args.seg_batch if args.seg_batch > 0 else next((b for b in (12, 8, 6, 4) if K % b == 0), 8)
     pipe = BgStepPipeline(cfg, H, W, device=dev, state_dict=sd, net_backend=args.net, seg_agent=seg_agent,
                           seg_batch=1 if args.sync_loop else seg_batch, object_filter=args.object_filter)

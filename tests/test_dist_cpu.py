@@ -141,3 +141,86 @@ def test_overall_background_allreduce_world2():
         assert np.array_equal(r, raw) and np.array_equal(c, cont[..., 0])
     bg_always, hole = oracle.overall_bg_finalize(raw, np.repeat(cont, 3, -1))
     assert hole[20:, :6].all() and bg_always[hole == 0].any()
+
+
+def _all_nets_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from video_unscreen_amd.dist import load_and_broadcast, network_layouts
+    names = ("vmatting", "schp", "deeplab", "stm")
+    got = load_and_broadcast({n: "synthetic" for n in names}, torch.device("cpu"), world)      # only rank 0 builds / reads them
+    ok = {}
+    if rank != 0:
+        from video_unscreen_amd.dist import load_checkpoint
+        for n in names:
+            ref = load_checkpoint(n, "synthetic")
+            lay = network_layouts()[n]()
+            ok[n] = (list(got[n].keys()) == [k for k, _ in lay] == list(ref.keys())
+                     and all(got[n][k].dtype == ref[k].dtype and torch.equal(got[n][k], ref[k]) for k in ref))
+    q.put((rank, ok, {n: sum(t.numel() for t in got[n].values()) for n in names}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_all_networks_world2():
+    """the weights of EVERY network of the path (matting UNet, SCHP, DeepLabv3+, STM) reach the other ranks from rank 0
+    in one float bucket + one int64 bucket, bit for bit, in the reference's key order and dtypes."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_all_nets_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[1][1] == {"vmatting": True, "schp": True, "deeplab": True, "stm": True}
+    assert res[0][2] == res[1][2] and res[0][2]["schp"] > 60e6 and res[0][2]["vmatting"] > 20e6
+
+
+def test_shard_start_semantics(oracle_lib):
+    """What a frame shard computes (stated in dist.py): every shard restarts alpha_pre like the reference's --range run
+    (bg_offline.py:34-35, 162-163).  Pinned on the oracle chain: shard [0, 3) equals the whole-clip run on its frames; shard [3, 6)
+    equals a run started at frame 3 - and its frames differ from the whole-clip run's only through alpha_pre, i.e. inside the
+    unknown band of the trimap (known pixels are clamped to the trimap, vmatting/agent.py:128-130)."""
+    import json
+    import __graft_entry__ as ge
+    from video_unscreen_amd.synth import SyntheticClip
+    from video_unscreen_amd.vmatting.net import MattingNet, synthetic_state_dict
+    cfg = json.loads(bytes(np.load(os.path.join(os.path.dirname(__file__), "golden", "orchestration.npz"))["cfg_json"]).decode())
+    H, W, n = 64, 96, 6
+    clip = SyntheticClip(H, W, n, config_id=2, device="cpu")
+    frames = [clip.frame(t) for t in range(n)]
+    bga = clip.bg_always.numpy()
+
+    class P:
+        net = MattingNet(synthetic_state_dict(0), device="cpu", dtype=torch.float32)
+
+        def cpu_net(self):
+            return self.net
+
+    def run(lo, hi):
+        outs, alpha_pre = [], None
+        for t in range(lo, hi):
+            f = frames[t]
+            o = ge.oracle_frame(oracle_lib, cfg, P(), f["frame"].numpy(), f["seg"].numpy(), f["bg"].numpy(), bga, alpha_pre)
+            alpha_pre = o["alpha"]
+            outs.append(o)
+        return outs
+
+    whole = run(0, n)
+    shards = [run(*shard_range(n, r, 2)) for r in range(2)]
+    assert [shard_range(n, r, 2) for r in range(2)] == [(0, 3), (3, 6)]
+    for t in range(3):                                     # rank 0: identical to the one-process run
+        assert np.array_equal(shards[0][t]["alpha"], whole[t]["alpha"]) and np.array_equal(shards[0][t]["fg"], whole[t]["fg"])
+    differs = False
+    for i, t in enumerate(range(3, 6)):                    # rank 1: same trimaps; alpha may differ, only where the trimap is unknown
+        a, b = shards[1][i], whole[t]
+        assert np.array_equal(a["trimap"], b["trimap"])
+        d = a["alpha"] != b["alpha"]
+        assert not d[a["trimap"] != 128].any()
+        differs |= bool(d.any())
+    assert differs, "the cut must be visible somewhere, or this test pins nothing"

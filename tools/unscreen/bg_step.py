@@ -28,7 +28,10 @@ import torch
 import torch.distributed as dist
 
 from video_unscreen_amd.bgestimate import OverallBackground
-from video_unscreen_amd.dist import broadcast_state, shard_range
+from video_unscreen_amd.binseg import HumanSegAgent
+from video_unscreen_amd.dist import broadcast_state, load_and_broadcast, shard_range
+from video_unscreen_amd.stm import STMAgent
+from video_unscreen_amd.vmatting import VMattingAgent
 from video_unscreen_amd.pipeline import BgStepPipeline
 from video_unscreen_amd.pipeline_bg import BgOnlinePipeline
 from video_unscreen_amd.utils.fileio import parallel_read_img, read_img, save_img, save_video
@@ -64,7 +67,14 @@ def main(cfg):
         # every rank starts its range untracked, exactly like a --range run of the reference
         print("get segmask using video segmentation")
         st = time.time()
-        pipe1 = BgOnlinePipeline(cfg, h, w, device=dev)          # HumanSegAgent + STMAgent, as bg_offline.py:13,44-45
+        # HumanSegAgent + STMAgent + VMattingAgent, as bg_offline.py:13,44-47; rank 0 reads the checkpoints, the others receive them
+        w1 = load_and_broadcast({"schp": cfg["binseg"].get("model_path"), "stm": cfg["stm"].get("model_path"),
+                                 "vmatting": cfg["vmatting"].get("model_path")}, dev, world)
+        idx = dev.index or 0
+        pipe1 = BgOnlinePipeline(cfg, h, w, device=dev,
+                                 segagent=HumanSegAgent(**dict(cfg["binseg"], cuda_device=idx, state_dict=w1["schp"])),
+                                 stmagent=STMAgent(**dict(cfg["stm"], cuda_device=idx, state_dict=w1["stm"])),
+                                 vmatagent=VMattingAgent(**dict(cfg["vmatting"], cuda_device=idx, state_dict=w1["vmatting"])))
         for i, f in enumerate(frames):
             fid = first + lo + i
             fd = torch.from_numpy(f).to(dev)

@@ -18,10 +18,12 @@ from .deeplab_net import HipDeepLabNet, deeplab_synthetic_state_dict
 class SegAgent():
 
     def __init__(self, model_path=None, input_long_side=912, crop_h=513, crop_w=513, stride_ratio=1 / 2., flip=True,
-                 cuda_device=0, crop_batch=4, plan_batch=4):
+                 cuda_device=0, crop_batch=4, plan_batch=4, state_dict=None):
         self.cuda_device = cuda_device if cuda_device is not None and cuda_device >= 0 else 0
         self.device = device(self.cuda_device)
-        if model_path is None or model_path == "synthetic":
+        if state_dict is not None:                     # weights handed over in memory (broadcast from rank 0)
+            sd = state_dict
+        elif model_path is None or model_path == "synthetic":
             sd = deeplab_synthetic_state_dict(0)       # no trained checkpoint exists offline
         else:
             sd = torch.load(model_path, map_location="cpu")        # a bare state dict (reference agent.py:58)

@@ -16,12 +16,14 @@ INPUT_SIZE = (473, 473)            # dataset_settings['lip']['input_size'] (agen
 
 class HumanSegAgent():
     def __init__(self, model_path=None, input_long_side=912, downscale=1, crop_h=473, crop_w=473,
-                 stride_ratio=1 / 2., flip=True, cuda_device=0):
+                 stride_ratio=1 / 2., flip=True, cuda_device=0, state_dict=None):
         self.input_size = INPUT_SIZE
         self.model_path = model_path
         self.cuda_device = cuda_device if cuda_device is not None and cuda_device >= 0 else 0
         self.device = device(self.cuda_device)
-        if model_path is None or model_path == "synthetic":
+        if state_dict is not None:                     # weights handed over in memory (broadcast from rank 0: dist.broadcast_networks)
+            sd = state_dict
+        elif model_path is None or model_path == "synthetic":
             sd = schp_synthetic_state_dict(0)          # no trained checkpoint exists offline
         else:
             sd = strip_module_prefix(torch.load(model_path, map_location="cpu"))   # DataParallel keys: module.*

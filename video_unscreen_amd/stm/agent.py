@@ -20,10 +20,12 @@ from .net_hip import HipStmNet
 
 class STMAgent():
 
-    def __init__(self, model_path, memory_step=5, memory_capacity=10, input_long_side=960, cuda_device=0, fix_memory_step=False):
+    def __init__(self, model_path, memory_step=5, memory_capacity=10, input_long_side=960, cuda_device=0, fix_memory_step=False, state_dict=None):
         self.cuda_device = cuda_device if cuda_device is not None and cuda_device >= 0 else 0
         self.device = device(self.cuda_device)
-        if model_path is None or model_path == "synthetic":
+        if state_dict is not None:                     # weights handed over in memory (broadcast from rank 0)
+            sd = state_dict
+        elif model_path is None or model_path == "synthetic":
             sd = stm_synthetic_state_dict(0)          # no trained checkpoint exists offline
         else:
             sd = torch.load(model_path, map_location="cpu")

@@ -13,12 +13,14 @@ from .net_hip import HipMattingNet
 
 class VMattingAgent():
 
-    def __init__(self, model_path, input_long_side=960, cuda_device=0, dtype=torch.float32):
+    def __init__(self, model_path, input_long_side=960, cuda_device=0, dtype=torch.float32, state_dict=None):
         if cuda_device is None or cuda_device < 0:
             raise RuntimeError("VMattingAgent: cuda_device < 0 (CPU) is not offered - the HIP path has no CPU fallback")
         self.cuda_device = cuda_device
         self.device = device(cuda_device)
-        if model_path is None or model_path == "synthetic":
+        if state_dict is not None:                     # weights handed over in memory (broadcast from rank 0)
+            weights = state_dict
+        elif model_path is None or model_path == "synthetic":
             weights = synthetic_state_dict(0)        # no trained checkpoint exists offline
         else:
             weights = torch.load(model_path, map_location='cpu')['state_dict']
