@@ -334,17 +334,25 @@ typedef struct usc_conv_desc {
                                       Layers of the same plan_batch give bit for bit the same per-image results at any `batch`:
                                       a pipeline that runs a batch-4 network and, for single frames, a batch-1 network gives
                                       both plan_batch = 4. */
+    const float* wino;             /* optional, 3x3 / stride 1 / pad 1 layers with Cin % 8 == 0 only: the Winograd F(2x2, 3x3) operand
+                                      U = G g G^T of the same weights, floats [Cin/8][16][2][Cout][4] with cin = 8c + 4h + q
+                                      (vmatting/net_hip.py pack_wino).  When given, the library may run the layer as 16 per-position
+                                      products on transformed 4x4 patches (2.25x fewer multiplications; results equal to the
+                                      direct form up to float rounding, ~2e-7 relative).  NULL: direct form. */
 } usc_conv_desc;
 
 /* Tuning hook (tools/dev/tune_convs.py): force the tile width (1 | 2 x 32 columns), the row groups per workgroup (4 | 2 | 1
  * x 32 pixels), the grid K split and the K groups per workgroup of every layer planned from the calling thread; 0 = the
  * library's own plan (cost model). */
 void usc_conv_force_plan(int nt, int rowgroups, int ksplit, int kgroups);
+/* Tests / tuning: -1 = the library decides per layer (default), 0 = never use the Winograd form, 1 = use it wherever it applies. */
+void usc_conv_force_winograd(int mode);
 
 /* The launch plan the library chooses for one layer (no device work): tile width in 32-column units, row groups and K groups
- * per workgroup, grid K split, workgroups and threads of the main launch, launches per layer (2 when the grid splits K).
+ * per workgroup, grid K split, workgroups and threads of the main launch, launches per layer (2 when the grid splits K),
+ * winograd = 1 when the layer runs in the Winograd form (then nt = rowgroups = 0).
  * Used by the profiling tools to label kernel traces (tools/dev/layer_table.py). */
-typedef struct usc_conv_plan_info { int nt, rowgroups, ksplit, kgroups, workgroups, threads, launches; } usc_conv_plan_info;
+typedef struct usc_conv_plan_info { int nt, rowgroups, ksplit, kgroups, workgroups, threads, launches, winograd; } usc_conv_plan_info;
 int usc_conv_plan_query(const usc_conv_desc* desc, usc_conv_plan_info* out);
 
 /* sizeof(usc_conv_desc) as the library was built: bindings check their struct definition against it. */
@@ -354,11 +362,12 @@ size_t usc_conv_desc_bytes(void);
 int usc_conv_sequence_f32(const usc_conv_desc* descs, int n, usc_stream_t stream);
 const char* usc_conv_last_error(void);
 
-/* The same layer list as a pre-instantiated hipGraph (one node per launch; edges follow the buffers each layer
- * reads, so independent branches run concurrently).  The descriptors are copied; the buffers they point to must
- * stay valid until usc_conv_graph_destroy.  A handle is instantiated once per stream it is launched on (at that stream's
- * first launch); launches of one handle must come from one host thread at a time, and - its layers sharing their
- * activation buffers - must not overlap on the device (launch it on one stream, or order the streams). */
+/* The same layer list as a pre-instantiated hipGraph: one node per launch, chained in list order (a linear chain: executable
+ * graphs with parallel branches fault in hipGraphLaunch on the ROCm runtime torch 2.10 bundles, see usc_conv.hip).  The
+ * descriptors are copied; the buffers they point to must stay valid until usc_conv_graph_destroy.  A handle is instantiated once
+ * per stream it is launched on (at that stream's first launch); launches of one handle must come from one host thread at a time,
+ * and - its layers sharing their activation buffers - must not overlap on the device (launch it on one stream, or order the
+ * streams). */
 int  usc_conv_graph_create(const usc_conv_desc* descs, int n, void** handle);
 int  usc_conv_graph_launch(void* handle, usc_stream_t stream);
 void usc_conv_graph_destroy(void* handle);   /* the one entry of this group that blocks: waits for the device to drain (a launch

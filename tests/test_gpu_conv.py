@@ -256,3 +256,75 @@ def test_conv_graphs_are_destroyed_for_real(hipnet):
         used.append(torch.cuda.memory_allocated())
     torch.cuda.synchronize()
     assert used[-1] <= used[2], used
+
+
+@pytest.mark.parametrize("cin,cout,h,w,batch,kw", [(8, 32, 17, 30, 1, 1), (32, 32, 20, 36, 1, 1), (64, 64, 33, 47, 1, 2),
+                                                    (128, 128, 12, 20, 2, 4), (32, 64, 9, 7, 3, 2), (256, 96, 16, 16, 1, 4),
+                                                    (16, 32, 64, 96, 1, 1)])
+def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw):
+    """conv_wino_kernel (Winograd F(2x2, 3x3): 3x3 / stride 1 / pad 1) against torch's float64 convolution: odd sizes (partial
+    tiles and blocks), images stacked along y, K groups, and the full fused epilogue."""
+    from video_unscreen_amd import _native as nv
+    g = torch.Generator().manual_seed(cin * 1000 + cout + h)
+    x = torch.randn(batch, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (1.5 / (3 * cin ** 0.5))
+    b = torch.randn(cout, generator=g)
+    r1 = torch.randn(batch, cout, h, w, generator=g)
+    r2 = torch.randn(batch, cout, h, w, generator=g)
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().view(batch * h, w, -1)
+    L = _Layer(hipnet)
+    taps, wk = hipnet.conv_taps(wt, 1)
+    lib = nv.load()
+    for fused in (False, True):
+        out = torch.full((batch * h, w, cout), float("nan"), device="cuda")
+        d = L.desc(nhwc(x).cuda(), out, taps, wk, b, h, w, cin, batch * h, w, cout, act=2 if fused else 0,
+                   res1=nhwc(r1) if fused else None, res2=nhwc(r2) if fused else None, scale=sc if fused else None,
+                   shift=sh if fused else None)
+        d.batch = batch
+        wino = hipnet.pack_wino(wt).cuda()
+        L.keep.append(wino)
+        d.wino = wino.data_ptr()
+        lib.usc_conv_force_winograd(1)
+        lib.usc_conv_force_plan(0, 0, 0, kw)
+        try:
+            arr = (hipnet.ConvDesc * 1)(d)
+            assert nv.conv_plans(arr, 1)[0]["winograd"]
+            L.run([d])
+        finally:
+            lib.usc_conv_force_winograd(-1)
+            lib.usc_conv_force_plan(0, 0, 0, 0)
+        y = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+        if fused:
+            y = y + r1.double()
+            y = torch.where(y > 0, y, y * 0.2)
+            y = y * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + r2.double()
+        got = out.cpu().view(batch, h, w, cout).permute(0, 3, 1, 2).double()
+        assert torch.isfinite(got).all()
+        err = (got - y).abs().max() / y.abs().max()
+        assert err < 2e-5, (fused, float(err))
+
+
+def test_winograd_is_batch_invariant_and_deterministic(hipnet):
+    """Per-image results of a Winograd layer do not depend on the batch it runs in, nor on the run."""
+    from video_unscreen_amd import _native as nv
+    cin, cout, h, w = 64, 64, 30, 30
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(3, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    taps, wk = hipnet.conv_taps(wt, 1)
+    L = _Layer(hipnet)
+    wino = hipnet.pack_wino(wt).cuda()
+    outs = []
+    for batch in (1, 3, 3):
+        xs = x[:batch].permute(0, 2, 3, 1).contiguous().view(batch * h, w, cin).cuda()
+        out = torch.empty((batch * h, w, cout), device="cuda")
+        d = L.desc(xs, out, taps, wk, None, h, w, cin, batch * h, w, cout)
+        d.batch, d.plan_batch, d.wino = batch, 3, wino.data_ptr()
+        nv.load().usc_conv_force_winograd(1)
+        try:
+            L.run([d])
+        finally:
+            nv.load().usc_conv_force_winograd(-1)
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1][:h]) and torch.equal(outs[1], outs[2])

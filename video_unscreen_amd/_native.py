@@ -81,6 +81,7 @@ _SIGNATURES = {
     "usc_remove_invalid_objects_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp, C.c_size_t, _vp]),
     "usc_upsample_taps_accum_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "usc_conv_force_plan": (None, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "usc_conv_force_winograd": (None, [C.c_int]),
     "usc_bg_accumulate_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "usc_bg_finalize_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "usc_remove_invalid_objects_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
@@ -129,7 +130,7 @@ class NativeError(RuntimeError):
 
 
 class ConvPlanInfo(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("nt", "rowgroups", "ksplit", "kgroups", "workgroups", "threads", "launches")]
+    _fields_ = [(n, C.c_int) for n in ("nt", "rowgroups", "ksplit", "kgroups", "workgroups", "threads", "launches", "winograd")]
 
 
 def conv_plans(desc_array, n):
@@ -142,7 +143,8 @@ def conv_plans(desc_array, n):
         rc = load().usc_conv_plan_query(base + i * size, C.byref(info))
         if rc != 0:
             raise NativeError(f"usc_conv_plan_query failed ({rc}): {load().usc_conv_last_error().decode()}")
-        out.append({"plan": f"{info.nt},{info.rowgroups},{info.ksplit},{info.kgroups}", "workgroups": info.workgroups,
+        out.append({"plan": f"winograd,KW={info.kgroups}" if info.winograd else f"{info.nt},{info.rowgroups},{info.ksplit},{info.kgroups}",
+                    "winograd": bool(info.winograd), "workgroups": info.workgroups,
                     "threads": info.threads, "launches": info.launches})
     return out
 

@@ -292,6 +292,229 @@ __global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d
     }
 }
 
+
+// ---- Winograd F(2x2, 3x3) for the 3x3 / stride-1 / pad-1 layers (78 % of the matting net's flops) ---------------------------
+// Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A : 16 multiplications per 2x2 output tile and (cin, cout) pair instead of 36, so
+// the matrix cores do 2.25x less work; the transforms are additions on the (otherwise idle) vector ALU.  As an implicit GEMM:
+// for each of the 16 positions (a, b) of the transformed 4x4 patch, M_ab[tile][cout] = sum_cin V_ab[tile][cin] U_ab[cin][cout].
+//   * a wave owns a block of 8 x 4 tiles (16 x 8 output pixels) x 32 output channels: 16 accumulators of 32 x 32 (256 registers,
+//     the accumulation half of the unified register file), one per position.  One wave per SIMD; a K step is 8 input channels =
+//     64 independent MFMAs (4096 cycles), long enough to cover every load of the next step behind it;
+//   * A side: the block's 10 x 18 input patch (8 channels = 32 bytes per pixel) is staged through the wave's private LDS image
+//     exactly like conv_mfma_kernel stages its rows (register prefetch one step ahead, ds_write at the end of the step, no
+//     barrier); lane (tile, half) reads its tile's 4 x 4 patch as 16 ds_read_b128, transforms it (32 float4 additions) and the
+//     four components of each transformed float4 feed four MFMAs, as in conv_mfma_kernel;
+//   * B side: U = G g G^T is prepared on the host (vmatting/net_hip.py pack_wino) in the fragment order [cin/8][position][half]
+//     [cout][4], read straight from global memory, one float4 per position and step, re-requested into the registers a position
+//     has just consumed;
+//   * epilogue: the output transform A^T M A is elementwise over the 16 accumulators (24 additions per element), its four
+//     2x2 phases go through the LDS image like conv_mfma_kernel's tile and take the same fused epilogue;
+//   * KW waves of a workgroup may split the channel range of one block (partial output tiles meet in LDS, slice order).
+// Summation order depends on the shape (and KW) only: run-to-run and batch-to-batch identical results.  Results differ from
+// the direct kernel's by float rounding (relative 2e-7 per layer): the planner's choice is a function of the shape alone.
+constexpr int WPITCH = 12;                  // floats per patch pixel in LDS: 8 channels + 4 pad
+constexpr int WPATCH_W = 18, WPATCH_H = 10; // input patch of a block of 8 x 4 tiles
+constexpr int WSLOTS = WPATCH_W * WPATCH_H * 2;     // 16-byte slots of one stage (360)
+constexpr int WIMG = 4 * 32 * APITCH;       // floats of a wave's LDS image: 4 output phases x 32 tiles x APITCH (>= one stage)
+static_assert(WIMG >= WPATCH_W * WPATCH_H * WPITCH, "the stage must fit the epilogue image");
+
+template <int KW, bool IN_RELU>
+__global__ __launch_bounds__(256) void conv_wino_kernel(usc_conv_desc d) {
+    __shared__ __attribute__((aligned(16))) float Ws[4][WIMG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nnb = d.Cout >> 5;
+    const int nimg = d.batch > 1 ? d.batch : 1;
+    const int H = d.IH, W = d.IW;                                  // per image; output has the same size
+    const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
+    const int BH = (TH + 3) >> 2, BW = (TW + 7) >> 3;
+    const int ntiles = nimg * BH * BW * nnb;                        // wave tiles
+    const int nwg = (int)gridDim.x, xcd = (int)blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;      // XCD-aware order (see above)
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
+    constexpr int TPW = 4 / KW;                                     // wave tiles per workgroup
+    const int wt = wgid * TPW + wave / KW, kg = wave % KW;
+    const bool live = wt < ntiles;
+    if (KW == 1 && !live) return;
+    const int nb = live ? wt % nnb : 0, sb = live ? wt / nnb : 0;
+    const int img = sb / (BH * BW), brem = sb - img * (BH * BW), by = brem / BW, bx = brem - by * BW;
+    const int nb0 = nb * 32;
+    const int nch = d.Cin >> 3;                                     // K steps of 8 input channels
+    const int c_begin = live ? (int)((long long)kg * nch / KW) : 0, c_end = live ? (int)((long long)(kg + 1) * nch / KW) : 0;
+
+    // ---- weight fragments: [c][p][h][n][4] floats
+    const int wbytes = nch * 16 * 2 * d.Cout * 16;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.wino), 0, wbytes, 0x00020000);
+    const int wbase = ((lane >> 5) * d.Cout + nb0 + (lane & 31)) * 16;
+    const int wpos = 2 * d.Cout * 16, wstep = 16 * wpos;
+    float4 bf[16];
+    auto load_b = [&](int c, int p) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, c < c_end ? wbase + c * wstep + p * wpos : 0x7ffffff0, 0, 0);
+        bf[p] = *reinterpret_cast<const float4*>(&v);
+    };
+#pragma unroll
+    for (int p = 0; p < 16; p++) load_b(c_begin, p);
+
+    // ---- patch staging: slot s = pixel * 2 + half (16 bytes); 6 rounds of 64 lanes cover the 360 slots
+    constexpr int INVALID = 0x7fff0000;
+    const int y0 = 8 * by - 1, x0 = 16 * bx - 1;
+    int goff[6], loff[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const int s = r * 64 + lane;
+        const int pp = s >> 1, half = s & 1;
+        const int py = pp / WPATCH_W, px = pp - py * WPATCH_W;
+        const int y = y0 + py, x = x0 + px;
+        const bool ok = live && s < WSLOTS && y >= 0 && y < H && x >= 0 && x < W;
+        goff[r] = ok ? ((img * H + y) * W + x) * d.Cin * 4 + half * 16 : INVALID;
+        loff[r] = s < WSLOTS ? pp * WPITCH + half * 4 : -1;
+    }
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(d.in), 0, nimg * H * W * d.Cin * 4, 0x00020000);
+    float* const Aw = Ws[wave];
+    float4 ra[6];
+    auto load_a = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (c < c_end && goff[r] != INVALID) ? goff[r] + c * 32 : 0x7ffffff0, 0, 0);
+            ra[r] = *reinterpret_cast<const float4*>(&v);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            float4 a = ra[r];
+            if (IN_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+            if (r < 5 || loff[r] >= 0) *reinterpret_cast<float4*>(&Aw[loff[r]]) = a;
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; p++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[p][r] = 0.f;
+
+    // fragment base of this lane: tile t = lane & 31 -> (ty, tx) = (t >> 3, t & 7), half h = lane >> 5
+    const int fbase = ((2 * ((lane & 31) >> 3)) * WPATCH_W + 2 * (lane & 7)) * WPITCH + 4 * (lane >> 5);
+    auto add4 = [](const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+    auto sub4 = [](const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
+
+    // One K step.  The scheduler is fenced (sched_barrier) so that the requests for the next step are issued where they are
+    // written - the patch loads first, each position's weight fragment right after that position's MFMAs - instead of being sunk
+    // to the end of the step, where every one of them would be waited for at once.
+    auto step = [&](int c) {
+        float4 T[16];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) T[i * 4 + j] = *reinterpret_cast<const float4*>(&Aw[fbase + (i * WPATCH_W + j) * WPITCH]);
+        load_a(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {                       // T = B^T d, in place, column by column
+            const float4 d0 = T[0 + j], d1 = T[4 + j], d2 = T[8 + j], d3 = T[12 + j];
+            T[0 + j] = sub4(d0, d2);
+            T[4 + j] = add4(d1, d2);
+            T[8 + j] = sub4(d2, d1);
+            T[12 + j] = sub4(d1, d3);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            float4 V[4];                                    // V = T B
+            V[0] = sub4(T[a * 4 + 0], T[a * 4 + 2]);
+            V[1] = add4(T[a * 4 + 1], T[a * 4 + 2]);
+            V[2] = sub4(T[a * 4 + 2], T[a * 4 + 1]);
+            V[3] = sub4(T[a * 4 + 1], T[a * 4 + 3]);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int p = a * 4 + b;
+                const float4 w = bf[p];
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].x, w.x, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].y, w.y, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].z, w.z, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].w, w.w, acc[p], 0, 0, 0);
+                load_b(c + 1, p);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage();
+    };
+
+    load_a(c_begin);
+    stage();
+    for (int c = c_begin; c < c_end; c++) step(c);
+
+    // ---- output transform (elementwise over the accumulators): Y = A^T M A, phases (i, j) -> pixel (2 ty + i, 2 tx + j)
+    float* const T = Aw;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        f32x16 t0, t1, t2, t3;                              // tmp[a] = (M A)[a][j]
+        if (j == 0) { t0 = acc[0] + acc[1] + acc[2]; t1 = acc[4] + acc[5] + acc[6]; t2 = acc[8] + acc[9] + acc[10]; t3 = acc[12] + acc[13] + acc[14]; }
+        else { t0 = acc[1] - acc[2] - acc[3]; t1 = acc[5] - acc[6] - acc[7]; t2 = acc[9] - acc[10] - acc[11]; t3 = acc[13] - acc[14] - acc[15]; }
+        const f32x16 ya = t0 + t1 + t2, yb = t1 - t2 - t3;   // i = 0, 1
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            T[(0 * 2 + j) * 32 * APITCH + row * APITCH + (lane & 31)] = ya[r];
+            T[(1 * 2 + j) * 32 * APITCH + row * APITCH + (lane & 31)] = yb[r];
+        }
+    }
+    if (KW > 1) __syncthreads();
+    if (kg != 0 || !live) return;
+
+    // ---- fused epilogue: lane -> (4 tiles 8 apart, 4 channels), per phase
+    const int out_ld = d.out_ld > 0 ? d.out_ld : d.Cout;
+    const int out_bytes = d.OHf * d.OWf * d.Cout * 4;
+    const int erow = lane >> 3, ec4 = (lane & 7) * 4;
+    const int n = nb0 + ec4, nb4 = n * 4;
+    const bool has_r1 = d.res1 != nullptr, has_r2 = d.res2 != nullptr, has_aff = d.scale != nullptr;
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, d.OHf * d.OWf * out_ld * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(d.res1), 0, has_r1 ? (d.OHf >> d.res1_shift) * (d.OWf >> d.res1_shift) * d.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.res2), 0, has_r2 ? out_bytes : 0, 0x00020000);
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bias;
+    if (d.bias) bias = *reinterpret_cast<const float4*>(d.bias + n);
+    if (has_aff) { sc = *reinterpret_cast<const float4*>(d.scale + n); sh = *reinterpret_cast<const float4*>(d.shift + n); }
+    // activation without branches: negative inputs are multiplied by `slope` (1: none, 0.2 / 0.01: leaky) or replaced by +0 (ReLU)
+    const float slope = d.act == USC_ACT_LEAKY ? 0.2f : d.act == USC_ACT_LEAKY01 ? 0.01f : 1.f;
+    const bool relu = d.act == USC_ACT_RELU;
+#pragma unroll
+    for (int ph = 0; ph < 4; ph++) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ps++) {
+            const int t = ps * 8 + erow;
+            const int oy = 2 * (4 * by + (t >> 3)) + (ph >> 1), ox = 2 * (8 * bx + (t & 7)) + (ph & 1);
+            const bool ok = oy < H && ox < W;
+            const int Y = img * H + oy;
+            const int opix = Y * W + ox;
+            const int oo = ok ? (opix * out_ld + d.out_c0) * 4 + nb4 : INVALID;
+            const int o2 = ok ? opix * d.Cout * 4 + nb4 : INVALID;
+            const int o1 = ok ? ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (ox >> d.res1_shift)) * d.Cout * 4 + nb4 : INVALID;
+            const u32x4 r1u = __builtin_amdgcn_raw_buffer_load_b128(r1_rsrc, o1, 0, 0);
+            const u32x4 r2u = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, o2, 0, 0);
+            float4 tv = *reinterpret_cast<const float4*>(&T[ph * 32 * APITCH + t * APITCH + ec4]);
+#pragma unroll
+            for (int k = 1; k < KW; k++) {                   // slice order
+                const float4 u = *reinterpret_cast<const float4*>(&Ws[wave + k][ph * 32 * APITCH + t * APITCH + ec4]);
+                tv.x += u.x; tv.y += u.y; tv.z += u.z; tv.w += u.w;
+            }
+            const float4 r1 = *reinterpret_cast<const float4*>(&r1u), r2 = *reinterpret_cast<const float4*>(&r2u);
+            float v[4] = {tv.x + bias.x, tv.y + bias.y, tv.z + bias.z, tv.w + bias.w};
+            const float a1[4] = {r1.x, r1.y, r1.z, r1.w}, a2[4] = {r2.x, r2.y, r2.z, r2.w};
+            const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float x = v[e] + a1[e];
+                const float neg = relu ? 0.f : x * slope;
+                x = x > 0.f ? x : neg;
+                if (has_aff) x = x * s4[e] + h4[e];
+                v[e] = x + a2[e];
+            }
+            const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), out_rsrc, oo, 0, 0);
+        }
+    }
+}
+
 // Second half of a split-K layer: sum the K slices in a fixed order (deterministic), then the fused epilogue.
 // One lane per (output pixel, 4 channels).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(usc_conv_desc d) {
@@ -389,6 +612,8 @@ static thread_local int g_force_nt = 0, g_force_rg = 0, g_force_s = 0, g_force_k
 extern "C" void usc_conv_force_plan(int nt, int rowgroups, int ksplit, int kgroups) {
     g_force_nt = nt; g_force_rg = rowgroups; g_force_s = ksplit; g_force_kw = kgroups;
 }
+static thread_local int g_force_wino = -1;
+extern "C" void usc_conv_force_winograd(int mode) { g_force_wino = mode; }
 
 // One layer = one main launch (+ one reduce launch when K is split).
 struct LayerPlan {
@@ -398,6 +623,7 @@ struct LayerPlan {
     bool reduce;
     dim3 rgrid;
     int nt = 0, rg = 0, kw = 0;            // for usc_conv_plan_query
+    bool wino = false;
 };
 
 static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
@@ -432,6 +658,38 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     // Two 32-column tiles per wave only while that still leaves >= 2 workgroups per CU.
     const int plan_batch = d.plan_batch > 1 ? d.plan_batch : 1;
     const long long m_plan = M / nbatch * plan_batch;
+    // Winograd form (conv_wino_kernel): the standard 3x3 / stride 1 / pad 1 layer whose caller supplied the transformed weights.
+    // The choice and the K groups are functions of the per-image shape and plan_batch only.
+    {
+        static const signed char sdy[9] = {-1, -1, -1, 0, 0, 0, 1, 1, 1}, sdx[9] = {-1, 0, 1, -1, 0, 1, -1, 0, 1};
+        bool std3 = d.wino && d.ntaps == 9 && nphase == 1 && d.in_stride == 1 && d.out_stride == 1 && d.Cin % 8 == 0 &&
+                    d.res1_shift >= 0 && d.IW == d.OW && (long long)d.IH * nbatch == d.OH && d.OHf == d.OH && d.OWf == d.OW;
+        for (int t = 0; std3 && t < 9; t++) std3 = d.dy[t] == sdy[t] && d.dx[t] == sdx[t];
+        if (std3 && g_force_wino != 0) {
+            const int TH = (d.IH + 1) / 2, TW = (d.IW + 1) / 2;
+            const long long wt_plan = (long long)plan_batch * ((TH + 3) / 4) * ((TW + 7) / 8) * (d.Cout / 32);
+            const long long wt = (long long)nbatch * ((TH + 3) / 4) * ((TW + 7) / 8) * (d.Cout / 32);
+            const int nsteps = d.Cin / 8;
+            int kw = 1;                                       // K groups: fill the chip's 1024 SIMDs (one wave per SIMD)
+            if (wt_plan < 768 && nsteps >= 2) kw = 2;
+            if (wt_plan * 2 < 768 && nsteps >= 4) kw = 4;
+            if (g_force_kw == 1 || g_force_kw == 2 || g_force_kw == 4) kw = g_force_kw <= nsteps ? g_force_kw : 1;
+            const bool worth = wt_plan * kw >= 512;           // small maps stay with the direct kernel (16 K groups, grid splits)
+            if (worth || g_force_wino == 1) {
+                p.wino = true;
+                p.kw = kw;
+                p.d.ksplit = 1;
+                p.d.nphase = 1;
+                const long long waves = wt * kw;
+                p.grid = dim3((unsigned)((waves + 3) / 4));
+                p.block = dim3(256);
+#define USC_PICKW(KWV) (d.in_relu ? (void*)conv_wino_kernel<KWV, true> : (void*)conv_wino_kernel<KWV, false>)
+                p.fn = kw == 4 ? USC_PICKW(4) : kw == 2 ? USC_PICKW(2) : USC_PICKW(1);
+#undef USC_PICKW
+                return USC_OK;
+            }
+        }
+    }
     static const int nt2_min = getenv("USC_NT2_MIN") ? atoi(getenv("USC_NT2_MIN")) : 512;
     bool nt2 = (d.Cout % 64 == 0) && ((m_plan + 127) / 128 * (d.Cout / 64) * nphase >= nt2_min);
     if (g_force_nt) nt2 = g_force_nt == 2 && d.Cout % 64 == 0;
@@ -533,6 +791,7 @@ extern "C" int usc_conv_plan_query(const usc_conv_desc* desc, usc_conv_plan_info
     int rc = plan_layer(*desc, p);
     if (rc) return rc;
     out->nt = p.nt; out->rowgroups = p.rg; out->kgroups = p.kw; out->ksplit = p.d.kind == USC_CONV_HEAD ? 1 : p.d.ksplit;
+    out->winograd = p.wino ? 1 : 0;
     out->workgroups = (int)(p.grid.x * p.grid.y * p.grid.z);
     out->threads = (int)p.block.x;
     out->launches = p.reduce ? 2 : 1;
@@ -554,13 +813,18 @@ extern "C" int usc_conv_sequence_f32(const usc_conv_desc* descs, int n, usc_stre
     return USC_OK;
 }
 
-// ---- the same layers as a hipGraph: one node per launch, edges from the producers of in / res1 / res2 (and from the
-// previous user of a shared split-K slab), so independent branches (shortcut convs, the 1x1 up-branch) overlap the
-// ramp / tail of the main chain, and one hipGraphLaunch replaces ~85 kernel launches per frame.
+// ---- the same layers as a hipGraph: one node per launch, chained in list order - one hipGraphLaunch replaces the ~85 kernel
+// launches of a frame.  The graph is a LINEAR chain on purpose.  Round 1 gave it edges that followed the buffers (independent
+// branches could overlap) and hit a host segfault inside hipGraphLaunch, worked around by never destroying a graph.  Root cause
+// (profiles/r02/graph_segfault_root_cause.md: native backtrace + disassembly of the runtime torch bundles): an executable graph
+// with parallel branches owns internal streams; at launch the runtime walks them, SKIPS each one that shares the launch stream's
+// hardware queue and reads the next WITHOUT a bounds check - which internal stream collides depends on the process's whole
+// history of stream creation, so the fault came and went with test order and with destroy / no destroy.  A chain needs no
+// internal stream, the loop has nothing to walk.  Measured cost of giving up branch overlap: none (matting forward 1.59 ms as a
+// branched graph, 1.56 ms as serial launches).
 struct ConvGraph {
     hipGraph_t graph = nullptr;
-    // One instantiation per stream the graph is launched on: an executable graph that has run on one stream is not
-    // launched on another (observed to fault on ROCm 7.2 when the first stream was the null stream).
+    // One instantiation per stream the graph is launched on (kept from round 1; with chain graphs an exec could be shared).
     std::vector<std::pair<hipStream_t, hipGraphExec_t>> execs;
     std::vector<LayerPlan> plans;          // kernel arguments must outlive the graph
     int device = -1;                       // the device the graph was created (and is launched) on
@@ -581,13 +845,7 @@ extern "C" int usc_conv_graph_create(const usc_conv_desc* descs, int n, void** h
     for (int i = 0; i < n; i++) {
         LayerPlan& p = g->plans[i];
         std::vector<hipGraphNode_t> deps;
-        for (int j = i - 1; j >= 0; j--) {
-            const usc_conv_desc& q = g->plans[j].d;
-            const bool raw = q.out == p.d.in || q.out == p.d.res1 || q.out == p.d.res2;
-            const bool waw = q.out == p.d.out;                                   // phases / reuse of an output buffer
-            const bool slab = p.reduce && g->plans[j].reduce && q.slab == p.d.slab;
-            if (raw || waw || slab) deps.push_back(last[j]);
-        }
+        if (i > 0) deps.push_back(last[i - 1]);              // linear chain (see above)
         kargs[i] = &p.d;
         hipKernelNodeParams kp;
         memset(&kp, 0, sizeof(kp));

@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ("dy", C.c_byte * 16), ("dx", C.c_byte * 16),
                 ("nphase", C.c_int), ("wphase_stride", C.c_int), ("ksplit", C.c_int), ("in_relu", C.c_int),
                 ("slab", C.c_void_p), ("slab_bytes", C.c_size_t), ("out_ld", C.c_int), ("out_c0", C.c_int),
-                ("batch", C.c_int), ("plan_batch", C.c_int)]
+                ("batch", C.c_int), ("plan_batch", C.c_int), ("wino", C.c_void_p)]
 
 
 def d_out_elems(OH, OW, out_stride, OHf, OWf, Cout):
@@ -43,6 +43,20 @@ def pack_k_major(wk):
     if Kp != K:
         wk = torch.cat([wk, wk.new_zeros(Kp - K, N)], 0)
     return wk.view(Kp // 4, 4, N).permute(0, 2, 1).contiguous()
+
+
+_WINO_G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]], dtype=torch.float64)
+
+
+def pack_wino(w):
+    """Conv2d(3x3, stride 1) weight (Cout, Cin, 3, 3), Cin % 8 == 0 -> the Winograd F(2x2, 3x3) operand of conv_wino_kernel:
+    U[a][b] = G g G^T per (cout, cin) (float64, rounded once to float32), laid out [Cin/8][16 positions][2][Cout][4] with
+    cin = 8c + 4h + q - the order the kernel's weight fragments are read in (one 512-byte run per position and half)."""
+    co, ci, kh, kw = w.shape
+    assert (kh, kw) == (3, 3) and ci % 8 == 0
+    U = torch.einsum('ai,ocij,bj->abco', _WINO_G, w.double(), _WINO_G).float()          # (4, 4, Cin, Cout)
+    U = U.reshape(16, ci // 8, 2, 4, co)                                                 # [p][c][h][q][n]
+    return U.permute(1, 0, 2, 4, 3).contiguous()                                         # [c][p][h][n][q]
 
 
 def conv_taps(w, pad):
@@ -112,7 +126,7 @@ class HipMattingNet:
 
     def _add(self, x, out, taps, wk, bias, IH, IW, Cin, OH, OW, Cout, in_stride=1, out_stride=1, py=0, px=0,
              res1=None, res1_shift=0, act="none", scale=None, shift=None, res2=None, kind=0, OHf=None, OWf=None,
-             phases=None):
+             phases=None, wino=None):
         """phases: optional list of 4 (taps, wk) pairs (transposed conv); then `taps` / `wk` are ignored."""
         d = ConvDesc()
         d.inp, d.out = x.data_ptr(), out.data_ptr()
@@ -127,6 +141,8 @@ class HipMattingNet:
             d.nphase, d.wphase_stride = 1, 0
             taps_all = taps
         d.wpk = wp.data_ptr()
+        if wino is not None:                                   # 3x3 / stride 1: the Winograd operand of the same weights
+            d.wino = self._dev(pack_wino(wino)).data_ptr()
         # every layer gets its own 16-slice region of the split-K scratch, so layers on different graph branches
         # never share partial-sum memory
         tiles = ((OH * OW + 127) // 128) * max(Cout // 32, 1) * (4 if phases is not None else 1)
@@ -160,7 +176,8 @@ class HipMattingNet:
         taps, wk = conv_taps(w, c.pad)
         OH, OW = IH // c.stride, IW // c.stride
         out = out if out is not None else self._buf(OH, OW, co)
-        self._add(x, out, taps, wk, c.b, IH, IW, ci, OH, OW, co, in_stride=c.stride, act=kw.pop("act", c.act), **kw)
+        wino = w if (kh == 3 and c.stride == 1 and c.pad == 1 and ci % 8 == 0) else None
+        self._add(x, out, taps, wk, c.b, IH, IW, ci, OH, OW, co, in_stride=c.stride, act=kw.pop("act", c.act), wino=wino, **kw)
         return out
 
     def _convt(self, c, x, IH, IW, res2=None):
