@@ -20,8 +20,8 @@ class ConvGraphNet:
         plan_batch: the batch the kernel plans its tiles / K partition for; networks built with the same
         plan_batch give bit-identical per-image results whatever their batch."""
         from . import _native as nv
-        from .vmatting.net_hip import ConvDesc, conv_taps, pack_k_major
-        self.nv, self.ConvDesc, self.conv_taps, self.pack = nv, ConvDesc, conv_taps, pack_k_major
+        from .vmatting.net_hip import ConvDesc, conv_taps, pack_k_major, pack_wino
+        self.nv, self.ConvDesc, self.conv_taps, self.pack, self.pack_wino = nv, ConvDesc, conv_taps, pack_k_major, pack_wino
         if C.sizeof(ConvDesc) != nv.load().usc_conv_desc_bytes():
             raise nv.NativeError("ConvDesc (vmatting/net_hip.py) does not match usc_conv_desc of the built library: rebuild it")
         self.device = torch.device(device)
@@ -77,6 +77,8 @@ class ConvGraphNet:
         d = self.ConvDesc()
         d.inp, d.out = x.data_ptr(), out.data_ptr()
         d.wpk = wpk_buf.data_ptr() if wpk_buf is not None else self._dev(self.pack(wk.float())).data_ptr()
+        if wpk_buf is None and k == 3 and c.stride == 1 and c.dil == 1 and c.pad == 1 and cin_buf % 8 == 0:
+            d.wino = self._dev(self.pack_wino(w.float())).data_ptr()     # the library may run the layer in the Winograd form
         d.bias = bias_buf.data_ptr() if bias_buf is not None else self._dev(b).data_ptr()
         d.res1 = res1.data_ptr() if res1 is not None else None
         d.res2 = res2.data_ptr() if res2 is not None else None

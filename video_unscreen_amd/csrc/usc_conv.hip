@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d
 constexpr int WPITCH = 12;                  // floats per patch pixel in LDS: 8 channels + 4 pad
 constexpr int WPATCH_W = 18, WPATCH_H = 10; // input patch of a block of 8 x 4 tiles
 constexpr int WSLOTS = WPATCH_W * WPATCH_H * 2;     // 16-byte slots of one stage (360)
-constexpr int WIMG = 4 * 32 * APITCH;       // floats of a wave's LDS image: 4 output phases x 32 tiles x APITCH (>= one stage)
+constexpr int WIMG = 2 * 32 * APITCH;       // floats of a wave's LDS image: 2 output phases x 32 tiles x APITCH (>= one stage); 36 KB per workgroup
 static_assert(WIMG >= WPATCH_W * WPATCH_H * WPITCH, "the stage must fit the epilogue image");
 
 template <int KW, bool IN_RELU>
@@ -443,30 +443,15 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(usc_conv_desc d) {
     stage();
     for (int c = c_begin; c < c_end; c++) step(c);
 
-    // ---- output transform (elementwise over the accumulators): Y = A^T M A, phases (i, j) -> pixel (2 ty + i, 2 tx + j)
+    // ---- output transform (elementwise over the accumulators): Y = A^T M A, phases (i, j) -> pixel (2 ty + i, 2 tx + j),
+    // two phases (i = 0, 1 of one j) at a time through the LDS image, then the fused epilogue: lane -> (4 tiles 8 apart, 4 channels)
     float* const T = Aw;
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        f32x16 t0, t1, t2, t3;                              // tmp[a] = (M A)[a][j]
-        if (j == 0) { t0 = acc[0] + acc[1] + acc[2]; t1 = acc[4] + acc[5] + acc[6]; t2 = acc[8] + acc[9] + acc[10]; t3 = acc[12] + acc[13] + acc[14]; }
-        else { t0 = acc[1] - acc[2] - acc[3]; t1 = acc[5] - acc[6] - acc[7]; t2 = acc[9] - acc[10] - acc[11]; t3 = acc[13] - acc[14] - acc[15]; }
-        const f32x16 ya = t0 + t1 + t2, yb = t1 - t2 - t3;   // i = 0, 1
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            T[(0 * 2 + j) * 32 * APITCH + row * APITCH + (lane & 31)] = ya[r];
-            T[(1 * 2 + j) * 32 * APITCH + row * APITCH + (lane & 31)] = yb[r];
-        }
-    }
-    if (KW > 1) __syncthreads();
-    if (kg != 0 || !live) return;
-
-    // ---- fused epilogue: lane -> (4 tiles 8 apart, 4 channels), per phase
     const int out_ld = d.out_ld > 0 ? d.out_ld : d.Cout;
     const int out_bytes = d.OHf * d.OWf * d.Cout * 4;
     const int erow = lane >> 3, ec4 = (lane & 7) * 4;
     const int n = nb0 + ec4, nb4 = n * 4;
     const bool has_r1 = d.res1 != nullptr, has_r2 = d.res2 != nullptr, has_aff = d.scale != nullptr;
+    const bool writer = kg == 0 && live;
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, d.OHf * d.OWf * out_ld * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(d.res1), 0, has_r1 ? (d.OHf >> d.res1_shift) * (d.OWf >> d.res1_shift) * d.Cout * 4 : 0, 0x00020000);
@@ -478,39 +463,55 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(usc_conv_desc d) {
     const float slope = d.act == USC_ACT_LEAKY ? 0.2f : d.act == USC_ACT_LEAKY01 ? 0.01f : 1.f;
     const bool relu = d.act == USC_ACT_RELU;
 #pragma unroll
-    for (int ph = 0; ph < 4; ph++) {
+    for (int j = 0; j < 2; j++) {
+        f32x16 t0, t1, t2, t3;                              // tmp[a] = (M A)[a][j]
+        if (j == 0) { t0 = acc[0] + acc[1] + acc[2]; t1 = acc[4] + acc[5] + acc[6]; t2 = acc[8] + acc[9] + acc[10]; t3 = acc[12] + acc[13] + acc[14]; }
+        else { t0 = acc[1] - acc[2] - acc[3]; t1 = acc[5] - acc[6] - acc[7]; t2 = acc[9] - acc[10] - acc[11]; t3 = acc[13] - acc[14] - acc[15]; }
+        const f32x16 ya = t0 + t1 + t2, yb = t1 - t2 - t3;   // i = 0, 1
+        if (KW > 1 && j > 0) __syncthreads();                // K group 0 has read the previous pair of phases
 #pragma unroll
-        for (int ps = 0; ps < 4; ps++) {
-            const int t = ps * 8 + erow;
-            const int oy = 2 * (4 * by + (t >> 3)) + (ph >> 1), ox = 2 * (8 * bx + (t & 7)) + (ph & 1);
-            const bool ok = oy < H && ox < W;
-            const int Y = img * H + oy;
-            const int opix = Y * W + ox;
-            const int oo = ok ? (opix * out_ld + d.out_c0) * 4 + nb4 : INVALID;
-            const int o2 = ok ? opix * d.Cout * 4 + nb4 : INVALID;
-            const int o1 = ok ? ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (ox >> d.res1_shift)) * d.Cout * 4 + nb4 : INVALID;
-            const u32x4 r1u = __builtin_amdgcn_raw_buffer_load_b128(r1_rsrc, o1, 0, 0);
-            const u32x4 r2u = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, o2, 0, 0);
-            float4 tv = *reinterpret_cast<const float4*>(&T[ph * 32 * APITCH + t * APITCH + ec4]);
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            T[row * APITCH + (lane & 31)] = ya[r];
+            T[32 * APITCH + row * APITCH + (lane & 31)] = yb[r];
+        }
+        if (KW > 1) __syncthreads();
+        if (!writer) continue;
 #pragma unroll
-            for (int k = 1; k < KW; k++) {                   // slice order
-                const float4 u = *reinterpret_cast<const float4*>(&Ws[wave + k][ph * 32 * APITCH + t * APITCH + ec4]);
-                tv.x += u.x; tv.y += u.y; tv.z += u.z; tv.w += u.w;
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++) {
+                const int t = ps * 8 + erow;
+                const int oy = 2 * (4 * by + (t >> 3)) + i, ox = 2 * (8 * bx + (t & 7)) + j;
+                const bool ok = oy < H && ox < W;
+                const int Y = img * H + oy;
+                const int opix = Y * W + ox;
+                const int oo = ok ? (opix * out_ld + d.out_c0) * 4 + nb4 : INVALID;
+                const int o2 = ok ? opix * d.Cout * 4 + nb4 : INVALID;
+                const int o1 = ok ? ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (ox >> d.res1_shift)) * d.Cout * 4 + nb4 : INVALID;
+                const u32x4 r1u = __builtin_amdgcn_raw_buffer_load_b128(r1_rsrc, o1, 0, 0);
+                const u32x4 r2u = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, o2, 0, 0);
+                float4 tv = *reinterpret_cast<const float4*>(&T[i * 32 * APITCH + t * APITCH + ec4]);
+#pragma unroll
+                for (int k = 1; k < KW; k++) {               // slice order
+                    const float4 u = *reinterpret_cast<const float4*>(&Ws[wave + k][i * 32 * APITCH + t * APITCH + ec4]);
+                    tv.x += u.x; tv.y += u.y; tv.z += u.z; tv.w += u.w;
+                }
+                const float4 r1 = *reinterpret_cast<const float4*>(&r1u), r2 = *reinterpret_cast<const float4*>(&r2u);
+                float v[4] = {tv.x + bias.x, tv.y + bias.y, tv.z + bias.z, tv.w + bias.w};
+                const float a1[4] = {r1.x, r1.y, r1.z, r1.w}, a2[4] = {r2.x, r2.y, r2.z, r2.w};
+                const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float x = v[e] + a1[e];
+                    const float neg = relu ? 0.f : x * slope;
+                    x = x > 0.f ? x : neg;
+                    if (has_aff) x = x * s4[e] + h4[e];
+                    v[e] = x + a2[e];
+                }
+                const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), out_rsrc, oo, 0, 0);
             }
-            const float4 r1 = *reinterpret_cast<const float4*>(&r1u), r2 = *reinterpret_cast<const float4*>(&r2u);
-            float v[4] = {tv.x + bias.x, tv.y + bias.y, tv.z + bias.z, tv.w + bias.w};
-            const float a1[4] = {r1.x, r1.y, r1.z, r1.w}, a2[4] = {r2.x, r2.y, r2.z, r2.w};
-            const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                float x = v[e] + a1[e];
-                const float neg = relu ? 0.f : x * slope;
-                x = x > 0.f ? x : neg;
-                if (has_aff) x = x * s4[e] + h4[e];
-                v[e] = x + a2[e];
-            }
-            const float4 o = make_float4(v[0], v[1], v[2], v[3]);
-            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), out_rsrc, oo, 0, 0);
         }
     }
 }
