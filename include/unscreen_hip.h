@@ -211,14 +211,20 @@ int usc_stm_post(const float* p2, int lh, int lw, int cbuf, int in_h, int in_w, 
  * reference derives the first frame's output mask this way from the one-hot of mask0, agent.py:127, 172-201). */
 int usc_stm_mask_from_prob(const float* prob, int in_h, int in_w, int H, int W, uint8_t* out, usc_stream_t stream);
 
-/* unscreen/utils/region_fill.py:7-63 regionfill for the three channels of a BGR image at once (tools/unscreen/bg.py:79-81):
- * inside mask > 0 the discrete Laplace equation with the surrounding pixels as boundary values, solved by conjugate gradients
- * in float64 until every channel's residual norm has dropped by `rtol` (checked every 32 iterations: this call synchronises
- * the stream) or `max_iters`; the result is truncated to uint8 like the reference's astype (values agree with the reference's
- * direct solve to ~1e4 * rtol grey levels).  *iters_out (host, may be NULL) = iterations run. */
+/* Background inpainting of the online mode (unscreen/utils/region_fill.py:7-63 regionfill, per channel from
+ * tools/unscreen/bg.py:79): inside mask > 0 the three channels of img are replaced by the solution of the discrete Laplace
+ * equation with the surrounding pixels as boundary values - conjugate gradients preconditioned by a multigrid V-cycle, float64
+ * (csrc/usc_regionfill.hip; the reference calls a sparse direct solver: results agree to ~1e4 * rtol grey levels, i.e. +-1 level
+ * after the reference's astype(uint8) truncation, only next to integers).
+ * Like every device entry it only enqueues work: iterations [first_iter, first_iter + n_iters) are launched, the convergence test
+ * (every channel's residual norm reduced by rtol) runs ON THE DEVICE every two iterations, and once it has passed the kernels
+ * still queued return at once - so n_iters is a budget, not a count.  first_iter = 0 starts a solve (ws is initialised);
+ * first_iter > 0 continues the solve whose state is in ws (same img / mask / size) when a budget turned out too small.  `out`
+ * receives the current iterate truncated to uint8 either way.  status (DEVICE int[2], may be NULL) = {iterations run so far,
+ * converged 0 | 1}.  No host synchronisation, no state outside ws. */
 size_t usc_regionfill_ws_bytes(int H, int W);
-int usc_regionfill_u8(const uint8_t* img, const uint8_t* mask, int H, int W, uint8_t* out, double rtol, int max_iters,
-                      int* iters_out, void* ws, size_t ws_bytes, usc_stream_t stream);
+int usc_regionfill_u8(const uint8_t* img, const uint8_t* mask, int H, int W, uint8_t* out, double rtol, int first_iter, int n_iters,
+                      int* status, void* ws, size_t ws_bytes, usc_stream_t stream);
 
 /* remove_invalid_objects on the device (unscreen/utils/maskprocess.py:77-152) - no border following, no host round trip:
  * connected-component labels + per-crack shoelace terms + containment-tree sums (csrc/usc_objects.hip).  alpha is modified

@@ -276,9 +276,10 @@ def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw):
     L = _Layer(hipnet)
     taps, wk = hipnet.conv_taps(wt, 1)
     lib = nv.load()
+    xin = nhwc(x).cuda()
     for fused in (False, True):
         out = torch.full((batch * h, w, cout), float("nan"), device="cuda")
-        d = L.desc(nhwc(x).cuda(), out, taps, wk, b, h, w, cin, batch * h, w, cout, act=2 if fused else 0,
+        d = L.desc(xin, out, taps, wk, b, h, w, cin, batch * h, w, cout, act=2 if fused else 0,
                    res1=nhwc(r1) if fused else None, res2=nhwc(r2) if fused else None, scale=sc if fused else None,
                    shift=sh if fused else None)
         d.batch = batch

@@ -73,8 +73,8 @@ def test_argument_errors_are_reported(nv):
     assert lib.usc_cvt_color_u8(1, 16, 3, 2, None, None) == -1 and b"lab_tables" in lib.usc_last_error().lower()
     assert lib.usc_gmm_alpha_u8(None, 16, None, None, None, None) == -1
     assert lib.usc_color_correct_u8(1, 2, 8, 8, 3, 960, 0.95, 4, 5, None, 6, 16, None) == -3 and b"workspace" in lib.usc_last_error()
-    assert lib.usc_regionfill_u8(1, 2, 8, 8, 3, 1e-7, 100, None, 4, 16, None) == -3
-    assert lib.usc_regionfill_u8(1, 2, 8, 8, 3, 0.0, 100, None, 4, 1 << 30, None) == -1                      # rtol must be > 0
+    assert lib.usc_regionfill_u8(1, 2, 8, 8, 3, 1e-7, 0, 100, None, 4, 16, None) == -3
+    assert lib.usc_regionfill_u8(1, 2, 8, 8, 3, 0.0, 0, 100, None, 4, 1 << 30, None) == -1                      # rtol must be > 0
     assert lib.usc_segagent_post(1, 65, 129, 129, 32, 2, 513, 513, 541, 962, 1080, 1920, 3, None, 4, 1 << 30, None) == -2      # > 64 crops
     assert lib.usc_upsample_nc_nhwc_f32(1, 4, 4, 6, 2, 8, 8, 8, 0, None) == -1                               # C % 4
     assert lib.usc_pack_kn_f32(1, 8, 8, 1, 8, 40, 32, 2, None) == -1                                         # Kpad % 32

@@ -75,7 +75,7 @@ _SIGNATURES = {
     "usc_stm_post": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "usc_stm_mask_from_prob": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "usc_regionfill_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
-    "usc_regionfill_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_double, C.c_int, C.POINTER(C.c_int), _vp, C.c_size_t, _vp]),
+    "usc_regionfill_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_double, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "usc_score_map_f64": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, _vp, _vp, _vp]),
     "usc_remove_invalid_objects_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "usc_remove_invalid_objects_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp, C.c_size_t, _vp]),
@@ -621,18 +621,31 @@ def stm_mask_from_prob(prob, H, W, out=None):
     return out
 
 
-def regionfill(img, mask, rtol=1e-7, max_iters=20000, out=None, ws=None, want_iters=False):
-    """Laplace inpainting of the three channels of img (H, W, 3) inside mask > 0 (reference utils/region_fill.py)."""
+def regionfill(img, mask, rtol=1e-7, max_iters=2000, out=None, ws=None, want_iters=False, budget=48, sync=True, status=None):
+    """Laplace inpainting of the three channels of img (H, W, 3) inside mask > 0 (reference utils/region_fill.py).
+    The C entry only enqueues work: `budget` iterations per call, the convergence test runs on the device and turns what is left
+    of the budget into no-ops.  sync=True (the NumPy-API default): after each budget the 8-byte status {iterations, converged} is
+    read back and the solve continued until it has converged (or max_iters).  sync=False: one budget, no host synchronisation -
+    the caller looks at `status` (device int32[2]) whenever it synchronises anyway (BgOnlinePipeline does).
+    want_iters: also return the iteration count (an int with sync=True, else the device status tensor)."""
     H, W, _ = img.shape
     out = torch.empty_like(img) if out is None else out
     need = load().usc_regionfill_ws_bytes(H, W)
     if ws is None or ws.numel() < need:
         ws = _ws(need, img.device)
-    it = C.c_int(0)
-    _check(load().usc_regionfill_u8(_dev_u8(img, "regionfill.img", (H, W, 3)), _dev_u8(mask, "regionfill.mask", (H, W)), H, W,
-                                    _dev_u8(out, "regionfill.out", (H, W, 3)), float(rtol), int(max_iters), C.byref(it), ws.data_ptr(),
-                                    ws.numel(), _stream()), "usc_regionfill_u8")
-    return (out, it.value) if want_iters else out
+    status = torch.zeros(2, dtype=torch.int32, device=img.device) if status is None else status
+    pi, pm, po = _dev_u8(img, "regionfill.img", (H, W, 3)), _dev_u8(mask, "regionfill.mask", (H, W)), _dev_u8(out, "regionfill.out", (H, W, 3))
+    it = 0
+    while True:
+        n = max(1, min(int(budget), int(max_iters) - it))
+        _check(load().usc_regionfill_u8(pi, pm, H, W, po, float(rtol), it, n, status.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+               "usc_regionfill_u8")
+        it += n
+        if not sync:
+            return (out, status) if want_iters else out
+        used, conv = (int(v) for v in status.cpu())
+        if conv or it >= max_iters:
+            return (out, used) if want_iters else out
 
 
 def bg_accumulate(frame, mask_dilated, raw, cont):

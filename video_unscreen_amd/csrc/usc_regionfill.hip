@@ -17,15 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include <string.h>
 
-#include <deque>
-#include <memory>
-#include <mutex>
-#include <tuple>
-#include <utility>
-#include <vector>
 
 #include "../../include/unscreen_hip.h"
 #include "usc_device.h"
@@ -133,7 +126,8 @@ __global__ __launch_bounds__(kThreads) void rf_init_kernel(const uint8_t* __rest
 
 // partial a.b over the mask
 __global__ __launch_bounds__(kThreads) void rf_dot_kernel(const uint8_t* __restrict__ mask, uint32_t n, const double* __restrict__ a,
-                                                          const double* __restrict__ b, double* __restrict__ part) {
+                                                          const double* __restrict__ b, double* __restrict__ part, const int* __restrict__ ctl) {
+    if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
     __shared__ double s_part[12];
     D3 acc = {{0., 0., 0.}};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -147,7 +141,8 @@ __global__ __launch_bounds__(kThreads) void rf_dot_kernel(const uint8_t* __restr
 // p = z + beta p, beta = rz_new / rz_old (first: p = z)
 __global__ __launch_bounds__(kThreads) void rf_p_kernel(const uint8_t* __restrict__ mask, uint32_t n, const double* __restrict__ z,
                                                         double* __restrict__ p, const double* __restrict__ part_rz_old,
-                                                        const double* __restrict__ part_rz_new, int first) {
+                                                        const double* __restrict__ part_rz_new, int first, const int* __restrict__ ctl) {
+    if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
     __shared__ double s_part[12];
     double beta[3] = {0., 0., 0.};
     if (!first) {
@@ -167,7 +162,8 @@ __global__ __launch_bounds__(kThreads) void rf_p_kernel(const uint8_t* __restric
 
 // Ap = A p ; partial p.Ap
 __global__ __launch_bounds__(kThreads) void rf_ap_kernel(const uint8_t* __restrict__ mask, int H, int W, const double* __restrict__ p,
-                                                         double* __restrict__ Ap, double* __restrict__ part_pap) {
+                                                         double* __restrict__ Ap, double* __restrict__ part_pap, const int* __restrict__ ctl) {
+    if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
     __shared__ double s_part[12];
     D3 acc = {{0., 0., 0.}};
     const uint32_t n = (uint32_t)H * (uint32_t)W;
@@ -189,7 +185,8 @@ __global__ __launch_bounds__(kThreads) void rf_ap_kernel(const uint8_t* __restri
 __global__ __launch_bounds__(kThreads) void rf_xr_kernel(const uint8_t* __restrict__ mask, uint32_t n, const double* __restrict__ p,
                                                          const double* __restrict__ Ap, double* __restrict__ x, double* __restrict__ r,
                                                          const double* __restrict__ part_rz, const double* __restrict__ part_pap,
-                                                         double* __restrict__ part_rr) {
+                                                         double* __restrict__ part_rr, const int* __restrict__ ctl) {
+    if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
     __shared__ double s_part[12];
     const D3 rz = sum_partials(part_rz, s_part), pap = sum_partials(part_pap, s_part);
     double alpha[3];
@@ -210,14 +207,31 @@ __global__ __launch_bounds__(kThreads) void rf_xr_kernel(const uint8_t* __restri
     store_partial(part_rr, block_sum(acc, s_part));
 }
 
-__global__ __launch_bounds__(kThreads) void rf_publish_kernel(const double* __restrict__ part_rr, double* __restrict__ scal, int slot) {
+// Sums r.r and decides on the device.  slot 0 (after rf_init): records r0.r0, resets the control block (done only if there is
+// nothing to solve).  slot 1 (after a block of `iters_add` iterations): records r.r, counts the iterations and sets done + converged
+// once every channel's residual has dropped by rtol (rtol2 = rtol^2) - from then on every iteration kernel returns at its first
+// instruction.  ctl = {done, iterations run, converged}.
+__global__ __launch_bounds__(kThreads) void rf_publish_kernel(const double* __restrict__ part_rr, double* __restrict__ scal, int slot,
+                                                             int* __restrict__ ctl, double rtol2, int iters_add) {
     __shared__ double s_part[12];
+    if (slot == 1 && ctl[0]) return;
     const D3 t = sum_partials(part_rr, s_part);
-    if (threadIdx.x == 0) { scal[3 * slot] = t.v[0]; scal[3 * slot + 1] = t.v[1]; scal[3 * slot + 2] = t.v[2]; }
+    if (threadIdx.x == 0) {
+        scal[3 * slot] = t.v[0]; scal[3 * slot + 1] = t.v[1]; scal[3 * slot + 2] = t.v[2];
+        bool done = true;
+        for (int c = 0; c < 3; c++) {
+            const double r0 = slot == 0 ? t.v[c] : scal[c];
+            if (r0 > 0. && !(t.v[c] <= rtol2 * r0)) done = false;
+        }
+        if (slot == 0) { ctl[0] = done ? 1 : 0; ctl[1] = 0; ctl[2] = done ? 1 : 0; }
+        else { ctl[1] += iters_add; if (done) { ctl[0] = 1; ctl[2] = 1; } }
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void rf_out_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ mask, uint32_t n,
-                                                          const double* __restrict__ x, uint8_t* __restrict__ out) {
+                                                          const double* __restrict__ x, uint8_t* __restrict__ out, const int* __restrict__ ctl,
+                                                          int* __restrict__ status) {
+    if (status && blockIdx.x == 0 && threadIdx.x == 0) { status[0] = ctl[1]; status[1] = ctl[2]; }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -277,7 +291,8 @@ __device__ __forceinline__ void mg_jacobi_cells(const uint8_t* __restrict__ mask
 }
 
 __global__ __launch_bounds__(kThreads) void mg_jacobi_kernel(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ zin,
-                                                             const double* __restrict__ r, double* __restrict__ zout) {
+                                                             const double* __restrict__ r, double* __restrict__ zout, const int* __restrict__ ctl) {
+    if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
     mg_jacobi_cells(mask, H, W, s, zin, r, zout, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
@@ -316,7 +331,8 @@ __device__ __forceinline__ void mg_jacobi2_cells(const uint8_t* __restrict__ mas
 }
 
 __global__ __launch_bounds__(kThreads) void mg_jacobi2_kernel(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ r,
-                                                              double* __restrict__ zout) {
+                                                              double* __restrict__ zout, const int* __restrict__ ctl) {
+    if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
     mg_jacobi2_cells(mask, H, W, s, r, zout, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
@@ -356,7 +372,8 @@ __device__ __forceinline__ void mg_prolong_jacobi_cells(const uint8_t* __restric
 
 __global__ __launch_bounds__(kThreads) void mg_prolong_jacobi_kernel(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ z,
                                                                      const double* __restrict__ zc, int Wc, const double* __restrict__ r,
-                                                                     double* __restrict__ zout) {
+                                                                     double* __restrict__ zout, const int* __restrict__ ctl) {
+    if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
     mg_prolong_jacobi_cells(mask, H, W, s, z, zc, Wc, r, zout, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
@@ -387,14 +404,16 @@ __device__ __forceinline__ void mg_restrict_cells(const uint8_t* __restrict__ mf
 
 __global__ __launch_bounds__(kThreads) void mg_restrict_kernel(const uint8_t* __restrict__ mf, int Hf, int Wf, double sf, const double* __restrict__ zf,
                                                                const double* __restrict__ rf, const uint8_t* __restrict__ mc, int Hc, int Wc,
-                                                               double* __restrict__ rc) {
+                                                               double* __restrict__ rc, const int* __restrict__ ctl) {
+    if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
     mg_restrict_cells(mf, Hf, Wf, sf, zf, rf, mc, Hc, Wc, rc, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // The coarse end of the V-cycle (levels first_tail .. L-1, a few thousand cells at most) inside ONE workgroup: the same
 // sweeps in the same order as the per-level kernels, separated by workgroup barriers instead of kernel boundaries
 // (every cell's arithmetic is identical, so the result does not depend on which path ran).
-__global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls) {
+__global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls, const int* __restrict__ ctl) {
+    if (ctl[0]) return;
     const uint32_t t = threadIdx.x, nt = blockDim.x;
     for (int l = ls.first_tail; l < ls.L; l++) {
         const Level& v = ls.lv[l];
@@ -444,32 +463,13 @@ int grid_of(size_t n) {                 // element-wise multigrid kernels: one c
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
-// Either launches on a stream or appends a kernel node to a linear-chain hipGraph (same call sites for both).
+// Plain stream launches (no graph, no cache: the entry point keeps no state between calls).
 struct Launcher {
     hipStream_t st = nullptr;
-    hipGraph_t graph = nullptr;              // non-null: record
-    hipGraphNode_t prev = nullptr;
-    bool ok = true;
-    std::deque<std::shared_ptr<void>> keep;  // argument storage of recorded nodes
-
-    template <typename... P, typename... A, size_t... I>
-    void add_node(void (*k)(P...), dim3 grid, dim3 block, std::index_sequence<I...>, A... a) {
-        auto tup = std::make_shared<std::tuple<P...>>(static_cast<P>(a)...);
-        keep.push_back(tup);
-        void* ptrs[] = {(void*)&std::get<I>(*tup)...};
-        hipKernelNodeParams kp;
-        memset(&kp, 0, sizeof(kp));
-        kp.func = (void*)k; kp.gridDim = grid; kp.blockDim = block; kp.sharedMemBytes = 0; kp.kernelParams = ptrs; kp.extra = nullptr;
-        hipGraphNode_t node;
-        if (hipGraphAddKernelNode(&node, graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp) != hipSuccess) { ok = false; return; }
-        prev = node;
-    }
-
     template <typename... P, typename... A>
     void launch(void (*k)(P...), dim3 grid, dim3 block, A... a) {
         static_assert(sizeof...(P) == sizeof...(A), "argument count");
-        if (graph) add_node(k, grid, block, std::index_sequence_for<P...>{}, a...);
-        else hipLaunchKernelGGL(k, grid, block, 0, st, static_cast<P>(a)...);
+        hipLaunchKernelGGL(k, grid, block, 0, st, static_cast<P>(a)...);
     }
 };
 
@@ -478,13 +478,15 @@ struct Solver {
     uint32_t n;
     Level lv[kMaxLevels];
     double *scal, *part_rr, *part_pap, *part_rz[2], *x, *p, *Ap;
+    int* ctl;                                       // {done, iterations run, converged}: the device-side convergence state
     uint8_t* mask0;
 
     void carve(void* ws, int H_, int W_) {
         H = H_; W = W_; n = (uint32_t)H * (uint32_t)W;
         uint8_t* cur = reinterpret_cast<uint8_t*>(ws);
         auto take = [&](size_t bytes) { uint8_t* q = cur; cur += rf_align(bytes); return q; };
-        scal = reinterpret_cast<double*>(take(256));                   // [0..2] = r0.r0, [3..5] = latest r.r
+        scal = reinterpret_cast<double*>(take(256));                   // [0..2] = r0.r0, [3..5] = latest r.r, bytes 128.. = ctl
+        ctl = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(scal) + 128);
         const size_t psz = (size_t)kBlocks * 3 * sizeof(double);
         part_rr = reinterpret_cast<double*>(take(psz));
         part_pap = reinterpret_cast<double*>(take(psz));
@@ -496,7 +498,7 @@ struct Solver {
         Ap = reinterpret_cast<double*>(take(v0));
         int hs[kMaxLevels], wsz[kMaxLevels];
         L = level_dims(H, W, hs, wsz);
-        static const double lvl_scale = getenv("USC_RF_SCALE") ? atof(getenv("USC_RF_SCALE")) : 1.;    // tuning knob, see the header
+        const double lvl_scale = 1.;                                   // coarse operator = the unscaled re-discretised stencil (see the header)
         for (int l = 0; l < L; l++) {
             const size_t vb = (size_t)hs[l] * wsz[l] * 3 * sizeof(double);
             lv[l].H = hs[l]; lv[l].W = wsz[l];
@@ -509,8 +511,6 @@ struct Solver {
         mask0 = lv[0].mask;
         first_tail = L - 1;
         while (first_tail > 1 && (size_t)lv[first_tail - 1].H * lv[first_tail - 1].W <= (size_t)kTailCells) first_tail--;
-        static const bool no_tail = getenv("USC_RF_NO_TAIL") != nullptr;           // debugging aid: per-level kernels all the way down
-        if (no_tail) first_tail = L;
     }
 
     // z_l = V-cycle(r_l): 2 pre-smoothing sweeps from zero, coarse correction, 2 post-smoothing sweeps; 17 sweeps on the last level
@@ -521,29 +521,29 @@ struct Solver {
             const Level& v = lv[l];
             const dim3 g(grid_of((size_t)v.H * v.W));
             if (l == L - 1) {
-                q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, (const double*)nullptr, v.r, v.z);
+                q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, (const double*)nullptr, v.r, v.z, ctl);
                 for (int k = 0; k < 8; k++) {
-                    q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.z, v.r, v.zt);
-                    q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.zt, v.r, v.z);
+                    q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.z, v.r, v.zt, ctl);
+                    q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, ctl);
                 }
             } else {
-                q.launch(mg_jacobi2_kernel, g, b, v.mask, v.H, v.W, v.s, v.r, v.z);             // two sweeps from zero
+                q.launch(mg_jacobi2_kernel, g, b, v.mask, v.H, v.W, v.s, v.r, v.z, ctl);             // two sweeps from zero
                 const Level& c = lv[l + 1];
-                q.launch(mg_restrict_kernel, dim3(grid_of((size_t)c.H * c.W)), b, v.mask, v.H, v.W, v.s, v.z, v.r, c.mask, c.H, c.W, c.r);
+                q.launch(mg_restrict_kernel, dim3(grid_of((size_t)c.H * c.W)), b, v.mask, v.H, v.W, v.s, v.z, v.r, c.mask, c.H, c.W, c.r, ctl);
             }
         }
         if (first_tail < L) {
             LevelSet ls;
             ls.L = L; ls.first_tail = first_tail;
             for (int l = 0; l < kMaxLevels; l++) ls.lv[l] = lv[l < L ? l : L - 1];
-            q.launch(mg_tail_kernel, dim3(1), dim3(kTailThreads), ls);
+            q.launch(mg_tail_kernel, dim3(1), dim3(kTailThreads), ls, ctl);
         }
         for (int l = last - 1; l >= 0; l--) {
             if (l == L - 1) continue;
             const Level& v = lv[l];
             const dim3 g(grid_of((size_t)v.H * v.W));
-            q.launch(mg_prolong_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.z, lv[l + 1].z, lv[l + 1].W, v.r, v.zt);   // correction + sweep
-            q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.zt, v.r, v.z);
+            q.launch(mg_prolong_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.z, lv[l + 1].z, lv[l + 1].W, v.r, v.zt, ctl);   // correction + sweep
+            q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, ctl);
         }
     }
 
@@ -552,38 +552,15 @@ struct Solver {
         const dim3 b(kThreads), g(kBlocks);           // reductions always use kBlocks blocks: the partial arrays have that many rows
         double* r = lv[0].r;
         vcycle(q);                                                                                   // z = M^-1 r
-        q.launch(rf_dot_kernel, g, b, mask0, n, r, lv[0].z, part_rz[cur ^ 1]);                       // r.z (new)
-        q.launch(rf_p_kernel, g, b, mask0, n, lv[0].z, p, part_rz[cur], part_rz[cur ^ 1], first);
+        q.launch(rf_dot_kernel, g, b, mask0, n, r, lv[0].z, part_rz[cur ^ 1], ctl);                       // r.z (new)
+        q.launch(rf_p_kernel, g, b, mask0, n, lv[0].z, p, part_rz[cur], part_rz[cur ^ 1], first, ctl);
         cur ^= 1;
-        q.launch(rf_ap_kernel, g, b, mask0, H, W, p, Ap, part_pap);
-        q.launch(rf_xr_kernel, g, b, mask0, n, p, Ap, x, r, part_rz[cur], part_pap, part_rr);
+        q.launch(rf_ap_kernel, g, b, mask0, H, W, p, Ap, part_pap, ctl);
+        q.launch(rf_xr_kernel, g, b, mask0, n, p, Ap, x, r, part_rz[cur], part_pap, part_rr, ctl);
     }
 };
 
-constexpr int kItersPerCheck = 4;
-
-// hipGraph of kItersPerCheck iterations + the residual publication.  It only references memory inside the workspace, so it
-// is cached per (workspace, size) and stays valid for as long as that workspace address is used with that size.
-struct CachedGraph { void* ws; int H, W; hipGraph_t graph; hipGraphExec_t exec; std::deque<std::shared_ptr<void>> keep; };
-std::mutex g_cache_mu;
-std::vector<CachedGraph> g_cache;
-
-hipGraphExec_t iteration_graph(const Solver& s, void* ws) {
-    std::lock_guard<std::mutex> lock(g_cache_mu);
-    for (auto& c : g_cache)
-        if (c.ws == ws && c.H == s.H && c.W == s.W) return c.exec;
-    Launcher q;
-    if (hipGraphCreate(&q.graph, 0) != hipSuccess) return nullptr;
-    int cur = 0;                                     // the graph starts after an even number of iterations
-    for (int k = 0; k < kItersPerCheck; k++) s.iteration(q, 0, cur);
-    q.launch(rf_publish_kernel, dim3(1), dim3(kThreads), s.part_rr, s.scal, 1);
-    hipGraphExec_t exec = nullptr;
-    if (!q.ok || hipGraphInstantiate(&exec, q.graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(q.graph); return nullptr; }
-    if (g_cache.size() >= 8) g_cache.erase(g_cache.begin());      // a handful of sizes at most; the oldest entry is dropped from the
-                                                                  // cache but its graph is not destroyed (see usc_conv_graph_destroy)
-    g_cache.push_back(CachedGraph{ws, s.H, s.W, q.graph, exec, std::move(q.keep)});
-    return exec;
-}
+constexpr int kItersPerCheck = 2;         // iterations between two device-side convergence tests
 
 }  // namespace
 
@@ -597,51 +574,39 @@ extern "C" size_t usc_regionfill_ws_bytes(int H, int W) {
     return total;
 }
 
-extern "C" int usc_regionfill_u8(const uint8_t* img, const uint8_t* mask, int H, int W, uint8_t* out, double rtol, int max_iters,
-                                 int* iters_out, void* ws, size_t ws_bytes, usc_stream_t stream) {
-    if (!img || !mask || !out || !ws || H <= 0 || W <= 0 || !(rtol > 0.) || max_iters < 1) return fail(USC_E_ARG, "usc_regionfill_u8: bad argument");
+extern "C" int usc_regionfill_u8(const uint8_t* img, const uint8_t* mask, int H, int W, uint8_t* out, double rtol, int first_iter,
+                                 int n_iters, int* status, void* ws, size_t ws_bytes, usc_stream_t stream) {
+    if (!img || !mask || !out || !ws || H <= 0 || W <= 0 || !(rtol > 0.) || first_iter < 0 || n_iters < 0 || (first_iter == 0 && n_iters < 1))
+        return fail(USC_E_ARG, "usc_regionfill_u8: bad argument");
     if (too_big(H, W) || (long long)H * W * 3 >= (1ll << 31)) return fail(USC_E_UNSUPPORTED, "usc_regionfill_u8: image too large");
     if (ws_bytes < usc_regionfill_ws_bytes(H, W)) return fail(USC_E_WORKSPACE, "usc_regionfill_u8: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     Solver s;
     s.carve(ws, H, W);
-    if (hipMemcpyAsync(s.mask0, mask, (size_t)H * W, hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return fail(USC_E_LAUNCH, "usc_regionfill_u8: mask copy failed");
-    Launcher direct;
-    direct.st = st;
+    Launcher q;
+    q.st = st;
     const dim3 b(kThreads);
-    for (int l = 1; l < s.L; l++)
-        direct.launch(mg_mask_down_kernel, dim3(grid_of((size_t)s.lv[l].H * s.lv[l].W)), b, s.lv[l - 1].mask, s.lv[l - 1].H, s.lv[l - 1].W,
-                      s.lv[l].mask, s.lv[l].H, s.lv[l].W);
-    direct.launch(rf_init_kernel, dim3(kBlocks), b, img, s.mask0, H, W, s.x, s.lv[0].r, s.part_rr);
-    direct.launch(rf_publish_kernel, dim3(1), b, s.part_rr, s.scal, 0);
-
-    auto converged = [&](bool& done) -> int {                           // one host round trip per kItersPerCheck iterations
-        double h[6];
-        if (hipMemcpyAsync(h, s.scal, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-            return fail(USC_E_LAUNCH, "usc_regionfill_u8: reading the residual failed");
-        done = true;
-        for (int c = 0; c < 3; c++)
-            if (h[c] > 0. && !(h[3 + c] <= rtol * rtol * h[c])) done = false;
-        return USC_OK;
-    };
-
-    int it = 0, cur = 0;
-    bool done = false;
-    // the first block of iterations (p = z on the very first) is launched kernel by kernel; the following ones replay a graph
-    for (; it < kItersPerCheck && it < max_iters; it++) s.iteration(direct, it == 0 ? 1 : 0, cur);
-    direct.launch(rf_publish_kernel, dim3(1), b, s.part_rr, s.scal, 1);
-    int rc = converged(done);
-    if (rc) return rc;
-    hipGraphExec_t exec = nullptr;
-    while (!done && it < max_iters) {
-        if (!exec && !(exec = iteration_graph(s, ws))) return fail(USC_E_LAUNCH, "usc_regionfill_u8: building the iteration graph failed");
-        if (hipGraphLaunch(exec, st) != hipSuccess) return fail(USC_E_LAUNCH, "usc_regionfill_u8: graph launch failed");
-        it += kItersPerCheck;
-        rc = converged(done);
-        if (rc) return rc;
+    const double rtol2 = rtol * rtol;
+    if (first_iter == 0) {                                      // a new solve: masks of every level, x0, r0, control block
+        if (hipMemcpyAsync(s.mask0, mask, (size_t)H * W, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return fail(USC_E_LAUNCH, "usc_regionfill_u8: mask copy failed");
+        for (int l = 1; l < s.L; l++)
+            q.launch(mg_mask_down_kernel, dim3(grid_of((size_t)s.lv[l].H * s.lv[l].W)), b, s.lv[l - 1].mask, s.lv[l - 1].H, s.lv[l - 1].W,
+                     s.lv[l].mask, s.lv[l].H, s.lv[l].W);
+        q.launch(rf_init_kernel, dim3(kBlocks), b, img, s.mask0, H, W, s.x, s.lv[0].r, s.part_rr);
+        q.launch(rf_publish_kernel, dim3(1), b, s.part_rr, s.scal, 0, s.ctl, rtol2, 0);
     }
-    if (iters_out) *iters_out = it;
-    direct.launch(rf_out_kernel, dim3(kBlocks), b, img, s.mask0, s.n, s.x, out);
+    // Iterations [first_iter, first_iter + n_iters), a convergence test on the device after every kItersPerCheck of them; once it has
+    // passed, the kernels still in the queue return at their first instruction.  No host synchronisation.
+    int cur = first_iter & 1;                                   // which r.z partial array holds the previous value
+    int since = 0;
+    for (int it = first_iter; it < first_iter + n_iters; it++) {
+        s.iteration(q, it == 0 ? 1 : 0, cur);
+        if (++since == kItersPerCheck || it + 1 == first_iter + n_iters) {
+            q.launch(rf_publish_kernel, dim3(1), b, s.part_rr, s.scal, 1, s.ctl, rtol2, since);
+            since = 0;
+        }
+    }
+    q.launch(rf_out_kernel, dim3(kBlocks), b, img, s.mask0, s.n, s.x, out, (const int*)s.ctl, status);
     return check_launch("regionfill kernels");
 }

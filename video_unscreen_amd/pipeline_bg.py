@@ -36,6 +36,8 @@ class BgOnlinePipeline:
         self._cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._ws_fill = torch.empty(nv.load().usc_regionfill_ws_bytes(H, W), dtype=torch.uint8, device=self.device)
         self._ws_diff = torch.empty(nv.load().usc_bgdiff_ws_bytes(H, W), dtype=torch.uint8, device=self.device)
+        self._fill_status = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self._fill_pending = None
         self.reset()
 
     def reset(self):
@@ -43,6 +45,35 @@ class BgOnlinePipeline:
         self.alpha_pre = torch.zeros((self.H, self.W), dtype=torch.uint8, device=self.device)
         self.prev_frame = None
         self.fill_iters = 0
+
+    def _fill(self, bg, hole):
+        """Inpaint the hole without a host synchronisation of its own: the iteration budget follows the previous frames (their
+        count + a margin; 48 to start with), the convergence test runs on the device, and the 8-byte status is read at the
+        step's next natural synchronisation point (exist_foreground) - if a budget ever turns out too small the solve is
+        continued there, before anything downstream has been consumed."""
+        budget = 48 if self.fill_iters <= 0 else min(400, self.fill_iters + max(8, self.fill_iters // 2))
+        bgimg = nv.regionfill(bg, hole, rtol=self.fill_rtol, ws=self._ws_fill, budget=budget, sync=False, status=self._fill_status)
+        self._fill_pending = (bg, hole, bgimg, budget)
+        return bgimg
+
+    def _fill_check(self):
+        """Called right after a host synchronisation: look at the inpainting status of this frame; True if the fill had to be
+        continued (the caller then recomputes what it derived from the background)."""
+        if self._fill_pending is None:
+            return False
+        bg, hole, bgimg, budget = self._fill_pending
+        self._fill_pending = None
+        used, conv = (int(v) for v in self._fill_status.cpu())
+        redo = not conv
+        it = budget
+        while not conv and it < 2000:
+            nv.load().usc_regionfill_u8(bg.data_ptr(), hole.data_ptr(), self.H, self.W, bgimg.data_ptr(), float(self.fill_rtol), it, 48,
+                                        self._fill_status.data_ptr(), self._ws_fill.data_ptr(), self._ws_fill.numel(),
+                                        torch.cuda.current_stream().cuda_stream)
+            it += 48
+            used, conv = (int(v) for v in self._fill_status.cpu())
+        self.fill_iters = used
+        return redo
 
     def _exist_foreground(self, mask):
         return int(nv.count_ge(mask, 128, out=self._cnt).item()) > self.cfg["fg_exist_thr"] * self.H * self.W
@@ -71,20 +102,35 @@ class BgOnlinePipeline:
             alpha1 = self.vmatagent.forward_device(frame, self.alpha_pre, trimap1)
             bg = nv.get_bg(alpha1, frame)
             hole = nv.morph((alpha1 > 128).to(torch.uint8) * 255, 3, 2, nv.DILATE)
-            bgimg, self.fill_iters = nv.regionfill(bg, hole, rtol=self.fill_rtol, ws=self._ws_fill, want_iters=True)
+            bgimg = self._fill(bg, hole)
             if passes == 1:
                 self.alpha_pre = alpha1
                 self.tracking_flag = self._exist_foreground(alpha1)
+                self._fill_check()                           # (continues the fill in place if its budget was too small)
                 self.prev_frame = frame
                 out.update(alphaor1=alphaor1, trimap1=trimap1, alpha1=alpha1, alpha=alpha1, bg_holes=bg, hole=hole, bgimg=bgimg)
                 return out
-            _, alpha_ensm = nv.bgdiff_mask(frame, bgimg, None, alpha1, 1.0, cfg["bg_mask"]["thr"], ws=self._ws_diff)
-            alphaor2 = self._object_filter(alpha_ensm)
-            trimap2 = self.trimapagent.forward_device(alphaor2)
-            alpha = self.vmatagent.forward_device(frame, self.alpha_pre, trimap2)
-            fg, bgp = nv.get_fg(frame, alpha, bgimg, paste_thr=1, want_bg=True)
-            out.update(alphaor1=alphaor1, trimap1=trimap1, alpha1=alpha1, bg_holes=bg, hole=hole, bgimg=bgimg, alpha_ensm=alpha_ensm,
-                       alphaor2=alphaor2, trimap2=trimap2, bg=bgp)
+
+            def second_pass():
+                _, alpha_ensm = nv.bgdiff_mask(frame, bgimg, None, alpha1, 1.0, cfg["bg_mask"]["thr"], ws=self._ws_diff)
+                alphaor2 = self._object_filter(alpha_ensm)
+                trimap2 = self.trimapagent.forward_device(alphaor2)
+                alpha = self.vmatagent.forward_device(frame, self.alpha_pre, trimap2)
+                fg, bgp = nv.get_fg(frame, alpha, bgimg, paste_thr=1, want_bg=True)
+                out.update(alphaor1=alphaor1, trimap1=trimap1, alpha1=alpha1, bg_holes=bg, hole=hole, bgimg=bgimg, alpha_ensm=alpha_ensm,
+                           alphaor2=alphaor2, trimap2=trimap2, bg=bgp)
+                return alpha, fg
+
+            alpha, fg = second_pass()
+            tracking_next = self._exist_foreground(alpha)      # host synchronisation: the fill's status is known now
+            if self._fill_check():                            # budget too small (rare): the fill was continued, redo what used it
+                alpha, fg = second_pass()
+                tracking_next = self._exist_foreground(alpha)
+            self.alpha_pre = alpha
+            self.tracking_flag = tracking_next
+            self.prev_frame = frame
+            out.update(alpha=alpha, fg=fg)
+            return out
         self.alpha_pre = alpha
         self.tracking_flag = self._exist_foreground(alpha)
         self.prev_frame = frame
