@@ -68,3 +68,66 @@ def test_bench_two_ranks_rehearsal():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["value"] > 0 and abs(out["value"] - 2 * 6 / (out["ms_per_step"] * 6 / 1e3)) < 1e-2 * out["value"]
+
+
+def test_bg_step_tool_raw_files_are_bit_exact(tmp_path):
+    """--io npy: no codec anywhere, so the files the streaming tool writes (decoder processes -> pinned ring -> uploads -> pipelined
+    loop -> downloads -> encoder processes) equal the in-process synchronous loop bit for bit."""
+    from video_unscreen_amd.synth import SyntheticClip
+    from video_unscreen_amd.utils.fileio import save_img
+    from video_unscreen_amd.vmatting.net import synthetic_state_dict
+    H, W, n = 270, 480, 7
+    root = tmp_path / "data"
+    src, dst = root / "src_img" / "3", root / "test_img" / "3"
+    src.mkdir(parents=True)
+    dst.mkdir(parents=True)
+    clip = SyntheticClip(H, W, n, config_id=2, device="cpu")
+    save_img(clip.bg_always.numpy(), str(dst / "always_bg.jpg"))
+    frames = [clip.frame(t) for t in range(n)]
+    for t, f in enumerate(frames):
+        np.save(src / f"{t:06d}.npy", f["frame"].numpy())
+        np.save(dst / f"segmask_{t:06d}.npy", f["seg"].numpy())
+        np.save(dst / f"bg_{t:06d}.npy", f["bg"].numpy())
+    wpath = tmp_path / "unet.pth"
+    torch.save({"state_dict": synthetic_state_dict(0)}, str(wpath))
+    cfg = json.load(open(os.path.join(ROOT, "configs", "bg.json")))
+    cfg["vmatting"]["model_path"] = str(wpath)
+    json.dump(cfg, open(tmp_path / "bg.json", "w"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "unscreen", "bg_step.py"), "--cfg", str(tmp_path / "bg.json"),
+                        "--video_id", "3", "--data_root", str(root), "--io", "npy", "--io_workers", "2"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    from video_unscreen_amd.pipeline import BgStepPipeline
+    from video_unscreen_amd.utils.fileio import read_img
+    pipe = BgStepPipeline(cfg, H, W, state_dict=synthetic_state_dict(0))
+    bga = torch.from_numpy(read_img(str(dst / "always_bg.jpg"))).cuda()
+    for t, f in enumerate(frames):
+        out = pipe.step(f["frame"].cuda(), f["seg"].cuda(), f["bg"].cuda(), bga)
+        assert np.array_equal(np.load(dst / f"alphamask_{t:06d}.npy"), out["alpha"].cpu().numpy()), t
+        assert np.array_equal(np.load(dst / f"fg_{t:06d}.npy"), out["fg"].cpu().numpy()), t
+
+
+def test_rccl_single_rank_collectives():
+    """The `nccl` (= RCCL) code path of the multi-GPU set-up, on the one GPU this box has: process-group init bound to the device,
+    the bucketed weight broadcast, the background broadcast, the all-reduce of the overall-background bucket and the MAX of the
+    elapsed time - so the driver's 8-GPU launch is not the first time any of it runs."""
+    code = r"""
+import os, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+from video_unscreen_amd.dist import _bucket_broadcast
+from video_unscreen_amd.vmatting.net import synthetic_state_dict
+sd = synthetic_state_dict(0)
+ft = [v.float() for k, v in sd.items() if not k.endswith("num_batches_tracked")]
+got = _bucket_broadcast(ft, 0, dev)
+assert all(torch.equal(a.cpu(), b) for a, b in zip(got, ft))
+bg = torch.arange(270 * 480 * 3, dtype=torch.uint8, device=dev).view(270, 480, 3)
+dist.broadcast(bg, src=0)
+acc = torch.ones(270 * 480 * 4, dtype=torch.float32, device=dev); dist.all_reduce(acc); assert float(acc.sum()) == 270 * 480 * 4
+t = torch.tensor([1.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t) == 1.5
+dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group(); print("rccl ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=600,
+                       env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

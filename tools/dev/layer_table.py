@@ -57,7 +57,7 @@ def table(layers_json, trace_csv):
     rows = []
     for r in csv.DictReader(open(trace_csv)):
         name = r.get("Kernel_Name") or r.get("Name")
-        if any(k in name for k in ("conv_mfma_kernel", "splitk_reduce_kernel", "head_conv_kernel")):
+        if any(k in name for k in ("conv_mfma_kernel", "conv_wino_kernel", "splitk_reduce_kernel", "head_conv_kernel")):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     rows.sort()
     assert len(rows) % per_fwd == 0, (len(rows), per_fwd)

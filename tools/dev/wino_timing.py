@@ -1,0 +1,39 @@
+"""In-kernel phase timing of conv_wino_kernel (library built with EXTRA=-DUSC_WINO_TIMING into a scratch copy): per wave shader-clock
+and 100 MHz real-time stamps at entry / after the prologue / after the K loop / at the end."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from video_unscreen_amd import _native as nv
+nv.LIB_PATH = os.environ["USC_TIMING_LIB"]
+from video_unscreen_amd.vmatting import net_hip as m
+lib = nv.load()
+for (cin, cout, h, w, kw) in ((32, 32, 272, 480, 1), (64, 32, 272, 480, 1), (64, 64, 136, 240, 2), (128, 128, 68, 120, 4), (32, 32, 544, 960, 1)):
+    x = torch.randn(h, w, cin, device="cuda"); wt = torch.randn(cout, cin, 3, 3) * 0.05
+    out = torch.empty(h, w, cout, device="cuda")
+    taps, wk = m.conv_taps(wt, 1)
+    wp = m.pack_k_major(wk.float()).cuda(); wn = m.pack_wino(wt).cuda()
+    ts = torch.zeros(4096 * 4 * 16, dtype=torch.int64, device="cuda")
+    d = m.ConvDesc()
+    d.inp, d.out, d.wpk, d.wino = x.data_ptr(), out.data_ptr(), wp.data_ptr(), wn.data_ptr()
+    d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = h, w, cin, h, w, h, w, cout
+    d.in_stride, d.out_stride, d.ntaps, d.nphase = 1, 1, 9, 1
+    d.slab, d.slab_bytes = ts.data_ptr(), 0
+    for i, (dy, dx) in enumerate(taps): d.dy[i], d.dx[i] = dy, dx
+    lib.usc_conv_force_winograd(1); lib.usc_conv_force_plan(0, 0, 0, kw)
+    arr = (m.ConvDesc * 1)(d)
+    plan = nv.conv_plans(arr, 1)[0]
+    for _ in range(3): lib.usc_conv_sequence_f32(arr, 1, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize(); ts.zero_(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); lib.usc_conv_sequence_f32(arr, 1, torch.cuda.current_stream().cuda_stream); e1.record(); torch.cuda.synchronize()
+    lib.usc_conv_force_winograd(-1); lib.usc_conv_force_plan(0, 0, 0, 0)
+    t = ts.cpu().view(-1, 8, 2)[: plan["workgroups"] * 4]
+    live = t[:, 3, 0] != 0
+    t = t[live].double()
+    cyc, rt = t[..., 0], t[..., 1]
+    t0 = rt[:, 0].min()
+    steps = cin // 8 // kw
+    print(f"cin {cin} cout {cout} {h}x{w} KW {kw}: {plan['workgroups']} WGs, event {e0.elapsed_time(e1)*1e3:.1f} us; waves {len(t)}")
+    print(f"   shader clock / real time (100 MHz): {((cyc[:,3]-cyc[:,0]) / (rt[:,3]-rt[:,0])).mean()*100:.0f} MHz")
+    print(f"   cycles: prologue {float((cyc[:,1]-cyc[:,0]).mean()):.0f}  K loop {float((cyc[:,2]-cyc[:,1]).mean()):.0f} ({float((cyc[:,2]-cyc[:,1]).mean())/steps:.0f} per step, ideal 4096)  epilogue {float((cyc[:,3]-cyc[:,2]).mean()):.0f}")
+    print(f"   wave start spread {float(rt[:,0].max()-t0)/100:.2f} us, first end {float(rt[:,3].min()-t0)/100:.2f} us, last end {float(rt[:,3].max()-t0)/100:.2f} us")

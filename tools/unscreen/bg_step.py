@@ -34,7 +34,9 @@ from video_unscreen_amd.stm import STMAgent
 from video_unscreen_amd.vmatting import VMattingAgent
 from video_unscreen_amd.pipeline import BgStepPipeline
 from video_unscreen_amd.pipeline_bg import BgOnlinePipeline
+from video_unscreen_amd.hostio import stream_clip
 from video_unscreen_amd.utils.fileio import parallel_read_img, read_img, save_img, save_video
+from video_unscreen_amd.utils.frameio import FrameReader, FrameWriter
 
 
 def main(cfg):
@@ -52,15 +54,17 @@ def main(cfg):
 
     st = time.time()
     stages = cfg["data"].get("stages", "3")
-    frame_paths = sorted(glob(osp.join(src_img_dir, cfg["data"]["src_img_tmpl"])))
+    ext = cfg["data"].get("io", "jpg")
+    frame_paths = sorted(glob(osp.join(src_img_dir, '*.' + ext))) or sorted(glob(osp.join(src_img_dir, cfg["data"]["src_img_tmpl"])))
     first = 0
     if cfg["data"]["range"]:
         a, b = cfg["data"]["range"]
         frame_paths, first = frame_paths[a:b], a
     lo, hi = shard_range(len(frame_paths), rank, world)          # this rank's contiguous range
-    frames = parallel_read_img(frame_paths[lo:hi])
-    h, w = frames[0].shape[:2]
-    print('{} frames. Reading Data Done! {:.2f}s'.format(len(frames), time.time() - st))
+    # stages 1 and 2 walk the clip in memory like the reference (bg_offline.py:36); stage 3 streams it (below)
+    frames = parallel_read_img(frame_paths[lo:hi]) if ("1" in stages or "2" in stages) else None
+    h, w = (frames[0] if frames else read_img(frame_paths[lo])).shape[:2]
+    print('{} frames. Reading Data Done! {:.2f}s'.format(hi - lo, time.time() - st))
     masks, bgs = [], []
 
     if "1" in stages:
@@ -85,8 +89,8 @@ def main(cfg):
             bgimg = out["bgimg"].cpu().numpy() if "bgimg" in out else f
             masks.append(seg[..., None].repeat(3, 2))
             bgs.append(bgimg)
-            save_img(seg, osp.join(dst_img_dir, 'segmask_{:06d}.jpg'.format(fid)))
-            save_img(bgimg, osp.join(dst_img_dir, 'bg_{:06d}.jpg'.format(fid)))
+            save_img(seg, osp.join(dst_img_dir, 'segmask_{:06d}.{}'.format(fid, ext)))
+            save_img(bgimg, osp.join(dst_img_dir, 'bg_{:06d}.{}'.format(fid, ext)))
         del pipe1
         print('stage 1: {} frames in {:.2f}s on rank {}'.format(len(frames), time.time() - st, rank))
 
@@ -103,7 +107,7 @@ def main(cfg):
         print("calculate overall bg image according to video segmentation and temporal constraints")
         st = time.time()
         if not masks:
-            masks = shard_of('segmask_*.jpg')
+            masks = shard_of('segmask_*.' + ext)
         acc = OverallBackground(h, w, device=dev)
         for f, m in zip(frames, masks):
             acc.add(torch.from_numpy(f).to(dev), torch.from_numpy(np.ascontiguousarray(m[..., 0])).to(dev))
@@ -118,11 +122,6 @@ def main(cfg):
         if world > 1:
             dist.destroy_process_group()
         return
-    if not masks:
-        masks = shard_of('segmask_*.jpg')
-    if not bgs:
-        bgs = shard_of('bg_*.jpg')
-
     st = time.time()
     # rank 0 owns the checkpoint and the overall background; RCCL broadcast to the others
     sd = None
@@ -134,20 +133,34 @@ def main(cfg):
     pipe = BgStepPipeline(cfg, h, w, device=dev, state_dict=sd)
     print('Building Agents Done! {:.2f}s'.format(time.time() - st))
 
-    def inputs():
-        for f, m, b in zip(frames, masks, bgs):
-            yield (torch.from_numpy(f).to(dev), torch.from_numpy(m).to(dev), torch.from_numpy(b).to(dev), bg_always)
+    # Stage 3 streams: decoder processes -> page-locked ring -> uploads -> the pipelined frame loop -> downloads -> encoder
+    # processes (utils/frameio.py, hostio.stream_clip).  Nothing is held but the rings; the lossy JPEG round trip of the masks
+    # and backgrounds (bg_offline.py:134-141) happens only when those files are JPEGs (--io jpg, the reference's layout).
+    def shard_paths(pattern):
+        paths = sorted(glob(osp.join(dst_img_dir, pattern)))
+        assert len(paths) >= first + len(frame_paths), "frames and {} must pair up".format(pattern)
+        if len(paths) != len(frame_paths):
+            paths = paths[first:first + len(frame_paths)]
+        return paths[lo:hi]
+    mask_paths = shard_paths('segmask_*.' + ext) or shard_paths('segmask_*.jpg')
+    bg_paths = shard_paths('bg_*.' + ext) or shard_paths('bg_*.jpg')
+    groups = list(zip(frame_paths[lo:hi], mask_paths, bg_paths))
+    workers = int(cfg["data"].get("io_workers", 6))
+    reader = FrameReader(groups, [(h, w, 3), (h, w), (h, w, 3)], workers=workers, depth=16)
+    writer = FrameWriter([(h, w), (h, w, 3)], workers=workers, depth=16)
 
-    def on_result(i, out):
+    def out_paths(i):
         fid = first + lo + i
-        save_img(out["alpha"].cpu().numpy(), osp.join(dst_img_dir, 'alphamask_{:06d}.jpg'.format(fid)))
-        save_img(out["fg"].cpu().numpy(), osp.join(dst_img_dir, 'fg_{:06d}.jpg'.format(fid)))
+        return (osp.join(dst_img_dir, 'alphamask_{:06d}.{}'.format(fid, ext)), osp.join(dst_img_dir, 'fg_{:06d}.{}'.format(fid, ext)))
 
     print("calculate fg image according to bg image")
     st = time.time()
-    n = pipe.run(inputs(), on_result=on_result)
+    n = stream_clip(pipe, reader, writer, out_paths, bg_always)
     torch.cuda.synchronize()
-    print('{} frames in {:.2f}s on rank {}'.format(n, time.time() - st, rank))
+    writer.close()
+    reader.close()
+    dt = time.time() - st
+    print('{} frames in {:.2f}s on rank {} ({:.1f} frames/s, files -> files, {} codec)'.format(n, dt, rank, n / max(dt, 1e-9), ext))
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -163,11 +176,14 @@ if __name__ == '__main__':
     parser.add_argument('--range', type=str, default=None, help="eg. 400-700")
     parser.add_argument('--stages', type=str, default="3", help='which of the stages 1, 2, 3 to run, e.g. "123"')
     parser.add_argument('--data_root', type=str, default=os.environ.get("UNSCREEN_DATA_ROOT", "./data/greenmat"))
+    parser.add_argument('--io', type=str, default="jpg", choices=["jpg", "npy"],
+                        help='file format of the intermediate and output images: jpg = the reference layout (lossy mask round trip), npy = raw arrays, no codec')
+    parser.add_argument('--io_workers', type=int, default=6, help='decoder and encoder processes of stage 3')
     args = parser.parse_args()
 
     cfg = json.load(open(args.cfg))
     cfg["data"] = {"range": [int(i) for i in args.range.split('-')] if args.range else None,
-                   "video_id": args.video_id, "stages": args.stages,
+                   "video_id": args.video_id, "stages": args.stages, "io": args.io, "io_workers": args.io_workers,
                    "src_img_dir": osp.join(args.data_root, 'src_img', args.video_id),
                    "src_img_tmpl": '*.jpg',
                    "dst_img_dir": osp.join(args.data_root, 'test_img', args.video_id),

@@ -78,7 +78,7 @@ _SIGNATURES = {
     "usc_regionfill_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_double, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "usc_score_map_f64": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, _vp, _vp, _vp]),
     "usc_remove_invalid_objects_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
-    "usc_remove_invalid_objects_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp, C.c_size_t, _vp]),
+    "usc_remove_invalid_objects_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _vp, C.c_size_t, _vp]),
     "usc_upsample_taps_accum_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "usc_conv_force_plan": (None, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "usc_conv_force_winograd": (None, [C.c_int]),
@@ -699,7 +699,8 @@ def humanseg_post(logits, C_classes, H, W, in_h=473, in_w=473, out=None, ws=None
 
 # ---------------------------------------------------------------- object filter on the device
 class DeviceObjectFilter:
-    """remove_invalid_objects without leaving the GPU: per-geometry cached score map + workspace."""
+    """remove_invalid_objects without leaving the GPU (workspace kept per instance; score_map() builds the float64 table the
+    kernels evaluate in closed form - tests compare it with the reference's)."""
 
     def __init__(self):
         self._score = {}
@@ -720,11 +721,10 @@ class DeviceObjectFilter:
         H, W = alpha.shape
         pa = _dev_u8(alpha, "remove_invalid_objects.alpha")
         ps = _dev_u8(seg, "remove_invalid_objects.seg", (H, W)) if seg is not None else None
-        score = self.score_map(H, W, center, alpha.device)
         need = load().usc_remove_invalid_objects_ws_bytes(H, W)
         if self._ws is None or self._ws.numel() < need or self._ws.device != alpha.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=alpha.device)
-        _check(load().usc_remove_invalid_objects_u8(pa, ps, H, W, score.data_ptr(), float(saliency_thr), float(consensus_thr),
+        _check(load().usc_remove_invalid_objects_u8(pa, ps, H, W, float(center[0]), float(center[1]), float(saliency_thr), float(consensus_thr),
                                                     self._ws.data_ptr(), self._ws.numel(), _stream()), "usc_remove_invalid_objects_u8")
         return alpha
 

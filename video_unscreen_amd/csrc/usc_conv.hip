@@ -312,16 +312,24 @@ __global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d
 //   * KW waves of a workgroup may split the channel range of one block (partial output tiles meet in LDS, slice order).
 // Summation order depends on the shape (and KW) only: run-to-run and batch-to-batch identical results.  Results differ from
 // the direct kernel's by float rounding (relative 2e-7 per layer): the planner's choice is a function of the shape alone.
-constexpr int WPITCH = 12;                  // floats per patch pixel in LDS: 8 channels + 4 pad
+constexpr int WPITCH = 12;                  // floats per patch pixel in LDS: the 8 channels of a K step + 4 pad
 constexpr int WPATCH_W = 18, WPATCH_H = 10; // input patch of a block of 8 x 4 tiles
 constexpr int WSLOTS = WPATCH_W * WPATCH_H * 2;     // 16-byte slots of one stage (360)
 constexpr int WIMG = 2 * 32 * APITCH;       // floats of a wave's LDS image: 2 output phases x 32 tiles x APITCH (>= one stage); 36 KB per workgroup
 static_assert(WIMG >= WPATCH_W * WPATCH_H * WPITCH, "the stage must fit the epilogue image");
 
+#ifdef USC_WINO_TIMING
+#define WINO_STAMP(k) do { if (d.slab && lane == 0) { long long* ts_ = reinterpret_cast<long long*>(d.slab) + ((size_t)blockIdx.x * 4 + wave) * 16; \
+        ts_[2 * (k)] = (long long)__builtin_readcyclecounter(); ts_[2 * (k) + 1] = (long long)__builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define WINO_STAMP(k) do { } while (0)
+#endif
+
 template <int KW, bool IN_RELU>
 __global__ __launch_bounds__(256) void conv_wino_kernel(usc_conv_desc d) {
     __shared__ __attribute__((aligned(16))) float Ws[4][WIMG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    WINO_STAMP(0);
     const int nnb = d.Cout >> 5;
     const int nimg = d.batch > 1 ? d.batch : 1;
     const int H = d.IH, W = d.IW;                                  // per image; output has the same size
@@ -345,40 +353,56 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(usc_conv_desc d) {
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.wino), 0, wbytes, 0x00020000);
     const int wbase = ((lane >> 5) * d.Cout + nb0 + (lane & 31)) * 16;
     const int wpos = 2 * d.Cout * 16, wstep = 16 * wpos;
-    float4 bf[16];
-    auto load_b = [&](int c, int p) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, c < c_end ? wbase + c * wstep + p * wpos : 0x7ffffff0, 0, 0);
-        bf[p] = *reinterpret_cast<const float4*>(&v);
-    };
+    // two row buffers of four positions: row a of a step multiplies out of buffer a & 1 and re-requests it for the row two
+    // further on (the weights come from L2: 32 MFMAs = ~1 us ahead is enough; 32 registers instead of 64)
+    float4 bf[2][4];
+    auto load_b = [&](int c, int a) {
 #pragma unroll
-    for (int p = 0; p < 16; p++) load_b(c_begin, p);
+        for (int b = 0; b < 4; b++) {
+#ifdef USC_WINO_NO_B                                        // ablation build (timing only): no weight traffic
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, 0x7ffffff0 + 0 * (c + a + b), 0, 0);
+#else
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, c < c_end ? wbase + c * wstep + (a * 4 + b) * wpos : 0x7ffffff0, 0, 0);
+#endif
+            bf[a & 1][b] = *reinterpret_cast<const float4*>(&v);
+        }
+    };
+    load_b(c_begin, 0);
+    load_b(c_begin, 1);
 
-    // ---- patch staging: slot s = pixel * 2 + half (16 bytes); 6 rounds of 64 lanes cover the 360 slots
+    // ---- patch staging: slot s = pixel * 2 + half (16 bytes); 6 rounds of 64 lanes cover the 360 slots.  The loads of step c + 2
+    // are requested at the start of step c (two register sets, 128 MFMAs = ~4 us ahead: with one wave per SIMD nothing else hides
+    // a cold miss of the activations; one step ahead measured 7700 cycles per step against 4100 of MFMA work) and go into the
+    // LDS image at the end of step c + 1, after that step has read its fragments.
     constexpr int INVALID = 0x7fff0000;
     const int y0 = 8 * by - 1, x0 = 16 * bx - 1;
     int goff[6], loff[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-        const int s = r * 64 + lane;
-        const int pp = s >> 1, half = s & 1;
+        const int sl = r * 64 + lane;
+        const int pp = sl >> 1, half = sl & 1;
         const int py = pp / WPATCH_W, px = pp - py * WPATCH_W;
         const int y = y0 + py, x = x0 + px;
-        const bool ok = live && s < WSLOTS && y >= 0 && y < H && x >= 0 && x < W;
+        const bool ok = live && sl < WSLOTS && y >= 0 && y < H && x >= 0 && x < W;
         goff[r] = ok ? ((img * H + y) * W + x) * d.Cin * 4 + half * 16 : INVALID;
-        loff[r] = s < WSLOTS ? pp * WPITCH + half * 4 : -1;
+        loff[r] = sl < WSLOTS ? pp * WPITCH + half * 4 : -1;
     }
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(d.in), 0, nimg * H * W * d.Cin * 4, 0x00020000);
     float* const Aw = Ws[wave];
-    float4 ra[6];
-    auto load_a = [&](int c) {
+    float4 ra0[6], ra1[6];
+    auto load_a = [&](int c, float4 (&ra)[6]) {
 #pragma unroll
         for (int r = 0; r < 6; r++) {
+#ifdef USC_WINO_NO_A                                        // ablation build (timing only): no activation traffic
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, 0x7ffffff0 + 0 * (c + goff[r]), 0, 0);
+#else
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (c < c_end && goff[r] != INVALID) ? goff[r] + c * 32 : 0x7ffffff0, 0, 0);
+#endif
             ra[r] = *reinterpret_cast<const float4*>(&v);
         }
     };
-    auto stage = [&]() {
+    auto stage = [&](const float4 (&ra)[6]) {
 #pragma unroll
         for (int r = 0; r < 6; r++) {
             float4 a = ra[r];
@@ -401,13 +425,13 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(usc_conv_desc d) {
     // One K step.  The scheduler is fenced (sched_barrier) so that the requests for the next step are issued where they are
     // written - the patch loads first, each position's weight fragment right after that position's MFMAs - instead of being sunk
     // to the end of the step, where every one of them would be waited for at once.
-    auto step = [&](int c) {
+    auto step = [&](int c, float4 (&ra_next)[6], float4 (&ra_far)[6]) {
         float4 T[16];
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) T[i * 4 + j] = *reinterpret_cast<const float4*>(&Aw[fbase + (i * WPATCH_W + j) * WPITCH]);
-        load_a(c + 1);
+        load_a(c + 2, ra_far);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; j++) {                       // T = B^T d, in place, column by column
@@ -417,31 +441,64 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(usc_conv_desc d) {
             T[8 + j] = sub4(d2, d1);
             T[12 + j] = sub4(d1, d3);
         }
+        // V = T B, one row of four positions at a time.  Row a + 1 is computed BETWEEN the MFMAs of row a (one position per
+        // group of four MFMAs), so that no MFMA reads an operand a vector instruction has only just written (measured: with each
+        // operand produced right in front of its MFMA a step took 7200 - 7700 cycles instead of 4100), and the row's 16 MFMAs go
+        // component-major, consecutive ones into DIFFERENT accumulators.
+        auto vrow = [&](int a, int b) {
+            return b == 0 ? sub4(T[a * 4 + 0], T[a * 4 + 2]) : b == 1 ? add4(T[a * 4 + 1], T[a * 4 + 2])
+                 : b == 2 ? sub4(T[a * 4 + 2], T[a * 4 + 1]) : sub4(T[a * 4 + 1], T[a * 4 + 3]);
+        };
+        float4 Vb[2][4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) Vb[0][b] = vrow(0, b);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-            float4 V[4];                                    // V = T B
-            V[0] = sub4(T[a * 4 + 0], T[a * 4 + 2]);
-            V[1] = add4(T[a * 4 + 1], T[a * 4 + 2]);
-            V[2] = sub4(T[a * 4 + 2], T[a * 4 + 1]);
-            V[3] = sub4(T[a * 4 + 1], T[a * 4 + 3]);
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int p = a * 4 + b;
-                const float4 w = bf[p];
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].x, w.x, acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].y, w.y, acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].z, w.z, acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].w, w.w, acc[p], 0, 0, 0);
-                load_b(c + 1, p);
-            }
+            float4 (&V)[4] = Vb[a & 1];
+            float4 (&Vn)[4] = Vb[(a + 1) & 1];
+            const float4 w0 = bf[a & 1][0], w1 = bf[a & 1][1], w2 = bf[a & 1][2], w3 = bf[a & 1][3];
+            acc[a * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].x, w0.x, acc[a * 4 + 0], 0, 0, 0);
+            acc[a * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].x, w1.x, acc[a * 4 + 1], 0, 0, 0);
+            acc[a * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].x, w2.x, acc[a * 4 + 2], 0, 0, 0);
+            acc[a * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].x, w3.x, acc[a * 4 + 3], 0, 0, 0);
+            if (a < 3) Vn[0] = vrow(a + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[a * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].y, w0.y, acc[a * 4 + 0], 0, 0, 0);
+            acc[a * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].y, w1.y, acc[a * 4 + 1], 0, 0, 0);
+            acc[a * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].y, w2.y, acc[a * 4 + 2], 0, 0, 0);
+            acc[a * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].y, w3.y, acc[a * 4 + 3], 0, 0, 0);
+            if (a < 3) Vn[1] = vrow(a + 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[a * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].z, w0.z, acc[a * 4 + 0], 0, 0, 0);
+            acc[a * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].z, w1.z, acc[a * 4 + 1], 0, 0, 0);
+            acc[a * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].z, w2.z, acc[a * 4 + 2], 0, 0, 0);
+            acc[a * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].z, w3.z, acc[a * 4 + 3], 0, 0, 0);
+            if (a < 3) Vn[2] = vrow(a + 1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[a * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].w, w0.w, acc[a * 4 + 0], 0, 0, 0);
+            acc[a * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].w, w1.w, acc[a * 4 + 1], 0, 0, 0);
+            acc[a * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].w, w2.w, acc[a * 4 + 2], 0, 0, 0);
+            acc[a * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].w, w3.w, acc[a * 4 + 3], 0, 0, 0);
+            if (a < 3) Vn[3] = vrow(a + 1, 3);
+            if (a < 2) load_b(c, a + 2);                     // rows 2, 3 of this step
+            else load_b(c + 1, a - 2);                      // rows 0, 1 of the next one
             __builtin_amdgcn_sched_barrier(0);
         }
-        stage();
+        stage(ra_next);                                     // chunk c + 1 (requested one step ago) into the image the fragments have left
     };
 
-    load_a(c_begin);
-    stage();
-    for (int c = c_begin; c < c_end; c++) step(c);
+    load_a(c_begin, ra0);
+    load_a(c_begin + 1, ra1);
+    stage(ra0);
+    WINO_STAMP(1);
+    int c = c_begin;
+    for (; c + 1 < c_end; c += 2) {
+        step(c, ra1, ra0);
+        step(c + 1, ra0, ra1);
+    }
+    if (c < c_end) step(c, ra1, ra0);          // odd count: the trailing requests are out of range (zeros, no traffic)
+    WINO_STAMP(2);
 
     // ---- output transform (elementwise over the accumulators): Y = A^T M A, phases (i, j) -> pixel (2 ty + i, 2 tx + j),
     // two phases (i = 0, 1 of one j) at a time through the LDS image, then the fused epilogue: lane -> (4 tiles 8 apart, 4 channels)
@@ -468,6 +525,24 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(usc_conv_desc d) {
         if (j == 0) { t0 = acc[0] + acc[1] + acc[2]; t1 = acc[4] + acc[5] + acc[6]; t2 = acc[8] + acc[9] + acc[10]; t3 = acc[12] + acc[13] + acc[14]; }
         else { t0 = acc[1] - acc[2] - acc[3]; t1 = acc[5] - acc[6] - acc[7]; t2 = acc[9] - acc[10] - acc[11]; t3 = acc[13] - acc[14] - acc[15]; }
         const f32x16 ya = t0 + t1 + t2, yb = t1 - t2 - t3;   // i = 0, 1
+        // residuals of the eight (i, ps) stores of this pair of phases: requested together, before the tile goes through LDS
+        int oo8[8];
+        u32x4 r1u[8], r2u[8];
+        if (writer) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i = q >> 2, ps = q & 3;
+                const int t = ps * 8 + erow;
+                const int oy = 2 * (4 * by + (t >> 3)) + i, ox = 2 * (8 * bx + (t & 7)) + j;
+                const bool ok = oy < H && ox < W;
+                const int Y = img * H + oy;
+                const int opix = Y * W + ox;
+                oo8[q] = ok ? (opix * out_ld + d.out_c0) * 4 + nb4 : INVALID;
+                if (has_r1) r1u[q] = __builtin_amdgcn_raw_buffer_load_b128(
+                    r1_rsrc, ok ? ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (ox >> d.res1_shift)) * d.Cout * 4 + nb4 : INVALID, 0, 0);
+                if (has_r2) r2u[q] = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, ok ? opix * d.Cout * 4 + nb4 : INVALID, 0, 0);
+            }
+        }
         if (KW > 1 && j > 0) __syncthreads();                // K group 0 has read the previous pair of phases
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -478,42 +553,34 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(usc_conv_desc d) {
         if (KW > 1) __syncthreads();
         if (!writer) continue;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int q = 0; q < 8; q++) {
+            const int i = q >> 2, ps = q & 3;
+            const int t = ps * 8 + erow;
+            float4 tv = *reinterpret_cast<const float4*>(&T[i * 32 * APITCH + t * APITCH + ec4]);
 #pragma unroll
-            for (int ps = 0; ps < 4; ps++) {
-                const int t = ps * 8 + erow;
-                const int oy = 2 * (4 * by + (t >> 3)) + i, ox = 2 * (8 * bx + (t & 7)) + j;
-                const bool ok = oy < H && ox < W;
-                const int Y = img * H + oy;
-                const int opix = Y * W + ox;
-                const int oo = ok ? (opix * out_ld + d.out_c0) * 4 + nb4 : INVALID;
-                const int o2 = ok ? opix * d.Cout * 4 + nb4 : INVALID;
-                const int o1 = ok ? ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (ox >> d.res1_shift)) * d.Cout * 4 + nb4 : INVALID;
-                const u32x4 r1u = __builtin_amdgcn_raw_buffer_load_b128(r1_rsrc, o1, 0, 0);
-                const u32x4 r2u = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, o2, 0, 0);
-                float4 tv = *reinterpret_cast<const float4*>(&T[i * 32 * APITCH + t * APITCH + ec4]);
-#pragma unroll
-                for (int k = 1; k < KW; k++) {               // slice order
-                    const float4 u = *reinterpret_cast<const float4*>(&Ws[wave + k][i * 32 * APITCH + t * APITCH + ec4]);
-                    tv.x += u.x; tv.y += u.y; tv.z += u.z; tv.w += u.w;
-                }
-                const float4 r1 = *reinterpret_cast<const float4*>(&r1u), r2 = *reinterpret_cast<const float4*>(&r2u);
-                float v[4] = {tv.x + bias.x, tv.y + bias.y, tv.z + bias.z, tv.w + bias.w};
-                const float a1[4] = {r1.x, r1.y, r1.z, r1.w}, a2[4] = {r2.x, r2.y, r2.z, r2.w};
-                const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float x = v[e] + a1[e];
-                    const float neg = relu ? 0.f : x * slope;
-                    x = x > 0.f ? x : neg;
-                    if (has_aff) x = x * s4[e] + h4[e];
-                    v[e] = x + a2[e];
-                }
-                const float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), out_rsrc, oo, 0, 0);
+            for (int k = 1; k < KW; k++) {                   // slice order
+                const float4 u = *reinterpret_cast<const float4*>(&Ws[wave + k][i * 32 * APITCH + t * APITCH + ec4]);
+                tv.x += u.x; tv.y += u.y; tv.z += u.z; tv.w += u.w;
             }
+            float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f), r2 = r1;
+            if (has_r1) r1 = *reinterpret_cast<const float4*>(&r1u[q]);
+            if (has_r2) r2 = *reinterpret_cast<const float4*>(&r2u[q]);
+            float v[4] = {tv.x + bias.x, tv.y + bias.y, tv.z + bias.z, tv.w + bias.w};
+            const float a1[4] = {r1.x, r1.y, r1.z, r1.w}, a2[4] = {r2.x, r2.y, r2.z, r2.w};
+            const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float x = v[e] + a1[e];
+                const float neg = relu ? 0.f : x * slope;
+                x = x > 0.f ? x : neg;
+                if (has_aff) x = x * s4[e] + h4[e];
+                v[e] = x + a2[e];
+            }
+            const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), out_rsrc, oo8[q], 0, 0);
         }
     }
+    WINO_STAMP(3);
 }
 
 // Second half of a split-K layer: sum the K slices in a fixed order (deterministic), then the fused epilogue.
@@ -675,7 +742,10 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
             if (wt_plan < 768 && nsteps >= 2) kw = 2;
             if (wt_plan * 2 < 768 && nsteps >= 4) kw = 4;
             if (g_force_kw == 1 || g_force_kw == 2 || g_force_kw == 4) kw = g_force_kw <= nsteps ? g_force_kw : 1;
-            const bool worth = wt_plan * kw >= 512;           // small maps stay with the direct kernel (16 K groups, grid splits)
+            // one wave per SIMD and one workgroup per CU: a grid of 257 ... ~700 workgroups would run a second, mostly empty round;
+            // small maps stay with the direct kernel (16 K groups, grid splits)
+            const long long wgs_plan = (wt_plan * kw + 3) / 4;
+            const bool worth = (wgs_plan >= 192 && wgs_plan <= 256) || wgs_plan >= 768;
             if (worth || g_force_wino == 1) {
                 p.wino = true;
                 p.kw = kw;

@@ -16,8 +16,9 @@
 //   * alpha is kept where the pixel's component is covered by a kept border (its own or an ancestor's) or the pixel lies on
 //     the chain of a kept hole border.
 // Validated against the oracle's border follower on random and structured masks (nested rings, checkerboards, diagonal
-// slits, shapes on the frame border, blobs with area around 100): tests/test_gpu_objects.py.  The float64 score sums are
-// accumulated with atomics, so they can differ from the host's in the last bit; they only enter threshold comparisons.
+// slits, shapes on the frame border, blobs with area around 100): tests/test_gpu_objects.py.  Everything is confined to the
+// bounding box of the foreground; the score sums are kept in 90-bit fixed point (two integer limbs, exact whatever the order of
+// the atomics), so a run is bit-reproducible and agrees with the host's float64 sums far below any threshold margin.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -30,8 +31,8 @@ using namespace usc;
 
 namespace {
 
-struct Comp {                      // one connected component (foreground or background), 96 bytes
-    int first;                     // raster-first pixel (padded index) = union-find root
+struct Comp {                      // one connected component (foreground or background), 112 bytes
+    int first;                     // raster-first pixel (domain index) = union-find root
     int parent;                    // component id of the enclosing component of the other class (-1: outside ring)
     int is_fg;
     int keep;                      // its border passed the area and score tests
@@ -40,9 +41,22 @@ struct Comp {                      // one connected component (foreground or bac
     unsigned long long cnt, sg;    // own pixels, sum of seg
     unsigned long long t_cnt, t_sg;          // subtree totals
     unsigned long long chain_sg;
-    double sc, t_sc, chain_sc;     // sums of the score map
+    // sums of the score map in fixed point, two limbs: score * 2^26 = hi + lo * 2^-32 (hi, lo integers; the lo limb truncated at
+    // 2^-58): integer sums are exact whatever the order, so the sums - and the threshold decisions - are the same on every run
+    unsigned long long sc_hi, sc_lo, t_sc_hi, t_sc_lo, chain_sc_hi, chain_sc_lo;
     long long area2;               // twice the signed polygon area of its border
 };
+
+// The work is restricted to the bounding box of alpha != 0, padded by a one-pixel background ring ("the domain"): outside it
+// there is only background that belongs to the outside component.  hdr (ints): [0] number of components, [1..4] the box as
+// maxima (H - ymin, W - xmin, ymax + 1, xmax + 1), so that a memset to zero initialises it; [3] == 0: no foreground at all.
+struct Dom { int y0, x0, Hb, Wb; };
+__device__ __forceinline__ bool load_dom(const int* __restrict__ hdr, int H, int W, Dom& d) {
+    const int m2 = hdr[3];
+    if (m2 == 0) return false;
+    d.y0 = H - hdr[1]; d.x0 = W - hdr[2]; d.Hb = m2 - d.y0; d.Wb = hdr[4] - d.x0;
+    return true;
+}
 
 __device__ __forceinline__ int ld_label(const int* lab, int i) { return __hip_atomic_load(&lab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -67,194 +81,299 @@ __device__ __forceinline__ void unite(int* lab, int a, int b) {
     }
 }
 
-__device__ __forceinline__ bool is_fg(const uint8_t* __restrict__ alpha, int H, int W, int py, int px) {     // padded coordinates
-    return py >= 1 && py <= H && px >= 1 && px <= W && alpha[(size_t)(py - 1) * W + (px - 1)] != 0;
+// domain coordinates: (py, px) in [0, Hb + 2) x [0, Wb + 2), the image pixel is (y0 + py - 1, x0 + px - 1)
+__device__ __forceinline__ bool is_fg(const uint8_t* __restrict__ alpha, int W, const Dom& d, int py, int px) {
+    return py >= 1 && py <= d.Hb && px >= 1 && px <= d.Wb && alpha[(size_t)(d.y0 + py - 1) * W + (d.x0 + px - 1)] != 0;
+}
+
+// maskprocess.py:155-189 get_score_map / build_score_map for one pixel (float64, the operations of the table builder below)
+__host__ __device__ __forceinline__ double lin(double a, double b, int n, int i) {
+    if (n == 1) return a;
+    if (i == n - 1) return b;
+    return (double)i * ((b - a) / (double)(n - 1)) + a;
+}
+__host__ __device__ __forceinline__ double score_raw(int y, int x, int H, int W, int cy, int cx) {
+    const double cv = x >= cx ? lin(0, 1, W - cx, x - cx) : lin(1, 0, cx, x);
+    const double rv = y >= cy ? lin(0, 1, H - cy, y - cy) : lin(1, 0, cy, y);
+    return sqrt(cv * cv + rv * rv);
+}
+__device__ __forceinline__ void score_fixed(int y, int x, int H, int W, int cy, int cx, double m, unsigned long long& hi, unsigned long long& lo) {
+    const double s = (m - score_raw(y, x, H, W, cy, cx)) / m;             // the table's value, in [0, 1]
+    const double t = s * 67108864.;                                        // 2^26: exact scaling
+    const double f = floor(t);
+    hi = (unsigned long long)f;
+    lo = (unsigned long long)((t - f) * 4294967296.);                      // exact difference, exact scaling, truncation
+}
+
+// A small per-workgroup table in LDS that combines contributions to the same component before they go to global memory:
+// atomics on one address serialise in the L2, and a silhouette is hundreds of thousands of pixels of ONE component.
+constexpr int kSlots = 32;
+struct BlockSums {
+    int key[kSlots];
+    unsigned long long v[4][kSlots];
+};
+__device__ __forceinline__ void sums_init(BlockSums& t) {
+    for (int i = threadIdx.x; i < kSlots; i += blockDim.x) { t.key[i] = -1; t.v[0][i] = t.v[1][i] = t.v[2][i] = t.v[3][i] = 0ull; }
+}
+__device__ __forceinline__ int sums_slot(BlockSums& t, int c) {          // -1: table full (the caller goes to global memory)
+    int h = c & (kSlots - 1);
+    for (int probe = 0; probe < kSlots; probe++) {
+        const int old = atomicCAS(&t.key[h], -1, c);
+        if (old == -1 || old == c) return h;
+        h = (h + 1) & (kSlots - 1);
+    }
+    return -1;
 }
 
 }  // namespace
 
+// Bounding box of alpha != 0 (maxima of H - y, W - x, y + 1, x + 1; hdr zeroed by the caller)
+__global__ __launch_bounds__(256) void obj_bbox_kernel(const uint8_t* __restrict__ alpha, int H, int W, int* __restrict__ hdr) {
+    const int n = H * W;
+    int m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += gridDim.x * blockDim.x * 16) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i + 16 <= n && ((reinterpret_cast<uintptr_t>(alpha) + i) & 15) == 0) v = *reinterpret_cast<const uint4*>(alpha + i);
+        else { uint8_t* pv = reinterpret_cast<uint8_t*>(&v); for (int k = 0; k < 16 && i + k < n; k++) pv[k] = alpha[i + k]; }
+        if ((v.x | v.y | v.z | v.w) == 0) continue;
+        const uint8_t* pv = reinterpret_cast<const uint8_t*>(&v);
+        for (int k = 0; k < 16; k++) {
+            if (!pv[k]) continue;
+            const int y = (i + k) / W, x = (i + k) - y * W;
+            m0 = max(m0, H - y); m1 = max(m1, W - x); m2 = max(m2, y + 1); m3 = max(m3, x + 1);
+        }
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        m0 = max(m0, __shfl_down(m0, off, kWave)); m1 = max(m1, __shfl_down(m1, off, kWave));
+        m2 = max(m2, __shfl_down(m2, off, kWave)); m3 = max(m3, __shfl_down(m3, off, kWave));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0 && m2 > 0) { atomicMax(&hdr[1], m0); atomicMax(&hdr[2], m1); atomicMax(&hdr[3], m2); atomicMax(&hdr[4], m3); }
+}
+
 // Labelling, step 1: rows are cut into 64-pixel segments (one wavefront each); every pixel starts with the index of the
 // first pixel of its run inside the segment (same class, contiguous) - one ballot and a few bit operations, no atomics.
-__global__ __launch_bounds__(256) void obj_runs_kernel(const uint8_t* __restrict__ alpha, int H, int W, int* __restrict__ lab,
-                                                       int* __restrict__ ncomp) {
-    const int Wp = W + 2;
+__global__ __launch_bounds__(256) void obj_runs_kernel(const uint8_t* __restrict__ alpha, int H, int W, const int* __restrict__ hdr,
+                                                       int* __restrict__ lab) {
+    Dom d;
+    if (!load_dom(hdr, H, W, d)) return;
+    const int Wp = d.Wb + 2;
     const int py = blockIdx.y, px = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & (kWave - 1);
+    if (py >= d.Hb + 2 || (int)blockIdx.x * 256 >= Wp) return;
     const bool live = px < Wp;
-    const bool f = live && is_fg(alpha, H, W, py, px);
+    const bool f = live && is_fg(alpha, W, d, py, px);
     const unsigned long long C = __ballot(f);
     const unsigned long long S = (C ^ (C << 1)) | 1ull;                      // bit l: lane l starts a run
     const unsigned long long upto = S & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
     const int start = 63 - __clzll((long long)upto);
     if (live) lab[py * Wp + px] = py * Wp + px - lane + start;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *ncomp = 0;
 }
 
 // Labelling, step 2: unions only where two runs START to touch - a segment boundary inside a run, the first vertically adjacent
 // pair of two runs, and, for the 8-connected foreground, the diagonal contacts at run ends - a few per run instead of a few per
 // pixel.  Roots end up at the smallest index of the component = its first pixel in raster order.
-__global__ __launch_bounds__(256) void obj_merge_kernel(const uint8_t* __restrict__ alpha, int H, int W, int* __restrict__ lab) {
-    const int Wp = W + 2, np = (H + 2) * Wp;
+__global__ __launch_bounds__(256) void obj_merge_kernel(const uint8_t* __restrict__ alpha, int H, int W, const int* __restrict__ hdr,
+                                                        int* __restrict__ lab) {
+    Dom d;
+    if (!load_dom(hdr, H, W, d)) return;
+    const int Wp = d.Wb + 2, np = (d.Hb + 2) * Wp;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
         const int py = i / Wp, px = i - py * Wp;
-        const bool c = is_fg(alpha, H, W, py, px);
+        const bool c = is_fg(alpha, W, d, py, px);
         const bool seg_start = (px & 63) == 0;
-        const bool w_same = px > 0 && is_fg(alpha, H, W, py, px - 1) == c;
+        const bool w_same = px > 0 && is_fg(alpha, W, d, py, px - 1) == c;
         const bool start_i = seg_start || !w_same;
         if (seg_start && w_same) unite(lab, i, i - 1);
         if (py == 0) continue;
-        const bool cn = is_fg(alpha, H, W, py - 1, px);
+        const bool cn = is_fg(alpha, W, d, py - 1, px);
         if (cn == c) {
-            const bool start_n = seg_start || px == 0 || is_fg(alpha, H, W, py - 1, px - 1) != cn;
+            const bool start_n = seg_start || px == 0 || is_fg(alpha, W, d, py - 1, px - 1) != cn;
             if (start_i || start_n) unite(lab, i, i - Wp);
         } else if (c) {                                      // foreground below background: diagonal contacts
-            if (px > 0 && !w_same && is_fg(alpha, H, W, py - 1, px - 1)) unite(lab, i, i - Wp - 1);
-            if (px + 1 < Wp && !is_fg(alpha, H, W, py, px + 1) && is_fg(alpha, H, W, py - 1, px + 1)) unite(lab, i, i - Wp + 1);
+            if (px > 0 && !w_same && is_fg(alpha, W, d, py - 1, px - 1)) unite(lab, i, i - Wp - 1);
+            if (px + 1 < Wp && !is_fg(alpha, W, d, py, px + 1) && is_fg(alpha, W, d, py - 1, px + 1)) unite(lab, i, i - Wp + 1);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void obj_flatten_kernel(const uint8_t* __restrict__ alpha, int H, int W, int* __restrict__ lab,
-                                                          int* __restrict__ cid, Comp* __restrict__ comps, int* __restrict__ ncomp, int kcap) {
-    const int Wp = W + 2, np = (H + 2) * Wp;
+__global__ __launch_bounds__(256) void obj_flatten_kernel(const uint8_t* __restrict__ alpha, int H, int W, int* __restrict__ hdr,
+                                                          int* __restrict__ lab, int* __restrict__ cid, Comp* __restrict__ comps, int kcap) {
+    Dom d;
+    if (!load_dom(hdr, H, W, d)) return;
+    const int Wp = d.Wb + 2, np = (d.Hb + 2) * Wp;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
         const int r = find_root(lab, i);
         lab[i] = r;
         if (r == i) {                                        // a root: give the component a dense id
-            const int id = atomicAdd(ncomp, 1);
+            const int id = atomicAdd(&hdr[0], 1);
             cid[i] = id;
             if (id < kcap) {
                 Comp c = {};
                 const int py = i / Wp, px = i - py * Wp;
-                c.first = i; c.parent = -1; c.is_fg = is_fg(alpha, H, W, py, px) ? 1 : 0;
+                c.first = i; c.parent = -1; c.is_fg = is_fg(alpha, W, d, py, px) ? 1 : 0;
                 comps[id] = c;
             }
         }
     }
 }
 
-// own sums of every component + parent links.  Atomics on one address serialise in the L2, and a silhouette is hundreds of
-// thousands of pixels of ONE component: every lane therefore walks 16 consecutive pixels and only flushes when the component
-// changes, and a wavefront whose lanes all end in the same component combines them first - one atomic triple per 1024 pixels.
-__global__ __launch_bounds__(256) void obj_stats_kernel(const uint8_t* __restrict__ seg, const double* __restrict__ score, int H, int W,
+// Own sums of every component + parent links.  A workgroup takes 4096 consecutive domain pixels: the component ids are fetched
+// with coalesced loads into LDS, every lane then walks 16 consecutive pixels and flushes a run of equal ids into the workgroup's
+// LDS table, and the table goes to global memory with one atomic per field and component - ~150 same-address atomics for a
+// 1080p silhouette instead of one per 64 pixels.
+constexpr int kStatsSpan = 4096;
+__global__ __launch_bounds__(256) void obj_stats_kernel(const uint8_t* __restrict__ seg, int H, int W, const int* __restrict__ hdr,
                                                         const int* __restrict__ lab, const int* __restrict__ cid, Comp* __restrict__ comps,
-                                                        int kcap) {
-    constexpr int PPT = 16;
-    const int Wp = W + 2, np = (H + 2) * Wp;
+                                                        int kcap, int cy, int cx, double smax) {
+    __shared__ int s_c[kStatsSpan];
+    __shared__ BlockSums tab;
+    Dom d;
+    if (!load_dom(hdr, H, W, d)) return;
+    const int Wp = d.Wb + 2, np = (d.Hb + 2) * Wp;
+    const int base = blockIdx.x * kStatsSpan;
+    if (base >= np) return;
     const int c_out = cid[0];
-    const int nthreads = (np + PPT - 1) / PPT;
-    const int total = (nthreads + 63) & ~63;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        int cur = -1;
-        double s = 0.;
-        unsigned long long g = 0, n = 0;
-        auto flush = [&]() {
-            if (cur >= 0 && n) { atomicAdd(&comps[cur].cnt, n); atomicAdd(&comps[cur].sg, g); atomicAdd(&comps[cur].sc, s); }
-            s = 0.; g = 0; n = 0;
-        };
-        const int i0 = t * PPT;
-        for (int k = 0; k < PPT; k++) {
-            const int i = i0 + k;
-            if (i >= np) break;
+    sums_init(tab);
+    for (int k = threadIdx.x; k < kStatsSpan; k += 256) {
+        const int i = base + k;
+        int c = -1;
+        if (i < np) {
             const int root = lab[i];
-            int c = cid[root];
+            c = cid[root];
             if (root == i && i > 0 && c < kcap) comps[c].parent = cid[lab[i - 1]];     // the pixel left of the first pixel
             if (c >= kcap || c == c_out) c = -1;             // the outside ring has no border: its sums are never used
-            if (c != cur) { flush(); cur = c; }
-            if (c >= 0) {
-                const int py = i / Wp, px = i - py * Wp;
-                n++;
-                if (py >= 1 && py <= H && px >= 1 && px <= W) {
-                    const size_t o = (size_t)(py - 1) * W + (px - 1);
-                    s += score[o];
-                    g += seg[o];
-                }
+        }
+        s_c[k] = c;
+    }
+    __syncthreads();
+    constexpr int PPT = kStatsSpan / 256;
+    int cur = -1;
+    unsigned long long n = 0, g = 0, hi = 0, lo = 0;
+    auto flush = [&]() {
+        if (cur >= 0 && n) {
+            const int sl = sums_slot(tab, cur);
+            if (sl >= 0) { atomicAdd(&tab.v[0][sl], n); atomicAdd(&tab.v[1][sl], g); atomicAdd(&tab.v[2][sl], hi); atomicAdd(&tab.v[3][sl], lo); }
+            else { atomicAdd(&comps[cur].cnt, n); atomicAdd(&comps[cur].sg, g); atomicAdd(&comps[cur].sc_hi, hi); atomicAdd(&comps[cur].sc_lo, lo); }
+        }
+        n = g = hi = lo = 0;
+    };
+    const int i0 = base + threadIdx.x * PPT;
+    int py = i0 / Wp, px = i0 - py * Wp;
+    for (int k = 0; k < PPT; k++) {
+        const int c = s_c[threadIdx.x * PPT + k];
+        if (c != cur) { flush(); cur = c; }
+        if (c >= 0) {
+            n++;
+            if (py >= 1 && py <= d.Hb && px >= 1 && px <= d.Wb) {
+                const int y = d.y0 + py - 1, x = d.x0 + px - 1;
+                unsigned long long h2, l2;
+                score_fixed(y, x, H, W, cy, cx, smax, h2, l2);
+                hi += h2; lo += l2;
+                g += seg[(size_t)y * W + x];
             }
         }
-        const int c0 = __shfl(cur, 0, kWave);
-        if (__all(cur == c0)) {                              // the wave's open segments belong to one component: combine them
-#pragma unroll
-            for (int off = kWave / 2; off > 0; off >>= 1) {
-                s += __shfl_down(s, off, kWave);
-                g += __shfl_down(g, off, kWave);
-                n += __shfl_down(n, off, kWave);
-            }
-            if ((threadIdx.x & (kWave - 1)) == 0) flush();
-        } else {
-            flush();
-        }
+        if (++px == Wp) { px = 0; py++; }
+    }
+    flush();
+    __syncthreads();
+    if (threadIdx.x < kSlots && tab.key[threadIdx.x] >= 0) {
+        Comp& q = comps[tab.key[threadIdx.x]];
+        atomicAdd(&q.cnt, tab.v[0][threadIdx.x]); atomicAdd(&q.sg, tab.v[1][threadIdx.x]);
+        atomicAdd(&q.sc_hi, tab.v[2][threadIdx.x]); atomicAdd(&q.sc_lo, tab.v[3][threadIdx.x]);
     }
 }
 
-// one term per crack between a foreground pixel and a background pixel
-__global__ __launch_bounds__(256) void obj_cracks_kernel(const uint8_t* __restrict__ alpha, const uint8_t* __restrict__ seg,
-                                                         const double* __restrict__ score, int H, int W, const int* __restrict__ lab,
-                                                         const int* __restrict__ cid, Comp* __restrict__ comps, int kcap) {
-    const int Wp = W + 2;
-    const int n = H * W;
+// one term per crack between a foreground pixel and a background pixel; the shoelace terms of one border are combined in the
+// workgroup's LDS table first (a silhouette's outer border is thousands of cracks of ONE component)
+__global__ __launch_bounds__(256) void obj_cracks_kernel(const uint8_t* __restrict__ alpha, const uint8_t* __restrict__ seg, int H, int W,
+                                                         const int* __restrict__ hdr, const int* __restrict__ lab, const int* __restrict__ cid,
+                                                         Comp* __restrict__ comps, int kcap, int cy, int cx, double smax) {
+    __shared__ BlockSums tab;
+    Dom d;
+    if (!load_dom(hdr, H, W, d)) return;
+    const int Wp = d.Wb + 2;
+    const int n = d.Hb * d.Wb;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int)(blockIdx.x * blockDim.x) >= n) return;
+    sums_init(tab);
+    __syncthreads();
     const int dy[4] = {-1, 0, 1, 0}, dx[4] = {0, 1, 0, -1};           // N, E, S, W; the walk along side d goes in direction d + 1
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (!alpha[i]) continue;
-        const int y = i / W, x = i - y * W, py = y + 1, px = x + 1;
-        const int f = cid[lab[py * Wp + px]];
-        if (f >= kcap) continue;
-        int seen[4];
-        int nseen = 0;
+    if (i < n) {
+        const int yy = i / d.Wb, xx = i - yy * d.Wb, py = yy + 1, px = xx + 1;           // domain-interior coordinates
+        const int y = d.y0 + yy, x = d.x0 + xx;                                           // image coordinates
+        if (alpha[(size_t)y * W + x]) {
+            const int f = cid[lab[py * Wp + px]];
+            if (f < kcap) {
+                int seen[4];
+                int nseen = 0;
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
-            const int by = py + dy[d], bx = px + dx[d];
-            if (is_fg(alpha, H, W, by, bx)) continue;
-            const int b = cid[lab[by * Wp + bx]];
-            if (b >= kcap) continue;
-            const int wy = dy[(d + 1) & 3], wx = dx[(d + 1) & 3];
-            int ny, nx;
-            if (is_fg(alpha, H, W, by + wy, bx + wx)) { ny = by + wy; nx = bx + wx; }          // concave corner: diagonal step
-            else if (is_fg(alpha, H, W, py + wy, px + wx)) { ny = py + wy; nx = px + wx; }     // straight
-            else { ny = py; nx = px; }                                                         // around the pixel's own corner
-            const long long term = (long long)x * (ny - 1) - (long long)(nx - 1) * y;
-            if (comps[b].parent == f) {                      // B is a hole of F: the hole's border
-                atomicAdd((unsigned long long*)&comps[b].area2, (unsigned long long)term);
-                bool dup = false;
-                for (int k = 0; k < nseen; k++) dup |= seen[k] == b;
-                if (!dup) {
-                    seen[nseen++] = b;
-                    atomicAdd(&comps[b].chain_cnt, 1u);
-                    atomicAdd(&comps[b].chain_sg, (unsigned long long)seg[i]);
-                    atomicAdd(&comps[b].chain_sc, score[i]);
+                for (int dd = 0; dd < 4; dd++) {
+                    const int by = py + dy[dd], bx = px + dx[dd];
+                    if (is_fg(alpha, W, d, by, bx)) continue;
+                    const int b = cid[lab[by * Wp + bx]];
+                    if (b >= kcap) continue;
+                    const int wy = dy[(dd + 1) & 3], wx = dx[(dd + 1) & 3];
+                    int ny, nx;
+                    if (is_fg(alpha, W, d, by + wy, bx + wx)) { ny = by + wy; nx = bx + wx; }          // concave corner: diagonal step
+                    else if (is_fg(alpha, W, d, py + wy, px + wx)) { ny = py + wy; nx = px + wx; }     // straight
+                    else { ny = py; nx = px; }                                                         // around the pixel's own corner
+                    // the shoelace sum of a closed chain does not depend on the origin: domain coordinates will do
+                    const long long term = (long long)xx * (ny - 1) - (long long)(nx - 1) * yy;
+                    const bool hole = comps[b].parent == f;   // B is a hole of F: the hole's border; else B encloses F: F's outer border
+                    const int target = hole ? b : f;
+                    const int sl = sums_slot(tab, target);
+                    if (sl >= 0) atomicAdd(&tab.v[0][sl], (unsigned long long)term);
+                    else atomicAdd((unsigned long long*)&comps[target].area2, (unsigned long long)term);
+                    if (hole) {
+                        bool dup = false;
+                        for (int k = 0; k < nseen; k++) dup |= seen[k] == b;
+                        if (!dup) {
+                            seen[nseen++] = b;
+                            unsigned long long h2, l2;
+                            score_fixed(y, x, H, W, cy, cx, smax, h2, l2);
+                            atomicAdd(&comps[b].chain_cnt, 1u);
+                            atomicAdd(&comps[b].chain_sg, (unsigned long long)seg[(size_t)y * W + x]);
+                            atomicAdd(&comps[b].chain_sc_hi, h2);
+                            atomicAdd(&comps[b].chain_sc_lo, l2);
+                        }
+                    }
                 }
-            } else {                                         // B encloses F: F's outer border
-                atomicAdd((unsigned long long*)&comps[f].area2, (unsigned long long)term);
             }
         }
     }
+    __syncthreads();
+    if (threadIdx.x < kSlots && tab.key[threadIdx.x] >= 0 && tab.v[0][threadIdx.x] != 0ull)
+        atomicAdd((unsigned long long*)&comps[tab.key[threadIdx.x]].area2, tab.v[0][threadIdx.x]);
 }
 
 // subtree totals: every component adds its own sums to all its ancestors
-__global__ __launch_bounds__(256) void obj_tree_sum_kernel(Comp* __restrict__ comps, const int* __restrict__ ncomp, int kcap) {
-    const int K = min(*ncomp, kcap);
+__global__ __launch_bounds__(256) void obj_tree_sum_kernel(Comp* __restrict__ comps, const int* __restrict__ hdr, int kcap) {
+    const int K = min(hdr[0], kcap);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < K; c += gridDim.x * blockDim.x) {
-        const unsigned long long n = comps[c].cnt, g = comps[c].sg;
-        const double s = comps[c].sc;
-        atomicAdd(&comps[c].t_cnt, n); atomicAdd(&comps[c].t_sg, g); atomicAdd(&comps[c].t_sc, s);
+        const unsigned long long n = comps[c].cnt, g = comps[c].sg, sh = comps[c].sc_hi, sl = comps[c].sc_lo;
+        atomicAdd(&comps[c].t_cnt, n); atomicAdd(&comps[c].t_sg, g); atomicAdd(&comps[c].t_sc_hi, sh); atomicAdd(&comps[c].t_sc_lo, sl);
         int a = comps[c].parent;
         for (int depth = 0; a >= 0 && comps[a].parent >= 0 && depth < (1 << 20); depth++) {      // stop below the outside ring
-            atomicAdd(&comps[a].t_cnt, n); atomicAdd(&comps[a].t_sg, g); atomicAdd(&comps[a].t_sc, s);
+            atomicAdd(&comps[a].t_cnt, n); atomicAdd(&comps[a].t_sg, g); atomicAdd(&comps[a].t_sc_hi, sh); atomicAdd(&comps[a].t_sc_lo, sl);
             a = comps[a].parent;
         }
     }
 }
 
 // maskprocess.py:121-147: area test, saliency / consensus test
-__global__ __launch_bounds__(256) void obj_decide_kernel(Comp* __restrict__ comps, const int* __restrict__ ncomp, int kcap, double denom,
+__global__ __launch_bounds__(256) void obj_decide_kernel(Comp* __restrict__ comps, const int* __restrict__ hdr, int kcap, double denom,
                                                          double saliency_thr, double consensus_thr) {
-    const int K = min(*ncomp, kcap);
+    const int K = min(hdr[0], kcap);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < K; c += gridDim.x * blockDim.x) {
         Comp& q = comps[c];
         int keep = 0;
         if (q.parent >= 0) {                                  // the outside ring has no border
             const long long a2 = q.area2 < 0 ? -q.area2 : q.area2;
             if ((double)a2 * 0.5 >= 100.) {
-                double ssum = q.t_sc, gsum = (double)q.t_sg, cnt = (double)q.t_cnt;
-                if (!q.is_fg) { ssum += q.chain_sc; gsum += (double)q.chain_sg; cnt += (double)q.chain_cnt; }
+                unsigned long long sh = q.t_sc_hi, sl = q.t_sc_lo;
+                double gsum = (double)q.t_sg, cnt = (double)q.t_cnt;
+                if (!q.is_fg) { sh += q.chain_sc_hi; sl += q.chain_sc_lo; gsum += (double)q.chain_sg; cnt += (double)q.chain_cnt; }
+                const double ssum = ((double)sh + (double)sl * (1. / 4294967296.)) * (1. / 67108864.);
                 const double sal = ssum / denom, cons = (gsum / cnt) / 255.;
                 keep = ((sal > saliency_thr && cons > consensus_thr) || sal > saliency_thr * 10) ? 1 : 0;
             }
@@ -263,8 +382,8 @@ __global__ __launch_bounds__(256) void obj_decide_kernel(Comp* __restrict__ comp
     }
 }
 
-__global__ __launch_bounds__(256) void obj_cover_kernel(Comp* __restrict__ comps, const int* __restrict__ ncomp, int kcap) {
-    const int K = min(*ncomp, kcap);
+__global__ __launch_bounds__(256) void obj_cover_kernel(Comp* __restrict__ comps, const int* __restrict__ hdr, int kcap) {
+    const int K = min(hdr[0], kcap);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < K; c += gridDim.x * blockDim.x) {
         int cov = 0, a = c;
         for (int depth = 0; a >= 0 && depth < (1 << 20) && !cov; depth++) { cov = comps[a].keep; a = comps[a].parent; }
@@ -272,24 +391,28 @@ __global__ __launch_bounds__(256) void obj_cover_kernel(Comp* __restrict__ comps
     }
 }
 
-__global__ __launch_bounds__(256) void obj_apply_kernel(uint8_t* __restrict__ alpha, int H, int W, const int* __restrict__ lab,
-                                                        const int* __restrict__ cid, const Comp* __restrict__ comps, int kcap) {
-    const int Wp = W + 2;
-    const int n = H * W;
+__global__ __launch_bounds__(256) void obj_apply_kernel(uint8_t* __restrict__ alpha, int H, int W, const int* __restrict__ hdr,
+                                                        const int* __restrict__ lab, const int* __restrict__ cid, const Comp* __restrict__ comps,
+                                                        int kcap) {
+    Dom d;
+    if (!load_dom(hdr, H, W, d)) return;
+    const int Wp = d.Wb + 2;
+    const int n = d.Hb * d.Wb;
     const int dy[4] = {-1, 0, 1, 0}, dx[4] = {0, 1, 0, -1};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (!alpha[i]) continue;
-        const int y = i / W, x = i - y * W, py = y + 1, px = x + 1;
+        const int yy = i / d.Wb, xx = i - yy * d.Wb, py = yy + 1, px = xx + 1;
+        const size_t o = (size_t)(d.y0 + yy) * W + (d.x0 + xx);
+        if (!alpha[o]) continue;
         const int f = cid[lab[py * Wp + px]];
         bool valid = f < kcap && comps[f].covered;
 #pragma unroll
-        for (int d = 0; d < 4 && !valid; d++) {
-            const int by = py + dy[d], bx = px + dx[d];
-            if (is_fg(alpha, H, W, by, bx)) continue;         // (neighbours are only ever cleared to 0 if they were foreground: see below)
+        for (int dd = 0; dd < 4 && !valid; dd++) {
+            const int by = py + dy[dd], bx = px + dx[dd];
+            if (is_fg(alpha, W, d, by, bx)) continue;         // (neighbours are only ever cleared to 0 if they were foreground: see below)
             const int b = cid[lab[by * Wp + bx]];
             valid = b < kcap && comps[b].keep && comps[b].parent == f;
         }
-        if (!valid) alpha[i] = 0;
+        if (!valid) alpha[o] = 0;
     }
 }
 
@@ -298,21 +421,13 @@ __global__ __launch_bounds__(256) void obj_apply_kernel(uint8_t* __restrict__ al
 // `comps[b].parent == f` with b a foreground component's id can never hold (a foreground component's parent is a background
 // component), so a cleared neighbour is never mistaken for a kept hole.
 
-// maskprocess.py:155-189 get_score_map / build_score_map on the device (float64, same operations as the host builder)
-__device__ __forceinline__ double lin(double a, double b, int n, int i) {
-    if (n == 1) return a;
-    if (i == n - 1) return b;
-    return (double)i * ((b - a) / (double)(n - 1)) + a;
-}
-
+// maskprocess.py:155-189 get_score_map / build_score_map as a table on the device (float64, same operations as the host builder)
 __global__ __launch_bounds__(256) void score_raw_kernel(int H, int W, int y0, int x0, double* __restrict__ out, unsigned long long* __restrict__ mx) {
     const int n = H * W;
     double m = 0.;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int y = i / W, x = i - y * W;
-        const double cv = x >= x0 ? lin(0, 1, W - x0, x - x0) : lin(1, 0, x0, x);
-        const double rv = y >= y0 ? lin(0, 1, H - y0, y - y0) : lin(1, 0, y0, y);
-        const double s = sqrt(cv * cv + rv * rv);
+        const double s = score_raw(y, x, H, W, y0, x0);
         out[i] = s;
         m = fmax(m, s);
     }
@@ -346,28 +461,35 @@ extern "C" size_t usc_remove_invalid_objects_ws_bytes(int H, int W) {
     return 256 + 2 * al256(np * sizeof(int)) + al256((size_t)comp_cap(H, W) * sizeof(Comp));
 }
 
-extern "C" int usc_remove_invalid_objects_u8(uint8_t* alpha, const uint8_t* seg, int H, int W, const double* score, double saliency_thr,
-                                             double consensus_thr, void* ws, size_t ws_bytes, usc_stream_t stream) {
-    if (!alpha || !score || !ws || H <= 0 || W <= 0) return fail(USC_E_ARG, "usc_remove_invalid_objects_u8: bad argument");
+extern "C" int usc_remove_invalid_objects_u8(uint8_t* alpha, const uint8_t* seg, int H, int W, double center_y, double center_x,
+                                             double saliency_thr, double consensus_thr, void* ws, size_t ws_bytes, usc_stream_t stream) {
+    if (!alpha || !ws || H <= 0 || W <= 0) return fail(USC_E_ARG, "usc_remove_invalid_objects_u8: bad argument");
     if ((long long)(H + 2) * (W + 2) >= (1ll << 30)) return fail(USC_E_UNSUPPORTED, "usc_remove_invalid_objects_u8: image too large");
     if (ws_bytes < usc_remove_invalid_objects_ws_bytes(H, W)) return fail(USC_E_WORKSPACE, "usc_remove_invalid_objects_u8: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int np = (H + 2) * (W + 2), kcap = comp_cap(H, W);
     uint8_t* base = reinterpret_cast<uint8_t*>(ws);
-    int* ncomp = reinterpret_cast<int*>(base);
+    int* hdr = reinterpret_cast<int*>(base);
     int* lab = reinterpret_cast<int*>(base + 256);
     int* cid = reinterpret_cast<int*>(base + 256 + al256((size_t)np * sizeof(int)));
     Comp* comps = reinterpret_cast<Comp*>(base + 256 + 2 * al256((size_t)np * sizeof(int)));
     if (!seg) seg = alpha;                                  // consensus against the input itself: alpha is only written by the last kernel
-    const dim3 b(256), gp(grid_for((size_t)np, 256)), gn(grid_for((size_t)H * W, 256)), gk(grid_for((size_t)kcap, 256));
-    hipLaunchKernelGGL(obj_runs_kernel, dim3((W + 2 + 255) / 256, H + 2), b, 0, st, alpha, H, W, lab, ncomp);
-    hipLaunchKernelGGL(obj_merge_kernel, gp, b, 0, st, alpha, H, W, lab);
-    hipLaunchKernelGGL(obj_flatten_kernel, gp, b, 0, st, alpha, H, W, lab, cid, comps, ncomp, kcap);
-    hipLaunchKernelGGL(obj_stats_kernel, dim3(grid_for((size_t)(np + 15) / 16, 256)), b, 0, st, seg, score, H, W, lab, cid, comps, kcap);
-    hipLaunchKernelGGL(obj_cracks_kernel, gn, b, 0, st, alpha, seg, score, H, W, lab, cid, comps, kcap);
-    hipLaunchKernelGGL(obj_tree_sum_kernel, gk, b, 0, st, comps, ncomp, kcap);
-    hipLaunchKernelGGL(obj_decide_kernel, gk, b, 0, st, comps, ncomp, kcap, (double)H * (double)W, saliency_thr, consensus_thr);
-    hipLaunchKernelGGL(obj_cover_kernel, gk, b, 0, st, comps, ncomp, kcap);
-    hipLaunchKernelGGL(obj_apply_kernel, gn, b, 0, st, alpha, H, W, lab, cid, comps, kcap);
+    // the score map is evaluated per pixel where it is needed (closed form, maskprocess.py:155-178); its normalising maximum sits
+    // at a corner of the image and is computed here with the same float64 operations
+    const int cy = (int)(H * center_y), cx = (int)(W * center_x);
+    double smax = 0.;
+    for (int k = 0; k < 4; k++) smax = fmax(smax, score_raw((k & 1) ? H - 1 : 0, (k & 2) ? W - 1 : 0, H, W, cy, cx));
+    if (hipMemsetAsync(hdr, 0, 256, st) != hipSuccess) return fail(USC_E_LAUNCH, "usc_remove_invalid_objects_u8: memset failed");
+    const dim3 b(256), gp(grid_for((size_t)np, 256)), gn(grid_for((size_t)H * W, 256)), gk(64);
+    hipLaunchKernelGGL(obj_bbox_kernel, dim3(grid_for((size_t)(H * W + 15) / 16, 256)), b, 0, st, alpha, H, W, hdr);
+    hipLaunchKernelGGL(obj_runs_kernel, dim3((W + 2 + 255) / 256, H + 2), b, 0, st, alpha, H, W, hdr, lab);
+    hipLaunchKernelGGL(obj_merge_kernel, gp, b, 0, st, alpha, H, W, hdr, lab);
+    hipLaunchKernelGGL(obj_flatten_kernel, gp, b, 0, st, alpha, H, W, hdr, lab, cid, comps, kcap);
+    hipLaunchKernelGGL(obj_stats_kernel, dim3((np + kStatsSpan - 1) / kStatsSpan), b, 0, st, seg, H, W, hdr, lab, cid, comps, kcap, cy, cx, smax);
+    hipLaunchKernelGGL(obj_cracks_kernel, dim3((H * W + 255) / 256), b, 0, st, alpha, seg, H, W, hdr, lab, cid, comps, kcap, cy, cx, smax);
+    hipLaunchKernelGGL(obj_tree_sum_kernel, gk, b, 0, st, comps, hdr, kcap);
+    hipLaunchKernelGGL(obj_decide_kernel, gk, b, 0, st, comps, hdr, kcap, (double)H * (double)W, saliency_thr, consensus_thr);
+    hipLaunchKernelGGL(obj_cover_kernel, gk, b, 0, st, comps, hdr, kcap);
+    hipLaunchKernelGGL(obj_apply_kernel, gn, b, 0, st, alpha, H, W, hdr, lab, cid, comps, kcap);
     return check_launch("remove_invalid_objects kernels");
 }

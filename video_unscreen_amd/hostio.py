@@ -42,10 +42,13 @@ class HostFrameIO:
         self._n_in = 0
         self._last_down = None
 
-    def inputs(self, host_frames, bg_always):
+    def inputs(self, host_frames, bg_always, on_uploaded=None):
         """Generator for BgStepPipeline.run(): uploads each host frame into the next staging slot on the upload stream and
-        yields (frame, seg, bg_i, bg_always, uploaded_event) device tensors."""
-        for frame_h, seg_h, bg_h in host_frames:
+        yields (frame, seg, bg_i, bg_always, uploaded_event) device tensors.  host_frames yields (frame, seg | None, bg_i) or
+        (frame, seg | None, bg_i, token); on_uploaded(event, token) is told when the host buffers may be reused (a FrameReader
+        slot to release)."""
+        for item in host_frames:
+            frame_h, seg_h, bg_h = item[:3]
             i = self._n_in % self.depth
             self._n_in += 1
             if self.done[i] is _BUSY:
@@ -60,12 +63,15 @@ class HostFrameIO:
                     self.segs[i].copy_(seg_h, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.up)
+            if on_uploaded is not None:
+                on_uploaded(ev, item[3] if len(item) > 3 else None)
             yield (self.frames[i], self.segs[i] if seg_h is not None else None, self.bgs[i], bg_always, ev)
 
-    def collect(self, alpha_host, fg_host):
-        """on_result callback for run(): copies frame n's alpha and fg to alpha_host[n] / fg_host[n] on the download stream
-        and marks the frame's staging slot free.  The pipeline's outputs live in its own ring of four, whose reuse waits for
-        these copies."""
+    def collect(self, alpha_host=None, fg_host=None, target=None, on_downloaded=None):
+        """on_result callback for run(): copies frame n's alpha and fg to alpha_host[n] / fg_host[n] - or to the pair of host
+        tensors target(n) returns, with a token as third element - on the download stream and marks the frame's staging slot free;
+        on_downloaded(event, token, n) is told when the copies have been enqueued (event = their completion).  The pipeline's
+        outputs live in its own ring of four, whose reuse waits for these copies."""
         main = torch.cuda.current_stream(self.pipe.device)
         base = self._n_in                            # inputs() of this run has not started yet: slots continue from here
 
@@ -74,15 +80,54 @@ class HostFrameIO:
             ev.record(main)
             self.done[(base + n) % self.depth] = ev  # frames are consumed in order: the slot input n was staged in
             self.down.wait_event(ev)
+            if target is not None:
+                a_h, f_h, token = target(n)
+            else:
+                a_h, f_h, token = alpha_host[n], fg_host[n], None
             with torch.cuda.stream(self.down):
-                alpha_host[n].copy_(out["alpha"], non_blocking=True)
-                fg_host[n].copy_(out["fg"], non_blocking=True)
+                a_h.copy_(out["alpha"], non_blocking=True)
+                f_h.copy_(out["fg"], non_blocking=True)
                 dn = torch.cuda.Event()
                 dn.record(self.down)
             self.pipe.note_output_consumed(out, dn)
             self._last_down = dn
+            if on_downloaded is not None:
+                on_downloaded(dn, token, n)
         return on_result
 
     def drain(self):
         self.up.synchronize()
         self.down.synchronize()
+
+
+def stream_clip(pipe, reader, writer, out_paths, bg_always, depth=None):
+    """bg_step stage 3 over files: FrameReader (decoder processes -> page-locked shared-memory slots) -> uploads -> the pipelined
+    frame loop -> downloads -> FrameWriter (encoder processes), all bounded and overlapped; nothing but queue bookkeeping runs on
+    the loop's thread.  reader yields (frame, segmask, bg_i) groups; out_paths(n) -> (alpha path, fg path).  Returns the frame count."""
+    import collections
+    from .utils.frameio import DeferredSubmit
+    io = HostFrameIO(pipe, depth)
+    deferred = DeferredSubmit(writer)
+    uploaded = collections.deque()                     # (event, reader slot) in upload order
+
+    def reap():
+        while uploaded and uploaded[0][0].query():
+            reader.release(uploaded.popleft()[1])
+
+    def host_frames():
+        for slot, (f, m, b) in reader:
+            reap()
+            yield f, m, b, slot
+
+    def target(n):
+        slot, (a, f) = writer.acquire()
+        return a, f, slot
+
+    n = pipe.run(io.inputs(host_frames(), bg_always, on_uploaded=lambda ev, slot: uploaded.append((ev, slot))),
+                 on_result=io.collect(target=target, on_downloaded=lambda ev, slot, k: deferred.submit_after(ev, slot, out_paths(k))))
+    io.drain()
+    while uploaded:
+        uploaded[0][0].synchronize()
+        reader.release(uploaded.popleft()[1])
+    deferred.close()
+    return n

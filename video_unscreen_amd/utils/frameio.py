@@ -1,0 +1,275 @@
+"""Frame I/O that keeps up with the GPU loop (reference unscreen/utils/fileio.py:31-62: a Pool(48) of
+cv2.imread that materialises the whole clip in RAM, then cv2.imwrite per frame on the main thread).
+
+    FrameReader   several decoder PROCESSES (JPEG via Pillow, or raw .npy - no codec) write straight into the slots of one
+                  shared-memory ring; the consumer gets the slots as torch views of that ring - page-locked (hipHostRegister)
+                  when a GPU is present, so hostio.HostFrameIO uploads from them without a staging copy.  Bounded: a slot is
+                  handed back with release() and only then reused; at most `depth` frame groups are ever in memory (the
+                  reference holds the clip: 1.9 GB at 1080p x 300, 7.5 GB at 4K).
+    FrameWriter   the mirror image: the consumer fills a free slot (the download target of the D2H copy), submit() hands it to
+                  an encoder process (JPEG / .npy), which frees the slot when the file is written.
+
+Frames are delivered and written in order.  A "group" is what one loop iteration needs: e.g. (frame, segmask, background)
+in, (alpha, foreground) out."""
+import multiprocessing as mp
+import os
+import queue
+import threading
+from multiprocessing import shared_memory
+
+import numpy as np
+import torch
+
+from .fileio import read_img, save_img
+
+_CTX = mp.get_context("spawn")         # no fork: the parent may hold a HIP context
+
+
+def _attach(name, nbytes):
+    shm = shared_memory.SharedMemory(name=name)
+    return shm, np.ndarray((nbytes,), np.uint8, buffer=shm.buf)
+
+
+def _decode_worker(shm_name, nbytes, slot_bytes, shapes, gray, tasks, done):
+    shm, ring = _attach(shm_name, nbytes)
+    try:
+        while True:
+            t = tasks.get()
+            if t is None:
+                break
+            seq, slot, paths = t
+            try:
+                off = slot * slot_bytes
+                for p, shp, g in zip(paths, shapes, gray):
+                    n = int(np.prod(shp))
+                    img = read_img(p)
+                    if g and img.ndim == 3:
+                        img = img[..., 0]                                  # masks stored as 3-channel JPEGs (bg_offline.py:134-141)
+                    if img.shape != tuple(shp):
+                        raise ValueError("%s: shape %s, expected %s" % (p, img.shape, tuple(shp)))
+                    ring[off:off + n] = np.ascontiguousarray(img).reshape(-1)
+                    off += n
+                done.put((seq, slot, None))
+            except Exception as e:                                         # surfaced to the consumer
+                done.put((seq, slot, repr(e)))
+    finally:
+        del ring
+        shm.close()
+
+
+def _encode_worker(shm_name, nbytes, slot_bytes, shapes, tasks, done):
+    shm, ring = _attach(shm_name, nbytes)
+    try:
+        while True:
+            t = tasks.get()
+            if t is None:
+                break
+            slot, paths = t
+            err = None
+            try:
+                off = slot * slot_bytes
+                for p, shp in zip(paths, shapes):
+                    n = int(np.prod(shp))
+                    save_img(ring[off:off + n].reshape(shp), p)
+                    off += n
+            except Exception as e:
+                err = repr(e)
+            done.put((slot, err))
+    finally:
+        del ring
+        shm.close()
+
+
+class _Ring:
+    def __init__(self, shapes, depth, pin):
+        self.shapes = [tuple(s) for s in shapes]
+        self.slot_bytes = int(sum(int(np.prod(s)) for s in self.shapes))
+        self.depth = depth
+        self.nbytes = self.slot_bytes * depth
+        self.shm = shared_memory.SharedMemory(create=True, size=self.nbytes)
+        self.np = np.ndarray((self.nbytes,), np.uint8, buffer=self.shm.buf)
+        self.t = torch.from_numpy(self.np)
+        self.pinned = False
+        if pin and torch.cuda.is_available():
+            rc = torch.cuda.cudart().cudaHostRegister(self.t.data_ptr(), self.nbytes, 0)
+            self.pinned = int(rc) == 0
+
+    def views(self, slot):
+        out, off = [], slot * self.slot_bytes
+        for s in self.shapes:
+            n = int(np.prod(s))
+            out.append(self.t[off:off + n].view(s))
+            off += n
+        return out
+
+    def close(self):
+        if self.pinned:
+            torch.cuda.cudart().cudaHostUnregister(self.t.data_ptr())
+            self.pinned = False
+        self.t = None
+        self.np = None
+        try:
+            self.shm.close()
+            self.shm.unlink()
+        except Exception:
+            pass
+
+
+class FrameReader:
+    """for slot, tensors in reader: ...; reader.release(slot)
+
+    groups: list of path tuples, one tuple per loop iteration (e.g. (frame_i.jpg, segmask_i.jpg, bg_i.jpg));
+    shapes: the array shape of each element of a tuple ((H, W, 3), (H, W), (H, W, 3)); a 2-D shape takes channel 0 of a
+    3-channel file.  workers decoder processes, `depth` slots."""
+
+    def __init__(self, groups, shapes, workers=8, depth=32, pin=True):
+        self.groups = list(groups)
+        self.ring = _Ring(shapes, depth, pin)
+        self.tasks, self.done = _CTX.Queue(), _CTX.Queue()
+        gray = [len(s) == 2 for s in self.ring.shapes]
+        self.procs = [_CTX.Process(target=_decode_worker, daemon=True,
+                                   args=(self.ring.shm.name, self.ring.nbytes, self.ring.slot_bytes, self.ring.shapes, gray, self.tasks, self.done))
+                      for _ in range(max(1, workers))]
+        for p in self.procs:
+            p.start()
+        self.free = list(range(depth))
+        self.next_submit = 0
+        self.next_deliver = 0
+        self.ready = {}
+        self._fill()
+
+    def _fill(self):
+        while self.free and self.next_submit < len(self.groups):
+            slot = self.free.pop()
+            self.tasks.put((self.next_submit, slot, self.groups[self.next_submit]))
+            self.next_submit += 1
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.next_deliver >= len(self.groups):
+            raise StopIteration
+        while self.next_deliver not in self.ready:
+            seq, slot, err = self.done.get()
+            if err:
+                self.close()
+                raise RuntimeError("FrameReader: " + err)
+            self.ready[seq] = slot
+        slot = self.ready.pop(self.next_deliver)
+        self.next_deliver += 1
+        return slot, self.ring.views(slot)
+
+    def release(self, slot):
+        self.free.append(slot)
+        self._fill()
+
+    def close(self):
+        for _ in self.procs:
+            self.tasks.put(None)
+        for p in self.procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.terminate()
+        self.procs = []
+        self.ring.close()
+
+    def __del__(self):
+        try:
+            if self.procs:
+                self.close()
+        except Exception:
+            pass
+
+
+class FrameWriter:
+    """slot, tensors = writer.acquire(); <fill tensors (e.g. as D2H targets), make sure the copies have finished>;
+    writer.submit(slot, paths); ... writer.close() waits for every file."""
+
+    def __init__(self, shapes, workers=8, depth=32, pin=True):
+        self.ring = _Ring(shapes, depth, pin)
+        self.tasks, self.done = _CTX.Queue(), _CTX.Queue()
+        self.procs = [_CTX.Process(target=_encode_worker, daemon=True,
+                                   args=(self.ring.shm.name, self.ring.nbytes, self.ring.slot_bytes, self.ring.shapes, self.tasks, self.done))
+                      for _ in range(max(1, workers))]
+        for p in self.procs:
+            p.start()
+        self.free = list(range(depth))
+        self.inflight = 0
+        self.errors = []
+        self._lock = threading.Lock()                     # submit() may come from DeferredSubmit's thread
+
+    def _reap(self, block):
+        try:
+            slot, err = self.done.get(block=block)
+        except queue.Empty:
+            return False
+        with self._lock:
+            self.inflight -= 1
+        self.free.append(slot)
+        if err:
+            self.errors.append(err)
+        return True
+
+    def acquire(self):
+        while self._reap(False):
+            pass
+        while not self.free:
+            self._reap(True)
+        if self.errors:
+            raise RuntimeError("FrameWriter: " + self.errors[0])
+        slot = self.free.pop()
+        return slot, self.ring.views(slot)
+
+    def submit(self, slot, paths):
+        with self._lock:
+            self.inflight += 1
+        self.tasks.put((slot, tuple(paths)))
+
+    def close(self):
+        while self.inflight:
+            self._reap(True)
+        for _ in self.procs:
+            self.tasks.put(None)
+        for p in self.procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.terminate()
+        self.procs = []
+        self.ring.close()
+        if self.errors:
+            raise RuntimeError("FrameWriter: " + self.errors[0])
+
+    def __del__(self):
+        try:
+            if self.procs:
+                self.close()
+        except Exception:
+            pass
+
+
+class DeferredSubmit:
+    """Hands a writer slot to the encoders once the GPU copies into it have finished, without blocking the frame loop: a helper
+    thread waits on the copy's event."""
+
+    def __init__(self, writer):
+        self.writer = writer
+        self.q = queue.Queue()
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _run(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            event, slot, paths = item
+            event.synchronize()
+            self.writer.submit(slot, paths)
+
+    def submit_after(self, event, slot, paths):
+        self.q.put((event, slot, paths))
+
+    def close(self):
+        self.q.put(None)
+        self.th.join()
