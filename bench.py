@@ -50,8 +50,8 @@ def parse():
                     help="frames per human-parsing forward in the pipelined loop (bit-identical masks, fewer launches per frame); "
                          "0 = the largest of 12, 8, 6, 4 that divides --steps (a short last group would ride in a full forward), else 8")
     ap.add_argument("--object-filter", default="auto", choices=["auto", "device", "host"],
-                    help="remove_invalid_objects: device = label-based HIP kernels, host = the border-following C++ twin on a worker "
-                         "thread; auto = host inside the pipelined run() (frees 0.5 ms of GPU time per frame), device in step()")
+                    help="remove_invalid_objects: device (= auto) = label-based HIP kernels, host = the border-following C++ twin on "
+                         "worker threads inside the pipelined run()")
     ap.add_argument("--no-seg", action="store_true",
                     help="stage-3 loop only (segmentation masks are inputs, as in the reference's bg_offline.py with its "
                          "stages 1-2 disabled); default: the human-parsing net runs on every frame (binseg + trimap + vmatting)")
@@ -109,8 +109,12 @@ def kernel_table(pipe, sample, H, W):
     add("get_fg", lambda: nv.get_fg(frame, alpha, slot.bg, paste_thr=1, out_fg=out["fg"]), 10 * N)
     cnt = torch.empty(1, dtype=torch.int64, device=frame.device)
     add("count_ge", lambda: nv.count_ge(alpha, 128, out=cnt), N)
-    t_graph = time_kernel(lambda: pipe.net(pipe.x7), iters=20, warm=3)
-    t_net = time_kernel(lambda: pipe.net.forward_serial(), iters=20, warm=3) if hasattr(pipe.net, "forward_serial") else t_graph
+    t_net = time_kernel(lambda: pipe.net(pipe.x7), iters=20, warm=3)           # the product path: planned stream launches
+    t_graph = t_net
+    if hasattr(pipe.net, "set_launch_mode"):
+        pipe.net.set_launch_mode("graph")
+        t_graph = time_kernel(lambda: pipe.net(pipe.x7), iters=20, warm=3)     # the same layers as one hipGraph replay
+        pipe.net.set_launch_mode("stream")
     return rows, t_net, t_graph
 
 
@@ -336,9 +340,9 @@ def main():
                        "binseg": (f"HumanSegAgent on every frame ({pipe.seg_batch} frames per network forward)" if seg_agent is not None
                                   else "masks are inputs (--no-seg)"),
                        "net_input": [pipe.in_h, pipe.in_w], "loop": "sync" if args.sync_loop else "pipelined", "convs": args.net,
-                       "object_filter": ("device (label-based HIP kernels)" if (args.object_filter == "device" or args.sync_loop) else
-                                         "host worker thread (border-following C++ in libunscreen_hip.so, same masks as the device "
-                                         "kernels; --object-filter device keeps the whole frame on the GPU)"),
+                       "object_filter": ("host worker threads (border-following C++ in libunscreen_hip.so; same masks as the device kernels)"
+                                         if args.object_filter == "host" and not args.sync_loop else
+                                         "device (label-based HIP kernels inside the foreground's bounding box, usc_objects.hip): no CPU stage in the loop"),
                        "weights": "keyed-deterministic synthetic (no checkpoint offline)"},
         }
         if host_io:
@@ -349,17 +353,17 @@ def main():
             t1 = timed(lambda: run(frames[:Wm]), lambda: run(frames[Wm:Wm + K]))
             result["device_resident"] = {"value": round(K / t1, 2), "unit": "frames/s",
                                          "note": "same loop, frames already in HBM, alpha / fg not copied out"}
-        if world == 1 and not args.sync_loop and args.object_filter != "device":
-            # the same timed loop with every stage on the GPU, for the record (not `value`)
-            chosen, pipe.object_filter, pipe._filter_choice = pipe._filter_choice, "device", "device"
+        if world == 1 and not args.sync_loop and args.object_filter != "host":
+            # the same timed loop with remove_invalid_objects on host worker threads (round 1's default), for the record (not `value`)
+            chosen_f, chosen_c = pipe.object_filter, pipe._filter_choice
+            pipe.object_filter, pipe._filter_choice = "host", "host"
             if host_io:
                 t1 = timed(lambda: run_host(0, Wm), lambda: run_host(Wm, K))
             else:
                 t1 = timed(lambda: run(frames[:Wm]), lambda: run(frames[Wm:Wm + K]))
-            result["all_device"] = {"value": round(K / t1, 2), "unit": "frames/s",
-                                    "note": "same loop and boundary as `value` with remove_invalid_objects on the GPU too (usc_objects.hip)"}
-            pipe._filter_choice = chosen
-            pipe.object_filter = "device" if chosen == "auto" else chosen
+            result["host_object_filter"] = {"value": round(K / t1, 2), "unit": "frames/s",
+                                            "note": "same loop and boundary as `value` with remove_invalid_objects on two host worker threads"}
+            pipe.object_filter, pipe._filter_choice = chosen_f, chosen_c
         if not args.no_kernel_table:                         # (other ranks wait at the final barrier: not inside the timed region)
             rows, t_net, t_graph = kernel_table(pipe, frames[Wm], H, W)
             dom = max(rows, key=lambda r: r["us"])
@@ -367,13 +371,13 @@ def main():
             gflop = UNET_GFLOP_544x960 * scale
             tf = gflop / t_net / 1e3
             if args.net == "hip":
-                # dominant kernel of the frame: conv_mfma_kernel (usc_conv.hip).  One "launch" here is one network forward =
-                # num_layers conv launches; flops are the algorithmic 2*M*N*K of the reference module (torch flop counter,
-                # SURVEY.md section 6).  Time: HIP events around forwards whose layers are launched one after the other on ONE
-                # stream (usc_conv_sequence_f32) with nothing beside them - the quantity profiles/r02/unet_layer_table.md
-                # (rocprofv3 kernel trace of the same launches, tools/dev/layer_table.py) sums per layer.  The product launches
-                # the same layers as a hipGraph whose independent branches overlap: ms_per_forward_graph.
-                result["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel (all %d conv launches of one forward)" % pipe.net.num_layers,
+                # dominant kernels of the frame: conv_mfma_kernel / conv_wino_kernel (usc_conv.hip).  One "launch" here is one network
+                # forward = num_layers conv launches; flops are the algorithmic 2*M*N*K of the reference module (torch flop counter,
+                # SURVEY.md section 6) - the Winograd layers execute 2.25x fewer.  Time: HIP events around forwards whose layers are
+                # launched one after the other on ONE stream with nothing beside them (the product's launch mode) - the quantity
+                # profiles/r02/unet_layer_table.md (rocprofv3 kernel trace of the same launches, tools/dev/layer_table.py) sums per
+                # layer.  ms_per_forward_graph: the same layers as one hipGraph replay (slower on this runtime).
+                result["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_wino_kernel (all %d conv launches of one forward)" % pipe.net.num_layers,
                                       "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(H, W),
                                       "alg_gflop_per_forward": round(gflop, 2), "ms_per_forward": round(t_net * 1e3, 3),
@@ -387,11 +391,11 @@ def main():
                                       "unit": "GB/s", "frac": dom["frac_hbm_peak"], "traffic": None,
                                       "alg_bytes_per_launch": dom["alg_bytes"], "us_per_launch": dom["us"]}
             result["kernels"] = rows
-            what = ("matting UNet-18, hand-written f32 MFMA implicit-GEMM convs (usc_conv.hip), %d fused launches" % pipe.net.num_layers
+            what = ("matting UNet-18, hand-written f32 MFMA implicit-GEMM / Winograd convs (usc_conv.hip), %d fused launches" % pipe.net.num_layers
                     if args.net == "hip" else "matting UNet-18 via PyTorch-ROCm (MIOpen)")
-            result["net"] = {"bound": "mfma", "what": what, "ms": round(t_graph * 1e3, 3),
-                             "achieved": round(gflop / t_graph / 1e3, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(gflop / t_graph / 1e3 / MFMA_F32_PEAK_TFLOPS, 4)}
+            result["net"] = {"bound": "mfma", "what": what, "ms": round(t_net * 1e3, 3),
+                             "achieved": round(gflop / t_net / 1e3, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(gflop / t_net / 1e3 / MFMA_F32_PEAK_TFLOPS, 4)}
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed at N = 1 only
             clip_cpu = SyntheticClip(H, W, args.cpu_frames, config_id=2, device="cpu")
             cf = []

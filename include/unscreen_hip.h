@@ -370,13 +370,18 @@ size_t usc_conv_desc_bytes(void);
 int usc_conv_sequence_f32(const usc_conv_desc* descs, int n, usc_stream_t stream);
 const char* usc_conv_last_error(void);
 
-/* The same layer list as a pre-instantiated hipGraph: one node per launch, chained in list order (a linear chain: executable
+/* The same layer list planned once and kept behind a handle; launched either as stream launches or as a pre-instantiated hipGraph:
+ * one node per launch, chained in list order (a linear chain: executable
  * graphs with parallel branches fault in hipGraphLaunch on the ROCm runtime torch 2.10 bundles, see usc_conv.hip).  The
  * descriptors are copied; the buffers they point to must stay valid until usc_conv_graph_destroy.  A handle is instantiated once
  * per stream it is launched on (at that stream's first launch); launches of one handle must come from one host thread at a time,
  * and - its layers sharing their activation buffers - must not overlap on the device (launch it on one stream, or order the
  * streams). */
+#define USC_CONV_LAUNCH_STREAM 0   /* default: the planned launches are enqueued one by one on the stream (no re-planning, ~3 us of host
+                                    * time per layer; measured 1.49 ms per matting forward against 1.67 ms for the graph replay) */
+#define USC_CONV_LAUNCH_GRAPH  1   /* one hipGraphLaunch per call: least host time (one call per forward) */
 int  usc_conv_graph_create(const usc_conv_desc* descs, int n, void** handle);
+int  usc_conv_graph_set_mode(void* handle, int mode);
 int  usc_conv_graph_launch(void* handle, usc_stream_t stream);
 void usc_conv_graph_destroy(void* handle);   /* the one entry of this group that blocks: waits for the device to drain (a launch
                                               * of the graph may still be queued), then destroys the graph, its execs and plans */

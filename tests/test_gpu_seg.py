@@ -64,9 +64,11 @@ def test_schp_hip_convs_match_torch_plan(nv, H, W):
 
 @pytest.mark.parametrize("H,W", [(270, 480), (1080, 1920)])
 def test_humanseg_agent_vs_oracle_chain(nv, oracle_lib, H, W):
-    """Whole agent vs oracle pre -> folded plan on torch-CPU -> oracle post.  The mask is an argmax of float logits,
-    so pixels whose top-2 margin is below the conv round-off may flip: bounded at 0.05 % here; given the SAME logits
-    the post-processing is bit-exact (test above)."""
+    """Whole agent vs oracle pre -> folded plan on torch-CPU -> oracle post.  The mask is an argmax of float logits (person iff
+    some class > 0 beats the background class), so a pixel may only differ where that decision is a tie at the conv stack's
+    round-off: every differing pixel must have |max_{c>0} logit - logit_0| < 1e-4 in the oracle's full-resolution logits, and
+    there are at most 64 of them (the parity report of this build counts 2 - 16 at these sizes); given the SAME logits the
+    post-processing is bit-exact (test above)."""
     from video_unscreen_amd.binseg import HumanSegAgent
     from video_unscreen_amd.binseg.schp_net import SchpNetTorch
     from video_unscreen_amd.synth import SyntheticClip
@@ -78,7 +80,13 @@ def test_humanseg_agent_vs_oracle_chain(nv, oracle_lib, H, W):
     want = oracle_lib.humanseg_post(logits, H, W)
     assert got.shape == (H, W) and got.dtype == np.uint8 and set(np.unique(got)) <= {0, 255}
     assert 0.02 < (want > 0).mean() < 0.98
-    assert (got != want).mean() < 5e-4, (got != want).mean()
+    diff = got != want
+    assert diff.sum() <= 64, int(diff.sum())
+    if diff.any():                                    # the differing pixels are ties: person-vs-background margin below the round-off
+        up = oracle_lib.upsample_align_corners(logits, 473, 473)                         # (473, 473, 20)
+        full = oracle_lib.warp_affine(up, oracle_lib.humanseg_affine(W, H, inv=True), H, W)      # the reference's H x W x 20 tensor
+        margin = np.abs(full[..., 1:].max(axis=-1) - full[..., 0])
+        assert margin[diff].max() < 1e-4, float(margin[diff].max())
     # and bit-exact when fed the device logits themselves
     mask_dev, lg = agent.forward_device(dev(frame), return_logits=True)
     want2 = oracle_lib.humanseg_post(lg.cpu().numpy()[..., :20].transpose(2, 0, 1), H, W)

@@ -93,7 +93,7 @@ def _x8(frame, masks=None):
     return x.cuda()
 
 
-@pytest.mark.parametrize("H,W", [(64, 96), (272, 480)])
+@pytest.mark.parametrize("H,W", [(64, 96), (272, 480), (544, 960)])          # 544 x 960: the network input of a 1080p / 4K frame
 def test_stm_hip_net_matches_torch_plan(nv, H, W):
     from video_unscreen_amd.stm.net import StmNetTorch, stm_synthetic_state_dict
     from video_unscreen_amd.stm.net_hip import HipStmNet

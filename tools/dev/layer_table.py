@@ -26,16 +26,16 @@ def run(forwards):
     from video_unscreen_amd import _native as nv
     from video_unscreen_amd.vmatting.net import synthetic_state_dict
     from video_unscreen_amd.vmatting.net_hip import HipMattingNet
-    net = HipMattingNet(synthetic_state_dict(0), 544, 960, use_graph=False)
+    net = HipMattingNet(synthetic_state_dict(0), 544, 960)        # launch mode "stream": the product's
     net.x8.normal_()
     torch.cuda.synchronize()
     for _ in range(WARM + forwards):
-        net.forward_serial()
+        net()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(forwards):
-        net.forward_serial()
+        net()
     e1.record()
     e1.synchronize()
     layers = []

@@ -1,8 +1,8 @@
 #!/bin/bash
-# gpurun_out/prof_r01 (tools/dev/run_profiles.sh on the GPU box) -> the tables committed under profiles/r01/.
+# gpurun_out/prof_r02 (tools/dev/run_profiles.sh on the GPU box) -> the tables committed under profiles/r02/.
 # usage: tools/dev/make_profile_summaries.sh <unprofiled ms per matting forward>
 set -e
-P=gpurun_out/prof_r01; D=profiles/r01
+P=gpurun_out/prof_r02; D=profiles/r02
 python tools/dev/summarize_profiles.py $P/default_trace/t_kernel_stats.csv $P/default_fetch/t_counter_collection.csv $P/default_write/t_counter_collection.csv 16 \
   "bench.py default (human-parsing seg, 4 frames per forward, + stage-3 loop, 1080p), final code of round 1; PMC passes use --sync-loop (1 frame per forward)" > $D/default_kernels_and_traffic.md
 python tools/dev/summarize_profiles.py $P/no_seg_trace/t_kernel_stats.csv $P/no_seg_fetch/t_counter_collection.csv $P/no_seg_write/t_counter_collection.csv 16 \

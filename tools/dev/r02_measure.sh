@@ -10,13 +10,13 @@ timeout -k 10 400 python bench.py > $o/bench_default.json 2> $o/bench_default.er
 python - <<PY
 import json
 z=json.load(open("$o/bench_default.json"))
-print("default:", z["value"], "fps; device_resident", z.get("device_resident",{}).get("value"), "all_device", z.get("all_device",{}).get("value"), "roofline", z["roofline"]["achieved"], z["roofline"]["frac"], z["roofline"]["ms_per_forward"], z["roofline"]["ms_per_forward_graph"])
+print("default:", z["value"], "fps; device_resident", z.get("device_resident",{}).get("value"), "host_filter", z.get("host_object_filter",{}).get("value"), "roofline", z["roofline"]["achieved"], z["roofline"]["frac"], z["roofline"]["ms_per_forward"], z["roofline"]["ms_per_forward_graph"])
 PY
 timeout -k 10 300 python bench.py --no-seg --no-cpu-baseline --no-kernel-table > $o/bench_no_seg.json 2> $o/bench_no_seg.err || { tail -20 $o/bench_no_seg.err; exit 1; }
 python - <<PY
 import json
 z=json.load(open("$o/bench_no_seg.json"))
-print("no-seg:", z["value"], "fps; device_resident", z.get("device_resident",{}).get("value"), "all_device", z.get("all_device",{}).get("value"))
+print("no-seg:", z["value"], "fps; device_resident", z.get("device_resident",{}).get("value"), "host_filter", z.get("host_object_filter",{}).get("value"))
 PY
 R=$PWD
 cd /tmp && export TMPDIR=/tmp

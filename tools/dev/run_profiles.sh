@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): rocprofv3 kernel-trace + two PMC passes of bench.py (default and --no-seg), outputs under
-# gpurun_out/prof_r01/.  Summaries are made afterwards with tools/dev/summarize_profiles.py and committed under profiles/r01/.
+# gpurun_out/prof_r02/.  Summaries are made afterwards with tools/dev/summarize_profiles.py and committed under profiles/r02/.
 set -e
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/prof_r01
+OUT=$ROOT/gpurun_out/prof_r02
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for mode in default no_seg; do

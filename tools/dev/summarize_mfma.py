@@ -13,6 +13,9 @@ def short(name):
     if "conv_mfma_kernel" in name:
         m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+)", name)
         return "conv_mfma_kernel<NT=%s, RG=%s, KW=%s>" % m.groups() if m else "conv_mfma_kernel"
+    if "conv_wino_kernel" in name:
+        m = re.search(r"conv_wino_kernel<(\d+)", name)
+        return "conv_wino_kernel<KW=%s>" % m.group(1) if m else "conv_wino_kernel"
     for o in ("splitk_reduce_kernel", "head_conv_kernel"):
         if o in name:
             return o

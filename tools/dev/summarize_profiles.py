@@ -10,7 +10,7 @@ import re
 import sys
 
 stats_f, fetch_f, write_f, frames, title = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
-OURS = ("conv_mfma_kernel", "splitk_reduce_kernel", "head_conv_kernel", "bgdiff_point_kernel", "gate_kernel", "trimap_small_kernel",
+OURS = ("conv_mfma_kernel", "conv_wino_kernel", "splitk_reduce_kernel", "head_conv_kernel", "bgdiff_point_kernel", "gate_kernel", "trimap_small_kernel",
         "trimap_up_kernel", "vmat_pre_kernel", "vmat_post_kernel", "get_fg_kernel", "seg_pre_kernel", "seg_up_kernel",
         "seg_warp_argmax_kernel", "upsample_ac_nhwc_kernel", "count_ge_kernel", "morph_tile_kernel", "inrange_hsv_kernel")
 
@@ -55,14 +55,14 @@ for k, (c, t) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
     fk = f[1] / f[0] if f[0] else float("nan")
     wk = w[1] / w[0] if w[0] else float("nan")
     print(f"| {k} | {c} | {t/c/1e3:.2f} | {100*t/tot:.1f}% | {fk:.0f} | {2*fk*1024/1e6:.2f} | {wk*1024/1e6:.2f} |")
-conv_f = sum(v[1] for k, v in fe.items() if k.startswith(("conv_mfma", "splitk", "head_conv")))
-conv_w = sum(v[1] for k, v in wr.items() if k.startswith(("conv_mfma", "splitk", "head_conv")))
+conv_f = sum(v[1] for k, v in fe.items() if k.startswith(("conv_mfma", "conv_wino", "splitk", "head_conv")))
+conv_w = sum(v[1] for k, v in wr.items() if k.startswith(("conv_mfma", "conv_wino", "splitk", "head_conv")))
 heads = fe.get("head_conv_kernel", [0, 0.0])[0]            # one head launch per matting forward
 if frames <= 0:
     frames = heads
-print(f"\nAll conv-stack launches (conv_mfma + splitk_reduce + head) divided by the {frames} forwards of the PMC run: "
+print(f"\nAll conv-stack launches (conv_mfma + conv_wino + splitk_reduce + head) divided by the {frames} forwards of the PMC run: "
       f"FETCH_SIZE {conv_f/frames*1024/1e6:.1f} MB raw / {2*conv_f/frames*1024/1e6:.1f} MB x2, WRITE_SIZE {conv_w/frames*1024/1e6:.1f} MB per forward.")
 import json
 json.dump({"forwards": frames, "fetch_raw_bytes_per_forward": conv_f / frames * 1024, "write_bytes_per_forward": conv_w / frames * 1024,
-           "note": "conv_mfma + splitk_reduce + head_conv launches; FETCH_SIZE raw (x2 for 16-B/lane streaming reads per MI355X_MICROARCH.md)"},
+           "note": "conv_mfma + conv_wino + splitk_reduce + head_conv launches; FETCH_SIZE raw (x2 for 16-B/lane streaming reads per MI355X_MICROARCH.md)"},
           open(sys.argv[6], "w")) if len(sys.argv) > 6 else None

@@ -124,6 +124,12 @@ class ConvGraphNet:
             else:
                 a()
 
+    def set_launch_mode(self, mode):
+        """"stream" (default) or "graph": how every conv segment is enqueued (usc_conv_graph_set_mode)."""
+        for kind, a, _ in self._segments:
+            if kind == "conv":
+                self.nv.load().usc_conv_graph_set_mode(a, {"stream": 0, "graph": 1}[mode])
+
     def n_layers(self):
         return sum(len(arr) for kind, _, arr in self._segments if kind == "conv")
 

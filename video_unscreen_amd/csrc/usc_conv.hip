@@ -899,6 +899,7 @@ struct ConvGraph {
     std::vector<std::pair<hipStream_t, hipGraphExec_t>> execs;
     std::vector<LayerPlan> plans;          // kernel arguments must outlive the graph
     int device = -1;                       // the device the graph was created (and is launched) on
+    int mode = USC_CONV_LAUNCH_STREAM;     // how usc_conv_graph_launch enqueues the layers
 };
 
 extern "C" int usc_conv_graph_create(const usc_conv_desc* descs, int n, void** handle) {
@@ -949,6 +950,15 @@ extern "C" int usc_conv_graph_launch(void* handle, usc_stream_t stream) {
     usc_debug_arm_segv_backtrace();
     ConvGraph* g = (ConvGraph*)handle;
     hipStream_t st = (hipStream_t)stream;
+    if (g->mode == USC_CONV_LAUNCH_STREAM) {                // the planned launches, one after the other on the stream
+        for (LayerPlan& p : g->plans) {
+            void* args[] = {&p.d};
+            hipError_t e = hipLaunchKernel(p.fn, p.grid, p.block, args, 0, st);
+            if (e == hipSuccess && p.reduce) e = hipLaunchKernel((void*)splitk_reduce_kernel, p.rgrid, dim3(256), args, 0, st);
+            if (e != hipSuccess) return conv_fail(USC_E_LAUNCH, hipGetErrorString(e));
+        }
+        return USC_OK;
+    }
     hipGraphExec_t exec = nullptr;
     for (auto& se : g->execs)
         if (se.first == st) exec = se.second;
@@ -958,6 +968,12 @@ extern "C" int usc_conv_graph_launch(void* handle, usc_stream_t stream) {
     }
     hipError_t e = hipGraphLaunch(exec, st);
     if (e != hipSuccess) return conv_fail(USC_E_LAUNCH, hipGetErrorString(e));
+    return USC_OK;
+}
+
+extern "C" int usc_conv_graph_set_mode(void* handle, int mode) {
+    if (!handle || (mode != USC_CONV_LAUNCH_STREAM && mode != USC_CONV_LAUNCH_GRAPH)) return conv_fail(USC_E_ARG, "usc_conv_graph_set_mode: bad argument");
+    ((ConvGraph*)handle)->mode = mode;
     return USC_OK;
 }
 

@@ -67,9 +67,9 @@ class BgStepPipeline:
         segmentation; the masks are bit-identical to per-frame forwards, the launches per frame drop).
         object_filter: "device" = remove_invalid_objects from connected-component labels on the GPU (0.5 ms at 1080p, the frame
         never leaves HBM, no host synchronisation); "host" = the border-following C++ stage (1 byte / pixel down and up,
-        1.3 ms on one core).  Both give identical masks.  "auto" (default): step() uses the device filter; run() hands the
-        mask to the host stage on its worker thread, where it costs the GPU nothing - the pipelined loop is GPU-bound, so
-        that is the faster choice (measured: 240 vs 225 frames/s at 1080p)."""
+        1.3 ms on one core, on worker threads inside run()).  Both give identical masks.  "auto" (default) = "device": since the
+        device filter works inside the foreground's bounding box with LDS-combined sums it is the faster loop (round 2, 1080p:
+        337 frames/s all on the device against 324 with the host stage), and it leaves no CPU thread in the per-rank loop."""
         self.cfg = cfg
         self.H, self.W = H, W
         self._enqueue_lock = threading.Lock()
@@ -200,8 +200,6 @@ class BgStepPipeline:
         are taken to be produced on the current stream.  Calls on_result(index, dict) per frame (the dict's tensors are
         only valid until two more frames have been submitted).  Returns the frame count."""
         chosen = self.object_filter
-        if self._filter_choice == "auto":
-            self.object_filter = "host"
         try:
             return self._run(inputs, on_result)
         finally:

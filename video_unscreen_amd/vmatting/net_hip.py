@@ -257,6 +257,12 @@ class HipMattingNet:
 
     __call__ = forward
 
+    def set_launch_mode(self, mode):
+        """"stream" (default: the planned launches one by one on the stream) or "graph" (one hipGraphLaunch per forward)."""
+        rc = nv.load().usc_conv_graph_set_mode(self._graph, {"stream": 0, "graph": 1}[mode])
+        if rc != 0:
+            raise nv.NativeError(f"usc_conv_graph_set_mode failed ({rc})")
+
     def forward_serial(self):
         """The same layers launched one after the other on the current stream (no graph, no branch overlap): what the per-layer
         profile table and bench.py's roofline time."""
