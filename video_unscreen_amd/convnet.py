@@ -3,6 +3,7 @@ kernel).  A network is a list of segments: runs of fused convolution layers, eac
 (usc_conv_graph_create), separated by "glue" callables (pooling, bilinear resampling into concat slices) that are
 enqueued on the same stream.  All activations are NHWC float32 buffers allocated once."""
 import ctypes as C
+import sys
 
 import torch
 import torch.nn.functional as F
@@ -143,10 +144,9 @@ class ConvGraphNet:
         self._keep = []
 
     def __del__(self):
-        import sys
-        if sys.is_finalizing():            # the HIP runtime may already be gone: the process frees everything anyway
-            return
         try:
+            if sys.is_finalizing():        # the HIP runtime may already be gone: the process frees everything anyway
+                return
             self.close()
         except Exception:
             pass

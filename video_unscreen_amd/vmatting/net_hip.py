@@ -7,6 +7,7 @@ in a conv epilogue, ConvTranspose2d(k4, s2, p1) runs as its four 2x2 output phas
 2x2-stride-2 conv.  All tensors are NHWC float32 buffers allocated once per frame size.
 """
 import ctypes as C
+import sys
 
 import torch
 import torch.nn.functional as F
@@ -105,10 +106,9 @@ class HipMattingNet:
         self._keep = []
 
     def __del__(self):
-        import sys
-        if sys.is_finalizing():            # the HIP runtime may already be gone: the process frees everything anyway
-            return
         try:
+            if sys.is_finalizing():        # the HIP runtime may already be gone: the process frees everything anyway
+                return
             self.close()
         except Exception:
             pass
