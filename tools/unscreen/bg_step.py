@@ -146,6 +146,8 @@ def main(cfg):
     bg_paths = shard_paths('bg_*.' + ext) or shard_paths('bg_*.jpg')
     groups = list(zip(frame_paths[lo:hi], mask_paths, bg_paths))
     workers = int(cfg["data"].get("io_workers", 6))
+    print("calculate fg image according to bg image")
+    st = time.time()                                   # the files -> files figure includes starting the codec processes
     reader = FrameReader(groups, [(h, w, 3), (h, w), (h, w, 3)], workers=workers, depth=16)
     writer = FrameWriter([(h, w), (h, w, 3)], workers=workers, depth=16)
 
@@ -153,8 +155,6 @@ def main(cfg):
         fid = first + lo + i
         return (osp.join(dst_img_dir, 'alphamask_{:06d}.{}'.format(fid, ext)), osp.join(dst_img_dir, 'fg_{:06d}.{}'.format(fid, ext)))
 
-    print("calculate fg image according to bg image")
-    st = time.time()
     n = stream_clip(pipe, reader, writer, out_paths, bg_always)
     torch.cuda.synchronize()
     writer.close()

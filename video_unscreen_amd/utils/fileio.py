@@ -9,8 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 from datetime import datetime
 from glob import glob
 
-import numpy as np
-from PIL import Image
+from .._imgcodec import read_img, save_img
 
 __all__ = ["read_txt_list", "write_txt_list", "return_date", "return_time", "read_img", "parallel_read_img",
            "save_img", "save_video", "delete_mode"]
@@ -35,28 +34,9 @@ def return_time():
     return datetime.now().strftime('%m%d') + "_" + datetime.now().strftime('%H%M')
 
 
-def read_img(path):
-    """3-channel uint8 BGR array (what cv2.imread returns), or a .npy array as is."""
-    if path.endswith(".npy"):
-        return np.load(path)
-    im = Image.open(path).convert("RGB")
-    return np.ascontiguousarray(np.asarray(im)[:, :, ::-1])
-
-
 def parallel_read_img(framepaths, workers=16):
     with ThreadPoolExecutor(workers) as pool:
         return list(pool.map(read_img, framepaths))
-
-
-def save_img(img, save_path, downsacle=1):
-    assert isinstance(downsacle, int)
-    if save_path.endswith(".npy"):
-        np.save(save_path, img)
-        return
-    im = Image.fromarray(img if img.ndim == 2 else np.ascontiguousarray(img[:, :, ::-1]))
-    if downsacle != 1:
-        im = im.resize((im.width // downsacle, im.height // downsacle), Image.BILINEAR)
-    im.save(save_path, quality=95)
 
 
 def save_video(cfg, mode, fps=30):

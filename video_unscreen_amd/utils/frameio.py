@@ -20,64 +20,28 @@ from multiprocessing import shared_memory
 import numpy as np
 import torch
 
-from .fileio import read_img, save_img
+from .._io_workers import decode_worker as _decode_worker, encode_worker as _encode_worker
 
 _CTX = mp.get_context("spawn")         # no fork: the parent may hold a HIP context
 
 
-def _attach(name, nbytes):
-    shm = shared_memory.SharedMemory(name=name)
-    return shm, np.ndarray((nbytes,), np.uint8, buffer=shm.buf)
+class _light_children:
+    """A spawned child re-imports the parent's main script (as __mp_main__) before it runs its target - for tools/unscreen/*.py that
+    is `import torch` + the whole package, seconds per worker.  The workers need none of it (_io_workers.py: numpy + Pillow), so the
+    script's path is hidden from multiprocessing while they are started."""
 
+    def __enter__(self):
+        import sys
+        self.main = sys.modules.get("__main__")
+        self.saved = {}
+        for k in ("__file__", "__spec__"):
+            if self.main is not None and hasattr(self.main, k):
+                self.saved[k] = getattr(self.main, k)
+                setattr(self.main, k, None)
 
-def _decode_worker(shm_name, nbytes, slot_bytes, shapes, gray, tasks, done):
-    shm, ring = _attach(shm_name, nbytes)
-    try:
-        while True:
-            t = tasks.get()
-            if t is None:
-                break
-            seq, slot, paths = t
-            try:
-                off = slot * slot_bytes
-                for p, shp, g in zip(paths, shapes, gray):
-                    n = int(np.prod(shp))
-                    img = read_img(p)
-                    if g and img.ndim == 3:
-                        img = img[..., 0]                                  # masks stored as 3-channel JPEGs (bg_offline.py:134-141)
-                    if img.shape != tuple(shp):
-                        raise ValueError("%s: shape %s, expected %s" % (p, img.shape, tuple(shp)))
-                    ring[off:off + n] = np.ascontiguousarray(img).reshape(-1)
-                    off += n
-                done.put((seq, slot, None))
-            except Exception as e:                                         # surfaced to the consumer
-                done.put((seq, slot, repr(e)))
-    finally:
-        del ring
-        shm.close()
-
-
-def _encode_worker(shm_name, nbytes, slot_bytes, shapes, tasks, done):
-    shm, ring = _attach(shm_name, nbytes)
-    try:
-        while True:
-            t = tasks.get()
-            if t is None:
-                break
-            slot, paths = t
-            err = None
-            try:
-                off = slot * slot_bytes
-                for p, shp in zip(paths, shapes):
-                    n = int(np.prod(shp))
-                    save_img(ring[off:off + n].reshape(shp), p)
-                    off += n
-            except Exception as e:
-                err = repr(e)
-            done.put((slot, err))
-    finally:
-        del ring
-        shm.close()
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            setattr(self.main, k, v)
 
 
 class _Ring:
@@ -130,8 +94,9 @@ class FrameReader:
         self.procs = [_CTX.Process(target=_decode_worker, daemon=True,
                                    args=(self.ring.shm.name, self.ring.nbytes, self.ring.slot_bytes, self.ring.shapes, gray, self.tasks, self.done))
                       for _ in range(max(1, workers))]
-        for p in self.procs:
-            p.start()
+        with _light_children():
+            for p in self.procs:
+                p.start()
         self.free = list(range(depth))
         self.next_submit = 0
         self.next_deliver = 0
@@ -192,8 +157,9 @@ class FrameWriter:
         self.procs = [_CTX.Process(target=_encode_worker, daemon=True,
                                    args=(self.ring.shm.name, self.ring.nbytes, self.ring.slot_bytes, self.ring.shapes, self.tasks, self.done))
                       for _ in range(max(1, workers))]
-        for p in self.procs:
-            p.start()
+        with _light_children():
+            for p in self.procs:
+                p.start()
         self.free = list(range(depth))
         self.inflight = 0
         self.errors = []
