@@ -1,0 +1,42 @@
+"""Per-phase shader-clock stamps of conv_wino_kernel's K loop (library built with EXTRA=-DUSC_WINO_TIMING2): for the h = 0 and the
+h = 1 waves, when each fragment phase and each MFMA phase of the first steps starts and ends, relative to the wave's own entry."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from video_unscreen_amd import _native as nv
+nv.LIB_PATH = os.environ["USC_TIMING_LIB"]
+from video_unscreen_amd.vmatting import net_hip as m
+lib = nv.load()
+for (cin, cout, h, w, kw) in ((32, 32, 272, 480, 1), (64, 64, 136, 240, 2)):
+    x = torch.randn(h, w, cin, device="cuda"); wt = torch.randn(cout, cin, 3, 3) * 0.05
+    out = torch.empty(h, w, cout, device="cuda")
+    taps, wk = m.conv_taps(wt, 1)
+    wp = m.pack_k_major(wk.float()).cuda(); wn = m.pack_wino(wt).cuda()
+    ts = torch.zeros(4096 * 8 * 16, dtype=torch.int64, device="cuda")
+    d = m.ConvDesc()
+    d.inp, d.out, d.wpk, d.wino = x.data_ptr(), out.data_ptr(), wp.data_ptr(), wn.data_ptr()
+    d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = h, w, cin, h, w, h, w, cout
+    d.in_stride, d.out_stride, d.ntaps, d.nphase = 1, 1, 9, 1
+    d.slab, d.slab_bytes = ts.data_ptr(), 0
+    for i, (dy, dx) in enumerate(taps): d.dy[i], d.dx[i] = dy, dx
+    lib.usc_conv_force_winograd(1); lib.usc_conv_force_plan(0, 0, 0, kw)
+    arr = (m.ConvDesc * 1)(d)
+    plan = nv.conv_plans(arr, 1)[0]
+    for _ in range(3): lib.usc_conv_sequence_f32(arr, 1, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize(); ts.zero_(); torch.cuda.synchronize()
+    lib.usc_conv_sequence_f32(arr, 1, torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+    lib.usc_conv_force_winograd(-1); lib.usc_conv_force_plan(0, 0, 0, 0)
+    t = ts.cpu().view(-1, 16)[: plan["workgroups"] * 8].double()
+    t = t[t[:, 15] != 0]
+    hh = torch.arange(len(t)) % 8 >= 4
+    print(f"cin {cin} cout {cout} {h}x{w} KW {kw}: {plan['workgroups']} WGs; cycles since the wave's entry (mean over waves)")
+    names = {0: "entry", 1: "prologue done", 14: "K loop done", 15: "end"}
+    for nm, sel in (("h=0", ~hh), ("h=1", hh)):
+        r = (t[sel] - t[sel][:, :1]).mean(0)
+        prev = 0.0
+        line = []
+        for k in range(16):
+            if t[sel][:, k].min() == 0: continue
+            line.append(f"[{k}] {float(r[k]):.0f} (+{float(r[k]) - prev:.0f})")
+            prev = float(r[k])
+        print("  " + nm + ": " + "  ".join(line))

@@ -12,7 +12,7 @@ for (cin, cout, h, w, kw) in ((32, 32, 272, 480, 1), (64, 32, 272, 480, 1), (64,
     out = torch.empty(h, w, cout, device="cuda")
     taps, wk = m.conv_taps(wt, 1)
     wp = m.pack_k_major(wk.float()).cuda(); wn = m.pack_wino(wt).cuda()
-    ts = torch.zeros(4096 * 4 * 16, dtype=torch.int64, device="cuda")
+    ts = torch.zeros(4096 * 8 * 16, dtype=torch.int64, device="cuda")
     d = m.ConvDesc()
     d.inp, d.out, d.wpk, d.wino = x.data_ptr(), out.data_ptr(), wp.data_ptr(), wn.data_ptr()
     d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = h, w, cin, h, w, h, w, cout
@@ -27,13 +27,17 @@ for (cin, cout, h, w, kw) in ((32, 32, 272, 480, 1), (64, 32, 272, 480, 1), (64,
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); lib.usc_conv_sequence_f32(arr, 1, torch.cuda.current_stream().cuda_stream); e1.record(); torch.cuda.synchronize()
     lib.usc_conv_force_winograd(-1); lib.usc_conv_force_plan(0, 0, 0, 0)
-    t = ts.cpu().view(-1, 8, 2)[: plan["workgroups"] * 4]
-    live = t[:, 3, 0] != 0
+    t = ts.cpu().view(-1, 8, 2)[: plan["workgroups"] * 8]          # 8 waves per workgroup
+    live = t[:, 6, 0] != 0
     t = t[live].double()
     cyc, rt = t[..., 0], t[..., 1]
     t0 = rt[:, 0].min()
     steps = cin // 8 // kw
     print(f"cin {cin} cout {cout} {h}x{w} KW {kw}: {plan['workgroups']} WGs, event {e0.elapsed_time(e1)*1e3:.1f} us; waves {len(t)}")
-    print(f"   shader clock / real time (100 MHz): {((cyc[:,3]-cyc[:,0]) / (rt[:,3]-rt[:,0])).mean()*100:.0f} MHz")
-    print(f"   cycles: prologue {float((cyc[:,1]-cyc[:,0]).mean()):.0f}  K loop {float((cyc[:,2]-cyc[:,1]).mean()):.0f} ({float((cyc[:,2]-cyc[:,1]).mean())/steps:.0f} per step, ideal 4096)  epilogue {float((cyc[:,3]-cyc[:,2]).mean()):.0f}")
-    print(f"   wave start spread {float(rt[:,0].max()-t0)/100:.2f} us, first end {float(rt[:,3].min()-t0)/100:.2f} us, last end {float(rt[:,3].max()-t0)/100:.2f} us")
+    print(f"   shader clock / real time (100 MHz): {((cyc[:,6]-cyc[:,0]) / (rt[:,6]-rt[:,0])).mean()*100:.0f} MHz")
+    print(f"   cycles: prologue {float((cyc[:,1]-cyc[:,0]).mean()):.0f}  K loop {float((cyc[:,2]-cyc[:,1]).mean()):.0f} ({float((cyc[:,2]-cyc[:,1]).mean())/steps:.0f} per step of 2 x 32 MFMAs on the SIMD, ideal 4096)  epilogue {float((cyc[:,6]-cyc[:,2]).mean()):.0f}")
+    hh = torch.arange(len(cyc)) % 8 >= 4
+    for nm, sel in (("h=0 waves", ~hh), ("h=1 waves", hh)):
+        c = cyc[sel]
+        print(f"   {nm}: K loop {float((c[:,2]-c[:,1]).mean()):.0f}; output transform {float((c[:,3]-c[:,2]).mean()):.0f}; residual requests {float((c[:,4]-c[:,3]).mean()):.0f}; round 0 {float((c[:,5]-c[:,4]).mean()):.0f}; rounds 1-3 {float((c[:,6]-c[:,5]).mean()):.0f}")
+    print(f"   wave start spread {float(rt[:,0].max()-t0)/100:.2f} us, first end {float(rt[:,6].min()-t0)/100:.2f} us, last end {float(rt[:,6].max()-t0)/100:.2f} us")

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -295,292 +296,427 @@ __global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d
 
 // ---- Winograd F(2x2, 3x3) for the 3x3 / stride-1 / pad-1 layers (78 % of the matting net's flops) ---------------------------
 // Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A : 16 multiplications per 2x2 output tile and (cin, cout) pair instead of 36, so
-// the matrix cores do 2.25x less work; the transforms are additions on the (otherwise idle) vector ALU.  As an implicit GEMM:
-// for each of the 16 positions (a, b) of the transformed 4x4 patch, M_ab[tile][cout] = sum_cin V_ab[tile][cin] U_ab[cin][cout].
-//   * a wave owns a block of 8 x 4 tiles (16 x 8 output pixels) x 32 output channels: 16 accumulators of 32 x 32 (256 registers,
-//     the accumulation half of the unified register file), one per position.  One wave per SIMD; a K step is 8 input channels =
-//     64 independent MFMAs (4096 cycles), long enough to cover every load of the next step behind it;
-//   * A side: the block's 10 x 18 input patch (8 channels = 32 bytes per pixel) is staged through the wave's private LDS image
-//     exactly like conv_mfma_kernel stages its rows (register prefetch one step ahead, ds_write at the end of the step, no
-//     barrier); lane (tile, half) reads its tile's 4 x 4 patch as 16 ds_read_b128, transforms it (32 float4 additions) and the
-//     four components of each transformed float4 feed four MFMAs, as in conv_mfma_kernel;
+// the matrix cores do 2.25x less work; the transforms are additions on the vector ALU.  As an implicit GEMM: for each of the 16
+// positions (a, b) of the transformed 4x4 patch, M_ab[tile][cout] = sum_cin V_ab[tile][cin] U_ab[cin][cout].
+//   * a UNIT is a block of 8 x 4 tiles (16 x 8 output pixels) x 32 output channels x one K group of the input channels.  Two
+//     waves share a unit: wave h owns the positions of rows a = 2h, 2h + 1 - eight accumulators of 32 x 32 (128 registers), so a
+//     wave fits in half a SIMD's register file and every SIMD holds TWO waves.  A workgroup is 8 waves = 4 units: waves 0..3 are
+//     the h = 0 halves, waves 4..7 the h = 1 halves (a unit's two waves land on the same SIMD);
+//   * the two waves of a SIMD work in opposite phases, half a K step apart: while one issues the 32 MFMAs of a step (2048 cycles
+//     of matrix-pipe time), the other stages the next activations, reads its fragments of the patch and transforms them - the
+//     vector work, the LDS traffic and every wait on memory of one wave sit in the shadow of the other wave's MFMAs (a single
+//     wave per SIMD that did both measured 6100 - 6900 cycles per 4096 cycles of MFMA work: profiles/r02/wino_phase_timing.md);
+//     a workgroup barrier separates the phases (the pair shares the staged patch);
+//   * A side: the unit's 10 x 18 input patch (8 channels = 32 bytes per pixel) goes global -> registers (one step ahead) -> one of
+//     two LDS images per pair, each wave staging half of it.  The image is stored as four parity sub-images (pixel row / column
+//     parity) with a 19-slot row pitch: the 16 lanes of a ds_read_b128 phase (8 tiles of one tile row, two tile rows) then hit 64
+//     distinct banks.  Lane (tile, half) reads three rows of its tile's 4 x 4 patch (12 ds_read_b128), column-transforms them to
+//     its two rows of T = B^T d and row-transforms on the fly in the MFMA phase; the four components of a float4 feed four MFMAs;
 //   * B side: U = G g G^T is prepared on the host (vmatting/net_hip.py pack_wino) in the fragment order [cin/8][position][half]
-//     [cout][4], read straight from global memory, one float4 per position and step, re-requested into the registers a position
-//     has just consumed;
-//   * epilogue: the output transform A^T M A is elementwise over the 16 accumulators (24 additions per element), its four
-//     2x2 phases go through the LDS image like conv_mfma_kernel's tile and take the same fused epilogue;
-//   * KW waves of a workgroup may split the channel range of one block (partial output tiles meet in LDS, slice order).
+//     [cout][4], read straight from global memory, one float4 per position and step, re-requested (for the next step) into the
+//     registers a row of positions has just consumed;
+//   * epilogue: each wave output-transforms its two rows into partial sums of the four 2x2 output phases; per phase the partial
+//     tiles of all waves of the unit's group (2 position halves x KW K groups) meet in LDS in accumulator layout, every wave of
+//     the group sums (fixed order) and finishes 16 / (2 KW) of the 16 accumulator registers: bias, residuals, activation,
+//     per-channel affine, 128-byte runs of channels stored straight from the accumulator layout.
 // Summation order depends on the shape (and KW) only: run-to-run and batch-to-batch identical results.  Results differ from
 // the direct kernel's by float rounding (relative 2e-7 per layer): the planner's choice is a function of the shape alone.
-constexpr int WPITCH = 12;                  // floats per patch pixel in LDS: the 8 channels of a K step + 4 pad
-constexpr int WPATCH_W = 18, WPATCH_H = 10; // input patch of a block of 8 x 4 tiles
-constexpr int WSLOTS = WPATCH_W * WPATCH_H * 2;     // 16-byte slots of one stage (360)
-constexpr int WIMG = 2 * 32 * APITCH;       // floats of a wave's LDS image: 2 output phases x 32 tiles x APITCH (>= one stage); 36 KB per workgroup
-static_assert(WIMG >= WPATCH_W * WPATCH_H * WPITCH, "the stage must fit the epilogue image");
+constexpr int WSUBROW = 19, WSUB = 5 * WSUBROW;     // parity sub-image: 5 rows of 9 pixels x 2 halves, row pitch 19 slots
+constexpr int WIMG = 384 * 4;               // floats of one LDS image: 4 x 95 = 380 slots, padded to 6 requests of 64 (6144 bytes)
+constexpr int WREGION = 8 * 16 * 64;        // floats of one epilogue exchange region: 8 waves x 16 registers x 64 lanes (32 KB)
+constexpr int WLDS = 2 * WREGION;           // 64 KB: two exchange regions; the K loop uses 4 pairs x 2 images = 48 KB of it
+static_assert(WLDS >= 4 * 2 * WIMG, "the patch images must fit");
 
-#ifdef USC_WINO_TIMING
-#define WINO_STAMP(k) do { if (d.slab && lane == 0) { long long* ts_ = reinterpret_cast<long long*>(d.slab) + ((size_t)blockIdx.x * 4 + wave) * 16; \
+#ifdef USC_WINO_TIMING2          // per-phase stamps of the first three K steps: 16 shader-clock slots per wave
+#define WINO_STAMP(k) do { } while (0)
+#define WINO_PH(k) do { if (d.slab && lane == 0 && (k) < 16) reinterpret_cast<long long*>(d.slab)[((size_t)blockIdx.x * 8 + wave) * 16 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#elif defined(USC_WINO_TIMING)
+#define WINO_PH(k) do { } while (0)
+#define WINO_STAMP(k) do { if (d.slab && lane == 0) { long long* ts_ = reinterpret_cast<long long*>(d.slab) + ((size_t)blockIdx.x * 8 + wave) * 16; \
         ts_[2 * (k)] = (long long)__builtin_readcyclecounter(); ts_[2 * (k) + 1] = (long long)__builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define WINO_STAMP(k) do { } while (0)
+#define WINO_PH(k) do { } while (0)
 #endif
 
 template <int KW, bool IN_RELU>
-__global__ __launch_bounds__(256) void conv_wino_kernel(usc_conv_desc d) {
-    __shared__ __attribute__((aligned(16))) float Ws[4][WIMG];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
+    __shared__ __attribute__((aligned(16))) float Ls[WLDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = wave >> 2, sub = wave & 3;                        // position half (rows 2h, 2h + 1) and pair of this wave
     WINO_STAMP(0);
+    WINO_PH(0);
     const int nnb = d.Cout >> 5;
     const int nimg = d.batch > 1 ? d.batch : 1;
     const int H = d.IH, W = d.IW;                                  // per image; output has the same size
     const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
     const int BH = (TH + 3) >> 2, BW = (TW + 7) >> 3;
-    const int ntiles = nimg * BH * BW * nnb;                        // wave tiles
+    const int ntiles = nimg * BH * BW * nnb;                        // blocks x channel groups
     const int nwg = (int)gridDim.x, xcd = (int)blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;      // XCD-aware order (see above)
     const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
-    constexpr int TPW = 4 / KW;                                     // wave tiles per workgroup
-    const int wt = wgid * TPW + wave / KW, kg = wave % KW;
+    constexpr int TPW = 4 / KW;                                     // blocks x channel groups per workgroup
+    const int wt = wgid * TPW + sub / KW, kg = sub % KW;
     const bool live = wt < ntiles;
-    if (KW == 1 && !live) return;
+    // (integer division runs on the vector ALU: readfirstlane brings the wave-uniform results back to scalar registers, which
+    // the scalar-offset addressing of the epilogue needs)
     const int nb = live ? wt % nnb : 0, sb = live ? wt / nnb : 0;
-    const int img = sb / (BH * BW), brem = sb - img * (BH * BW), by = brem / BW, bx = brem - by * BW;
-    const int nb0 = nb * 32;
+    const int img = __builtin_amdgcn_readfirstlane(sb / (BH * BW)), brem = sb - img * (BH * BW);
+    const int by = __builtin_amdgcn_readfirstlane(brem / BW), bx = brem - by * BW;
+    const int nb0 = __builtin_amdgcn_readfirstlane(nb * 32);
     const int nch = d.Cin >> 3;                                     // K steps of 8 input channels
-    const int c_begin = live ? (int)((long long)kg * nch / KW) : 0, c_end = live ? (int)((long long)(kg + 1) * nch / KW) : 0;
+    const int nmax = (nch + KW - 1) / KW;                           // steps of the longest K group: the workgroup's phase count
+    const int c_begin = live ? kg * nmax : 0;                       // the planner splits K evenly: nch = KW * nmax
 
-    // ---- weight fragments: [c][p][h][n][4] floats
+    // ---- weight fragments: [c][p][k half][n][4] floats; this wave's positions are p = (2h + ar) * 4 + b.  The lane part of the
+    // address is a constant, the (step, position) part goes through the scalar offset: no address registers per load.
     const int wbytes = nch * 16 * 2 * d.Cout * 16;
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.wino), 0, wbytes, 0x00020000);
-    const int wbase = ((lane >> 5) * d.Cout + nb0 + (lane & 31)) * 16;
     const int wpos = 2 * d.Cout * 16, wstep = 16 * wpos;
-    // two row buffers of four positions: row a of a step multiplies out of buffer a & 1 and re-requests it for the row two
-    // further on (the weights come from L2: 32 MFMAs = ~1 us ahead is enough; 32 registers instead of 64)
+    const int wbase = ((lane >> 5) * d.Cout + nb0 + (lane & 31)) * 16;
     float4 bf[2][4];
-    auto load_b = [&](int c, int a) {
+    auto load_b = [&](int c, int ar) {                              // (past the last step: the next K group's, or zeros - unused)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-#ifdef USC_WINO_NO_B                                        // ablation build (timing only): no weight traffic
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, 0x7ffffff0 + 0 * (c + a + b), 0, 0);
-#else
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, c < c_end ? wbase + c * wstep + (a * 4 + b) * wpos : 0x7ffffff0, 0, 0);
-#endif
-            bf[a & 1][b] = *reinterpret_cast<const float4*>(&v);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wbase, c * wstep + (8 * h + ar * 4 + b) * wpos, 0);
+            bf[ar][b] = *reinterpret_cast<const float4*>(&v);
         }
     };
     load_b(c_begin, 0);
     load_b(c_begin, 1);
 
-    // ---- patch staging: slot s = pixel * 2 + half (16 bytes); 6 rounds of 64 lanes cover the 360 slots.  The loads of step c + 2
-    // are requested at the start of step c (two register sets, 128 MFMAs = ~4 us ahead: with one wave per SIMD nothing else hides
-    // a cold miss of the activations; one step ahead measured 7700 cycles per step against 4100 of MFMA work) and go into the
-    // LDS image at the end of step c + 1, after that step has read its fragments.
+    // ---- patch staging, global memory -> LDS without passing through registers (buffer_load ... lds: lane l of a request
+    // writes 16 bytes at LDS base + 16 l): each LDS slot (16 bytes = 4 channels of one patch pixel) of the image is assigned the
+    // global address of the pixel half it holds, out-of-image pixels and the layout's holes an out-of-range offset (= zeros).
+    // An image is 384 slots = 6 requests of 64 lanes; wave h issues requests 3h .. 3h + 2.  Slot s = sub-image (s / 95: pixel
+    // row parity x 2 + column parity), row (s % 95) / 19, pixel pair ((s % 19) >> 1), half (s & ... & 1).
     constexpr int INVALID = 0x7fff0000;
     const int y0 = 8 * by - 1, x0 = 16 * bx - 1;
-    int goff[6], loff[6];
+    int goff[3];
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
-        const int sl = r * 64 + lane;
-        const int pp = sl >> 1, half = sl & 1;
-        const int py = pp / WPATCH_W, px = pp - py * WPATCH_W;
+    for (int r = 0; r < 3; r++) {
+        const int sl = (3 * h + r) * 64 + lane;
+        const int sp = sl / WSUB, rem = sl - sp * WSUB;
+        const int row = rem / WSUBROW, q = rem - row * WSUBROW;
+        const int py = 2 * row + (sp >> 1), px = 2 * (q >> 1) + (sp & 1), half = q & 1;
         const int y = y0 + py, x = x0 + px;
-        const bool ok = live && sl < WSLOTS && y >= 0 && y < H && x >= 0 && x < W;
+        const bool ok = live && sl < 4 * WSUB && q < 18 && y >= 0 && y < H && x >= 0 && x < W;
         goff[r] = ok ? ((img * H + y) * W + x) * d.Cin * 4 + half * 16 : INVALID;
-        loff[r] = sl < WSLOTS ? pp * WPITCH + half * 4 : -1;
     }
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(d.in), 0, nimg * H * W * d.Cin * 4, 0x00020000);
-    float* const Aw = Ws[wave];
-    float4 ra0[6], ra1[6];
-    auto load_a = [&](int c, float4 (&ra)[6]) {
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-#ifdef USC_WINO_NO_A                                        // ablation build (timing only): no activation traffic
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, 0x7ffffff0 + 0 * (c + goff[r]), 0, 0);
-#else
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (c < c_end && goff[r] != INVALID) ? goff[r] + c * 32 : 0x7ffffff0, 0, 0);
-#endif
-            ra[r] = *reinterpret_cast<const float4*>(&v);
-        }
+    const int img0 = sub * 2 * WIMG;                                // the pair's two images (float index into Ls)
+    auto issue_a = [&](int c) {                                     // the patch of step c -> image (c - c_begin) & 1
+        const int dst = img0 + ((c - c_begin) & 1) * WIMG + 3 * h * 256;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst], 16, goff[0], c * 32, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 256], 16, goff[1], c * 32, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 512], 16, goff[2], c * 32, 0, 0);
     };
-    auto stage = [&](const float4 (&ra)[6]) {
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-            float4 a = ra[r];
-            if (IN_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-            if (r < 5 || loff[r] >= 0) *reinterpret_cast<float4*>(&Aw[loff[r]]) = a;
-        }
-    };
+    auto wait_vm0 = [] { __builtin_amdgcn_s_waitcnt(0x0F70); };     // vmcnt(0): every load of this wave has landed (LDS ones too)
+    // Phase barrier of the K loop: LDS accesses of this wave are complete, nothing else is implied.  (__syncthreads() carries a
+    // workgroup release fence, which the compiler turns into a wait for the global -> LDS requests in flight - exactly the latency
+    // the phase structure is there to hide; it still waits for them in front of the next ds_read, where they are needed.)
+    auto phase_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-    f32x16 acc[16];
+    f32x16 acc[8];
 #pragma unroll
-    for (int p = 0; p < 16; p++)
+    for (int p = 0; p < 8; p++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[p][r] = 0.f;
 
-    // fragment base of this lane: tile t = lane & 31 -> (ty, tx) = (t >> 3, t & 7), half h = lane >> 5
-    const int fbase = ((2 * ((lane & 31) >> 3)) * WPATCH_W + 2 * (lane & 7)) * WPITCH + 4 * (lane >> 5);
+    // fragment base of this lane: tile t = lane & 31 -> (ty, tx) = (t >> 3, t & 7), channel half = lane >> 5.  Patch pixel
+    // (2 ty + i, 2 tx + j) lives in sub-image (i & 1, j & 1) at row ty + (i >> 1), pixel tx + (j >> 1).  This wave reads the patch
+    // rows i = h, h + 1, h + 2.
+    const int fb = ((((lane & 31) >> 3) * WSUBROW + 2 * (lane & 7) + (lane >> 5))) * 4;
     auto add4 = [](const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
     auto sub4 = [](const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
-
-    // One K step.  The scheduler is fenced (sched_barrier) so that the requests for the next step are issued where they are
-    // written - the patch loads first, each position's weight fragment right after that position's MFMAs - instead of being sunk
-    // to the end of the step, where every one of them would be waited for at once.
-    auto step = [&](int c, float4 (&ra_next)[6], float4 (&ra_far)[6]) {
-        float4 T[16];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) T[i * 4 + j] = *reinterpret_cast<const float4*>(&Aw[fbase + (i * WPATCH_W + j) * WPITCH]);
-        load_a(c + 2, ra_far);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {                       // T = B^T d, in place, column by column
-            const float4 d0 = T[0 + j], d1 = T[4 + j], d2 = T[8 + j], d3 = T[12 + j];
-            T[0 + j] = sub4(d0, d2);
-            T[4 + j] = add4(d1, d2);
-            T[8 + j] = sub4(d2, d1);
-            T[12 + j] = sub4(d1, d3);
-        }
-        // V = T B, one row of four positions at a time.  Row a + 1 is computed BETWEEN the MFMAs of row a (one position per
-        // group of four MFMAs), so that no MFMA reads an operand a vector instruction has only just written (measured: with each
-        // operand produced right in front of its MFMA a step took 7200 - 7700 cycles instead of 4100), and the row's 16 MFMAs go
-        // component-major, consecutive ones into DIFFERENT accumulators.
-        auto vrow = [&](int a, int b) {
-            return b == 0 ? sub4(T[a * 4 + 0], T[a * 4 + 2]) : b == 1 ? add4(T[a * 4 + 1], T[a * 4 + 2])
-                 : b == 2 ? sub4(T[a * 4 + 2], T[a * 4 + 1]) : sub4(T[a * 4 + 1], T[a * 4 + 3]);
-        };
-        float4 Vb[2][4];
-#pragma unroll
-        for (int b = 0; b < 4; b++) Vb[0][b] = vrow(0, b);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            float4 (&V)[4] = Vb[a & 1];
-            float4 (&Vn)[4] = Vb[(a + 1) & 1];
-            const float4 w0 = bf[a & 1][0], w1 = bf[a & 1][1], w2 = bf[a & 1][2], w3 = bf[a & 1][3];
-            acc[a * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].x, w0.x, acc[a * 4 + 0], 0, 0, 0);
-            acc[a * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].x, w1.x, acc[a * 4 + 1], 0, 0, 0);
-            acc[a * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].x, w2.x, acc[a * 4 + 2], 0, 0, 0);
-            acc[a * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].x, w3.x, acc[a * 4 + 3], 0, 0, 0);
-            if (a < 3) Vn[0] = vrow(a + 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[a * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].y, w0.y, acc[a * 4 + 0], 0, 0, 0);
-            acc[a * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].y, w1.y, acc[a * 4 + 1], 0, 0, 0);
-            acc[a * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].y, w2.y, acc[a * 4 + 2], 0, 0, 0);
-            acc[a * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].y, w3.y, acc[a * 4 + 3], 0, 0, 0);
-            if (a < 3) Vn[1] = vrow(a + 1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[a * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].z, w0.z, acc[a * 4 + 0], 0, 0, 0);
-            acc[a * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].z, w1.z, acc[a * 4 + 1], 0, 0, 0);
-            acc[a * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].z, w2.z, acc[a * 4 + 2], 0, 0, 0);
-            acc[a * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].z, w3.z, acc[a * 4 + 3], 0, 0, 0);
-            if (a < 3) Vn[2] = vrow(a + 1, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[a * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].w, w0.w, acc[a * 4 + 0], 0, 0, 0);
-            acc[a * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].w, w1.w, acc[a * 4 + 1], 0, 0, 0);
-            acc[a * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].w, w2.w, acc[a * 4 + 2], 0, 0, 0);
-            acc[a * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].w, w3.w, acc[a * 4 + 3], 0, 0, 0);
-            if (a < 3) Vn[3] = vrow(a + 1, 3);
-            if (a < 2) load_b(c, a + 2);                     // rows 2, 3 of this step
-            else load_b(c + 1, a - 2);                      // rows 0, 1 of the next one
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        stage(ra_next);                                     // chunk c + 1 (requested one step ago) into the image the fragments have left
+    auto relu4 = [](const float4& a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); };
+    auto vrow = [&](const float4 (&T)[4], int b) {                  // one element of a row of V = T B
+        return b == 0 ? sub4(T[0], T[2]) : b == 1 ? add4(T[1], T[2]) : b == 2 ? sub4(T[2], T[1]) : sub4(T[1], T[3]);
     };
 
-    load_a(c_begin, ra0);
-    load_a(c_begin + 1, ra1);
-    stage(ra0);
+    float4 V0[4], V1[4];                                            // handed from the fragment phase to the MFMA phase
+    // Fragment phase of step c: this wave's two rows of T = B^T d from the staged image, then its two rows of V = T B.  (The MFMA
+    // phase carries no vector arithmetic at all: next to f32 32x32 MFMAs, whose accumulators travel through the same register
+    // ports, every vector instruction of the same wave measurably delays the matrix pipe.)
+    auto frag_phase = [&](int c, auto hh) {
+        constexpr int HH = decltype(hh)::value;
+        const int cur = img0 + ((c - c_begin) & 1) * WIMG + fb;
+        float4 Ta[4], Tb[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int co = ((j & 1) * WSUB + (j >> 1) * 2) * 4;
+            float4 e[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                e[k] = *reinterpret_cast<const float4*>(&Ls[cur + ((((HH + k) & 1) * 2) * WSUB + ((HH + k) >> 1) * WSUBROW) * 4 + co]);
+                if (IN_RELU) e[k] = relu4(e[k]);
+            }
+            if (HH == 0) { Ta[j] = sub4(e[0], e[2]); Tb[j] = add4(e[1], e[2]); }       // rows 0, 1: d0 - d2, d1 + d2
+            else { Ta[j] = sub4(e[1], e[0]); Tb[j] = sub4(e[0], e[2]); }               // rows 2, 3: d2 - d1, d1 - d3
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++) { V0[b] = vrow(Ta, b); V1[b] = vrow(Tb, b); }
+    };
+    // MFMA phase of step c: 2 rows x 4 positions x 4 components, component-major within a row (consecutive MFMAs into different
+    // accumulators); each row's weight fragments are re-requested for step c + 1 as soon as the row is done.
+#define USC_WROW(AR, V, COMP)                                                                                                    \
+        acc[AR * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].COMP, bf[AR][0].COMP, acc[AR * 4 + 0], 0, 0, 0);             \
+        acc[AR * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].COMP, bf[AR][1].COMP, acc[AR * 4 + 1], 0, 0, 0);             \
+        acc[AR * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].COMP, bf[AR][2].COMP, acc[AR * 4 + 2], 0, 0, 0);             \
+        acc[AR * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].COMP, bf[AR][3].COMP, acc[AR * 4 + 3], 0, 0, 0);
+    auto mfma_phase = [&](int c) {
+        __builtin_amdgcn_s_setprio(1);
+        USC_WROW(0, V0, x) USC_WROW(0, V0, y) USC_WROW(0, V0, z) USC_WROW(0, V0, w)
+        load_b(c + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        USC_WROW(1, V1, x) USC_WROW(1, V1, y) USC_WROW(1, V1, z) USC_WROW(1, V1, w)
+        load_b(c + 1, 1);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    issue_a(c_begin);
+    wait_vm0();
+    __syncthreads();
     WINO_STAMP(1);
-    int c = c_begin;
-    for (; c + 1 < c_end; c += 2) {
-        step(c, ra1, ra0);
-        step(c + 1, ra0, ra1);
+    WINO_PH(1);
+    // Phase ph: the h = 0 wave runs half-phase k = ph, the h = 1 wave k = ph - 1; even k = fragment phase, odd k = MFMA phase of
+    // step k >> 1.  The image of local step s is requested during phase 2s - 2 by both waves (its LDS image was last read in phase
+    // 2s - 3): by the h = 0 wave when its fragment phase has read image s - 1, by the h = 1 wave at the start of its MFMA phase;
+    // it is read in phases 2s (h = 0) and 2s + 1 (h = 1), each wave waiting for its own requests in front of its own reads (the
+    // compiler places that wait) and the phase barrier in between publishing them to the partner.  Every wave of the workgroup
+    // runs nmax steps (the planner only splits K evenly; a wave without a unit multiplies zeros): no state of the loop is
+    // modified under a condition, which is what lets the compiler keep the accumulators in place.
+    if (h == 0) {
+        const std::integral_constant<int, 0> H0;
+        for (int s = 0; s < nmax; s++) {
+            const int c = c_begin + s;
+            WINO_PH(2 + 4 * s);
+            frag_phase(c, H0);
+            if (s + 1 < nmax) issue_a(c + 1);
+            WINO_PH(3 + 4 * s);
+            phase_barrier();
+            WINO_PH(4 + 4 * s);
+            mfma_phase(c);
+            WINO_PH(5 + 4 * s);
+            phase_barrier();
+        }
+        WINO_PH(14);
+    } else {
+        const std::integral_constant<int, 1> H1;
+        if (nmax > 1) issue_a(c_begin + 1);
+        phase_barrier();
+        WINO_PH(2);
+        frag_phase(c_begin, H1);
+        WINO_PH(3);
+        phase_barrier();
+        for (int s = 1; s < nmax; s++) {
+            const int c = c_begin + s;
+            if (s + 1 < nmax) issue_a(c + 1);
+            WINO_PH(4 * s);
+            mfma_phase(c - 1);
+            WINO_PH(1 + 4 * s);
+            phase_barrier();
+            WINO_PH(2 + 4 * s);
+            frag_phase(c, H1);
+            WINO_PH(3 + 4 * s);
+            phase_barrier();
+        }
+        WINO_PH(4 * nmax);
+        mfma_phase(c_begin + nmax - 1);
+        WINO_PH(14);
     }
-    if (c < c_end) step(c, ra1, ra0);          // odd count: the trailing requests are out of range (zeros, no traffic)
+#undef USC_WROW
     WINO_STAMP(2);
 
-    // ---- output transform (elementwise over the accumulators): Y = A^T M A, phases (i, j) -> pixel (2 ty + i, 2 tx + j),
-    // two phases (i = 0, 1 of one j) at a time through the LDS image, then the fused epilogue: lane -> (4 tiles 8 apart, 4 channels)
-    float* const T = Aw;
+    // ---- output transform of this wave's rows: partial sums of the phases (i, j) -> pixel (2 ty + i, 2 tx + j).
+    // A^T = [1 1 1 0; 0 1 -1 -1]: rows a = 0, 1 give Y0 += s0 + s1, Y1 += s1; rows a = 2, 3 give Y0 += s2, Y1 -= s2 + s3.
+    f32x16 Yp[4];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const f32x16 s0 = j == 0 ? acc[0] + acc[1] + acc[2] : acc[1] - acc[2] - acc[3];
+        const f32x16 s1 = j == 0 ? acc[4] + acc[5] + acc[6] : acc[5] - acc[6] - acc[7];
+        const f32x16 t = s0 + s1;
+        if (h == 0) { Yp[j] = t; Yp[2 + j] = s1; }
+        else { Yp[j] = s0; Yp[2 + j] = -t; }
+    }
+    WINO_STAMP(3);
+    // ---- the group of this block x channel group: G = 2 KW waves (member m = 2 kg + h); member m finishes registers
+    // [m NR, (m + 1) NR) of every phase.  Register r of lane l is tile (ty, tx) = (r >> 2, (r & 3) + 4 (l >> 5)), channel l & 31:
+    // everything about a register's pixel is wave-uniform except the 8-pixel step of the upper half-wave, so addresses are one
+    // lane offset per tensor plus a scalar offset per (register, phase).
+    constexpr int G = 2 * KW, NR = 16 / G;
+    const int me = 2 * kg + h;
+    const int ubase = (sub / KW) * KW;                              // first pair of the group
     const int out_ld = d.out_ld > 0 ? d.out_ld : d.Cout;
-    const int out_bytes = d.OHf * d.OWf * d.Cout * 4;
-    const int erow = lane >> 3, ec4 = (lane & 7) * 4;
-    const int n = nb0 + ec4, nb4 = n * 4;
+    const int n = nb0 + (lane & 31), lh = lane >> 5;
     const bool has_r1 = d.res1 != nullptr, has_r2 = d.res2 != nullptr, has_aff = d.scale != nullptr;
-    const bool writer = kg == 0 && live;
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, d.OHf * d.OWf * out_ld * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(d.res1), 0, has_r1 ? (d.OHf >> d.res1_shift) * (d.OWf >> d.res1_shift) * d.Cout * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.res2), 0, has_r2 ? out_bytes : 0, 0x00020000);
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bias;
-    if (d.bias) bias = *reinterpret_cast<const float4*>(d.bias + n);
-    if (has_aff) { sc = *reinterpret_cast<const float4*>(d.scale + n); sh = *reinterpret_cast<const float4*>(d.shift + n); }
-    // activation without branches: negative inputs are multiplied by `slope` (1: none, 0.2 / 0.01: leaky) or replaced by +0 (ReLU)
-    const float slope = d.act == USC_ACT_LEAKY ? 0.2f : d.act == USC_ACT_LEAKY01 ? 0.01f : 1.f;
-    const bool relu = d.act == USC_ACT_RELU;
+    const __amdgpu_buffer_rsrc_t r2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.res2), 0, has_r2 ? d.OHf * d.OWf * d.Cout * 4 : 0, 0x00020000);
+    const float bias = d.bias ? d.bias[n] : 0.f;
+    const float sc = has_aff ? d.scale[n] : 1.f, sh = has_aff ? d.shift[n] : 0.f;
+    // activation without branches: max(x, slope x) with slope = 1 (none), 0.2 / 0.01 (leaky), 0 (ReLU)
+    const float slope = d.act == USC_ACT_LEAKY ? 0.2f : d.act == USC_ACT_LEAKY01 ? 0.01f : d.act == USC_ACT_RELU ? 0.f : 1.f;
+    const int vo_out = (8 * lh * out_ld + n) * 4;                   // lane parts of the byte offsets
+    const int vo_r2 = (8 * lh * d.Cout + n) * 4;
+    const int vo_r1 = ((8 >> d.res1_shift) * lh * d.Cout + n) * 4;
+    WINO_STAMP(4);
+    const bool interior = live && 8 * by + 8 <= H && 16 * bx + 16 <= W;
+    const bool plain = !has_r1 && !has_r2 && !has_aff;
+    const std::true_type yes;
+    const std::false_type no;
+    if constexpr (KW == 1) {
+        // The group is the pair: wave h finishes the two phases of output row parity i = h in full (32 values per lane), its
+        // partials of the other two phases go to the partner through LDS ([wave][8 quads of registers][lane][4] floats, 8 KB per
+        // wave) - one exchange, one barrier.  h0's partial + h1's partial, as in the general scheme (addition commutes).
+        auto finish_pair = [&](auto hh, auto full_c, auto edge_c) {
+            constexpr int HH = decltype(hh)::value;
+            constexpr bool FULL = decltype(full_c)::value, EDGE = decltype(edge_c)::value;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        f32x16 t0, t1, t2, t3;                              // tmp[a] = (M A)[a][j]
-        if (j == 0) { t0 = acc[0] + acc[1] + acc[2]; t1 = acc[4] + acc[5] + acc[6]; t2 = acc[8] + acc[9] + acc[10]; t3 = acc[12] + acc[13] + acc[14]; }
-        else { t0 = acc[1] - acc[2] - acc[3]; t1 = acc[5] - acc[6] - acc[7]; t2 = acc[9] - acc[10] - acc[11]; t3 = acc[13] - acc[14] - acc[15]; }
-        const f32x16 ya = t0 + t1 + t2, yb = t1 - t2 - t3;   // i = 0, 1
-        // residuals of the eight (i, ps) stores of this pair of phases: requested together, before the tile goes through LDS
-        int oo8[8];
-        u32x4 r1u[8], r2u[8];
-        if (writer) {
+            for (int jj = 0; jj < 2; jj++)
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int i = q >> 2, ps = q & 3;
-                const int t = ps * 8 + erow;
-                const int oy = 2 * (4 * by + (t >> 3)) + i, ox = 2 * (8 * bx + (t & 7)) + j;
-                const bool ok = oy < H && ox < W;
-                const int Y = img * H + oy;
-                const int opix = Y * W + ox;
-                oo8[q] = ok ? (opix * out_ld + d.out_c0) * 4 + nb4 : INVALID;
-                if (has_r1) r1u[q] = __builtin_amdgcn_raw_buffer_load_b128(
-                    r1_rsrc, ok ? ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (ox >> d.res1_shift)) * d.Cout * 4 + nb4 : INVALID, 0, 0);
-                if (has_r2) r2u[q] = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, ok ? opix * d.Cout * 4 + nb4 : INVALID, 0, 0);
+                for (int qd = 0; qd < 4; qd++) {
+                    const f32x16& y = Yp[2 * (1 - HH) + jj];
+                    *reinterpret_cast<float4*>(&Ls[((wave * 8 + jj * 4 + qd) * 64 + lane) * 4]) = make_float4(y[4 * qd], y[4 * qd + 1], y[4 * qd + 2], y[4 * qd + 3]);
+                }
+            float r1p[2][16], r2p[2][16];
+            if (FULL) {
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int oy = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)) + HH), ox = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3) + jj);
+                        const bool ok = live && oy < H && ox + 8 * lh < W;
+                        const int Y = img * H + oy;
+                        const int s1o = __builtin_amdgcn_readfirstlane(((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (ox >> d.res1_shift)) * d.Cout * 4);
+                        const int s2o = __builtin_amdgcn_readfirstlane(((Y * W + ox) * d.Cout) * 4);
+                        r1p[jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1_rsrc, ok ? vo_r1 : INVALID, s1o, 0));
+                        r2p[jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2_rsrc, ok ? vo_r2 : INVALID, s2o, 0));
+                    }
             }
+            __syncthreads();
+            WINO_STAMP(5);
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                for (int qd = 0; qd < 4; qd++) {
+                    const float4 u = *reinterpret_cast<const float4*>(&Ls[(((wave ^ 4) * 8 + jj * 4 + qd) * 64 + lane) * 4]);
+                    const float uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int r = 4 * qd + e;
+                        float x = Yp[2 * HH + jj][r] + uu[e] + bias;
+                        if (FULL) x += r1p[jj][r];
+                        x = fmaxf(x, x * slope);
+                        if (FULL) { x = x * sc + sh; x += r2p[jj][r]; }
+                        const int oy = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)) + HH), ox = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3) + jj);
+                        const int so = __builtin_amdgcn_readfirstlane((((img * H + oy) * W + ox) * out_ld + d.out_c0) * 4);
+                        int vo = vo_out;
+                        if (EDGE) vo = (live && oy < H && ox + 8 * lh < W) ? vo_out : INVALID;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), out_rsrc, vo, so, 0);
+                    }
+                }
+        };
+        const std::integral_constant<int, 0> H0e;
+        const std::integral_constant<int, 1> H1e;
+        if (h == 0) {
+            if (plain) { if (interior) finish_pair(H0e, no, no); else finish_pair(H0e, no, yes); }
+            else { if (interior) finish_pair(H0e, yes, no); else finish_pair(H0e, yes, yes); }
+        } else {
+            if (plain) { if (interior) finish_pair(H1e, no, no); else finish_pair(H1e, no, yes); }
+            else { if (interior) finish_pair(H1e, yes, no); else finish_pair(H1e, yes, yes); }
         }
-        if (KW > 1 && j > 0) __syncthreads();                // K group 0 has read the previous pair of phases
+    } else {
+    // ---- K groups: G = 2 KW waves (member m = 2 kg + h); member m finishes registers [m NR, (m + 1) NR) of every phase, in four
+    // rounds (one per phase) through two alternating exchange regions.
+    // ALL residual values of the four rounds are requested before the first store is issued: loads and stores share one
+    // in-order counter, a load waited for after a store would wait for that store's round trip.
+    int oyq[NR], oxq[NR], so0[NR];
+    float r1v[4][NR], r2v[4][NR];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            T[row * APITCH + (lane & 31)] = ya[r];
-            T[32 * APITCH + row * APITCH + (lane & 31)] = yb[r];
-        }
-        if (KW > 1) __syncthreads();
-        if (!writer) continue;
+    for (int q = 0; q < NR; q++) {
+        const int r = me * NR + q;
+        oyq[q] = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)));
+        oxq[q] = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3));
+        so0[q] = __builtin_amdgcn_readfirstlane((((img * H + oyq[q]) * W + oxq[q]) * out_ld + d.out_c0) * 4);
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int i = q >> 2, ps = q & 3;
-            const int t = ps * 8 + erow;
-            float4 tv = *reinterpret_cast<const float4*>(&T[i * 32 * APITCH + t * APITCH + ec4]);
-#pragma unroll
-            for (int k = 1; k < KW; k++) {                   // slice order
-                const float4 u = *reinterpret_cast<const float4*>(&Ws[wave + k][i * 32 * APITCH + t * APITCH + ec4]);
-                tv.x += u.x; tv.y += u.y; tv.z += u.z; tv.w += u.w;
-            }
-            float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f), r2 = r1;
-            if (has_r1) r1 = *reinterpret_cast<const float4*>(&r1u[q]);
-            if (has_r2) r2 = *reinterpret_cast<const float4*>(&r2u[q]);
-            float v[4] = {tv.x + bias.x, tv.y + bias.y, tv.z + bias.z, tv.w + bias.w};
-            const float a1[4] = {r1.x, r1.y, r1.z, r1.w}, a2[4] = {r2.x, r2.y, r2.z, r2.w};
-            const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                float x = v[e] + a1[e];
-                const float neg = relu ? 0.f : x * slope;
-                x = x > 0.f ? x : neg;
-                if (has_aff) x = x * s4[e] + h4[e];
-                v[e] = x + a2[e];
-            }
-            const float4 o = make_float4(v[0], v[1], v[2], v[3]);
-            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), out_rsrc, oo8[q], 0, 0);
-        }
+        for (int rd = 0; rd < 4; rd++) { r1v[rd][q] = 0.f; r2v[rd][q] = 0.f; }
     }
-    WINO_STAMP(3);
+    if (has_r1) {
+#pragma unroll
+        for (int q = 0; q < NR; q++)
+#pragma unroll
+            for (int rd = 0; rd < 4; rd++) {
+                const int i = rd >> 1, j = rd & 1;
+                const bool ok = live && oyq[q] + i < H && oxq[q] + 8 * lh + j < W;
+                const int Y = img * H + oyq[q] + i;
+                const int so = __builtin_amdgcn_readfirstlane(((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + ((oxq[q] + j) >> d.res1_shift)) * d.Cout * 4);
+                r1v[rd][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1_rsrc, ok ? vo_r1 : INVALID, so, 0));
+            }
+    }
+    if (has_r2) {
+#pragma unroll
+        for (int q = 0; q < NR; q++)
+#pragma unroll
+            for (int rd = 0; rd < 4; rd++) {
+                const int i = rd >> 1, j = rd & 1;
+                const bool ok = live && oyq[q] + i < H && oxq[q] + 8 * lh + j < W;
+                const int so = __builtin_amdgcn_readfirstlane((((img * H + oyq[q] + i) * W + oxq[q] + j) * d.Cout) * 4);
+                r2v[rd][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2_rsrc, ok ? vo_r2 : INVALID, so, 0));
+            }
+    }
+    // Exchange layout of a round: [wave][quad of registers][lane][4] floats - b128 writes and reads, lane-contiguous.  The
+    // rounds exist in four variants: with / without the residual + affine arithmetic, and for blocks that lie wholly inside the
+    // image (no per-lane validity) or not - ~7 instead of ~18 instructions per stored value in the common case.
+    auto rounds = [&](auto full_c, auto edge_c) {
+        constexpr bool FULL = decltype(full_c)::value, EDGE = decltype(edge_c)::value;
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++) {
+            const int i = rd >> 1, j = rd & 1;
+            float* const reg = Ls + (rd & 1) * WREGION;
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++)
+                *reinterpret_cast<float4*>(&reg[((wave * 4 + qd) * 64 + lane) * 4]) =
+                    make_float4(Yp[rd][4 * qd], Yp[rd][4 * qd + 1], Yp[rd][4 * qd + 2], Yp[rd][4 * qd + 3]);
+            __syncthreads();
+            float v[NR];
+#pragma unroll
+            for (int q = 0; q < NR; q++) v[q] = 0.f;
+#pragma unroll
+            for (int m = 0; m < G; m++) {                         // fixed order: K group major, position half minor
+                const int w2 = (m & 1) * 4 + ubase + (m >> 1);
+                if constexpr (NR >= 4) {
+#pragma unroll
+                    for (int blk = 0; blk < NR / 4; blk++) {
+                        const float4 u = *reinterpret_cast<const float4*>(&reg[((w2 * 4 + me * (NR / 4) + blk) * 64 + lane) * 4]);
+                        v[4 * blk] += u.x; v[4 * blk + 1] += u.y; v[4 * blk + 2] += u.z; v[4 * blk + 3] += u.w;
+                    }
+                } else {
+                    const float2 u = *reinterpret_cast<const float2*>(&reg[((w2 * 4 + (me >> 1)) * 64 + lane) * 4 + 2 * (me & 1)]);
+                    v[0] += u.x; v[1] += u.y;
+                }
+            }
+            const int pdelta = (i * W + j) * out_ld * 4;
+#pragma unroll
+            for (int q = 0; q < NR; q++) {
+                float x = v[q] + bias;
+                if (FULL) x += r1v[rd][q];
+                x = fmaxf(x, x * slope);
+                if (FULL) { x = x * sc + sh; x += r2v[rd][q]; }
+                int vo = vo_out;
+                if (EDGE) vo = (live && oyq[q] + i < H && oxq[q] + 8 * lh + j < W) ? vo_out : INVALID;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), out_rsrc, vo, so0[q] + pdelta, 0);
+            }
+            if (rd == 0) WINO_STAMP(5);
+        }
+    };
+    if (plain) { if (interior) rounds(no, no); else rounds(no, yes); }
+    else { if (interior) rounds(yes, no); else rounds(yes, yes); }
+    }
+    WINO_STAMP(6);
+    WINO_PH(15);
 }
 
 // Second half of a split-K layer: sum the K slices in a fixed order (deterministic), then the fused epilogue.
@@ -738,14 +874,23 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
             const long long wt_plan = (long long)plan_batch * ((TH + 3) / 4) * ((TW + 7) / 8) * (d.Cout / 32);
             const long long wt = (long long)nbatch * ((TH + 3) / 4) * ((TW + 7) / 8) * (d.Cout / 32);
             const int nsteps = d.Cin / 8;
-            int kw = 1;                                       // K groups: fill the chip's 1024 SIMDs (one wave per SIMD)
-            if (wt_plan < 768 && nsteps >= 2) kw = 2;
-            if (wt_plan * 2 < 768 && nsteps >= 4) kw = 4;
-            if (g_force_kw == 1 || g_force_kw == 2 || g_force_kw == 4) kw = g_force_kw <= nsteps ? g_force_kw : 1;
-            // one wave per SIMD and one workgroup per CU: a grid of 257 ... ~700 workgroups would run a second, mostly empty round;
-            // small maps stay with the direct kernel (16 K groups, grid splits)
-            const long long wgs_plan = (wt_plan * kw + 3) / 4;
-            const bool worth = (wgs_plan >= 192 && wgs_plan <= 256) || wgs_plan >= 768;
+            // K groups: a unit (block x channel group x K group) is two waves, a workgroup 4 units, a CU holds one workgroup.
+            // K is only split evenly (every wave of a workgroup runs the same number of steps).  Cost model in microseconds,
+            // fitted to profiles/r02/unet_layer_table.md and schp_layers.txt: a round of workgroups costs 6.5 (launch ramp, first
+            // loads, output transform + exchange + stores) + 2.45 per K step (two MFMA phases of 32 on every SIMD); the direct
+            // kernel 6 + flops / 118 TFLOP/s + output bytes / 3 TB/s (its epilogue is exposed when K is short).  All inputs are
+            // plan quantities.
+            int kw = 1;
+            double wino_us = 1e30;
+            for (int k = 1; k <= 4; k *= 2) {
+                if (nsteps % k) continue;
+                const long long wgs = (wt_plan * k + 3) / 4;
+                const double t = (double)((wgs + 255) / 256) * (6.5 + (nsteps / k) * 2.45);
+                if (t < wino_us - 1e-9) { wino_us = t; kw = k; }
+            }
+            if (g_force_kw == 1 || g_force_kw == 2 || g_force_kw == 4) kw = (nsteps % g_force_kw == 0) ? g_force_kw : 1;
+            const double direct_us = 6.0 + 2.0 * (double)m_plan * d.Cout * 9.0 * d.Cin / 118e6 + (double)m_plan * d.Cout * 4.0 / 3e6;
+            const bool worth = wino_us < direct_us;
             if (worth || g_force_wino == 1) {
                 p.wino = true;
                 p.kw = kw;
@@ -753,7 +898,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
                 p.d.nphase = 1;
                 const long long waves = wt * kw;
                 p.grid = dim3((unsigned)((waves + 3) / 4));
-                p.block = dim3(256);
+                p.block = dim3(512);                              // 4 units x 2 position halves
 #define USC_PICKW(KWV) (d.in_relu ? (void*)conv_wino_kernel<KWV, true> : (void*)conv_wino_kernel<KWV, false>)
                 p.fn = kw == 4 ? USC_PICKW(4) : kw == 2 ? USC_PICKW(2) : USC_PICKW(1);
 #undef USC_PICKW
