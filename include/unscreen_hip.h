@@ -228,13 +228,15 @@ int usc_regionfill_u8(const uint8_t* img, const uint8_t* mask, int H, int W, uin
 
 /* remove_invalid_objects on the device (unscreen/utils/maskprocess.py:77-152) - no border following, no host round trip:
  * connected-component labels + per-crack shoelace terms + containment-tree sums (csrc/usc_objects.hip).  alpha is modified
- * in place; seg may be NULL (consensus against alpha itself); (center_y, center_x) = the score map's centre as ratios
+ * in place when src is NULL (or == alpha); otherwise alpha receives the filtered copy of src, which stays untouched (the copy
+ * rides on the first scan: the reference's `alpha = remove_invalid_objects(cfg, alphaor.copy())` pattern without a pass of
+ * its own).  seg may be NULL (consensus against alpha itself); (center_y, center_x) = the score map's centre as ratios
  * (build_score_map, maskprocess.py:181-189: landscape / portrait entry of cfg) - the map itself (maskprocess.py:155-178) is
  * evaluated per pixel inside the kernels, and its sums are kept in integer fixed point: results are the same on every run.
  * usc_score_map_f64 builds the map as a float64 table (tests; ws8 = 8 bytes of device scratch). */
 int usc_score_map_f64(int H, int W, double center_y, double center_x, double* out, void* ws8, usc_stream_t stream);
 size_t usc_remove_invalid_objects_ws_bytes(int H, int W);
-int usc_remove_invalid_objects_u8(uint8_t* alpha, const uint8_t* seg, int H, int W, double center_y, double center_x,
+int usc_remove_invalid_objects_u8(const uint8_t* src, uint8_t* alpha, const uint8_t* seg, int H, int W, double center_y, double center_x,
                                   double saliency_thr, double consensus_thr, void* ws, size_t ws_bytes, usc_stream_t stream);
 
 /* Overall background of a clip (tools/unscreen/bg_offline.py:99-130; the stage is switched off with `if 0:` in the reference).

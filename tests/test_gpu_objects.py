@@ -32,6 +32,10 @@ def _check(nv, oracle_lib, flt, alpha, seg, thr):
     want = oracle_lib.remove_invalid_objects(cfg, alpha.copy(), None if seg is None else seg.copy())
     got = flt(dev(alpha), None if seg is None else dev(seg), center, thr, 0.5).cpu().numpy()
     assert np.array_equal(got, want), f"{(H, W)} thr {thr}: {(got != want).sum()} px differ"
+    # the same through the "filtered copy of src" form: src untouched, the destination's previous content irrelevant
+    src, dst = dev(alpha), torch.full(alpha.shape, 173, dtype=torch.uint8, device="cuda")
+    got2 = flt(dst, None if seg is None else dev(seg), center, thr, 0.5, src=src)
+    assert got2 is dst and np.array_equal(dst.cpu().numpy(), want) and np.array_equal(src.cpu().numpy(), alpha)
     return want
 
 

@@ -78,7 +78,7 @@ _SIGNATURES = {
     "usc_regionfill_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_double, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "usc_score_map_f64": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, _vp, _vp, _vp]),
     "usc_remove_invalid_objects_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
-    "usc_remove_invalid_objects_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _vp, C.c_size_t, _vp]),
+    "usc_remove_invalid_objects_u8": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _vp, C.c_size_t, _vp]),
     "usc_upsample_taps_accum_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "usc_conv_force_plan": (None, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "usc_conv_force_winograd": (None, [C.c_int]),
@@ -717,15 +717,17 @@ class DeviceObjectFilter:
             self._score[key] = out
         return self._score[key]
 
-    def __call__(self, alpha, seg, center, saliency_thr, consensus_thr):
-        """alpha (H, W) uint8 CUDA, modified in place and returned; seg (H, W) uint8 CUDA or None."""
+    def __call__(self, alpha, seg, center, saliency_thr, consensus_thr, src=None):
+        """alpha (H, W) uint8 CUDA, modified in place and returned; seg (H, W) uint8 CUDA or None.  With src (same shape), alpha
+        becomes the filtered copy of src and src stays as it is."""
         H, W = alpha.shape
         pa = _dev_u8(alpha, "remove_invalid_objects.alpha")
+        psrc = _dev_u8(src, "remove_invalid_objects.src", (H, W)) if src is not None else None
         ps = _dev_u8(seg, "remove_invalid_objects.seg", (H, W)) if seg is not None else None
         need = load().usc_remove_invalid_objects_ws_bytes(H, W)
         if self._ws is None or self._ws.numel() < need or self._ws.device != alpha.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=alpha.device)
-        _check(load().usc_remove_invalid_objects_u8(pa, ps, H, W, float(center[0]), float(center[1]), float(saliency_thr), float(consensus_thr),
+        _check(load().usc_remove_invalid_objects_u8(psrc, pa, ps, H, W, float(center[0]), float(center[1]), float(saliency_thr), float(consensus_thr),
                                                     self._ws.data_ptr(), self._ws.numel(), _stream()), "usc_remove_invalid_objects_u8")
         return alpha
 

@@ -128,13 +128,19 @@ __device__ __forceinline__ int sums_slot(BlockSums& t, int c) {          // -1: 
 }  // namespace
 
 // Bounding box of alpha != 0 (maxima of H - y, W - x, y + 1, x + 1; hdr zeroed by the caller)
-__global__ __launch_bounds__(256) void obj_bbox_kernel(const uint8_t* __restrict__ alpha, int H, int W, int* __restrict__ hdr) {
+// (`copy_to`: the scan also deposits the mask there - the caller's "filter a copy of src" costs no pass of its own)
+__global__ __launch_bounds__(256) void obj_bbox_kernel(const uint8_t* __restrict__ alpha, uint8_t* __restrict__ copy_to, int H, int W,
+                                                       int* __restrict__ hdr) {
     const int n = H * W;
     int m0 = 0, m1 = 0, m2 = 0, m3 = 0;
     for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += gridDim.x * blockDim.x * 16) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (i + 16 <= n && ((reinterpret_cast<uintptr_t>(alpha) + i) & 15) == 0) v = *reinterpret_cast<const uint4*>(alpha + i);
         else { uint8_t* pv = reinterpret_cast<uint8_t*>(&v); for (int k = 0; k < 16 && i + k < n; k++) pv[k] = alpha[i + k]; }
+        if (copy_to) {
+            if (i + 16 <= n && ((reinterpret_cast<uintptr_t>(copy_to) + i) & 15) == 0) *reinterpret_cast<uint4*>(copy_to + i) = v;
+            else { const uint8_t* pv = reinterpret_cast<const uint8_t*>(&v); for (int k = 0; k < 16 && i + k < n; k++) copy_to[i + k] = pv[k]; }
+        }
         if ((v.x | v.y | v.z | v.w) == 0) continue;
         const uint8_t* pv = reinterpret_cast<const uint8_t*>(&v);
         for (int k = 0; k < 16; k++) {
@@ -461,8 +467,9 @@ extern "C" size_t usc_remove_invalid_objects_ws_bytes(int H, int W) {
     return 256 + 2 * al256(np * sizeof(int)) + al256((size_t)comp_cap(H, W) * sizeof(Comp));
 }
 
-extern "C" int usc_remove_invalid_objects_u8(uint8_t* alpha, const uint8_t* seg, int H, int W, double center_y, double center_x,
+extern "C" int usc_remove_invalid_objects_u8(const uint8_t* src, uint8_t* alpha, const uint8_t* seg, int H, int W, double center_y, double center_x,
                                              double saliency_thr, double consensus_thr, void* ws, size_t ws_bytes, usc_stream_t stream) {
+    if (src == alpha) src = nullptr;
     if (!alpha || !ws || H <= 0 || W <= 0) return fail(USC_E_ARG, "usc_remove_invalid_objects_u8: bad argument");
     if ((long long)(H + 2) * (W + 2) >= (1ll << 30)) return fail(USC_E_UNSUPPORTED, "usc_remove_invalid_objects_u8: image too large");
     if (ws_bytes < usc_remove_invalid_objects_ws_bytes(H, W)) return fail(USC_E_WORKSPACE, "usc_remove_invalid_objects_u8: workspace too small");
@@ -473,7 +480,7 @@ extern "C" int usc_remove_invalid_objects_u8(uint8_t* alpha, const uint8_t* seg,
     int* lab = reinterpret_cast<int*>(base + 256);
     int* cid = reinterpret_cast<int*>(base + 256 + al256((size_t)np * sizeof(int)));
     Comp* comps = reinterpret_cast<Comp*>(base + 256 + 2 * al256((size_t)np * sizeof(int)));
-    if (!seg) seg = alpha;                                  // consensus against the input itself: alpha is only written by the last kernel
+    if (!seg) seg = src ? src : alpha;                      // consensus against the input itself: alpha is only written by the last kernel
     // the score map is evaluated per pixel where it is needed (closed form, maskprocess.py:155-178); its normalising maximum sits
     // at a corner of the image and is computed here with the same float64 operations
     const int cy = (int)(H * center_y), cx = (int)(W * center_x);
@@ -481,7 +488,7 @@ extern "C" int usc_remove_invalid_objects_u8(uint8_t* alpha, const uint8_t* seg,
     for (int k = 0; k < 4; k++) smax = fmax(smax, score_raw((k & 1) ? H - 1 : 0, (k & 2) ? W - 1 : 0, H, W, cy, cx));
     if (hipMemsetAsync(hdr, 0, 256, st) != hipSuccess) return fail(USC_E_LAUNCH, "usc_remove_invalid_objects_u8: memset failed");
     const dim3 b(256), gp(grid_for((size_t)np, 256)), gn(grid_for((size_t)H * W, 256)), gk(64);
-    hipLaunchKernelGGL(obj_bbox_kernel, dim3(grid_for((size_t)(H * W + 15) / 16, 256)), b, 0, st, alpha, H, W, hdr);
+    hipLaunchKernelGGL(obj_bbox_kernel, dim3(grid_for((size_t)(H * W + 15) / 16, 256)), b, 0, st, src ? src : alpha, src ? alpha : (uint8_t*)nullptr, H, W, hdr);
     hipLaunchKernelGGL(obj_runs_kernel, dim3((W + 2 + 255) / 256, H + 2), b, 0, st, alpha, H, W, hdr, lab);
     hipLaunchKernelGGL(obj_merge_kernel, gp, b, 0, st, alpha, H, W, hdr, lab);
     hipLaunchKernelGGL(obj_flatten_kernel, gp, b, 0, st, alpha, H, W, hdr, lab, cid, comps, kcap);

@@ -148,8 +148,8 @@ class BgStepPipeline:
             slot.copied.record()
 
     def _front_filter_device(self, slot):
-        slot.alphaor.copy_(slot.gate)                      # the gate itself stays: it is alpha_pre of the first frame
-        self.dfilter(slot.alphaor, None, self.center, self.sal_thr, self.cons_thr)
+        # alphaor = filtered copy of the gate; the gate itself stays (it is alpha_pre of the first frame)
+        self.dfilter(slot.alphaor, None, self.center, self.sal_thr, self.cons_thr, src=slot.gate)
         nv.trimap(slot.alphaor, self.long_side, self.ksize, self.iters, out=slot.trimap, ws=self.ws_trimap)
         slot.ready.record()
 

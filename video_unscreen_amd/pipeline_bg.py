@@ -79,8 +79,8 @@ class BgOnlinePipeline:
         return int(nv.count_ge(mask, 128, out=self._cnt).item()) > self.cfg["fg_exist_thr"] * self.H * self.W
 
     def _object_filter(self, mask):
-        return self.filter(mask.clone(), None, self.center, self.cfg["objectremoval"]["saliency_thr"],
-                           self.cfg["objectremoval"]["consensus_thr"])
+        return self.filter(torch.empty_like(mask), None, self.center, self.cfg["objectremoval"]["saliency_thr"],
+                           self.cfg["objectremoval"]["consensus_thr"], src=mask)        # filtered copy; the copy rides on the first scan
 
     def step(self, frame, passes=2):
         """frame (H, W, 3) uint8 BGR CUDA -> dict(segmask, alpha, fg, bg, + the intermediates of every stage).

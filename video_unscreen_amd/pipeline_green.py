@@ -72,8 +72,8 @@ class GreenPipeline:
             # the fitted background colour is known on the host; only the agent's early-outs hand back an image of their own
             bg_color = self.cfagent.last_bg_color if self.cfagent.last_bg_color is not None else bgimg[0, 0].cpu().numpy()
             # object filter on the device (labels, no border following): consensus against segmask unless tracking
-            alphaor = self.filter(alphacf.clone(), None if tracking else segmask, self.center, cfg["objectremoval"]["saliency_thr"],
-                                  cfg["objectremoval"]["consensus_thr"])
+            alphaor = self.filter(torch.empty_like(alphacf), None if tracking else segmask, self.center, cfg["objectremoval"]["saliency_thr"],
+                                  cfg["objectremoval"]["consensus_thr"], src=alphacf)
             # (an empty mask comes back as an all-zero trimap - what generate_trimap_withbg's early return hands on - without
             # asking the host: the kernels decide on device counters)
             trimap = self.trimapagent.forward_device_withbg(alphaor, frame, bg_color)
