@@ -299,8 +299,20 @@ def main():
         else:
             pipe.run(io.inputs(frames_h[first:first + n], bg_always), on_result=io.collect(alpha_h, fg_h))
 
+    def spin_up(seconds=0.25):
+        """The clip is generated and pinned on the CPU for seconds while the GPU idles in a low power state, and W warm-up frames
+        (30 ms at W = 10) do not bring its clocks back: untimed matting forwards on a scratch input do (measured: the same 300
+        timed frames run 3.5 % slower without; nothing here touches the pipeline's state or the frames)."""
+        x = torch.zeros_like(pipe.x7)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(20):
+                pipe.net(x)
+            torch.cuda.synchronize()
+
     def timed(fn_warm, fn):
         pipe.reset()
+        spin_up()
         fn_warm()
         torch.cuda.synchronize()
         if world > 1:

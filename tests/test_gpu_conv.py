@@ -258,12 +258,14 @@ def test_conv_graphs_are_destroyed_for_real(hipnet):
     assert used[-1] <= used[2], used
 
 
-@pytest.mark.parametrize("cin,cout,h,w,batch,kw", [(8, 32, 17, 30, 1, 1), (32, 32, 20, 36, 1, 1), (64, 64, 33, 47, 1, 2),
-                                                    (128, 128, 12, 20, 2, 4), (32, 64, 9, 7, 3, 2), (256, 96, 16, 16, 1, 4),
-                                                    (16, 32, 64, 96, 1, 1)])
-def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw):
+@pytest.mark.parametrize("cin,cout,h,w,batch,kw,dil", [(8, 32, 17, 30, 1, 1, 1), (32, 32, 20, 36, 1, 1, 1), (64, 64, 33, 47, 1, 2, 1),
+                                                        (128, 128, 12, 20, 2, 4, 1), (32, 64, 9, 7, 3, 2, 1), (256, 96, 16, 16, 1, 4, 1),
+                                                        (16, 32, 64, 96, 1, 1, 1), (64, 64, 30, 30, 2, 2, 2), (32, 32, 18, 42, 1, 1, 2),
+                                                        (32, 64, 27, 15, 2, 1, 3)])
+def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw, dil):
     """conv_wino_kernel (Winograd F(2x2, 3x3): 3x3 / stride 1 / pad 1) against torch's float64 convolution: odd sizes (partial
-    tiles and blocks), images stacked along y, K groups, and the full fused epilogue."""
+    tiles and blocks), images stacked along y, K groups, the full fused epilogue, and dilated layers (dil x dil standard
+    convolutions on the pixel-parity sub-images)."""
     from video_unscreen_amd import _native as nv
     g = torch.Generator().manual_seed(cin * 1000 + cout + h)
     x = torch.randn(batch, cin, h, w, generator=g)
@@ -275,6 +277,7 @@ def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw):
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().view(batch * h, w, -1)
     L = _Layer(hipnet)
     taps, wk = hipnet.conv_taps(wt, 1)
+    taps = [(dy * dil, dx * dil) for dy, dx in taps]
     lib = nv.load()
     xin = nhwc(x).cuda()
     for fused in (False, True):
@@ -295,7 +298,7 @@ def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw):
         finally:
             lib.usc_conv_force_winograd(-1)
             lib.usc_conv_force_plan(0, 0, 0, 0)
-        y = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+        y = F.conv2d(x.double(), wt.double(), b.double(), padding=dil, dilation=dil)
         if fused:
             y = y + r1.double()
             y = torch.where(y > 0, y, y * 0.2)

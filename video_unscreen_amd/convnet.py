@@ -78,7 +78,7 @@ class ConvGraphNet:
         d = self.ConvDesc()
         d.inp, d.out = x.data_ptr(), out.data_ptr()
         d.wpk = wpk_buf.data_ptr() if wpk_buf is not None else self._dev(self.pack(wk.float())).data_ptr()
-        if wpk_buf is None and k == 3 and c.stride == 1 and c.dil == 1 and c.pad == 1 and cin_buf % 8 == 0:
+        if wpk_buf is None and k == 3 and c.stride == 1 and c.pad == c.dil and cin_buf % 8 == 0 and IH % c.dil == 0 and IW % c.dil == 0:
             d.wino = self._dev(self.pack_wino(w.float())).data_ptr()     # the library may run the layer in the Winograd form
         d.bias = bias_buf.data_ptr() if bias_buf is not None else self._dev(b).data_ptr()
         d.res1 = res1.data_ptr() if res1 is not None else None

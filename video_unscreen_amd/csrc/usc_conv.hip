@@ -348,8 +348,13 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     WINO_STAMP(0);
     WINO_PH(0);
     const int nnb = d.Cout >> 5;
-    const int nimg = d.batch > 1 ? d.batch : 1;
-    const int H = d.IH, W = d.IW;                                  // per image; output has the same size
+    // Dilation D (taps at +-D): the layer is D x D independent standard convolutions, one per pixel-parity class of the image -
+    // every image counts as D x D virtual images of (IH / D) x (IW / D) pixels whose pixel (y, x) is the real pixel
+    // (y D + py, x D + px).  All geometry below is in virtual-image coordinates; pix() maps to the real pixel index.
+    const int D = d.dx[5];
+    const int nimg = (d.batch > 1 ? d.batch : 1) * D * D;
+    const int H = d.IH / D, W = d.IW / D;                           // per (virtual) image; output has the same size
+    const int WR = d.IW;
     const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
     const int BH = (TH + 3) >> 2, BW = (TW + 7) >> 3;
     const int ntiles = nimg * BH * BW * nnb;                        // blocks x channel groups
@@ -364,6 +369,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     const int img = __builtin_amdgcn_readfirstlane(sb / (BH * BW)), brem = sb - img * (BH * BW);
     const int by = __builtin_amdgcn_readfirstlane(brem / BW), bx = brem - by * BW;
     const int nb0 = __builtin_amdgcn_readfirstlane(nb * 32);
+    const int imr = img / (D * D), par = img - imr * (D * D), pary = par / D;
+    const int pix0 = __builtin_amdgcn_readfirstlane((imr * d.IH + pary) * WR + par - pary * D);      // real pixel index of virtual (0, 0)
+    auto pix = [&](int y, int x) { return pix0 + (y * WR + x) * D; };
     const int nch = d.Cin >> 3;                                     // K steps of 8 input channels
     const int nmax = (nch + KW - 1) / KW;                           // steps of the longest K group: the workgroup's phase count
     const int c_begin = live ? kg * nmax : 0;                       // the planner splits K evenly: nch = KW * nmax
@@ -401,10 +409,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         const int py = 2 * row + (sp >> 1), px = 2 * (q >> 1) + (sp & 1), half = q & 1;
         const int y = y0 + py, x = x0 + px;
         const bool ok = live && sl < 4 * WSUB && q < 18 && y >= 0 && y < H && x >= 0 && x < W;
-        goff[r] = ok ? ((img * H + y) * W + x) * d.Cin * 4 + half * 16 : INVALID;
+        goff[r] = ok ? pix(y, x) * d.Cin * 4 + half * 16 : INVALID;
     }
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(d.in), 0, nimg * H * W * d.Cin * 4, 0x00020000);
+        const_cast<float*>(d.in), 0, (d.batch > 1 ? d.batch : 1) * d.IH * d.IW * d.Cin * 4, 0x00020000);
     const int img0 = sub * 2 * WIMG;                                // the pair's two images (float index into Ls)
     auto issue_a = [&](int c) {                                     // the patch of step c -> image (c - c_begin) & 1
         const int dst = img0 + ((c - c_begin) & 1) * WIMG + 3 * h * 256;
@@ -559,9 +567,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     const float sc = has_aff ? d.scale[n] : 1.f, sh = has_aff ? d.shift[n] : 0.f;
     // activation without branches: max(x, slope x) with slope = 1 (none), 0.2 / 0.01 (leaky), 0 (ReLU)
     const float slope = d.act == USC_ACT_LEAKY ? 0.2f : d.act == USC_ACT_LEAKY01 ? 0.01f : d.act == USC_ACT_RELU ? 0.f : 1.f;
-    const int vo_out = (8 * lh * out_ld + n) * 4;                   // lane parts of the byte offsets
-    const int vo_r2 = (8 * lh * d.Cout + n) * 4;
-    const int vo_r1 = ((8 >> d.res1_shift) * lh * d.Cout + n) * 4;
+    const int vo_out = (8 * lh * D * out_ld + n) * 4;                   // lane parts of the byte offsets
+    const int vo_r2 = (8 * lh * D * d.Cout + n) * 4;
+    const int vo_r1 = ((8 >> d.res1_shift) * lh * D * d.Cout + n) * 4;
     WINO_STAMP(4);
     const bool interior = live && 8 * by + 8 <= H && 16 * bx + 16 <= W;
     const bool plain = !has_r1 && !has_r2 && !has_aff;
@@ -589,9 +597,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                     for (int r = 0; r < 16; r++) {
                         const int oy = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)) + HH), ox = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3) + jj);
                         const bool ok = live && oy < H && ox + 8 * lh < W;
-                        const int Y = img * H + oy;
-                        const int s1o = __builtin_amdgcn_readfirstlane(((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (ox >> d.res1_shift)) * d.Cout * 4);
-                        const int s2o = __builtin_amdgcn_readfirstlane(((Y * W + ox) * d.Cout) * 4);
+                        const int Y = img * H + oy;             // (a half-resolution residual only exists for D = 1: planner)
+                        const int s1o = __builtin_amdgcn_readfirstlane(d.res1_shift ? ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (ox >> d.res1_shift)) * d.Cout * 4
+                                                                                    : pix(oy, ox) * d.Cout * 4);
+                        const int s2o = __builtin_amdgcn_readfirstlane(pix(oy, ox) * d.Cout * 4);
                         r1p[jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1_rsrc, ok ? vo_r1 : INVALID, s1o, 0));
                         r2p[jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2_rsrc, ok ? vo_r2 : INVALID, s2o, 0));
                     }
@@ -612,7 +621,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                         x = fmaxf(x, x * slope);
                         if (FULL) { x = x * sc + sh; x += r2p[jj][r]; }
                         const int oy = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)) + HH), ox = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3) + jj);
-                        const int so = __builtin_amdgcn_readfirstlane((((img * H + oy) * W + ox) * out_ld + d.out_c0) * 4);
+                        const int so = __builtin_amdgcn_readfirstlane((pix(oy, ox) * out_ld + d.out_c0) * 4);
                         int vo = vo_out;
                         if (EDGE) vo = (live && oy < H && ox + 8 * lh < W) ? vo_out : INVALID;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), out_rsrc, vo, so, 0);
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         const int r = me * NR + q;
         oyq[q] = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)));
         oxq[q] = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3));
-        so0[q] = __builtin_amdgcn_readfirstlane((((img * H + oyq[q]) * W + oxq[q]) * out_ld + d.out_c0) * 4);
+        so0[q] = __builtin_amdgcn_readfirstlane((pix(oyq[q], oxq[q]) * out_ld + d.out_c0) * 4);
 #pragma unroll
         for (int rd = 0; rd < 4; rd++) { r1v[rd][q] = 0.f; r2v[rd][q] = 0.f; }
     }
@@ -652,7 +661,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                 const int i = rd >> 1, j = rd & 1;
                 const bool ok = live && oyq[q] + i < H && oxq[q] + 8 * lh + j < W;
                 const int Y = img * H + oyq[q] + i;
-                const int so = __builtin_amdgcn_readfirstlane(((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + ((oxq[q] + j) >> d.res1_shift)) * d.Cout * 4);
+                const int so = __builtin_amdgcn_readfirstlane(d.res1_shift ? ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + ((oxq[q] + j) >> d.res1_shift)) * d.Cout * 4
+                                                                           : pix(oyq[q] + i, oxq[q] + j) * d.Cout * 4);
                 r1v[rd][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1_rsrc, ok ? vo_r1 : INVALID, so, 0));
             }
     }
@@ -663,7 +673,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
             for (int rd = 0; rd < 4; rd++) {
                 const int i = rd >> 1, j = rd & 1;
                 const bool ok = live && oyq[q] + i < H && oxq[q] + 8 * lh + j < W;
-                const int so = __builtin_amdgcn_readfirstlane((((img * H + oyq[q] + i) * W + oxq[q] + j) * d.Cout) * 4);
+                const int so = __builtin_amdgcn_readfirstlane(pix(oyq[q] + i, oxq[q] + j) * d.Cout * 4);
                 r2v[rd][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2_rsrc, ok ? vo_r2 : INVALID, so, 0));
             }
     }
@@ -698,7 +708,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                     v[0] += u.x; v[1] += u.y;
                 }
             }
-            const int pdelta = (i * W + j) * out_ld * 4;
+            const int pdelta = (i * WR + j) * D * out_ld * 4;
 #pragma unroll
             for (int q = 0; q < NR; q++) {
                 float x = v[q] + bias;
@@ -866,13 +876,15 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     // The choice and the K groups are functions of the per-image shape and plan_batch only.
     {
         static const signed char sdy[9] = {-1, -1, -1, 0, 0, 0, 1, 1, 1}, sdx[9] = {-1, 0, 1, -1, 0, 1, -1, 0, 1};
-        bool std3 = d.wino && d.ntaps == 9 && nphase == 1 && d.in_stride == 1 && d.out_stride == 1 && d.Cin % 8 == 0 &&
+        const int D = d.ntaps == 9 ? d.dx[5] : 0;                    // dilation: a dilated layer is D x D standard ones on the parity sub-images
+        bool std3 = d.wino && d.ntaps == 9 && nphase == 1 && d.in_stride == 1 && d.out_stride == 1 && d.Cin % 8 == 0 && D >= 1 && D <= 4 &&
+                    d.IH % D == 0 && d.IW % D == 0 && (D == 1 || (d.res1_shift == 0)) &&
                     d.res1_shift >= 0 && d.IW == d.OW && (long long)d.IH * nbatch == d.OH && d.OHf == d.OH && d.OWf == d.OW;
-        for (int t = 0; std3 && t < 9; t++) std3 = d.dy[t] == sdy[t] && d.dx[t] == sdx[t];
+        for (int t = 0; std3 && t < 9; t++) std3 = d.dy[t] == sdy[t] * D && d.dx[t] == sdx[t] * D;
         if (std3 && g_force_wino != 0) {
-            const int TH = (d.IH + 1) / 2, TW = (d.IW + 1) / 2;
-            const long long wt_plan = (long long)plan_batch * ((TH + 3) / 4) * ((TW + 7) / 8) * (d.Cout / 32);
-            const long long wt = (long long)nbatch * ((TH + 3) / 4) * ((TW + 7) / 8) * (d.Cout / 32);
+            const int TH = (d.IH / D + 1) / 2, TW = (d.IW / D + 1) / 2;
+            const long long wt_plan = (long long)plan_batch * D * D * ((TH + 3) / 4) * ((TW + 7) / 8) * (d.Cout / 32);
+            const long long wt = (long long)nbatch * D * D * ((TH + 3) / 4) * ((TW + 7) / 8) * (d.Cout / 32);
             const int nsteps = d.Cin / 8;
             // K groups: a unit (block x channel group x K group) is two waves, a workgroup 4 units, a CU holds one workgroup.
             // K is only split evenly (every wave of a workgroup runs the same number of steps).  Cost model in microseconds,
