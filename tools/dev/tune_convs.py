@@ -32,8 +32,9 @@ def nets():
         n = HipMattingNet(synthetic_state_dict(0), 544, 960)
         yield "unet 544x960", n, list(n._descs)
     if "schp" in which:
-        n = HipSchpNet(schp_synthetic_state_dict(0), 473, 473, batch=4, plan_batch=4)
-        yield "schp 473x473 b4", n, [d for k, a, arr in n._segments if k == "conv" for d in arr]
+        sb = int(os.environ.get("SCHP_B", "4"))
+        n = HipSchpNet(schp_synthetic_state_dict(0), 473, 473, batch=sb, plan_batch=sb)
+        yield "schp 473x473 b%d" % sb, n, [d for k, a, arr in n._segments if k == "conv" for d in arr]
     if "deeplab" in which:
         n = HipDeepLabNet(deeplab_synthetic_state_dict(0), 513, 513, batch=4, plan_batch=4)
         yield "deeplab 513x513 b4", n, [d for k, a, arr in n._segments if k == "conv" for d in arr]

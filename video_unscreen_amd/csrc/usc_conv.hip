@@ -575,13 +575,17 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     const bool plain = !has_r1 && !has_r2 && !has_aff;
     const std::true_type yes;
     const std::false_type no;
+#ifdef USC_WINO_NO_PAIR_EPILOGUE
+    if constexpr (false) {
+#else
     if constexpr (KW == 1) {
+#endif
         // The group is the pair: wave h finishes the two phases of output row parity i = h in full (32 values per lane), its
         // partials of the other two phases go to the partner through LDS ([wave][8 quads of registers][lane][4] floats, 8 KB per
         // wave) - one exchange, one barrier.  h0's partial + h1's partial, as in the general scheme (addition commutes).
-        auto finish_pair = [&](auto hh, auto full_c, auto edge_c) {
+        auto finish_pair = [&](auto hh, auto r1_c, auto r2a_c, auto edge_c) {
             constexpr int HH = decltype(hh)::value;
-            constexpr bool FULL = decltype(full_c)::value, EDGE = decltype(edge_c)::value;
+            constexpr bool R1 = decltype(r1_c)::value, R2A = decltype(r2a_c)::value, EDGE = decltype(edge_c)::value;
 #pragma unroll
             for (int jj = 0; jj < 2; jj++)
 #pragma unroll
@@ -589,19 +593,42 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                     const f32x16& y = Yp[2 * (1 - HH) + jj];
                     *reinterpret_cast<float4*>(&Ls[((wave * 8 + jj * 4 + qd) * 64 + lane) * 4]) = make_float4(y[4 * qd], y[4 * qd + 1], y[4 * qd + 2], y[4 * qd + 3]);
                 }
+            // residual values: requested before the barrier, all of them before the first store, and only where a residual exists
+            // (R1: variants with a first residual; R2A: with a per-channel affine and / or a second residual).  A half-resolution
+            // residual (nearest x2 upsampling: res1_shift = 1) is the same value for both column phases of a tile: requested once.
             float r1p[2][16], r2p[2][16];
-            if (FULL) {
+            if (R1 || R2A) {
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { r1p[jj][r] = 0.f; r2p[jj][r] = 0.f; }
+            }
+            if (R1 && has_r1) {
+                const bool r1_shared = d.res1_shift == 1;
 #pragma unroll
                 for (int jj = 0; jj < 2; jj++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const int oy = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)) + HH), ox = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3) + jj);
                         const bool ok = live && oy < H && ox + 8 * lh < W;
-                        const int Y = img * H + oy;             // (a half-resolution residual only exists for D = 1: planner)
-                        const int s1o = __builtin_amdgcn_readfirstlane(d.res1_shift ? ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (ox >> d.res1_shift)) * d.Cout * 4
-                                                                                    : pix(oy, ox) * d.Cout * 4);
+                        if (jj == 0 || !r1_shared) {
+                            const int Y = img * H + oy;         // (a half-resolution residual only exists for D = 1: planner)
+                            const int s1o = __builtin_amdgcn_readfirstlane(d.res1_shift ? ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (ox >> d.res1_shift)) * d.Cout * 4
+                                                                                        : pix(oy, ox) * d.Cout * 4);
+                            r1p[jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1_rsrc, ok ? vo_r1 : INVALID, s1o, 0));
+                        } else {
+                            r1p[jj][r] = r1p[0][r];
+                        }
+                    }
+            }
+            if (R2A && has_r2) {
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int oy = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)) + HH), ox = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3) + jj);
+                        const bool ok = live && oy < H && ox + 8 * lh < W;
                         const int s2o = __builtin_amdgcn_readfirstlane(pix(oy, ox) * d.Cout * 4);
-                        r1p[jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1_rsrc, ok ? vo_r1 : INVALID, s1o, 0));
                         r2p[jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2_rsrc, ok ? vo_r2 : INVALID, s2o, 0));
                     }
             }
@@ -617,9 +644,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                     for (int e = 0; e < 4; e++) {
                         const int r = 4 * qd + e;
                         float x = Yp[2 * HH + jj][r] + uu[e] + bias;
-                        if (FULL) x += r1p[jj][r];
+                        if (R1) x += r1p[jj][r];
                         x = fmaxf(x, x * slope);
-                        if (FULL) { x = x * sc + sh; x += r2p[jj][r]; }
+                        if (R2A) { x = x * sc + sh; x += r2p[jj][r]; }
                         const int oy = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)) + HH), ox = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3) + jj);
                         const int so = __builtin_amdgcn_readfirstlane((pix(oy, ox) * out_ld + d.out_c0) * 4);
                         int vo = vo_out;
@@ -628,15 +655,15 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                     }
                 }
         };
-        const std::integral_constant<int, 0> H0e;
-        const std::integral_constant<int, 1> H1e;
-        if (h == 0) {
-            if (plain) { if (interior) finish_pair(H0e, no, no); else finish_pair(H0e, no, yes); }
-            else { if (interior) finish_pair(H0e, yes, no); else finish_pair(H0e, yes, yes); }
-        } else {
-            if (plain) { if (interior) finish_pair(H1e, no, no); else finish_pair(H1e, no, yes); }
-            else { if (interior) finish_pair(H1e, yes, no); else finish_pair(H1e, yes, yes); }
-        }
+        const bool r2a = has_r2 || has_aff;
+        auto dispatch = [&](auto hh) {
+            if (plain) { if (interior) finish_pair(hh, no, no, no); else finish_pair(hh, no, no, yes); }
+            else if (!r2a) { if (interior) finish_pair(hh, yes, no, no); else finish_pair(hh, yes, no, yes); }
+            else if (!has_r1) { if (interior) finish_pair(hh, no, yes, no); else finish_pair(hh, no, yes, yes); }
+            else { if (interior) finish_pair(hh, yes, yes, no); else finish_pair(hh, yes, yes, yes); }
+        };
+        if (h == 0) dispatch(std::integral_constant<int, 0>());
+        else dispatch(std::integral_constant<int, 1>());
     } else {
     // ---- K groups: G = 2 KW waves (member m = 2 kg + h); member m finishes registers [m NR, (m + 1) NR) of every phase, in four
     // rounds (one per phase) through two alternating exchange regions.

@@ -20,6 +20,7 @@
 // bounding box of the foreground; the score sums are kept in 90-bit fixed point (two integer limbs, exact whatever the order of
 // the atomics), so a run is bit-reproducible and agrees with the host's float64 sums far below any threshold margin.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <math.h>
 #include <stdint.h>
 
@@ -142,11 +143,21 @@ __global__ __launch_bounds__(256) void obj_bbox_kernel(const uint8_t* __restrict
             else { const uint8_t* pv = reinterpret_cast<const uint8_t*>(&v); for (int k = 0; k < 16 && i + k < n; k++) copy_to[i + k] = pv[k]; }
         }
         if ((v.x | v.y | v.z | v.w) == 0) continue;
-        const uint8_t* pv = reinterpret_cast<const uint8_t*>(&v);
-        for (int k = 0; k < 16; k++) {
-            if (!pv[k]) continue;
-            const int y = (i + k) / W, x = (i + k) - y * W;
-            m0 = max(m0, H - y); m1 = max(m1, W - x); m2 = max(m2, y + 1); m3 = max(m3, x + 1);
+        // first and last non-zero byte of the group (one division for the group; a group that wraps to the next row is split)
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+        int kf = 0, kl = 15;
+        for (int q = 0; q < 4; q++) if (w4[q]) { kf = 4 * q + (__ffs((int)w4[q]) - 1) / 8; break; }
+        for (int q = 3; q >= 0; q--) if (w4[q]) { kl = 4 * q + (31 - __clz((int)w4[q])) / 8; break; }
+        const int y = i / W, x = i - y * W;
+        if (x + kl < W) {                                    // the common case: the group's non-zero bytes lie in one row
+            m0 = max(m0, H - y); m2 = max(m2, y + 1); m1 = max(m1, W - (x + kf)); m3 = max(m3, x + kl + 1);
+        } else {
+            const uint8_t* pv = reinterpret_cast<const uint8_t*>(&v);
+            for (int k = kf; k <= kl; k++) {
+                if (!pv[k]) continue;
+                const int yy = (i + k) / W, xx = (i + k) - yy * W;
+                m0 = max(m0, H - yy); m1 = max(m1, W - xx); m2 = max(m2, yy + 1); m3 = max(m3, xx + 1);
+            }
         }
     }
 #pragma unroll
@@ -154,50 +165,90 @@ __global__ __launch_bounds__(256) void obj_bbox_kernel(const uint8_t* __restrict
         m0 = max(m0, __shfl_down(m0, off, kWave)); m1 = max(m1, __shfl_down(m1, off, kWave));
         m2 = max(m2, __shfl_down(m2, off, kWave)); m3 = max(m3, __shfl_down(m3, off, kWave));
     }
-    if ((threadIdx.x & (kWave - 1)) == 0 && m2 > 0) { atomicMax(&hdr[1], m0); atomicMax(&hdr[2], m1); atomicMax(&hdr[3], m2); atomicMax(&hdr[4], m3); }
+    // one set of atomics per workgroup (they all hit the same four words: a 1080p silhouette used to issue ~2000 of them,
+    // which serialise in the L2 - 50 us for a 2 MB scan)
+    __shared__ int s_m[4][4];
+    const int wv = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) { s_m[wv][0] = m0; s_m[wv][1] = m1; s_m[wv][2] = m2; s_m[wv][3] = m3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int m = max(max(s_m[0][threadIdx.x], s_m[1][threadIdx.x]), max(s_m[2][threadIdx.x], s_m[3][threadIdx.x]));
+        if (m > 0) atomicMax(&hdr[1 + threadIdx.x], m);
+    }
 }
 
-// Labelling, step 1: rows are cut into 64-pixel segments (one wavefront each); every pixel starts with the index of the
-// first pixel of its run inside the segment (same class, contiguous) - one ballot and a few bit operations, no atomics.
+// Labelling, step 1: one wavefront per domain row walks it in 64-pixel segments; every pixel starts with the index of the first
+// pixel of its run (same class, contiguous) - one ballot and a few bit operations per segment, the run that crosses a segment
+// boundary carries its start along.  No atomics, and no unions inside a row are left for step 2.
 __global__ __launch_bounds__(256) void obj_runs_kernel(const uint8_t* __restrict__ alpha, int H, int W, const int* __restrict__ hdr,
                                                        int* __restrict__ lab) {
+    Dom d;
+    if (!load_dom(hdr, H, W, d)) return;
+    const int Wp = d.Wb + 2;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int py = blockIdx.x * 4 + threadIdx.x / kWave;
+    if (py >= d.Hb + 2) return;
+    int carry_start = 0;                                     // start of the run the previous segment ended in
+    bool carry_c = false;
+    for (int x0 = 0; x0 < Wp; x0 += kWave) {
+        const int px = x0 + lane;
+        const bool live = px < Wp;
+        const bool f = live && is_fg(alpha, W, d, py, px);
+        const unsigned long long C = __ballot(f);
+        unsigned long long S = C ^ (C << 1);                                  // bit l (l > 0): lane l starts a run
+        const bool first_starts = x0 == 0 || ((C & 1ull) != 0) != carry_c;
+        S = (S & ~1ull) | (first_starts ? 1ull : 0ull);
+        const unsigned long long upto = S & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        const int start = upto ? py * Wp + x0 + (63 - __clzll((long long)upto)) : carry_start;
+        if (live) lab[py * Wp + px] = start;
+        const int last = min(kWave, Wp - x0) - 1;                             // the segment's last live lane
+        carry_start = __shfl(start, last, kWave);
+        carry_c = ((C >> last) & 1ull) != 0;
+    }
+}
+
+// Labelling, step 2: unions only where two runs START to touch - the first vertically adjacent pair of two runs and, for the
+// 8-connected foreground, the diagonal contacts at run ends - a few per run instead of a few per pixel.  Roots end up at the
+// smallest index of the component = its first pixel in raster order.
+// One lane per domain pixel, one wavefront per 64-pixel segment of a row (the geometry of obj_runs_kernel): the classes of the
+// segment and of the segment above come from two ballots, every neighbour test is a bit of them; only the lanes at the two
+// ends of a segment read a neighbouring segment's pixel.
+__global__ __launch_bounds__(256) void obj_merge_kernel(const uint8_t* __restrict__ alpha, int H, int W, const int* __restrict__ hdr,
+                                                        int* __restrict__ lab) {
     Dom d;
     if (!load_dom(hdr, H, W, d)) return;
     const int Wp = d.Wb + 2;
     const int py = blockIdx.y, px = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & (kWave - 1);
     if (py >= d.Hb + 2 || (int)blockIdx.x * 256 >= Wp) return;
     const bool live = px < Wp;
-    const bool f = live && is_fg(alpha, W, d, py, px);
-    const unsigned long long C = __ballot(f);
-    const unsigned long long S = (C ^ (C << 1)) | 1ull;                      // bit l: lane l starts a run
-    const unsigned long long upto = S & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-    const int start = 63 - __clzll((long long)upto);
-    if (live) lab[py * Wp + px] = py * Wp + px - lane + start;
-}
-
-// Labelling, step 2: unions only where two runs START to touch - a segment boundary inside a run, the first vertically adjacent
-// pair of two runs, and, for the 8-connected foreground, the diagonal contacts at run ends - a few per run instead of a few per
-// pixel.  Roots end up at the smallest index of the component = its first pixel in raster order.
-__global__ __launch_bounds__(256) void obj_merge_kernel(const uint8_t* __restrict__ alpha, int H, int W, const int* __restrict__ hdr,
-                                                        int* __restrict__ lab) {
-    Dom d;
-    if (!load_dom(hdr, H, W, d)) return;
-    const int Wp = d.Wb + 2, np = (d.Hb + 2) * Wp;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
-        const int py = i / Wp, px = i - py * Wp;
-        const bool c = is_fg(alpha, W, d, py, px);
-        const bool seg_start = (px & 63) == 0;
-        const bool w_same = px > 0 && is_fg(alpha, W, d, py, px - 1) == c;
-        const bool start_i = seg_start || !w_same;
-        if (seg_start && w_same) unite(lab, i, i - 1);
-        if (py == 0) continue;
-        const bool cn = is_fg(alpha, W, d, py - 1, px);
-        if (cn == c) {
-            const bool start_n = seg_start || px == 0 || is_fg(alpha, W, d, py - 1, px - 1) != cn;
-            if (start_i || start_n) unite(lab, i, i - Wp);
-        } else if (c) {                                      // foreground below background: diagonal contacts
-            if (px > 0 && !w_same && is_fg(alpha, W, d, py - 1, px - 1)) unite(lab, i, i - Wp - 1);
-            if (px + 1 < Wp && !is_fg(alpha, W, d, py, px + 1) && is_fg(alpha, W, d, py - 1, px + 1)) unite(lab, i, i - Wp + 1);
+    const bool c = live && is_fg(alpha, W, d, py, px);
+    const bool cn = live && py > 0 && is_fg(alpha, W, d, py - 1, px);
+    const unsigned long long C = __ballot(c), CN = __ballot(cn);
+    if (!live) return;
+    const int i = py * Wp + px;
+    // the pixel to the left: the previous lane, or (lane 0) the last pixel of the previous segment
+    const bool wc = lane > 0 ? ((C >> (lane - 1)) & 1ull) != 0 : (px > 0 && is_fg(alpha, W, d, py, px - 1));
+    const bool w_same = px > 0 && wc == c;
+    const bool start_i = !w_same;
+    if (py == 0) return;
+    if (cn == c) {
+        bool start_n = px == 0;
+        if (!start_i && !start_n) {
+            const bool nwc = lane > 0 ? ((CN >> (lane - 1)) & 1ull) != 0 : is_fg(alpha, W, d, py - 1, px - 1);
+            start_n = nwc != cn;
+        }
+        if (start_i || start_n) unite(lab, i, i - Wp);
+    } else if (c) {                                          // foreground below background: diagonal contacts
+        if (px > 0 && !w_same) {
+            const bool nw = lane > 0 ? ((CN >> (lane - 1)) & 1ull) != 0 : is_fg(alpha, W, d, py - 1, px - 1);
+            if (nw) unite(lab, i, i - Wp - 1);
+        }
+        if (px + 1 < Wp) {
+            const bool e = lane < kWave - 1 ? ((C >> (lane + 1)) & 1ull) != 0 : is_fg(alpha, W, d, py, px + 1);
+            if (!e) {
+                const bool ne = lane < kWave - 1 ? ((CN >> (lane + 1)) & 1ull) != 0 : is_fg(alpha, W, d, py - 1, px + 1);
+                if (ne) unite(lab, i, i - Wp + 1);
+            }
         }
     }
 }
@@ -352,10 +403,14 @@ __global__ __launch_bounds__(256) void obj_cracks_kernel(const uint8_t* __restri
         atomicAdd((unsigned long long*)&comps[tab.key[threadIdx.x]].area2, tab.v[0][threadIdx.x]);
 }
 
-// subtree totals: every component adds its own sums to all its ancestors
-__global__ __launch_bounds__(256) void obj_tree_sum_kernel(Comp* __restrict__ comps, const int* __restrict__ hdr, int kcap) {
+// Subtree totals (every component adds its own sums to all its ancestors), then maskprocess.py:121-147 (area test, saliency /
+// consensus test), then "is a kept component among my ancestors": three passes over the component table with a dependency
+// between them - ONE workgroup walks them with barriers in between (a clean mask has a handful of components; one launch
+// instead of three, and a single CU busy for a few microseconds, matters more to the frame loop than the width of the pass).
+__global__ __launch_bounds__(1024) void obj_tree_decide_cover_kernel(Comp* __restrict__ comps, const int* __restrict__ hdr, int kcap, double denom,
+                                                                     double saliency_thr, double consensus_thr) {
     const int K = min(hdr[0], kcap);
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < K; c += gridDim.x * blockDim.x) {
+    for (int c = threadIdx.x; c < K; c += blockDim.x) {
         const unsigned long long n = comps[c].cnt, g = comps[c].sg, sh = comps[c].sc_hi, sl = comps[c].sc_lo;
         atomicAdd(&comps[c].t_cnt, n); atomicAdd(&comps[c].t_sg, g); atomicAdd(&comps[c].t_sc_hi, sh); atomicAdd(&comps[c].t_sc_lo, sl);
         int a = comps[c].parent;
@@ -364,35 +419,29 @@ __global__ __launch_bounds__(256) void obj_tree_sum_kernel(Comp* __restrict__ co
             a = comps[a].parent;
         }
     }
-}
-
-// maskprocess.py:121-147: area test, saliency / consensus test
-__global__ __launch_bounds__(256) void obj_decide_kernel(Comp* __restrict__ comps, const int* __restrict__ hdr, int kcap, double denom,
-                                                         double saliency_thr, double consensus_thr) {
-    const int K = min(hdr[0], kcap);
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < K; c += gridDim.x * blockDim.x) {
+    __threadfence();
+    __syncthreads();
+    for (int c = threadIdx.x; c < K; c += blockDim.x) {
         Comp& q = comps[c];
         int keep = 0;
         if (q.parent >= 0) {                                  // the outside ring has no border
             const long long a2 = q.area2 < 0 ? -q.area2 : q.area2;
             if ((double)a2 * 0.5 >= 100.) {
-                unsigned long long sh = q.t_sc_hi, sl = q.t_sc_lo;
-                double gsum = (double)q.t_sg, cnt = (double)q.t_cnt;
+                unsigned long long sh = __hip_atomic_load(&q.t_sc_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), sl = __hip_atomic_load(&q.t_sc_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                double gsum = (double)__hip_atomic_load(&q.t_sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), cnt = (double)__hip_atomic_load(&q.t_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!q.is_fg) { sh += q.chain_sc_hi; sl += q.chain_sc_lo; gsum += (double)q.chain_sg; cnt += (double)q.chain_cnt; }
                 const double ssum = ((double)sh + (double)sl * (1. / 4294967296.)) * (1. / 67108864.);
                 const double sal = ssum / denom, cons = (gsum / cnt) / 255.;
                 keep = ((sal > saliency_thr && cons > consensus_thr) || sal > saliency_thr * 10) ? 1 : 0;
             }
         }
-        q.keep = keep;
+        __hip_atomic_store(&q.keep, keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-
-__global__ __launch_bounds__(256) void obj_cover_kernel(Comp* __restrict__ comps, const int* __restrict__ hdr, int kcap) {
-    const int K = min(hdr[0], kcap);
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < K; c += gridDim.x * blockDim.x) {
+    __threadfence();
+    __syncthreads();
+    for (int c = threadIdx.x; c < K; c += blockDim.x) {
         int cov = 0, a = c;
-        for (int depth = 0; a >= 0 && depth < (1 << 20) && !cov; depth++) { cov = comps[a].keep; a = comps[a].parent; }
+        for (int depth = 0; a >= 0 && depth < (1 << 20) && !cov; depth++) { cov = __hip_atomic_load(&comps[a].keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); a = comps[a].parent; }
         comps[c].covered = cov;
     }
 }
@@ -487,16 +536,14 @@ extern "C" int usc_remove_invalid_objects_u8(const uint8_t* src, uint8_t* alpha,
     double smax = 0.;
     for (int k = 0; k < 4; k++) smax = fmax(smax, score_raw((k & 1) ? H - 1 : 0, (k & 2) ? W - 1 : 0, H, W, cy, cx));
     if (hipMemsetAsync(hdr, 0, 256, st) != hipSuccess) return fail(USC_E_LAUNCH, "usc_remove_invalid_objects_u8: memset failed");
-    const dim3 b(256), gp(grid_for((size_t)np, 256)), gn(grid_for((size_t)H * W, 256)), gk(64);
-    hipLaunchKernelGGL(obj_bbox_kernel, dim3(grid_for((size_t)(H * W + 15) / 16, 256)), b, 0, st, src ? src : alpha, src ? alpha : (uint8_t*)nullptr, H, W, hdr);
-    hipLaunchKernelGGL(obj_runs_kernel, dim3((W + 2 + 255) / 256, H + 2), b, 0, st, alpha, H, W, hdr, lab);
-    hipLaunchKernelGGL(obj_merge_kernel, gp, b, 0, st, alpha, H, W, hdr, lab);
+    const dim3 b(256), gp(grid_for((size_t)np, 256)), gn(grid_for((size_t)H * W, 256));
+    hipLaunchKernelGGL(obj_bbox_kernel, dim3((unsigned)std::min<size_t>(128, ((size_t)(H * W + 15) / 16 + 255) / 256)), b, 0, st, src ? src : alpha, src ? alpha : (uint8_t*)nullptr, H, W, hdr);
+    hipLaunchKernelGGL(obj_runs_kernel, dim3((H + 2 + 3) / 4), b, 0, st, alpha, H, W, hdr, lab);
+    hipLaunchKernelGGL(obj_merge_kernel, dim3((W + 2 + 255) / 256, H + 2), b, 0, st, alpha, H, W, hdr, lab);
     hipLaunchKernelGGL(obj_flatten_kernel, gp, b, 0, st, alpha, H, W, hdr, lab, cid, comps, kcap);
     hipLaunchKernelGGL(obj_stats_kernel, dim3((np + kStatsSpan - 1) / kStatsSpan), b, 0, st, seg, H, W, hdr, lab, cid, comps, kcap, cy, cx, smax);
     hipLaunchKernelGGL(obj_cracks_kernel, dim3((H * W + 255) / 256), b, 0, st, alpha, seg, H, W, hdr, lab, cid, comps, kcap, cy, cx, smax);
-    hipLaunchKernelGGL(obj_tree_sum_kernel, gk, b, 0, st, comps, hdr, kcap);
-    hipLaunchKernelGGL(obj_decide_kernel, gk, b, 0, st, comps, hdr, kcap, (double)H * (double)W, saliency_thr, consensus_thr);
-    hipLaunchKernelGGL(obj_cover_kernel, gk, b, 0, st, comps, hdr, kcap);
+    hipLaunchKernelGGL(obj_tree_decide_cover_kernel, dim3(1), dim3(1024), 0, st, comps, hdr, kcap, (double)H * (double)W, saliency_thr, consensus_thr);
     hipLaunchKernelGGL(obj_apply_kernel, gn, b, 0, st, alpha, H, W, hdr, lab, cid, comps, kcap);
     return check_launch("remove_invalid_objects kernels");
 }

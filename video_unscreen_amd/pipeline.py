@@ -209,7 +209,7 @@ class BgStepPipeline:
         main = torch.cuda.current_stream(self.device)
         # the pipeline's side streams live as long as it does: the conv graphs are instantiated once per stream they run on
         if getattr(self, "_front_stream", None) is None:
-            self._front_stream = torch.cuda.Stream(self.device)
+            self._front_stream = torch.cuda.Stream(self.device, priority=getattr(self, "front_priority", 0))
         front = self._front_stream
         work = queue.Queue()
         err = []
@@ -243,7 +243,7 @@ class BgStepPipeline:
             ahead = []                                      # inputs whose segmentation mask is already enqueued
             batched = self.seg_agent is not None and self.seg_batch > 1
             if batched and getattr(self, "_seg_stream", None) is None:
-                self._seg_stream = torch.cuda.Stream(self.device)
+                self._seg_stream = torch.cuda.Stream(self.device, priority=getattr(self, "seg_priority", 0))
             seg_stream = self._seg_stream if batched else None
             state = {"exhausted": False, "ngroups": 0}
 
