@@ -44,6 +44,7 @@ def parse():
                     help="time the loop with inputs already in HBM and outputs left there (round 1's figure) as `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--no-spin-up", action="store_true", help="skip the untimed clock spin-up in front of the warm-up frames (counter-collecting profile runs)")
     ap.add_argument("--sync-loop", action="store_true", help="use the synchronous step() instead of the pipelined run()")
     ap.add_argument("--cpu-frames", type=int, default=5)
     ap.add_argument("--seg-batch", type=int, default=0,
@@ -303,6 +304,8 @@ def main():
         """The clip is generated and pinned on the CPU for seconds while the GPU idles in a low power state, and W warm-up frames
         (30 ms at W = 10) do not bring its clocks back: untimed matting forwards on a scratch input do (measured: the same 300
         timed frames run 3.5 % slower without; nothing here touches the pipeline's state or the frames)."""
+        if args.no_spin_up:
+            return
         x = torch.zeros_like(pipe.x7)
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < seconds:

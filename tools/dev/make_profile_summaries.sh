@@ -10,4 +10,4 @@ python tools/dev/summarize_profiles.py $P/no_seg_trace/t_kernel_stats.csv $P/no_
 cp $P/default_trace/t_kernel_stats.csv $D/bench_default_kernel_stats.csv
 cp $P/no_seg_trace/t_kernel_stats.csv $D/bench_no_seg_kernel_stats.csv
 cp $P/no_seg_trace.json $D/bench_no_seg_profiled_run.json
-python tools/dev/summarize_mfma.py $P/no_seg_mfma/t_counter_collection.csv $P/no_seg_mfma/t_kernel_trace.csv 32 ${1:-1.50} > $D/mfma_utilisation.md
+python tools/dev/summarize_mfma.py $P/no_seg_mfma/t_counter_collection.csv $P/no_seg_mfma/t_kernel_trace.csv 0 ${1:-1.50} > $D/mfma_utilisation.md

@@ -33,6 +33,8 @@ for r in csv.DictReader(open(cc)):
     s = short(r["Kernel_Name"])
     if s and r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
         busy[s] += float(r["Counter_Value"])
+if forwards <= 0:                                 # one head launch per matting forward
+    forwards = dur["head_conv_kernel"][0]
 print("## MFMA utilisation of the conv stack (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, bench.py --no-seg --sync-loop, %d frames)\n" % forwards)
 print("| kernel | launches | avg duration in this pass (us) | SQ_VALU_MFMA_BUSY_CYCLES / launch | MFMA pipe busy = busy / (duration x 2.4 GHz x 1024 SIMDs) |")
 print("|---|---|---|---|---|")
