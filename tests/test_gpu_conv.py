@@ -258,11 +258,13 @@ def test_conv_graphs_are_destroyed_for_real(hipnet):
     assert used[-1] <= used[2], used
 
 
-@pytest.mark.parametrize("cin,cout,h,w,batch,kw,dil", [(8, 32, 17, 30, 1, 1, 1), (32, 32, 20, 36, 1, 1, 1), (64, 64, 33, 47, 1, 2, 1),
-                                                        (128, 128, 12, 20, 2, 4, 1), (32, 64, 9, 7, 3, 2, 1), (256, 96, 16, 16, 1, 4, 1),
-                                                        (16, 32, 64, 96, 1, 1, 1), (64, 64, 30, 30, 2, 2, 2), (32, 32, 18, 42, 1, 1, 2),
-                                                        (32, 64, 27, 15, 2, 1, 3)])
-def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw, dil):
+@pytest.mark.parametrize("cin,cout,h,w,batch,kw,dil,lin", [
+    (8, 32, 17, 30, 1, 1, 1, 0), (32, 32, 20, 36, 1, 1, 1, 0), (64, 64, 33, 47, 1, 2, 1, 0), (128, 128, 12, 20, 2, 4, 1, 0), (32, 64, 9, 7, 3, 2, 1, 0),
+    (256, 96, 16, 16, 1, 4, 1, 0), (16, 32, 64, 96, 1, 1, 1, 0), (64, 64, 30, 30, 2, 2, 2, 0), (32, 32, 18, 42, 1, 1, 2, 0), (32, 64, 27, 15, 2, 1, 3, 0),
+    # blocks of 32 consecutive tiles (tile rows of >= 11 tiles): runs that start mid-row, wrap over up to four rows, end in a partial block
+    (32, 32, 20, 36, 1, 1, 1, 1), (64, 64, 33, 47, 1, 2, 1, 1), (16, 32, 64, 96, 1, 1, 1, 1), (128, 128, 68, 120, 1, 4, 1, 1), (32, 64, 23, 22, 3, 2, 1, 1),
+    (32, 32, 18, 44, 1, 1, 2, 1), (8, 32, 31, 45, 2, 1, 1, 1)])
+def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw, dil, lin):
     """conv_wino_kernel (Winograd F(2x2, 3x3): 3x3 / stride 1 / pad 1) against torch's float64 convolution: odd sizes (partial
     tiles and blocks), images stacked along y, K groups, the full fused epilogue, and dilated layers (dil x dil standard
     convolutions on the pixel-parity sub-images)."""
@@ -291,11 +293,14 @@ def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw, dil):
         d.wino = wino.data_ptr()
         lib.usc_conv_force_winograd(1)
         lib.usc_conv_force_plan(0, 0, 0, kw)
+        os.environ["USC_WINO_LIN"] = str(lin)
         try:
             arr = (hipnet.ConvDesc * 1)(d)
-            assert nv.conv_plans(arr, 1)[0]["winograd"]
+            plan = nv.conv_plans(arr, 1)[0]
+            assert plan["winograd"] and ("-lin" in plan["plan"]) == bool(lin), plan
             L.run([d])
         finally:
+            os.environ["USC_WINO_LIN"] = "-1"
             lib.usc_conv_force_winograd(-1)
             lib.usc_conv_force_plan(0, 0, 0, 0)
         y = F.conv2d(x.double(), wt.double(), b.double(), padding=dil, dilation=dil)

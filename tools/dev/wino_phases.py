@@ -7,7 +7,7 @@ from video_unscreen_amd import _native as nv
 nv.LIB_PATH = os.environ["USC_TIMING_LIB"]
 from video_unscreen_amd.vmatting import net_hip as m
 lib = nv.load()
-for (cin, cout, h, w, kw) in ((32, 32, 272, 480, 1), (64, 64, 136, 240, 2)):
+for (cin, cout, h, w, kw) in ((32, 32, 272, 480, 1), (64, 64, 136, 240, 2), (128, 128, 68, 120, 4), (256, 256, 34, 60, 4)):
     x = torch.randn(h, w, cin, device="cuda"); wt = torch.randn(cout, cin, 3, 3) * 0.05
     out = torch.empty(h, w, cout, device="cuda")
     taps, wk = m.conv_taps(wt, 1)

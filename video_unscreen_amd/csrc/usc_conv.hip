@@ -339,9 +339,21 @@ static_assert(WLDS >= 4 * 2 * WIMG, "the patch images must fit");
 #define WINO_PH(k) do { } while (0)
 #endif
 
-template <int KW, bool IN_RELU>
+// LIN: units are runs of 32 CONSECUTIVE tiles in raster order (tiles per image / 32 blocks, rounded up once per image) instead of
+// 8 x 4 rectangles - the 34 x 60 tiles of a 68 x 120 map are 64 blocks instead of 72, so that 4 channel groups make 256 units:
+// one workgroup per CU.  A block is then up to four row segments; every segment stages its own four pixel rows (no vertical
+// sharing between tile rows), stored per (patch row, column parity, channel half) as arrays over the column pairs - consecutive
+// tiles read consecutive 16-byte slots.  Needs TW >= 11 (at most four segments: 16 x (32 + 4) slots = 9 requests of 64).
+constexpr int WLIN_IMG = 576 * 4;           // floats of one LDS image of the linear form
+constexpr int WLDS_LIN = 8 * WLIN_IMG > WLDS ? 8 * WLIN_IMG : WLDS;        // 72 KB
+
+struct VA { int vo, so; bool ok; };          // where a finished value goes: lane offset, scalar offset, exists
+
+template <int KW, bool IN_RELU, bool LIN>
 __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
-    __shared__ __attribute__((aligned(16))) float Ls[WLDS];
+    __shared__ __attribute__((aligned(16))) float Ls[WLDS_LIN];     // (a template-dependent bound makes the host pass drop the kernel's stub without a word)
+    constexpr int IMGF = LIN ? WLIN_IMG : WIMG;                     // floats per LDS image
+    constexpr int NG = LIN ? 5 : 3;                                 // global -> LDS requests of a wave per image
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = wave >> 2, sub = wave & 3;                        // position half (rows 2h, 2h + 1) and pair of this wave
@@ -357,7 +369,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     const int WR = d.IW;
     const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
     const int BH = (TH + 3) >> 2, BW = (TW + 7) >> 3;
-    const int ntiles = nimg * BH * BW * nnb;                        // blocks x channel groups
+    const int ntile_img = TH * TW, nblk_img = LIN ? (ntile_img + 31) >> 5 : BH * BW;
+    const int ntiles = nimg * nblk_img * nnb;                       // blocks x channel groups
     const int nwg = (int)gridDim.x, xcd = (int)blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;      // XCD-aware order (see above)
     const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
     constexpr int TPW = 4 / KW;                                     // blocks x channel groups per workgroup
@@ -366,8 +379,41 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     // (integer division runs on the vector ALU: readfirstlane brings the wave-uniform results back to scalar registers, which
     // the scalar-offset addressing of the epilogue needs)
     const int nb = live ? wt % nnb : 0, sb = live ? wt / nnb : 0;
-    const int img = __builtin_amdgcn_readfirstlane(sb / (BH * BW)), brem = sb - img * (BH * BW);
-    const int by = __builtin_amdgcn_readfirstlane(brem / BW), bx = brem - by * BW;
+    const int img = __builtin_amdgcn_readfirstlane(sb / nblk_img), brem = sb - img * nblk_img;
+    const int by = LIN ? 0 : __builtin_amdgcn_readfirstlane(brem / BW), bx = LIN ? 0 : brem - by * BW;
+    // linear form: the block's (up to four) row segments - tile row, first tile column, length, first tile index inside the
+    // block, slots per plane (length + 1 column pairs), first LDS slot.  All wave-uniform.
+    int seg_row[4] = {0, 0, 0, 0}, seg_a[4] = {0, 0, 0, 0}, seg_len[4] = {0, 0, 0, 0}, seg_start[4] = {0, 0, 0, 0}, seg_L[4] = {0, 0, 0, 0}, seg_slot[4] = {0, 0, 0, 0};
+    float seg_rL[4] = {0.f, 0.f, 0.f, 0.f};                         // 1 / seg_L (one v_rcp_f32 each: the decoding below is exact with 1 ulp)
+    int cnt = 0, nslots = 0;
+    if (LIN) {
+        const int T0 = brem * 32;
+        cnt = live ? min(32, ntile_img - T0) : 0;
+        const int ty0 = __builtin_amdgcn_readfirstlane(T0 / TW), a0 = T0 - ty0 * TW;
+        int used = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int a = k == 0 ? a0 : 0;
+            const int len = max(0, min(TW - a, cnt - used));
+            seg_row[k] = ty0 + k; seg_a[k] = __builtin_amdgcn_readfirstlane(a); seg_len[k] = __builtin_amdgcn_readfirstlane(len);
+            seg_start[k] = __builtin_amdgcn_readfirstlane(used); seg_L[k] = len > 0 ? seg_len[k] + 1 : 0; seg_slot[k] = __builtin_amdgcn_readfirstlane(nslots);
+            seg_rL[k] = len > 0 ? __builtin_amdgcn_rcpf((float)seg_L[k]) : 0.f;
+            used += len;
+            nslots += 16 * seg_L[k];
+        }
+    }
+    // tile t of the block (t = the MFMA row) -> its segment and position (dead tiles of a partial block -> segment 0, position 0)
+    auto lin_seg = [&](int t, int& row, int& a, int& L, int& slot0, int& p) {
+        int k_start = seg_start[0];
+        row = seg_row[0]; a = seg_a[0]; L = seg_L[0]; slot0 = seg_slot[0];
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            const bool in = seg_len[k] > 0 && t >= seg_start[k];
+            row = in ? seg_row[k] : row; a = in ? seg_a[k] : a; L = in ? seg_L[k] : L; slot0 = in ? seg_slot[k] : slot0; k_start = in ? seg_start[k] : k_start;
+        }
+        p = t < cnt ? t - k_start : 0;
+        if (t >= cnt) { row = seg_row[0]; a = seg_a[0]; L = seg_L[0]; slot0 = seg_slot[0]; }
+    };
     const int nb0 = __builtin_amdgcn_readfirstlane(nb * 32);
     const int imr = img / (D * D), par = img - imr * (D * D), pary = par / D;
     const int pix0 = __builtin_amdgcn_readfirstlane((imr * d.IH + pary) * WR + par - pary * D);      // real pixel index of virtual (0, 0)
@@ -400,25 +446,48 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     // row parity x 2 + column parity), row (s % 95) / 19, pixel pair ((s % 19) >> 1), half (s & ... & 1).
     constexpr int INVALID = 0x7fff0000;
     const int y0 = 8 * by - 1, x0 = 16 * bx - 1;
-    int goff[3];
+    int goff[5];                                                    // (NG used; a template-dependent bound here makes the host pass drop the kernel stub silently)
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const int sl = (3 * h + r) * 64 + lane;
-        const int sp = sl / WSUB, rem = sl - sp * WSUB;
-        const int row = rem / WSUBROW, q = rem - row * WSUBROW;
-        const int py = 2 * row + (sp >> 1), px = 2 * (q >> 1) + (sp & 1), half = q & 1;
-        const int y = y0 + py, x = x0 + px;
-        const bool ok = live && sl < 4 * WSUB && q < 18 && y >= 0 && y < H && x >= 0 && x < W;
-        goff[r] = ok ? pix(y, x) * d.Cin * 4 + half * 16 : INVALID;
+    for (int r = 0; r < NG; r++) {
+        const int sl = (NG * h + r) * 64 + lane;
+        if (!LIN) {
+            const int sp = sl / WSUB, rem = sl - sp * WSUB;
+            const int row = rem / WSUBROW, q = rem - row * WSUBROW;
+            const int py = 2 * row + (sp >> 1), px = 2 * (q >> 1) + (sp & 1), half = q & 1;
+            const int y = y0 + py, x = x0 + px;
+            const bool ok = live && sl < 4 * WSUB && q < 18 && y >= 0 && y < H && x >= 0 && x < W;
+            goff[r] = ok ? pix(y, x) * d.Cin * 4 + half * 16 : INVALID;
+        } else {
+            // slot -> segment k (slots of segment k: [seg_slot[k], + 16 L_k)); inside: [plane = (patch row i, column parity cp)]
+            // [column pair][channel half]: pixel (2 row_k - 1 + i, 2 (a_k + pair) - 1 + cp)
+            int row = seg_row[0], a0s = seg_a[0], L = seg_L[0], s0 = seg_slot[0];
+            float rL = seg_rL[0];
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                const bool in = seg_L[k] > 0 && sl >= seg_slot[k];
+                row = in ? seg_row[k] : row; a0s = in ? seg_a[k] : a0s; L = in ? seg_L[k] : L; s0 = in ? seg_slot[k] : s0;
+                rL = in ? seg_rL[k] : rL;
+            }
+            const int q = (sl - s0) >> 1, hf = (sl - s0) & 1;                       // the two halves of a pixel are neighbouring slots: lanes 2k, 2k + 1 fetch 32 contiguous bytes
+            const int plane = (int)(((float)q + 0.5f) * rL);                        // exact: q < 288, L <= 33 (the fraction is >= 0.5 / L away from an integer)
+            const int pair = q - plane * L;
+            const int y = 2 * row - 1 + (plane >> 1), x = 2 * (a0s + pair) - 1 + (plane & 1);
+            const bool ok = live && sl < nslots && y >= 0 && y < H && x >= 0 && x < W;
+            goff[r] = ok ? pix(y, x) * d.Cin * 4 + hf * 16 : INVALID;
+        }
     }
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(d.in), 0, (d.batch > 1 ? d.batch : 1) * d.IH * d.IW * d.Cin * 4, 0x00020000);
-    const int img0 = sub * 2 * WIMG;                                // the pair's two images (float index into Ls)
+    const int img0 = sub * 2 * IMGF;                                // the pair's two images (float index into Ls)
     auto issue_a = [&](int c) {                                     // the patch of step c -> image (c - c_begin) & 1
-        const int dst = img0 + ((c - c_begin) & 1) * WIMG + 3 * h * 256;
+        const int dst = img0 + ((c - c_begin) & 1) * IMGF + NG * h * 256;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst], 16, goff[0], c * 32, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 256], 16, goff[1], c * 32, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 512], 16, goff[2], c * 32, 0, 0);
+        if (LIN) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 768], 16, goff[NG - 2], c * 32, 0, 0);
+            if (h == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 1024], 16, goff[NG - 1], c * 32, 0, 0);   // 9 requests: 5 + 4
+        }
     };
     auto wait_vm0 = [] { __builtin_amdgcn_s_waitcnt(0x0F70); };     // vmcnt(0): every load of this wave has landed (LDS ones too)
     // Phase barrier of the K loop: LDS accesses of this wave are complete, nothing else is implied.  (__syncthreads() carries a
@@ -436,6 +505,17 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     // (2 ty + i, 2 tx + j) lives in sub-image (i & 1, j & 1) at row ty + (i >> 1), pixel tx + (j >> 1).  This wave reads the patch
     // rows i = h, h + 1, h + 2.
     const int fb = ((((lane & 31) >> 3) * WSUBROW + 2 * (lane & 7) + (lane >> 5))) * 4;
+    // linear form: patch pixel (i, j) of tile (segment k, position p) is slot seg_slot[k] + 2 ((i 2 + (j & 1)) L_k + p + (j >> 1)) + half
+    // (consecutive tiles are 32 bytes apart: a two-way bank conflict on the fragment reads, which sit in the partner's MFMA shadow,
+    // bought for staging requests whose lane pairs fetch whole 32-byte sectors)
+    int fa[3] = {0, 0, 0}, fs2 = 0;
+    if (LIN) {
+        int row, a, L, s0, pp;
+        lin_seg(lane & 31, row, a, L, s0, pp);
+#pragma unroll
+        for (int k = 0; k < 3; k++) fa[k] = (s0 + 2 * ((h + k) * 2 * L + pp) + (lane >> 5)) * 4;
+        fs2 = 2 * L * 4;
+    }
     auto add4 = [](const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
     auto sub4 = [](const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
     auto relu4 = [](const float4& a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); };
@@ -449,7 +529,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     // ports, every vector instruction of the same wave measurably delays the matrix pipe.)
     auto frag_phase = [&](int c, auto hh) {
         constexpr int HH = decltype(hh)::value;
-        const int cur = img0 + ((c - c_begin) & 1) * WIMG + fb;
+        const int cur = img0 + ((c - c_begin) & 1) * IMGF + (LIN ? 0 : fb);
         float4 Ta[4], Tb[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -457,7 +537,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
             float4 e[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                e[k] = *reinterpret_cast<const float4*>(&Ls[cur + ((((HH + k) & 1) * 2) * WSUB + ((HH + k) >> 1) * WSUBROW) * 4 + co]);
+                if (LIN) e[k] = *reinterpret_cast<const float4*>(&Ls[cur + fa[k] + (j & 1) * fs2 + (j >> 1) * 8]);
+                else e[k] = *reinterpret_cast<const float4*>(&Ls[cur + ((((HH + k) & 1) * 2) * WSUB + ((HH + k) >> 1) * WSUBROW) * 4 + co]);
                 if (IN_RELU) e[k] = relu4(e[k]);
             }
             if (HH == 0) { Ta[j] = sub4(e[0], e[2]); Tb[j] = add4(e[1], e[2]); }       // rows 0, 1: d0 - d2, d1 + d2
@@ -571,10 +652,63 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     const int vo_r2 = (8 * lh * D * d.Cout + n) * 4;
     const int vo_r1 = ((8 >> d.res1_shift) * lh * D * d.Cout + n) * 4;
     WINO_STAMP(4);
-    const bool interior = live && 8 * by + 8 <= H && 16 * bx + 16 <= W;
+    const bool interior = LIN ? (cnt == 32 && !(H & 1) && !(W & 1)) : (live && 8 * by + 8 <= H && 16 * bx + 16 <= W);
     const bool plain = !has_r1 && !has_r2 && !has_aff;
     const std::true_type yes;
     const std::false_type no;
+    // Where the value of accumulator register r goes.  Rectangular blocks: register r of lane l is tile (r >> 2, (r & 3) + 4 (l >>
+    // 5)) of the block, so everything but the 8-pixel step of the upper half-wave is wave-uniform: one lane offset per tensor
+    // (vo_*) + a scalar offset per value.  Linear blocks: tile (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the run lies in some segment:
+    // per-lane pixel index `pb` of its output pixel (0, 0) + flags (bit 0 tile exists, bit 1 row 1 exists, bit 2 column 1 exists),
+    // computed once per register (lin_geom), + a scalar offset per output phase.
+    auto lin_geom = [&](int r, int& pb, int& fl) {
+        int row, a, L, s0, pp;
+        const int t = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        lin_seg(t, row, a, L, s0, pp);
+        const int oy = 2 * row, ox = 2 * (a + pp);
+        pb = pix(oy, ox);
+        fl = (t < cnt ? 1 : 0) | (oy + 1 < H ? 2 : 0) | (ox + 1 < W ? 4 : 0);
+    };
+    auto lin_ok = [](int fl, int i, int j) { return (fl & 1) && (i == 0 || (fl & 2)) && (j == 0 || (fl & 4)); };
+    auto a_out = [&](int r, int pb, int fl, int i, int j) {
+        VA v;
+        if (LIN) {
+            v.vo = (pb * out_ld + n) * 4; v.so = __builtin_amdgcn_readfirstlane(((i * WR + j) * D * out_ld + d.out_c0) * 4); v.ok = lin_ok(fl, i, j);
+        } else {
+            const int oy = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)) + i), ox = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3) + j);
+            v.vo = vo_out; v.so = __builtin_amdgcn_readfirstlane((pix(oy, ox) * out_ld + d.out_c0) * 4); v.ok = live && oy < H && ox + 8 * lh < W;
+        }
+        return v;
+    };
+    auto a_r2 = [&](int r, int pb, int fl, int i, int j) {
+        VA v;
+        if (LIN) {
+            v.vo = (pb * d.Cout + n) * 4; v.so = __builtin_amdgcn_readfirstlane((i * WR + j) * D * d.Cout * 4); v.ok = lin_ok(fl, i, j);
+        } else {
+            const int oy = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)) + i), ox = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3) + j);
+            v.vo = vo_r2; v.so = __builtin_amdgcn_readfirstlane(pix(oy, ox) * d.Cout * 4); v.ok = live && oy < H && ox + 8 * lh < W;
+        }
+        return v;
+    };
+    auto a_r1 = [&](int r, int pb, int fl, int i, int j) {            // (a half-resolution residual only exists for D = 1: planner)
+        VA v;
+        if (LIN) {
+            if (d.res1_shift) {                                        // D = 1: pb = (img H + oy) W + ox
+                const int Y = pb / W, X = pb - Y * W;
+                v.vo = ((((Y + i) >> d.res1_shift) * (d.OWf >> d.res1_shift) + ((X + j) >> d.res1_shift)) * d.Cout + n) * 4; v.so = 0;
+            } else {
+                v.vo = (pb * d.Cout + n) * 4; v.so = __builtin_amdgcn_readfirstlane((i * WR + j) * D * d.Cout * 4);
+            }
+            v.ok = lin_ok(fl, i, j);
+        } else {
+            const int oy = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)) + i), ox = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3) + j);
+            const int Y = img * H + oy;
+            v.vo = vo_r1;
+            v.so = __builtin_amdgcn_readfirstlane(d.res1_shift ? ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (ox >> d.res1_shift)) * d.Cout * 4 : pix(oy, ox) * d.Cout * 4);
+            v.ok = live && oy < H && ox + 8 * lh < W;
+        }
+        return v;
+    };
 #ifdef USC_WINO_NO_PAIR_EPILOGUE
     if constexpr (false) {
 #else
@@ -593,6 +727,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                     const f32x16& y = Yp[2 * (1 - HH) + jj];
                     *reinterpret_cast<float4*>(&Ls[((wave * 8 + jj * 4 + qd) * 64 + lane) * 4]) = make_float4(y[4 * qd], y[4 * qd + 1], y[4 * qd + 2], y[4 * qd + 3]);
                 }
+            int g_pb[16], g_fl[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) { g_pb[r] = 0; g_fl[r] = 0; if (LIN) lin_geom(r, g_pb[r], g_fl[r]); }
             // residual values: requested before the barrier, all of them before the first store, and only where a residual exists
             // (R1: variants with a first residual; R2A: with a per-channel affine and / or a second residual).  A half-resolution
             // residual (nearest x2 upsampling: res1_shift = 1) is the same value for both column phases of a tile: requested once.
@@ -609,13 +746,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                 for (int jj = 0; jj < 2; jj++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const int oy = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)) + HH), ox = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3) + jj);
-                        const bool ok = live && oy < H && ox + 8 * lh < W;
                         if (jj == 0 || !r1_shared) {
-                            const int Y = img * H + oy;         // (a half-resolution residual only exists for D = 1: planner)
-                            const int s1o = __builtin_amdgcn_readfirstlane(d.res1_shift ? ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + (ox >> d.res1_shift)) * d.Cout * 4
-                                                                                        : pix(oy, ox) * d.Cout * 4);
-                            r1p[jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1_rsrc, ok ? vo_r1 : INVALID, s1o, 0));
+                            const VA v = a_r1(r, g_pb[r], g_fl[r], HH, jj);
+                            r1p[jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1_rsrc, v.ok ? v.vo : INVALID, v.so, 0));
                         } else {
                             r1p[jj][r] = r1p[0][r];
                         }
@@ -626,10 +759,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                 for (int jj = 0; jj < 2; jj++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const int oy = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)) + HH), ox = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3) + jj);
-                        const bool ok = live && oy < H && ox + 8 * lh < W;
-                        const int s2o = __builtin_amdgcn_readfirstlane(pix(oy, ox) * d.Cout * 4);
-                        r2p[jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2_rsrc, ok ? vo_r2 : INVALID, s2o, 0));
+                        const VA v = a_r2(r, g_pb[r], g_fl[r], HH, jj);
+                        r2p[jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2_rsrc, v.ok ? v.vo : INVALID, v.so, 0));
                     }
             }
             __syncthreads();
@@ -647,11 +778,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                         if (R1) x += r1p[jj][r];
                         x = fmaxf(x, x * slope);
                         if (R2A) { x = x * sc + sh; x += r2p[jj][r]; }
-                        const int oy = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)) + HH), ox = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3) + jj);
-                        const int so = __builtin_amdgcn_readfirstlane((pix(oy, ox) * out_ld + d.out_c0) * 4);
-                        int vo = vo_out;
-                        if (EDGE) vo = (live && oy < H && ox + 8 * lh < W) ? vo_out : INVALID;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), out_rsrc, vo, so, 0);
+                        const VA v = a_out(r, g_pb[r], g_fl[r], HH, jj);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), out_rsrc, (!EDGE || v.ok) ? v.vo : INVALID, v.so, 0);
                     }
                 }
         };
@@ -669,14 +797,12 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     // rounds (one per phase) through two alternating exchange regions.
     // ALL residual values of the four rounds are requested before the first store is issued: loads and stores share one
     // in-order counter, a load waited for after a store would wait for that store's round trip.
-    int oyq[NR], oxq[NR], so0[NR];
+    int q_pb[NR], q_fl[NR];
     float r1v[4][NR], r2v[4][NR];
 #pragma unroll
     for (int q = 0; q < NR; q++) {
-        const int r = me * NR + q;
-        oyq[q] = __builtin_amdgcn_readfirstlane(2 * (4 * by + (r >> 2)));
-        oxq[q] = __builtin_amdgcn_readfirstlane(16 * bx + 2 * (r & 3));
-        so0[q] = __builtin_amdgcn_readfirstlane((pix(oyq[q], oxq[q]) * out_ld + d.out_c0) * 4);
+        q_pb[q] = 0; q_fl[q] = 0;
+        if (LIN) lin_geom(me * NR + q, q_pb[q], q_fl[q]);
 #pragma unroll
         for (int rd = 0; rd < 4; rd++) { r1v[rd][q] = 0.f; r2v[rd][q] = 0.f; }
     }
@@ -685,12 +811,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         for (int q = 0; q < NR; q++)
 #pragma unroll
             for (int rd = 0; rd < 4; rd++) {
-                const int i = rd >> 1, j = rd & 1;
-                const bool ok = live && oyq[q] + i < H && oxq[q] + 8 * lh + j < W;
-                const int Y = img * H + oyq[q] + i;
-                const int so = __builtin_amdgcn_readfirstlane(d.res1_shift ? ((Y >> d.res1_shift) * (d.OWf >> d.res1_shift) + ((oxq[q] + j) >> d.res1_shift)) * d.Cout * 4
-                                                                           : pix(oyq[q] + i, oxq[q] + j) * d.Cout * 4);
-                r1v[rd][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1_rsrc, ok ? vo_r1 : INVALID, so, 0));
+                const VA v = a_r1(me * NR + q, q_pb[q], q_fl[q], rd >> 1, rd & 1);
+                r1v[rd][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1_rsrc, v.ok ? v.vo : INVALID, v.so, 0));
             }
     }
     if (has_r2) {
@@ -698,10 +820,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         for (int q = 0; q < NR; q++)
 #pragma unroll
             for (int rd = 0; rd < 4; rd++) {
-                const int i = rd >> 1, j = rd & 1;
-                const bool ok = live && oyq[q] + i < H && oxq[q] + 8 * lh + j < W;
-                const int so = __builtin_amdgcn_readfirstlane(pix(oyq[q] + i, oxq[q] + j) * d.Cout * 4);
-                r2v[rd][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2_rsrc, ok ? vo_r2 : INVALID, so, 0));
+                const VA v = a_r2(me * NR + q, q_pb[q], q_fl[q], rd >> 1, rd & 1);
+                r2v[rd][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2_rsrc, v.ok ? v.vo : INVALID, v.so, 0));
             }
     }
     // Exchange layout of a round: [wave][quad of registers][lane][4] floats - b128 writes and reads, lane-contiguous.  The
@@ -735,16 +855,14 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                     v[0] += u.x; v[1] += u.y;
                 }
             }
-            const int pdelta = (i * WR + j) * D * out_ld * 4;
 #pragma unroll
             for (int q = 0; q < NR; q++) {
                 float x = v[q] + bias;
                 if (FULL) x += r1v[rd][q];
                 x = fmaxf(x, x * slope);
                 if (FULL) { x = x * sc + sh; x += r2v[rd][q]; }
-                int vo = vo_out;
-                if (EDGE) vo = (live && oyq[q] + i < H && oxq[q] + 8 * lh + j < W) ? vo_out : INVALID;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), out_rsrc, vo, so0[q] + pdelta, 0);
+                const VA a = a_out(me * NR + q, q_pb[q], q_fl[q], i, j);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), out_rsrc, (!EDGE || a.ok) ? a.vo : INVALID, a.so, 0);
             }
             if (rd == 0) WINO_STAMP(5);
         }
@@ -864,7 +982,7 @@ struct LayerPlan {
     bool reduce;
     dim3 rgrid;
     int nt = 0, rg = 0, kw = 0;            // for usc_conv_plan_query
-    bool wino = false;
+    bool wino = false, lin = false;
 };
 
 static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
@@ -910,35 +1028,48 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
         for (int t = 0; std3 && t < 9; t++) std3 = d.dy[t] == sdy[t] * D && d.dx[t] == sdx[t] * D;
         if (std3 && g_force_wino != 0) {
             const int TH = (d.IH / D + 1) / 2, TW = (d.IW / D + 1) / 2;
-            const long long wt_plan = (long long)plan_batch * D * D * ((TH + 3) / 4) * ((TW + 7) / 8) * (d.Cout / 32);
-            const long long wt = (long long)nbatch * D * D * ((TH + 3) / 4) * ((TW + 7) / 8) * (d.Cout / 32);
-            const int nsteps = d.Cin / 8;
+            // blocks per (virtual) image: 8 x 4 rectangles, or runs of 32 consecutive tiles (at most four row segments: TW >= 11).
             // K groups: a unit (block x channel group x K group) is two waves, a workgroup 4 units, a CU holds one workgroup.
             // K is only split evenly (every wave of a workgroup runs the same number of steps).  Cost model in microseconds,
-            // fitted to profiles/r02/unet_layer_table.md and schp_layers.txt: a round of workgroups costs 6.5 (launch ramp, first
-            // loads, output transform + exchange + stores) + 2.45 per K step (two MFMA phases of 32 on every SIMD); the direct
-            // kernel 6 + flops / 118 TFLOP/s + output bytes / 3 TB/s (its epilogue is exposed when K is short).  All inputs are
-            // plan quantities.
+            // fitted to profiles/r02/unet_layer_table.md and schp_layers_b12.txt: a round of workgroups costs 6.5 (launch ramp, first
+            // loads, output transform + exchange + stores) + 2.45 per K step (two MFMA phases of 32 on every SIMD; 2.8 in the linear
+            // form, which stages 9 instead of 6 requests per step and shares no pixel rows between tile rows); the direct kernel
+            // 6 + flops / 118 TFLOP/s + output bytes / 3 TB/s (its epilogue is exposed when K is short).  All inputs are plan
+            // quantities.
+            const long long blk_rect = (long long)((TH + 3) / 4) * ((TW + 7) / 8), blk_lin = ((long long)TH * TW + 31) / 32;
+            static thread_local int force_lin = -1;
+            if (const char* e = getenv("USC_WINO_LIN")) force_lin = atoi(e);        // tests / A-B timing: 0 never, 1 wherever admissible
+            const int nsteps = d.Cin / 8;
             int kw = 1;
+            bool lin = false;
             double wino_us = 1e30;
-            for (int k = 1; k <= 4; k *= 2) {
-                if (nsteps % k) continue;
-                const long long wgs = (wt_plan * k + 3) / 4;
-                const double t = (double)((wgs + 255) / 256) * (6.5 + (nsteps / k) * 2.45);
-                if (t < wino_us - 1e-9) { wino_us = t; kw = k; }
+            for (int l = 0; l < 2; l++) {
+                if (l == 1 && (TW < 11 || force_lin == 0)) continue;
+                if (l == 0 && force_lin == 1 && TW >= 11) continue;
+                const long long units = (long long)plan_batch * D * D * (l ? blk_lin : blk_rect) * (d.Cout / 32);
+                for (int k = 1; k <= 4; k *= 2) {
+                    if (nsteps % k) continue;
+                    if ((g_force_kw == 1 || g_force_kw == 2 || g_force_kw == 4) && nsteps % g_force_kw == 0 && k != g_force_kw) continue;
+                    const long long wgs = (units * k + 3) / 4;
+                    const double t = (double)((wgs + 255) / 256) * (6.5 + (nsteps / k) * (l ? 2.8 : 2.45));
+                    if (t < wino_us - 1e-9) { wino_us = t; kw = k; lin = l == 1; }
+                }
             }
-            if (g_force_kw == 1 || g_force_kw == 2 || g_force_kw == 4) kw = (nsteps % g_force_kw == 0) ? g_force_kw : 1;
+            const long long blk = lin ? blk_lin : blk_rect;
+            const long long wt = (long long)nbatch * D * D * blk * (d.Cout / 32);
             const double direct_us = 6.0 + 2.0 * (double)m_plan * d.Cout * 9.0 * d.Cin / 118e6 + (double)m_plan * d.Cout * 4.0 / 3e6;
             const bool worth = wino_us < direct_us;
             if (worth || g_force_wino == 1) {
                 p.wino = true;
+                p.lin = lin;
                 p.kw = kw;
                 p.d.ksplit = 1;
                 p.d.nphase = 1;
                 const long long waves = wt * kw;
                 p.grid = dim3((unsigned)((waves + 3) / 4));
                 p.block = dim3(512);                              // 4 units x 2 position halves
-#define USC_PICKW(KWV) (d.in_relu ? (void*)conv_wino_kernel<KWV, true> : (void*)conv_wino_kernel<KWV, false>)
+#define USC_PICKW(KWV) (lin ? (d.in_relu ? (void*)conv_wino_kernel<KWV, true, true> : (void*)conv_wino_kernel<KWV, false, true>) \
+                           : (d.in_relu ? (void*)conv_wino_kernel<KWV, true, false> : (void*)conv_wino_kernel<KWV, false, false>))
                 p.fn = kw == 4 ? USC_PICKW(4) : kw == 2 ? USC_PICKW(2) : USC_PICKW(1);
 #undef USC_PICKW
                 return USC_OK;
@@ -1046,7 +1177,7 @@ extern "C" int usc_conv_plan_query(const usc_conv_desc* desc, usc_conv_plan_info
     int rc = plan_layer(*desc, p);
     if (rc) return rc;
     out->nt = p.nt; out->rowgroups = p.rg; out->kgroups = p.kw; out->ksplit = p.d.kind == USC_CONV_HEAD ? 1 : p.d.ksplit;
-    out->winograd = p.wino ? 1 : 0;
+    out->winograd = p.wino ? (p.lin ? 2 : 1) : 0;                 // 2: blocks of 32 consecutive tiles
     out->workgroups = (int)(p.grid.x * p.grid.y * p.grid.z);
     out->threads = (int)p.block.x;
     out->launches = p.reduce ? 2 : 1;
