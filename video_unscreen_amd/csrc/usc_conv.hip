@@ -35,6 +35,7 @@
 #include "../../include/unscreen_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -516,33 +517,33 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         for (int k = 0; k < 3; k++) fa[k] = (s0 + 2 * ((h + k) * 2 * L + pp) + (lane >> 5)) * 4;
         fs2 = 2 * L * 4;
     }
-    auto add4 = [](const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
-    auto sub4 = [](const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
-    auto relu4 = [](const float4& a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); };
-    auto vrow = [&](const float4 (&T)[4], int b) {                  // one element of a row of V = T B
-        return b == 0 ? sub4(T[0], T[2]) : b == 1 ? add4(T[1], T[2]) : b == 2 ? sub4(T[2], T[1]) : sub4(T[1], T[3]);
+    // (vector types, not float4 structs: additions of <4 x float> become two v_pk_add_f32 - half the vector instructions that
+    // compete with the partner wave's MFMAs for the register ports)
+    auto relu4 = [](const f32x4& a) { return f32x4{fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)}; };
+    auto vrow = [&](const f32x4 (&T)[4], int b) {                   // one element of a row of V = T B
+        return b == 0 ? T[0] - T[2] : b == 1 ? T[1] + T[2] : b == 2 ? T[2] - T[1] : T[1] - T[3];
     };
 
-    float4 V0[4], V1[4];                                            // handed from the fragment phase to the MFMA phase
+    f32x4 V0[4], V1[4];                                             // handed from the fragment phase to the MFMA phase
     // Fragment phase of step c: this wave's two rows of T = B^T d from the staged image, then its two rows of V = T B.  (The MFMA
     // phase carries no vector arithmetic at all: next to f32 32x32 MFMAs, whose accumulators travel through the same register
     // ports, every vector instruction of the same wave measurably delays the matrix pipe.)
     auto frag_phase = [&](int c, auto hh) {
         constexpr int HH = decltype(hh)::value;
         const int cur = img0 + ((c - c_begin) & 1) * IMGF + (LIN ? 0 : fb);
-        float4 Ta[4], Tb[4];
+        f32x4 Ta[4], Tb[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int co = ((j & 1) * WSUB + (j >> 1) * 2) * 4;
-            float4 e[3];
+            f32x4 e[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                if (LIN) e[k] = *reinterpret_cast<const float4*>(&Ls[cur + fa[k] + (j & 1) * fs2 + (j >> 1) * 8]);
-                else e[k] = *reinterpret_cast<const float4*>(&Ls[cur + ((((HH + k) & 1) * 2) * WSUB + ((HH + k) >> 1) * WSUBROW) * 4 + co]);
+                if (LIN) e[k] = *reinterpret_cast<const f32x4*>(&Ls[cur + fa[k] + (j & 1) * fs2 + (j >> 1) * 8]);
+                else e[k] = *reinterpret_cast<const f32x4*>(&Ls[cur + ((((HH + k) & 1) * 2) * WSUB + ((HH + k) >> 1) * WSUBROW) * 4 + co]);
                 if (IN_RELU) e[k] = relu4(e[k]);
             }
-            if (HH == 0) { Ta[j] = sub4(e[0], e[2]); Tb[j] = add4(e[1], e[2]); }       // rows 0, 1: d0 - d2, d1 + d2
-            else { Ta[j] = sub4(e[1], e[0]); Tb[j] = sub4(e[0], e[2]); }               // rows 2, 3: d2 - d1, d1 - d3
+            if (HH == 0) { Ta[j] = e[0] - e[2]; Tb[j] = e[1] + e[2]; }                 // rows 0, 1: d0 - d2, d1 + d2
+            else { Ta[j] = e[1] - e[0]; Tb[j] = e[0] - e[2]; }                         // rows 2, 3: d2 - d1, d1 - d3
         }
 #pragma unroll
         for (int b = 0; b < 4; b++) { V0[b] = vrow(Ta, b); V1[b] = vrow(Tb, b); }
