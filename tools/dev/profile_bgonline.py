@@ -34,6 +34,7 @@ a1 = timed("matting net", lambda: pipe.vmatagent.forward_device(frames[4], pipe.
 bg = timed("get_bg", lambda: nv.get_bg(a1, frames[4]))
 hole = timed("hole (thr + dilate)", lambda: nv.morph((a1 > 128).to(torch.uint8) * 255, 3, 2, nv.DILATE))
 bgimg = timed("regionfill", lambda: nv.regionfill(bg, hole, ws=pipe._ws_fill))
+print("   hole fraction %.3f, iterations %d" % (float((hole > 0).float().mean()), nv.regionfill(bg, hole, ws=pipe._ws_fill, want_iters=True)[1]), flush=True)
 timed("bgdiff", lambda: nv.bgdiff_mask(frames[4], bgimg, None, a1, 1.0, 25, ws=pipe._ws_diff))
 timed("get_fg", lambda: nv.get_fg(frames[4], a1, bgimg, paste_thr=1, want_bg=True))
 timed("exist_foreground", lambda: pipe._exist_foreground(a1))

@@ -251,7 +251,7 @@ namespace {
 struct Level { int H, W; double s; uint8_t* mask; double *z, *zt, *r; };
 struct LevelSet { int L, first_tail; Level lv[kMaxLevels]; };
 constexpr int kTailThreads = 1024;
-constexpr int kTailCells = 9000;           // levels with at most this many cells run inside the single-workgroup tail kernel
+constexpr int kTailCells = 2500;           // levels with at most this many cells run inside the single-workgroup tail kernel (one CU: ~12 us per sweep of 8000 cells, measured)
 }  // namespace
 
 __global__ __launch_bounds__(kThreads) void mg_mask_down_kernel(const uint8_t* __restrict__ mf, int Hf, int Wf, uint8_t* __restrict__ mc,
@@ -294,6 +294,34 @@ __global__ __launch_bounds__(kThreads) void mg_jacobi_kernel(const uint8_t* __re
                                                              const double* __restrict__ r, double* __restrict__ zout, const int* __restrict__ ctl) {
     if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
     mg_jacobi_cells(mask, H, W, s, zin, r, zout, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// The last sweep of a V-cycle on level 0 and the dot product r . z that follows it in the CG iteration, in one pass: launched with
+// kBlocks workgroups, every workgroup sums the cells rf_dot_kernel would have given it, in the same order (same partial sums,
+// bit for bit), one launch and one pass over r and z less per iteration.
+__global__ __launch_bounds__(kThreads) void mg_jacobi_dot_kernel(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ zin,
+                                                                 const double* __restrict__ r, double* __restrict__ zout, double* __restrict__ part,
+                                                                 const int* __restrict__ ctl) {
+    if (ctl[0]) return;
+    __shared__ double s_part[12];
+    D3 acc = {{0., 0., 0.}};
+    const uint32_t n = (uint32_t)H * (uint32_t)W;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (!mask[i]) continue;
+        const int y = (int)(i / (uint32_t)W), x = (int)(i - (uint32_t)y * (uint32_t)W);
+        const Nbr nb = neighbours(y, x, H, W);
+        const double w = kOmega / (s * (double)nb.n);
+        double a[3];
+        stencil3(mask, zin, i, nb, a);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double rc = r[3 * (size_t)i + c];
+            const double z = zin[3 * (size_t)i + c] + w * (rc - s * a[c]);
+            zout[3 * (size_t)i + c] = z;
+            acc.v[c] += rc * z;
+        }
+    }
+    store_partial(part, block_sum(acc, s_part));
 }
 
 // Two sweeps from zero in one pass: z1 = omega / (s n) r is pointwise, so the second sweep evaluates it on the fly for the
@@ -412,11 +440,38 @@ __global__ __launch_bounds__(kThreads) void mg_restrict_kernel(const uint8_t* __
 // The coarse end of the V-cycle (levels first_tail .. L-1, a few thousand cells at most) inside ONE workgroup: the same
 // sweeps in the same order as the per-level kernels, separated by workgroup barriers instead of kernel boundaries
 // (every cell's arithmetic is identical, so the result does not depend on which path ran).
+// The vectors (z, zt, r) of the coarsest levels live in LDS for the duration of the kernel: the tail is a chain of ~33 tiny
+// phases separated by barriers, and a phase on global memory costs a round trip to the L2 (~2.5 us) however few cells it has.
+constexpr int kTailLdsDoubles = 6144;      // 48 KB: at 1080p the levels 17 x 30, 9 x 15 and 5 x 8 (25 of the 33 phases)
 __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls, const int* __restrict__ ctl) {
     if (ctl[0]) return;
+    __shared__ double s_buf[kTailLdsDoubles];
+    __shared__ int s_off[kMaxLevels];                      // first double of a level's three vectors in s_buf, -1: the level stays in global memory
     const uint32_t t = threadIdx.x, nt = blockDim.x;
+    if (t == 0) {
+        int used = 0;
+        bool open = true;
+        for (int l = kMaxLevels - 1; l >= 0; l--) {
+            s_off[l] = -1;
+            if (l >= ls.L || l <= ls.first_tail || !open) continue;      // (the first tail level receives its r from a kernel before this one)
+            const int need = 3 * 3 * ls.lv[l].H * ls.lv[l].W;
+            if (used + need > kTailLdsDoubles) { open = false; continue; }
+            s_off[l] = used;
+            used += need;
+        }
+    }
+    __syncthreads();
+    auto level = [&](int l) {
+        Level v = ls.lv[l];
+        const int o = s_off[l];
+        if (o >= 0) {
+            const int nv = 3 * v.H * v.W;
+            v.z = s_buf + o; v.zt = s_buf + o + nv; v.r = s_buf + o + 2 * nv;
+        }
+        return v;
+    };
     for (int l = ls.first_tail; l < ls.L; l++) {
-        const Level& v = ls.lv[l];
+        const Level v = level(l);
         if (l == ls.L - 1) {
             mg_jacobi_cells(v.mask, v.H, v.W, v.s, nullptr, v.r, v.z, t, nt);
             __syncthreads();
@@ -429,14 +484,14 @@ __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls, cons
         } else {
             mg_jacobi2_cells(v.mask, v.H, v.W, v.s, v.r, v.z, t, nt);
             __syncthreads();
-            const Level& c = ls.lv[l + 1];
+            const Level c = level(l + 1);
             mg_restrict_cells(v.mask, v.H, v.W, v.s, v.z, v.r, c.mask, c.H, c.W, c.r, t, nt);
             __syncthreads();
         }
     }
     for (int l = ls.L - 2; l >= ls.first_tail; l--) {
-        const Level& v = ls.lv[l];
-        mg_prolong_jacobi_cells(v.mask, v.H, v.W, v.s, v.z, ls.lv[l + 1].z, ls.lv[l + 1].W, v.r, v.zt, t, nt);
+        const Level v = level(l), c = level(l + 1);
+        mg_prolong_jacobi_cells(v.mask, v.H, v.W, v.s, v.z, c.z, c.W, v.r, v.zt, t, nt);
         __syncthreads();
         mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, t, nt);
         __syncthreads();
@@ -514,7 +569,7 @@ struct Solver {
     }
 
     // z_l = V-cycle(r_l): 2 pre-smoothing sweeps from zero, coarse correction, 2 post-smoothing sweeps; 17 sweeps on the last level
-    void vcycle(Launcher& q) const {
+    void vcycle(Launcher& q, double* part_rz_new) const {
         const dim3 b(kThreads);
         const int last = first_tail < L ? first_tail : L;          // levels [0, last) run as per-level kernels
         for (int l = 0; l < last; l++) {
@@ -543,7 +598,8 @@ struct Solver {
             const Level& v = lv[l];
             const dim3 g(grid_of((size_t)v.H * v.W));
             q.launch(mg_prolong_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.z, lv[l + 1].z, lv[l + 1].W, v.r, v.zt, ctl);   // correction + sweep
-            q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, ctl);
+            if (l == 0 && part_rz_new) q.launch(mg_jacobi_dot_kernel, dim3(kBlocks), b, v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, part_rz_new, ctl);   // + r.z
+            else q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, ctl);
         }
     }
 
@@ -551,8 +607,9 @@ struct Solver {
     void iteration(Launcher& q, int first, int& cur) const {
         const dim3 b(kThreads), g(kBlocks);           // reductions always use kBlocks blocks: the partial arrays have that many rows
         double* r = lv[0].r;
-        vcycle(q);                                                                                   // z = M^-1 r
-        q.launch(rf_dot_kernel, g, b, mask0, n, r, lv[0].z, part_rz[cur ^ 1], ctl);                       // r.z (new)
+        const bool fused = first_tail >= 1 && L >= 2;                                                // level 0 ends with a per-level sweep
+        vcycle(q, fused ? part_rz[cur ^ 1] : nullptr);                                               // z = M^-1 r (+ the partial sums of r.z)
+        if (!fused) q.launch(rf_dot_kernel, g, b, mask0, n, r, lv[0].z, part_rz[cur ^ 1], ctl);           // r.z (new)
         q.launch(rf_p_kernel, g, b, mask0, n, lv[0].z, p, part_rz[cur], part_rz[cur ^ 1], first, ctl);
         cur ^= 1;
         q.launch(rf_ap_kernel, g, b, mask0, H, W, p, Ap, part_pap, ctl);
