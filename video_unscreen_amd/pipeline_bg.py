@@ -51,7 +51,9 @@ class BgOnlinePipeline:
         count + a margin; 48 to start with), the convergence test runs on the device, and the 8-byte status is read at the
         step's next natural synchronisation point (exist_foreground) - if a budget ever turns out too small the solve is
         continued there, before anything downstream has been consumed."""
-        budget = 48 if self.fill_iters <= 0 else min(400, self.fill_iters + max(8, self.fill_iters // 2))
+        # (every iteration past convergence is 24 launches that return at their first instruction, ~60 us: the margin is kept small;
+        # the iteration count of consecutive frames barely moves, and a short budget only costs one continuation below)
+        budget = 48 if self.fill_iters <= 0 else min(400, self.fill_iters + max(6, self.fill_iters // 6))
         bgimg = nv.regionfill(bg, hole, rtol=self.fill_rtol, ws=self._ws_fill, budget=budget, sync=False, status=self._fill_status)
         self._fill_pending = (bg, hole, bgimg, budget)
         return bgimg
@@ -67,10 +69,10 @@ class BgOnlinePipeline:
         redo = not conv
         it = budget
         while not conv and it < 2000:
-            nv.load().usc_regionfill_u8(bg.data_ptr(), hole.data_ptr(), self.H, self.W, bgimg.data_ptr(), float(self.fill_rtol), it, 48,
+            nv.load().usc_regionfill_u8(bg.data_ptr(), hole.data_ptr(), self.H, self.W, bgimg.data_ptr(), float(self.fill_rtol), it, 16,
                                         self._fill_status.data_ptr(), self._ws_fill.data_ptr(), self._ws_fill.numel(),
                                         torch.cuda.current_stream().cuda_stream)
-            it += 48
+            it += 16
             used, conv = (int(v) for v in self._fill_status.cpu())
         self.fill_iters = used
         return redo
