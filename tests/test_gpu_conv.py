@@ -258,18 +258,22 @@ def test_conv_graphs_are_destroyed_for_real(hipnet):
     assert used[-1] <= used[2], used
 
 
-@pytest.mark.parametrize("cin,cout,h,w,batch,kw,dil,lin", [
-    (8, 32, 17, 30, 1, 1, 1, 0), (32, 32, 20, 36, 1, 1, 1, 0), (64, 64, 33, 47, 1, 2, 1, 0), (128, 128, 12, 20, 2, 4, 1, 0), (32, 64, 9, 7, 3, 2, 1, 0),
-    (256, 96, 16, 16, 1, 4, 1, 0), (16, 32, 64, 96, 1, 1, 1, 0), (64, 64, 30, 30, 2, 2, 2, 0), (32, 32, 18, 42, 1, 1, 2, 0), (32, 64, 27, 15, 2, 1, 3, 0),
+@pytest.mark.parametrize("cin,cout,h,w,batch,kw,dil,lin,split", [
+    (8, 32, 17, 30, 1, 1, 1, 0, 1), (32, 32, 20, 36, 1, 1, 1, 0, 1), (64, 64, 33, 47, 1, 2, 1, 0, 1), (128, 128, 12, 20, 2, 4, 1, 0, 1), (32, 64, 9, 7, 3, 2, 1, 0, 1),
+    (256, 96, 16, 16, 1, 4, 1, 0, 1), (16, 32, 64, 96, 1, 1, 1, 0, 1), (64, 64, 30, 30, 2, 2, 2, 0, 1), (32, 32, 18, 42, 1, 1, 2, 0, 1), (32, 64, 27, 15, 2, 1, 3, 0, 1),
     # blocks of 32 consecutive tiles (tile rows of >= 11 tiles): runs that start mid-row, wrap over up to four rows, end in a partial block
-    (32, 32, 20, 36, 1, 1, 1, 1), (64, 64, 33, 47, 1, 2, 1, 1), (16, 32, 64, 96, 1, 1, 1, 1), (128, 128, 68, 120, 1, 4, 1, 1), (32, 64, 23, 22, 3, 2, 1, 1),
-    (32, 32, 18, 44, 1, 1, 2, 1), (8, 32, 31, 45, 2, 1, 1, 1)])
-def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw, dil, lin):
+    (32, 32, 20, 36, 1, 1, 1, 1, 1), (64, 64, 33, 47, 1, 2, 1, 1, 1), (16, 32, 64, 96, 1, 1, 1, 1, 1), (128, 128, 68, 120, 1, 4, 1, 1, 1), (32, 64, 23, 22, 3, 2, 1, 1, 1),
+    (32, 32, 18, 44, 1, 1, 2, 1, 1), (8, 32, 31, 45, 2, 1, 1, 1, 1),
+    # K halves on two workgroups (partial tiles meet in the slab, the second to arrive finishes)
+    (128, 128, 12, 20, 2, 4, 1, 0, 2), (64, 64, 33, 47, 1, 2, 1, 1, 2), (256, 96, 16, 16, 1, 4, 1, 0, 2), (128, 128, 34, 60, 1, 4, 1, 1, 2),
+    (64, 64, 30, 30, 2, 2, 2, 0, 2), (32, 64, 9, 7, 3, 2, 1, 0, 2), (256, 256, 34, 60, 2, 4, 1, 1, 2)])
+def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw, dil, lin, split):
     """conv_wino_kernel (Winograd F(2x2, 3x3): 3x3 / stride 1 / pad 1) against torch's float64 convolution: odd sizes (partial
     tiles and blocks), images stacked along y, K groups, the full fused epilogue, and dilated layers (dil x dil standard
-    convolutions on the pixel-parity sub-images)."""
+    convolutions on the pixel-parity sub-images), and K split over two workgroups."""
     from video_unscreen_amd import _native as nv
     g = torch.Generator().manual_seed(cin * 1000 + cout + h)
+    slab = torch.empty(8 * 1024 * 1024, device="cuda").fill_(float("nan")) if split == 2 else None
     x = torch.randn(batch, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) * (1.5 / (3 * cin ** 0.5))
     b = torch.randn(cout, generator=g)
@@ -291,16 +295,26 @@ def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw, dil, l
         wino = hipnet.pack_wino(wt).cuda()
         L.keep.append(wino)
         d.wino = wino.data_ptr()
+        if slab is not None:
+            d.slab, d.slab_bytes = slab.data_ptr(), slab.numel() * 4
         lib.usc_conv_force_winograd(1)
         lib.usc_conv_force_plan(0, 0, 0, kw)
         os.environ["USC_WINO_LIN"] = str(lin)
+        os.environ["USC_WINO_SPLIT"] = str(split)
         try:
             arr = (hipnet.ConvDesc * 1)(d)
             plan = nv.conv_plans(arr, 1)[0]
-            assert plan["winograd"] and ("-lin" in plan["plan"]) == bool(lin), plan
+            assert plan["winograd"] and ("-lin" in plan["plan"]) == bool(lin) and ("S=2" in plan["plan"]) == (split == 2), plan
             L.run([d])
+            if split == 2:                                   # the same bits on every run, whichever workgroup arrives second
+                first = out.clone()
+                for _ in range(5):
+                    out.fill_(float("nan"))
+                    L.run([d])
+                    assert torch.equal(out, first)
         finally:
             os.environ["USC_WINO_LIN"] = "-1"
+            os.environ["USC_WINO_SPLIT"] = "0"
             lib.usc_conv_force_winograd(-1)
             lib.usc_conv_force_plan(0, 0, 0, 0)
         y = F.conv2d(x.double(), wt.double(), b.double(), padding=dil, dilation=dil)

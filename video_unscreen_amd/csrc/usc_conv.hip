@@ -347,6 +347,7 @@ static_assert(WLDS >= 4 * 2 * WIMG, "the patch images must fit");
 // tiles read consecutive 16-byte slots.  Needs TW >= 11 (at most four segments: 16 x (32 + 4) slots = 9 requests of 64).
 constexpr int WLIN_IMG = 576 * 4;           // floats of one LDS image of the linear form
 constexpr int WLDS_LIN = 8 * WLIN_IMG > WLDS ? 8 * WLIN_IMG : WLDS;        // 72 KB
+constexpr int WSLAB_TAIL = 65536;      // the slab's last bytes: arrival counters of layers that split K over two workgroups
 
 struct VA { int vo, so; bool ok; };          // where a finished value goes: lane offset, scalar offset, exists
 
@@ -373,7 +374,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     const int ntile_img = TH * TW, nblk_img = LIN ? (ntile_img + 31) >> 5 : BH * BW;
     const int ntiles = nimg * nblk_img * nnb;                       // blocks x channel groups
     const int nwg = (int)gridDim.x, xcd = (int)blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;      // XCD-aware order (see above)
-    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
+    const int wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
+    // K split across TWO workgroups (d.ksplit = 2, K groups only): neighbours in the XCD-local order take the two halves of the
+    // channel range of the same units; their partial output tiles meet in the slab, the workgroup that arrives second finishes.
+    const int S = d.ksplit == 2 ? 2 : 1;
+    const int ks = S == 2 ? (wid & 1) : 0, wgid = S == 2 ? (wid >> 1) : wid;
     constexpr int TPW = 4 / KW;                                     // blocks x channel groups per workgroup
     const int wt = wgid * TPW + sub / KW, kg = sub % KW;
     const bool live = wt < ntiles;
@@ -420,8 +425,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     const int pix0 = __builtin_amdgcn_readfirstlane((imr * d.IH + pary) * WR + par - pary * D);      // real pixel index of virtual (0, 0)
     auto pix = [&](int y, int x) { return pix0 + (y * WR + x) * D; };
     const int nch = d.Cin >> 3;                                     // K steps of 8 input channels
-    const int nmax = (nch + KW - 1) / KW;                           // steps of the longest K group: the workgroup's phase count
-    const int c_begin = live ? kg * nmax : 0;                       // the planner splits K evenly: nch = KW * nmax
+    const int nmax = nch / (KW * S);                                // steps per wave: the planner splits K evenly, nch = S * KW * nmax
+    const int c_begin = live ? (ks * KW + kg) * nmax : 0;
 
     // ---- weight fragments: [c][p][k half][n][4] floats; this wave's positions are p = (2h + ar) * 4 + b.  The lane part of the
     // address is a constant, the (step, position) part goes through the scalar offset: no address registers per load.
@@ -830,9 +835,19 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     // image (no per-lane validity) or not - ~7 instead of ~18 instructions per stored value in the common case.
     auto rounds = [&](auto full_c, auto edge_c) {
         constexpr bool FULL = decltype(full_c)::value, EDGE = decltype(edge_c)::value;
+        auto finish = [&](float x, int rd, int q) {               // bias, residual, activation, affine, second residual, store
+            x += bias;
+            if (FULL) x += r1v[rd][q];
+            x = fmaxf(x, x * slope);
+            if (FULL) { x = x * sc + sh; x += r2v[rd][q]; }
+            const VA a = a_out(me * NR + q, q_pb[q], q_fl[q], rd >> 1, rd & 1);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), out_rsrc, (!EDGE || a.ok) ? a.vo : INVALID, a.so, 0);
+        };
+        float vs[4][NR];
+        constexpr int SC = 0x11;                                  // sc0 | sc1 (two workgroups per unit, below)
+        const __amdgpu_buffer_rsrc_t sl_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.slab, 0, S == 2 ? (int)d.slab_bytes : 0, 0x00020000);
 #pragma unroll
         for (int rd = 0; rd < 4; rd++) {
-            const int i = rd >> 1, j = rd & 1;
             float* const reg = Ls + (rd & 1) * WREGION;
 #pragma unroll
             for (int qd = 0; qd < 4; qd++)
@@ -858,15 +873,35 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
             }
 #pragma unroll
             for (int q = 0; q < NR; q++) {
-                float x = v[q] + bias;
-                if (FULL) x += r1v[rd][q];
-                x = fmaxf(x, x * slope);
-                if (FULL) { x = x * sc + sh; x += r2v[rd][q]; }
-                const VA a = a_out(me * NR + q, q_pb[q], q_fl[q], i, j);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), out_rsrc, (!EDGE || a.ok) ? a.vo : INVALID, a.so, 0);
+                vs[rd][q] = v[q];
+                if (S == 1) finish(v[q], rd, q);
+                else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[q]), sl_rsrc, ((rd * 16 + me * NR + q) * 64 + lane) * 4,
+                                                           (wt * 2 + ks) * 16384, SC);
             }
             if (rd == 0) WINO_STAMP(5);
         }
+        if (S == 1) return;
+        // ---- two workgroups per unit: this one's sums went to the slab ([unit][half][phase][register][lane]) with system-scope
+        // write-through stores (the partner may sit on another XCD, whose L2 is not coherent with ours: sc0 sc1 on both sides instead
+        // of a release that writes the whole L2 back), then one relaxed atomic per workgroup counts arrivals; the second to arrive
+        // adds the first one's sums to its own (half 0 + half 1: addition commutes) and finishes.  The counters (last WSLAB_TAIL bytes of
+        // the slab, zeroed by the host once) only ever matter modulo 2.
+        int* const counter = reinterpret_cast<int*>(reinterpret_cast<char*>(d.slab) + d.slab_bytes - WSLAB_TAIL) + wt;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the stores have been acknowledged
+        __syncthreads();
+        int* const s_flag = reinterpret_cast<int*>(Ls);           // (the exchange regions are free: every wave is past its last read)
+        if ((wave & 3) == ubase && h == 0 && kg == 0 && lane == 0)
+            s_flag[sub / KW] = live ? (__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) : 0;
+        __syncthreads();
+        if (s_flag[sub / KW] == 0) return;                        // first to arrive (even count): the partner finishes
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++)
+#pragma unroll
+            for (int q = 0; q < NR; q++) {
+                const float o = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sl_rsrc, ((rd * 16 + me * NR + q) * 64 + lane) * 4,
+                                                                                               (wt * 2 + (1 - ks)) * 16384, SC));
+                finish(ks == 0 ? vs[rd][q] + o : o + vs[rd][q], rd, q);
+            }
     };
     if (plain) { if (interior) rounds(no, no); else rounds(no, yes); }
     else { if (interior) rounds(yes, no); else rounds(yes, yes); }
@@ -984,7 +1019,10 @@ struct LayerPlan {
     dim3 rgrid;
     int nt = 0, rg = 0, kw = 0;            // for usc_conv_plan_query
     bool wino = false, lin = false;
+    bool wsplit = false;                   // Winograd layer with two workgroups per unit: uses the arrival counters in the slab's tail
 };
+
+static inline void* wslab_counters(const usc_conv_desc& d) { return reinterpret_cast<char*>(d.slab) + d.slab_bytes - WSLAB_TAIL; }
 
 static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     if (!d.in || !d.out || !d.wpk || d.Cin <= 0 || d.Cin % 4 || d.ntaps < 1 || d.ntaps > 16 || d.OH <= 0 || d.OW <= 0)
@@ -1041,9 +1079,11 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
             static thread_local int force_lin = -1;
             if (const char* e = getenv("USC_WINO_LIN")) force_lin = atoi(e);        // tests / A-B timing: 0 never, 1 wherever admissible
             const int nsteps = d.Cin / 8;
-            int kw = 1;
+            int kw = 1, ws = 1;
             bool lin = false;
             double wino_us = 1e30;
+            static thread_local int force_ws = 0;
+            if (const char* e = getenv("USC_WINO_SPLIT")) force_ws = atoi(e);       // tests / A-B timing: 1 never, 2 wherever admissible
             for (int l = 0; l < 2; l++) {
                 if (l == 1 && (TW < 11 || force_lin == 0)) continue;
                 if (l == 0 && force_lin == 1 && TW >= 11) continue;
@@ -1051,9 +1091,16 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
                 for (int k = 1; k <= 4; k *= 2) {
                     if (nsteps % k) continue;
                     if ((g_force_kw == 1 || g_force_kw == 2 || g_force_kw == 4) && nsteps % g_force_kw == 0 && k != g_force_kw) continue;
-                    const long long wgs = (units * k + 3) / 4;
-                    const double t = (double)((wgs + 255) / 256) * (6.5 + (nsteps / k) * (l ? 2.8 : 2.45));
-                    if (t < wino_us - 1e-9) { wino_us = t; kw = k; lin = l == 1; }
+                    // a second workgroup per unit (K halves meet in the slab, the later one finishes): K groups only
+                    const long long units_cap = (long long)(nbatch > plan_batch ? nbatch : plan_batch) * D * D * (l ? blk_lin : blk_rect) * (d.Cout / 32);
+                    const bool ok2 = k > 1 && nsteps % (2 * k) == 0 && d.slab && units_cap * 4 <= WSLAB_TAIL &&
+                                     (size_t)units_cap * 2 * 16384 + WSLAB_TAIL <= d.slab_bytes && force_ws != 1;
+                    for (int sp = 1; sp <= 2; sp++) {
+                        if ((sp == 2 && !ok2) || (sp == 1 && ok2 && force_ws == 2)) continue;
+                        const long long wgs = (units * k + 3) / 4 * sp;
+                        const double t = (double)((wgs + 255) / 256) * (6.5 + (sp > 1 ? 3.5 : 0.0) + (nsteps / (k * sp)) * (l ? 2.8 : 2.45));
+                        if (t < wino_us - 1e-9) { wino_us = t; kw = k; lin = l == 1; ws = sp; }
+                    }
                 }
             }
             const long long blk = lin ? blk_lin : blk_rect;
@@ -1064,10 +1111,11 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
                 p.wino = true;
                 p.lin = lin;
                 p.kw = kw;
-                p.d.ksplit = 1;
+                p.d.ksplit = ws;
+                p.wsplit = ws == 2;
                 p.d.nphase = 1;
                 const long long waves = wt * kw;
-                p.grid = dim3((unsigned)((waves + 3) / 4));
+                p.grid = dim3((unsigned)((waves + 3) / 4 * ws));
                 p.block = dim3(512);                              // 4 units x 2 position halves
 #define USC_PICKW(KWV) (lin ? (d.in_relu ? (void*)conv_wino_kernel<KWV, true, true> : (void*)conv_wino_kernel<KWV, false, true>) \
                            : (d.in_relu ? (void*)conv_wino_kernel<KWV, true, false> : (void*)conv_wino_kernel<KWV, false, false>))
@@ -1105,7 +1153,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
         S = g_force_s ? g_force_s : 1;
         KW = g_force_kw ? g_force_kw : 1;
         RG = g_force_rg ? g_force_rg : 4;
-        if (S > 1 && (!d.slab || (size_t)S * plane_bytes > d.slab_bytes)) S = 1;
+        if (S > 1 && (!d.slab || (size_t)S * plane_bytes + WSLAB_TAIL > d.slab_bytes)) S = 1;
         if (S * KW > nch) { S = 1; KW = 1; }
         if (RG != 1 && RG != 2 && RG != 4) RG = 4;
         if (!exists(RG, KW)) { RG = 4; KW = nt2 ? (KW >= 2 ? 2 : 1) : (KW >= 4 ? 4 : KW >= 2 ? 2 : 1); }
@@ -1125,7 +1173,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
         for (int rg = 4; rg >= rg_min; rg >>= 1) {
             const long long blocks = (m_plan + 32 * rg - 1) / (32 * rg) * nblocks * nphase;
             for (int s = 1; s <= 16; s++) {
-                if (s > 1 && (!d.slab || (size_t)s * plane_bytes > d.slab_bytes)) break;
+                if (s > 1 && (!d.slab || (size_t)s * plane_bytes + WSLAB_TAIL > d.slab_bytes)) break;
                 for (int kw = 1; kw <= 16; kw *= 2) {
                     if (!exists(rg, kw)) continue;
                     if ((s > 1 && nch / (s * kw) < min_steps) || (kw > 1 && nch / (s * kw) < kw_steps)) continue;
@@ -1192,6 +1240,7 @@ extern "C" int usc_conv_sequence_f32(const usc_conv_desc* descs, int n, usc_stre
         LayerPlan p;
         int rc = plan_layer(descs[i], p);
         if (rc) return rc;
+        if (p.wsplit && hipMemsetAsync(wslab_counters(p.d), 0, WSLAB_TAIL, st) != hipSuccess) return conv_fail(USC_E_LAUNCH, "hipMemsetAsync (arrival counters) failed");
         void* args[] = {&p.d};
         hipError_t e = hipLaunchKernel(p.fn, p.grid, p.block, args, 0, st);
         if (e == hipSuccess && p.reduce) e = hipLaunchKernel((void*)splitk_reduce_kernel, p.rgrid, dim3(256), args, 0, st);
@@ -1226,6 +1275,10 @@ extern "C" int usc_conv_graph_create(const usc_conv_desc* descs, int n, void** h
     for (int i = 0; i < n; i++) {
         int rc = plan_layer(descs[i], g->plans[i]);
         if (rc) { delete g; return rc; }
+        // arrival counters of Winograd layers split over two workgroups: zero once, every launch leaves them even
+        if (g->plans[i].wsplit && hipMemset(wslab_counters(g->plans[i].d), 0, WSLAB_TAIL) != hipSuccess) {
+            delete g; return conv_fail(USC_E_LAUNCH, "hipMemset (arrival counters) failed");
+        }
     }
     if (hipGraphCreate(&g->graph, 0) != hipSuccess) { delete g; return conv_fail(USC_E_LAUNCH, "hipGraphCreate failed"); }
     std::vector<hipGraphNode_t> last(n);                     // node that completes layer i
