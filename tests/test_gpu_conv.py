@@ -328,6 +328,58 @@ def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw, dil, l
         assert err < 2e-5, (fused, float(err))
 
 
+@pytest.mark.parametrize("cin,cout,h,w", [
+    (32, 32, 12, 36), (64, 64, 17, 30), (8, 32, 20, 40), (128, 128, 34, 60), (256, 64, 9, 35), (32, 64, 7, 16),
+    (64, 32, 33, 100), (16, 32, 5, 4), (32, 32, 48, 96), (32, 32, 51, 333)])
+def test_winograd_transposed_layer_matches_torch(hipnet, cin, cout, h, w):
+    """conv_wino_kernel's transposed form (ConvTranspose2d(k 4, s 2, p 1) as Winograd F(3x3, 2x2) per output phase) against
+    torch's float64 transposed convolution: sizes that are no multiples of 3, narrow maps (blocks of whole tile rows), rows of
+    more than 32 tiles, bias / activation / second residual."""
+    from video_unscreen_amd import _native as nv
+    g = torch.Generator().manual_seed(cin * 1000 + cout + h)
+    x = torch.randn(1, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, 4, 4, generator=g) * (1.5 / (2 * cin ** 0.5))
+    b = torch.randn(cout, generator=g)
+    r2 = torch.randn(1, cout, 2 * h, 2 * w, generator=g)
+    L = _Layer(hipnet)
+    lib = nv.load()
+    xin = nhwc(x).cuda()
+    phases = [hipnet.convt_phase_taps(wt, py, px) for py in (0, 1) for px in (0, 1)]
+    packed = torch.stack([hipnet.pack_k_major(wk.float()) for _, wk in phases], 0).cuda()
+    wino = hipnet.pack_wino_t(wt).cuda()
+    for fused in (False, True):
+        out = torch.full((2 * h, 2 * w, cout), float("nan"), device="cuda")
+        d = L.desc(xin, out, phases[0][0], phases[0][1], b, h, w, cin, h, w, cout, out_stride=2, act=2 if fused else 0,
+                   res2=nhwc(r2) if fused else None)
+        d.wpk, d.nphase, d.wphase_stride = packed.data_ptr(), 4, packed[0].numel()
+        for i, (dy, dx) in enumerate([t for tp, _ in phases for t in tp]):
+            d.dy[i], d.dx[i] = dy, dx
+        d.wino = wino.data_ptr()
+        os.environ["USC_WINO_T3"] = "1"
+        try:
+            plan = nv.conv_plans((hipnet.ConvDesc * 1)(d), 1)[0]
+            assert "winograd-t3" in plan["plan"], plan
+            L.run([d])
+            first = out.clone()
+            L.run([d])
+            assert torch.equal(out, first)
+            os.environ["USC_WINO_T3"] = "0"                       # the direct kernel on the same descriptor
+            ref = torch.full_like(out, float("nan"))
+            d.out = ref.data_ptr()
+            assert "winograd" not in nv.conv_plans((hipnet.ConvDesc * 1)(d), 1)[0]["plan"]
+            L.run([d])
+        finally:
+            os.environ["USC_WINO_T3"] = "-1"
+        y = F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=2, padding=1)
+        if fused:
+            y = torch.where(y > 0, y, y * 0.2) + r2.double()
+        got = out.cpu().permute(2, 0, 1)[None].double()
+        assert torch.isfinite(got).all()
+        err = (got - y).abs().max() / y.abs().max()
+        assert err < 2e-5, (fused, float(err))
+        assert (ref.cpu().permute(2, 0, 1)[None].double() - y).abs().max() / y.abs().max() < 2e-5
+
+
 def test_winograd_is_batch_invariant_and_deterministic(hipnet):
     """Per-image results of a Winograd layer do not depend on the batch it runs in, nor on the run."""
     from video_unscreen_amd import _native as nv

@@ -7,16 +7,30 @@ from video_unscreen_amd import _native as nv
 nv.LIB_PATH = os.environ["USC_TIMING_LIB"]
 from video_unscreen_amd.vmatting import net_hip as m
 lib = nv.load()
-for (cin, cout, h, w, kw) in ((32, 32, 272, 480, 1), (64, 32, 272, 480, 1), (64, 64, 136, 240, 2), (128, 128, 68, 120, 4), (32, 32, 544, 960, 1)):
-    x = torch.randn(h, w, cin, device="cuda"); wt = torch.randn(cout, cin, 3, 3) * 0.05
-    out = torch.empty(h, w, cout, device="cuda")
-    taps, wk = m.conv_taps(wt, 1)
-    wp = m.pack_k_major(wk.float()).cuda(); wn = m.pack_wino(wt).cuda()
+T3 = os.environ.get("T3", "0") == "1"          # the transposed form (ConvTranspose2d k4 s2 p1) on the matting net's decoder shapes
+if T3: os.environ["USC_WINO_T3"] = "1"
+cases = ((128, 128, 68, 120, 1), (64, 64, 136, 240, 1), (32, 32, 272, 480, 1)) if T3 else \
+        ((32, 32, 272, 480, 1), (64, 32, 272, 480, 1), (64, 64, 136, 240, 2), (128, 128, 68, 120, 4), (32, 32, 544, 960, 1))
+for (cin, cout, h, w, kw) in cases:
+    x = torch.randn(h, w, cin, device="cuda")
     ts = torch.zeros(4096 * 8 * 16, dtype=torch.int64, device="cuda")
     d = m.ConvDesc()
+    if T3:
+        wt = torch.randn(cin, cout, 4, 4) * 0.05
+        out = torch.empty(2 * h, 2 * w, cout, device="cuda")
+        phases = [m.convt_phase_taps(wt, py, px) for py in (0, 1) for px in (0, 1)]
+        wp = torch.stack([m.pack_k_major(k.float()) for _, k in phases], 0).cuda(); wn = m.pack_wino_t(wt).cuda()
+        taps = [t for tp, _ in phases for t in tp]
+        d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = h, w, cin, h, w, 2 * h, 2 * w, cout
+        d.in_stride, d.out_stride, d.ntaps, d.nphase, d.wphase_stride = 1, 2, 4, 4, wp[0].numel()
+    else:
+        wt = torch.randn(cout, cin, 3, 3) * 0.05
+        out = torch.empty(h, w, cout, device="cuda")
+        taps, wk = m.conv_taps(wt, 1)
+        wp = m.pack_k_major(wk.float()).cuda(); wn = m.pack_wino(wt).cuda()
+        d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = h, w, cin, h, w, h, w, cout
+        d.in_stride, d.out_stride, d.ntaps, d.nphase = 1, 1, 9, 1
     d.inp, d.out, d.wpk, d.wino = x.data_ptr(), out.data_ptr(), wp.data_ptr(), wn.data_ptr()
-    d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = h, w, cin, h, w, h, w, cout
-    d.in_stride, d.out_stride, d.ntaps, d.nphase = 1, 1, 9, 1
     d.slab, d.slab_bytes = ts.data_ptr(), 0
     for i, (dy, dx) in enumerate(taps): d.dy[i], d.dx[i] = dy, dx
     lib.usc_conv_force_winograd(1); lib.usc_conv_force_plan(0, 0, 0, kw)

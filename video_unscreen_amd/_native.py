@@ -144,7 +144,7 @@ def conv_plans(desc_array, n):
         rc = load().usc_conv_plan_query(base + i * size, C.byref(info))
         if rc != 0:
             raise NativeError(f"usc_conv_plan_query failed ({rc}): {load().usc_conv_last_error().decode()}")
-        out.append({"plan": (f"winograd{'-lin' if info.winograd == 2 else ''},KW={info.kgroups}{',S=2' if info.ksplit == 2 else ''}") if info.winograd else f"{info.nt},{info.rowgroups},{info.ksplit},{info.kgroups}",
+        out.append({"plan": (f"winograd{('', '', '-lin', '-t3')[info.winograd]},KW={info.kgroups}{',S=2' if info.ksplit == 2 else ''}") if info.winograd else f"{info.nt},{info.rowgroups},{info.ksplit},{info.kgroups}",
                     "winograd": bool(info.winograd), "workgroups": info.workgroups,
                     "threads": info.threads, "launches": info.launches})
     return out

@@ -346,16 +346,31 @@ static_assert(WLDS >= 4 * 2 * WIMG, "the patch images must fit");
 // sharing between tile rows), stored per (patch row, column parity, channel half) as arrays over the column pairs - consecutive
 // tiles read consecutive 16-byte slots.  Needs TW >= 11 (at most four segments: 16 x (32 + 4) slots = 9 requests of 64).
 constexpr int WLIN_IMG = 576 * 4;           // floats of one LDS image of the linear form
-constexpr int WLDS_LIN = 8 * WLIN_IMG > WLDS ? 8 * WLIN_IMG : WLDS;        // 72 KB
+// T3: the four output phases of a ConvTranspose2d(k 4, s 2, p 1) are 2x2 convolutions of the input - Winograd F(3x3, 2x2) on
+// 4x4 patches at a stride of THREE pixels: 16 multiplications per 9 outputs instead of 36.  With G's last row negated on the
+// host the input transform B^T is F(2x2, 3x3)'s own, so the K loop is the same code; what changes is the geometry, the output
+// transform (A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1]: nine output phases) and the output addressing (pixel (2 (3 ty + i) + py,
+// 2 (3 tx + j) + px) of the doubled map).  The four units of a workgroup are the FOUR PHASES of one block x channel group (no K
+// groups): their 4x4 patches are windows of the same 5 x 5 pixels, so the workgroup stages ONE image per step - five pixel rows
+// x three column residues mod 3 as planes over the column triples (30 slots per triple: at most 30 x 36 = 17 requests of 64,
+// spread over the eight waves) - instead of four: a first version with an image per phase spent 7960 cycles per K step on its
+// 14 staging requests per pair (the same dependence on the request count as between the 8 x 4 and the linear form).
+constexpr int WT3_IMG = 24 * 256;           // floats of one LDS image of the transposed form: three requests per wave (24 KB)
+constexpr int WLDS_LIN = 3 * WT3_IMG + 8 * 192 + 8 * 128;      // floats of LDS per workgroup (82 KB): the transposed form's three images + tables
+constexpr int WT3_GOFF = 3 * WT3_IMG;       // (int index) the transposed form's request offsets: 8 waves x 3 x 64, past the images
+constexpr int WT3_FA = WT3_GOFF + 8 * 192;  // (int index) the transposed form's fragment addresses: 8 waves x 2 x 64
+static_assert(WLDS_LIN >= 8 * WLIN_IMG && WLDS_LIN >= WLDS && WLDS_LIN >= WT3_FA + 8 * 128, "every form's images and tables must fit");
 constexpr int WSLAB_TAIL = 65536;      // the slab's last bytes: arrival counters of layers that split K over two workgroups
 
 struct VA { int vo, so; bool ok; };          // where a finished value goes: lane offset, scalar offset, exists
 
-template <int KW, bool IN_RELU, bool LIN>
+template <int KW, bool IN_RELU, int MODE>                           // MODE 0: 8 x 4 blocks, 1: linear blocks, 2: transposed (T3, linear)
 __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     __shared__ __attribute__((aligned(16))) float Ls[WLDS_LIN];     // (a template-dependent bound makes the host pass drop the kernel's stub without a word)
-    constexpr int IMGF = LIN ? WLIN_IMG : WIMG;                     // floats per LDS image
-    constexpr int NG = LIN ? 5 : 3;                                 // global -> LDS requests of a wave per image
+    constexpr bool LIN = MODE != 0, T3 = MODE == 2;
+    constexpr int IMGF = T3 ? WT3_IMG : LIN ? WLIN_IMG : WIMG;      // floats per LDS image
+    constexpr int NG = LIN && !T3 ? 5 : 3;                          // global -> LDS requests of a wave per image
+    static_assert(!T3 || KW == 1, "the transposed form has no K groups: the four pairs are the four output phases");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = wave >> 2, sub = wave & 3;                        // position half (rows 2h, 2h + 1) and pair of this wave
@@ -365,13 +380,16 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     // Dilation D (taps at +-D): the layer is D x D independent standard convolutions, one per pixel-parity class of the image -
     // every image counts as D x D virtual images of (IH / D) x (IW / D) pixels whose pixel (y, x) is the real pixel
     // (y D + py, x D + px).  All geometry below is in virtual-image coordinates; pix() maps to the real pixel index.
-    const int D = d.dx[5];
-    const int nimg = (d.batch > 1 ? d.batch : 1) * D * D;
+    const int D = T3 ? 1 : d.dx[5];
+    const int NV = D * D;                                           // virtual images per image
+    const int nimg = (d.batch > 1 ? d.batch : 1) * NV;
     const int H = d.IH / D, W = d.IW / D;                           // per (virtual) image; output has the same size
     const int WR = d.IW;
-    const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
+    const int TH = T3 ? (H + 2) / 3 : (H + 1) >> 1, TW = T3 ? (W + 2) / 3 : (W + 1) >> 1;
     const int BH = (TH + 3) >> 2, BW = (TW + 7) >> 3;
-    const int ntile_img = TH * TW, nblk_img = LIN ? (ntile_img + 31) >> 5 : BH * BW;
+    // tiles per linear block: 32, or (T3, narrow maps) as many whole tile rows as fit in 32 tiles and four segments
+    const int nbt = T3 && TW < 11 ? min(4, 32 / TW) * TW : 32;
+    const int ntile_img = TH * TW, nblk_img = T3 ? (ntile_img + nbt - 1) / nbt : LIN ? (ntile_img + 31) >> 5 : BH * BW;
     const int ntiles = nimg * nblk_img * nnb;                       // blocks x channel groups
     const int nwg = (int)gridDim.x, xcd = (int)blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;      // XCD-aware order (see above)
     const int wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
@@ -380,7 +398,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     const int S = d.ksplit == 2 ? 2 : 1;
     const int ks = S == 2 ? (wid & 1) : 0, wgid = S == 2 ? (wid >> 1) : wid;
     constexpr int TPW = 4 / KW;                                     // blocks x channel groups per workgroup
-    const int wt = wgid * TPW + sub / KW, kg = sub % KW;
+    const int wt = T3 ? wgid : wgid * TPW + sub / KW, kg = sub % KW;  // (T3: the pairs are the phases of ONE block x channel group)
     const bool live = wt < ntiles;
     // (integer division runs on the vector ALU: readfirstlane brings the wave-uniform results back to scalar registers, which
     // the scalar-offset addressing of the epilogue needs)
@@ -393,8 +411,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     float seg_rL[4] = {0.f, 0.f, 0.f, 0.f};                         // 1 / seg_L (one v_rcp_f32 each: the decoding below is exact with 1 ulp)
     int cnt = 0, nslots = 0;
     if (LIN) {
-        const int T0 = brem * 32;
-        cnt = live ? min(32, ntile_img - T0) : 0;
+        const int T0 = brem * nbt;
+        cnt = live ? min(nbt, ntile_img - T0) : 0;
         const int ty0 = __builtin_amdgcn_readfirstlane(T0 / TW), a0 = T0 - ty0 * TW;
         int used = 0;
 #pragma unroll
@@ -405,7 +423,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
             seg_start[k] = __builtin_amdgcn_readfirstlane(used); seg_L[k] = len > 0 ? seg_len[k] + 1 : 0; seg_slot[k] = __builtin_amdgcn_readfirstlane(nslots);
             seg_rL[k] = len > 0 ? __builtin_amdgcn_rcpf((float)seg_L[k]) : 0.f;
             used += len;
-            nslots += 16 * seg_L[k];
+            nslots += (T3 ? 30 : 16) * seg_L[k];
         }
     }
     // tile t of the block (t = the MFMA row) -> its segment and position (dead tiles of a partial block -> segment 0, position 0)
@@ -421,8 +439,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         if (t >= cnt) { row = seg_row[0]; a = seg_a[0]; L = seg_L[0]; slot0 = seg_slot[0]; }
     };
     const int nb0 = __builtin_amdgcn_readfirstlane(nb * 32);
-    const int imr = img / (D * D), par = img - imr * (D * D), pary = par / D;
-    const int pix0 = __builtin_amdgcn_readfirstlane((imr * d.IH + pary) * WR + par - pary * D);      // real pixel index of virtual (0, 0)
+    const int imr = img / NV, par = T3 ? sub : img - imr * NV, pary = T3 ? par >> 1 : par / D, parx = par - pary * (T3 ? 2 : D);
+    const int pix0 = __builtin_amdgcn_readfirstlane(T3 ? imr * d.IH * WR : (imr * d.IH + pary) * WR + parx);      // real pixel index of virtual (0, 0)
     auto pix = [&](int y, int x) { return pix0 + (y * WR + x) * D; };
     const int nch = d.Cin >> 3;                                     // K steps of 8 input channels
     const int nmax = nch / (KW * S);                                // steps per wave: the planner splits K evenly, nch = S * KW * nmax
@@ -430,15 +448,16 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
 
     // ---- weight fragments: [c][p][k half][n][4] floats; this wave's positions are p = (2h + ar) * 4 + b.  The lane part of the
     // address is a constant, the (step, position) part goes through the scalar offset: no address registers per load.
-    const int wbytes = nch * 16 * 2 * d.Cout * 16;
+    const int wbytes = nch * 16 * 2 * d.Cout * 16 * (T3 ? 4 : 1);      // (T3: one operand per output phase)
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.wino), 0, wbytes, 0x00020000);
     const int wpos = 2 * d.Cout * 16, wstep = 16 * wpos;
+    const int wph0 = T3 ? __builtin_amdgcn_readfirstlane(par * nch * wstep) : 0;
     const int wbase = ((lane >> 5) * d.Cout + nb0 + (lane & 31)) * 16;
     float4 bf[2][4];
     auto load_b = [&](int c, int ar) {                              // (past the last step: the next K group's, or zeros - unused)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wbase, c * wstep + (8 * h + ar * 4 + b) * wpos, 0);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wbase, wph0 + c * wstep + (8 * h + ar * 4 + b) * wpos, 0);
             bf[ar][b] = *reinterpret_cast<const float4*>(&v);
         }
     };
@@ -455,7 +474,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     int goff[5];                                                    // (NG used; a template-dependent bound here makes the host pass drop the kernel stub silently)
 #pragma unroll
     for (int r = 0; r < NG; r++) {
-        const int sl = (NG * h + r) * 64 + lane;
+        const int sl = (T3 ? wave + 8 * r : NG * h + r) * 64 + lane;   // (T3: request w + 8 r of the workgroup's one image)
         if (!LIN) {
             const int sp = sl / WSUB, rem = sl - sp * WSUB;
             const int row = rem / WSUBROW, q = rem - row * WSUBROW;
@@ -477,15 +496,52 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
             const int q = (sl - s0) >> 1, hf = (sl - s0) & 1;                       // the two halves of a pixel are neighbouring slots: lanes 2k, 2k + 1 fetch 32 contiguous bytes
             const int plane = (int)(((float)q + 0.5f) * rL);                        // exact: q < 288, L <= 33 (the fraction is >= 0.5 / L away from an integer)
             const int pair = q - plane * L;
-            const int y = 2 * row - 1 + (plane >> 1), x = 2 * (a0s + pair) - 1 + (plane & 1);
+            // (T3: plane = (pixel row i of five, column residue cr), pixel (3 row - 1 + i, 3 (a_k + pair) - 1 + cr))
+            const int y = T3 ? 3 * row - 1 + plane / 3 : 2 * row - 1 + (plane >> 1);
+            const int x = T3 ? 3 * (a0s + pair) - 1 + plane % 3 : 2 * (a0s + pair) - 1 + (plane & 1);
             const bool ok = live && sl < nslots && y >= 0 && y < H && x >= 0 && x < W;
             goff[r] = ok ? pix(y, x) * d.Cin * 4 + hf * 16 : INVALID;
         }
     }
+    if (T3) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) reinterpret_cast<int*>(Ls)[WT3_GOFF + wave * 192 + r * 64 + lane] = goff[r];
+    }
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(d.in), 0, (d.batch > 1 ? d.batch : 1) * d.IH * d.IW * d.Cin * 4, 0x00020000);
-    const int img0 = sub * 2 * IMGF;                                // the pair's two images (float index into Ls)
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const unsigned long long in_addr = (unsigned long long)d.in;
+    const v4i_t in_v4 = {(int)(unsigned)in_addr, (int)((in_addr >> 32) & 0xffff), (d.batch > 1 ? d.batch : 1) * d.IH * d.IW * d.Cin * 4, 0x00020000};     // the same descriptor as in_rsrc, as four scalar registers
+    const int lds_base = (int)(unsigned)(unsigned long long)((__attribute__((address_space(3))) float*)Ls);
+    const int img0 = T3 ? 0 : sub * 2 * IMGF;                       // the pair's two images (float index into Ls)
     auto issue_a = [&](int c) {                                     // the patch of step c -> image (c - c_begin) & 1
+        if (T3) {
+            // requests w, w + 8, w + 16 of the image's (at most) 17.  All three are issued whether they hold slots or not (an
+            // empty one only writes zeros): under a condition the compiler loses count of the requests in flight and waits for
+            // EVERY outstanding load - the weight fragments just requested - in front of the next fragment read (measured: fragment
+            // phases of 1200 - 2700 cycles instead of 400).
+            // Waits: the image is shared by all pairs and the compiler places no wait between these requests and the fragment
+            // reads of OTHER waves, so images are requested two steps ahead (three images): every MFMA phase waits for weight
+            // fragments that were requested AFTER the image requests of the step before, the load counter is in order, so an image
+            // has landed one whole step before its first reader starts - behind two barriers - with a step and a half of latency
+            // budget.  (An explicit wait one phase after the request, with two images, cost 9900 cycles per step: the requests take
+            // about 4500 cycles to land.)
+            // The request offsets live in LDS, not in registers: the K loop has none to spare, and a spilled offset comes back through
+            // a scratch load - whose wait, the counter being in order, is a wait for the staging request issued just before it.
+            const int dst = ((c - c_begin) % 3) * IMGF + wave * 256;
+            typedef __attribute__((address_space(3))) volatile int lds_vint;      // (an LDS pointer: 32-bit addressing, ds_read_b32)
+            lds_vint* const go = (lds_vint*)Ls + WT3_GOFF + wave * 192 + lane;
+            const int g0 = go[0], g1 = go[64], g2 = go[128];
+            // (issued as inline assembly: the compiler, seeing LDS-writing loads it cannot tell apart from the fragment reads'
+            // addresses, would put a wait for the newest of them in front of every fragment phase.  Its own waits for ordinary
+            // loads stay correct with loads it does not know of in flight: the counter is in order, it can only wait longer.)
+            const int m0v = lds_base + dst * 4, so = c * 32;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, %5 offen lds\n\t"
+                         "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %5 offen lds\n\t"
+                         "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %5 offen lds"
+                         :: "s"(m0v), "v"(g0), "v"(g1), "v"(g2), "s"(in_v4), "s"(so) : "memory", "scc");       // (m0 is reserved: nothing else in this form uses it)
+            return;
+        }
         const int dst = img0 + ((c - c_begin) & 1) * IMGF + NG * h * 256;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst], 16, goff[0], c * 32, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 256], 16, goff[1], c * 32, 0, 0);
@@ -514,13 +570,22 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     // linear form: patch pixel (i, j) of tile (segment k, position p) is slot seg_slot[k] + 2 ((i 2 + (j & 1)) L_k + p + (j >> 1)) + half
     // (consecutive tiles are 32 bytes apart: a two-way bank conflict on the fragment reads, which sit in the partner's MFMA shadow,
     // bought for staging requests whose lane pairs fetch whole 32-byte sectors)
+    // transposed form: patch pixel (i, j) of phase (py, px) is pixel (py + i, px + j) of the staged five rows: plane (py + i,
+    // (px + j) mod 3), column triple p + (px + j) / 3
+    // (as few registers as possible live through the K loop: ONE spilled value reloaded in front of the fragment reads makes the
+    // wait for it a wait for every load in flight, the weight fragments just requested included - 2000 cycles per step.  T3: the
+    // row addresses are derived from the first, the column offsets are compile-time per column phase px)
     int fa[3] = {0, 0, 0}, fs2 = 0;
     if (LIN) {
         int row, a, L, s0, pp;
         lin_seg(lane & 31, row, a, L, s0, pp);
 #pragma unroll
-        for (int k = 0; k < 3; k++) fa[k] = (s0 + 2 * ((h + k) * 2 * L + pp) + (lane >> 5)) * 4;
+        for (int k = 0; k < 3; k++) fa[k] = (s0 + 2 * ((T3 ? (pary + h + k) * 3 : (h + k) * 2) * L + pp) + (lane >> 5)) * 4;
         fs2 = 2 * L * 4;
+        if (T3) {                                                   // (read back at the start of every fragment phase)
+            reinterpret_cast<int*>(Ls)[WT3_FA + wave * 128 + lane] = fa[0];
+            reinterpret_cast<int*>(Ls)[WT3_FA + wave * 128 + 64 + lane] = fs2;
+        }
     }
     // (vector types, not float4 structs: additions of <4 x float> become two v_pk_add_f32 - half the vector instructions that
     // compete with the partner wave's MFMAs for the register ports)
@@ -533,9 +598,15 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     // Fragment phase of step c: this wave's two rows of T = B^T d from the staged image, then its two rows of V = T B.  (The MFMA
     // phase carries no vector arithmetic at all: next to f32 32x32 MFMAs, whose accumulators travel through the same register
     // ports, every vector instruction of the same wave measurably delays the matrix pipe.)
-    auto frag_phase = [&](int c, auto hh) {
-        constexpr int HH = decltype(hh)::value;
-        const int cur = img0 + ((c - c_begin) & 1) * IMGF + (LIN ? 0 : fb);
+    auto frag_phase = [&](int c, auto hh, auto pxc) {
+        constexpr int HH = decltype(hh)::value, PX = decltype(pxc)::value;
+        const int cur = T3 ? ((c - c_begin) % 3) * IMGF : img0 + ((c - c_begin) & 1) * IMGF + (LIN ? 0 : fb);
+        int t3_fa = 0, t3_fs = 0;
+        if (T3) {
+            typedef __attribute__((address_space(3))) volatile int lds_vint;
+            lds_vint* const fp = (lds_vint*)Ls + WT3_FA + wave * 128 + lane;
+            t3_fa = fp[0]; t3_fs = fp[64];
+        }
         f32x4 Ta[4], Tb[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -543,7 +614,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
             f32x4 e[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                if (LIN) e[k] = *reinterpret_cast<const f32x4*>(&Ls[cur + fa[k] + (j & 1) * fs2 + (j >> 1) * 8]);
+                if (T3) e[k] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&Ls[cur + t3_fa + (k * 3 + (PX + j) % 3) * t3_fs + ((PX + j) / 3) * 8], 16));
+                else if (LIN) e[k] = *reinterpret_cast<const f32x4*>(&Ls[cur + fa[k] + (j & 1) * fs2 + (j >> 1) * 8]);
                 else e[k] = *reinterpret_cast<const f32x4*>(&Ls[cur + ((((HH + k) & 1) * 2) * WSUB + ((HH + k) >> 1) * WSUBROW) * 4 + co]);
                 if (IN_RELU) e[k] = relu4(e[k]);
             }
@@ -571,6 +643,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     };
 
     issue_a(c_begin);
+    if (T3 && nmax > 1) issue_a(c_begin + 1);                       // (transposed form: images are requested TWO steps ahead)
     wait_vm0();
     __syncthreads();
     WINO_STAMP(1);
@@ -582,13 +655,14 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     // compiler places that wait) and the phase barrier in between publishing them to the partner.  Every wave of the workgroup
     // runs nmax steps (the planner only splits K evenly; a wave without a unit multiplies zeros): no state of the loop is
     // modified under a condition, which is what lets the compiler keep the accumulators in place.
+    auto k_loop = [&](auto pxc) {
     if (h == 0) {
         const std::integral_constant<int, 0> H0;
         for (int s = 0; s < nmax; s++) {
             const int c = c_begin + s;
             WINO_PH(2 + 4 * s);
-            frag_phase(c, H0);
-            if (s + 1 < nmax) issue_a(c + 1);
+            frag_phase(c, H0, pxc);
+            if (s + 1 + T3 < nmax) issue_a(c + 1 + T3);
             WINO_PH(3 + 4 * s);
             phase_barrier();
             WINO_PH(4 + 4 * s);
@@ -599,21 +673,22 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         WINO_PH(14);
     } else {
         const std::integral_constant<int, 1> H1;
-        if (nmax > 1) issue_a(c_begin + 1);
+        if (nmax > 1 + T3) issue_a(c_begin + 1 + T3);
         phase_barrier();
         WINO_PH(2);
-        frag_phase(c_begin, H1);
+        frag_phase(c_begin, H1, pxc);
         WINO_PH(3);
+        if (T3) wait_vm0();                                     // (the image requested above: see the note on the transposed form's waits)
         phase_barrier();
         for (int s = 1; s < nmax; s++) {
             const int c = c_begin + s;
-            if (s + 1 < nmax) issue_a(c + 1);
+            if (s + 1 + T3 < nmax) issue_a(c + 1 + T3);
             WINO_PH(4 * s);
             mfma_phase(c - 1);
             WINO_PH(1 + 4 * s);
             phase_barrier();
             WINO_PH(2 + 4 * s);
-            frag_phase(c, H1);
+            frag_phase(c, H1, pxc);
             WINO_PH(3 + 4 * s);
             phase_barrier();
         }
@@ -621,12 +696,19 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         mfma_phase(c_begin + nmax - 1);
         WINO_PH(14);
     }
+    };
+    if constexpr (T3) {
+        if (parx == 0) k_loop(std::integral_constant<int, 0>()); else k_loop(std::integral_constant<int, 1>());
+    } else {
+        k_loop(std::integral_constant<int, 0>());
+    }
 #undef USC_WROW
     WINO_STAMP(2);
 
     // ---- output transform of this wave's rows: partial sums of the phases (i, j) -> pixel (2 ty + i, 2 tx + j).
     // A^T = [1 1 1 0; 0 1 -1 -1]: rows a = 0, 1 give Y0 += s0 + s1, Y1 += s1; rows a = 2, 3 give Y0 += s2, Y1 -= s2 + s3.
     f32x16 Yp[4];
+    if constexpr (!T3) {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const f32x16 s0 = j == 0 ? acc[0] + acc[1] + acc[2] : acc[1] - acc[2] - acc[3];
@@ -634,6 +716,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         const f32x16 t = s0 + s1;
         if (h == 0) { Yp[j] = t; Yp[2 + j] = s1; }
         else { Yp[j] = s0; Yp[2 + j] = -t; }
+    }
     }
     WINO_STAMP(3);
     // ---- the group of this block x channel group: G = 2 KW waves (member m = 2 kg + h); member m finishes registers
@@ -658,7 +741,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     const int vo_r2 = (8 * lh * D * d.Cout + n) * 4;
     const int vo_r1 = ((8 >> d.res1_shift) * lh * D * d.Cout + n) * 4;
     WINO_STAMP(4);
-    const bool interior = LIN ? (cnt == 32 && !(H & 1) && !(W & 1)) : (live && 8 * by + 8 <= H && 16 * bx + 16 <= W);
+    const bool interior = T3 ? (cnt == 32 && H % 3 == 0 && W % 3 == 0) : LIN ? (cnt == 32 && !(H & 1) && !(W & 1)) : (live && 8 * by + 8 <= H && 16 * bx + 16 <= W);
     const bool plain = !has_r1 && !has_r2 && !has_aff;
     const std::true_type yes;
     const std::false_type no;
@@ -715,10 +798,94 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         }
         return v;
     };
+    if constexpr (T3) {
+    // ---- transposed form: nine output phases (i, j) -> pixel (2 (3 ty + i) + py, 2 (3 tx + j) + px) of the doubled map.  With
+    // C_j(a) = sum_b A^T[j][b] M[a][b] (C_0 = M0 + M1 + M2, C_1 = M1 - M2, C_2 = M1 + M2 + M3) this wave's partial sums are
+    // h = 0 (rows a = 0, 1): Y_0j = C_j(0) + C_j(1), Y_1j = Y_2j = C_j(1); h = 1 (rows 2, 3): Y_0j = C_j(2), Y_1j = -C_j(2), Y_2j =
+    // C_j(2) + C_j(3).  Nine exchange rounds as in the general scheme below (member m = 2 kg + h of the unit's 2 KW waves finishes
+    // registers [m NR, (m + 1) NR) of every phase); the second residual of round rd + 1 is requested BEFORE the stores of round rd
+    // (loads and stores share one in-order counter: waiting for a load issued after a store would wait for the store).
+    // The planner admits layers with bias / activation / second residual only.
+    const int OW2 = d.OWf;
+    int q_pb[NR], q_fl[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        int row, a, L, s0, pp;
+        const int r = me * NR + q, t = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        lin_seg(t, row, a, L, s0, pp);
+        const int ty3 = 3 * row, tx3 = 3 * (a + pp);
+        q_pb[q] = (imr * 2 * H + 2 * ty3 + pary) * OW2 + 2 * tx3 + parx;
+        q_fl[q] = (t < cnt ? 1 : 0) | (ty3 + 1 < H ? 2 : 0) | (ty3 + 2 < H ? 4 : 0) | (tx3 + 1 < W ? 8 : 0) | (tx3 + 2 < W ? 16 : 0);
+    }
+    auto t3_ok = [](int fl, int i, int j) { return (fl & 1) && (i == 0 || (fl & (1 << i))) && (j == 0 || (fl & (4 << j))); };
+    auto t3_rounds = [&](auto edge_c) {
+        constexpr bool EDGE = decltype(edge_c)::value;
+        auto r2_request = [&](int rd, float (&dst)[NR]) {
+            const int i = rd % 3, j = rd / 3;
+            const int so = __builtin_amdgcn_readfirstlane((2 * i * OW2 + 2 * j) * d.Cout * 4);
+#pragma unroll
+            for (int q = 0; q < NR; q++)
+                dst[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2_rsrc, t3_ok(q_fl[q], i, j) ? (q_pb[q] * d.Cout + n) * 4 : INVALID, so, 0));
+        };
+        float r2c[NR], r2n[NR];
+#pragma unroll
+        for (int q = 0; q < NR; q++) { r2c[q] = 0.f; r2n[q] = 0.f; }
+        if (has_r2) r2_request(0, r2c);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const f32x16 s0 = j == 0 ? acc[0] + acc[1] + acc[2] : j == 1 ? acc[1] - acc[2] : acc[1] + acc[2] + acc[3];
+            const f32x16 s1 = j == 0 ? acc[4] + acc[5] + acc[6] : j == 1 ? acc[5] - acc[6] : acc[5] + acc[6] + acc[7];
+            const f32x16 t01 = s0 + s1;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int rd = j * 3 + i;
+                f32x16 y;
+                if (i == 0) y = h == 0 ? t01 : s0;
+                else if (i == 1) y = h == 0 ? s1 : -s0;
+                else y = h == 0 ? s1 : t01;
+                float* const reg = Ls + (rd & 1) * WREGION;
+#pragma unroll
+                for (int qd = 0; qd < 4; qd++)
+                    *reinterpret_cast<float4*>(&reg[((wave * 4 + qd) * 64 + lane) * 4]) = make_float4(y[4 * qd], y[4 * qd + 1], y[4 * qd + 2], y[4 * qd + 3]);
+                __syncthreads();
+                float v[NR];
+#pragma unroll
+                for (int q = 0; q < NR; q++) v[q] = 0.f;
+#pragma unroll
+                for (int m = 0; m < G; m++) {                     // fixed order: K group major, position half minor
+                    const int w2 = (m & 1) * 4 + ubase + (m >> 1);
+                    if constexpr (NR >= 4) {
+#pragma unroll
+                        for (int blk = 0; blk < NR / 4; blk++) {
+                            const float4 u = *reinterpret_cast<const float4*>(&reg[((w2 * 4 + me * (NR / 4) + blk) * 64 + lane) * 4]);
+                            v[4 * blk] += u.x; v[4 * blk + 1] += u.y; v[4 * blk + 2] += u.z; v[4 * blk + 3] += u.w;
+                        }
+                    } else {
+                        const float2 u = *reinterpret_cast<const float2*>(&reg[((w2 * 4 + (me >> 1)) * 64 + lane) * 4 + 2 * (me & 1)]);
+                        v[0] += u.x; v[1] += u.y;
+                    }
+                }
+                if (has_r2 && rd + 1 < 9) r2_request(rd + 1, r2n);
+                const int so = __builtin_amdgcn_readfirstlane(((2 * i * OW2 + 2 * j) * out_ld + d.out_c0) * 4);
+#pragma unroll
+                for (int q = 0; q < NR; q++) {
+                    float x = v[q] + bias;
+                    x = fmaxf(x, x * slope);
+                    x += r2c[q];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), out_rsrc,
+                                                          (EDGE ? t3_ok(q_fl[q], i, j) : true) ? (q_pb[q] * out_ld + n) * 4 : INVALID, so, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < NR; q++) r2c[q] = r2n[q];
+                if (rd == 0) WINO_STAMP(5);
+            }
+        }
+    };
+    if (interior) t3_rounds(no); else t3_rounds(yes);
 #ifdef USC_WINO_NO_PAIR_EPILOGUE
-    if constexpr (false) {
+    } else if constexpr (false) {
 #else
-    if constexpr (KW == 1) {
+    } else if constexpr (KW == 1) {
 #endif
         // The group is the pair: wave h finishes the two phases of output row parity i = h in full (32 values per lane), its
         // partials of the other two phases go to the partner through LDS ([wave][8 quads of registers][lane][4] floats, 8 KB per
@@ -1019,6 +1186,7 @@ struct LayerPlan {
     dim3 rgrid;
     int nt = 0, rg = 0, kw = 0;            // for usc_conv_plan_query
     bool wino = false, lin = false;
+    bool t3 = false;                       // transposed Winograd form
     bool wsplit = false;                   // Winograd layer with two workgroups per unit: uses the arrival counters in the slab's tail
 };
 
@@ -1056,6 +1224,38 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     // Two 32-column tiles per wave only while that still leaves >= 2 workgroups per CU.
     const int plan_batch = d.plan_batch > 1 ? d.plan_batch : 1;
     const long long m_plan = M / nbatch * plan_batch;
+    // Transposed Winograd form (conv_wino_kernel, MODE 2): the four-phase ConvTranspose2d(k 4, s 2, p 1) layer (phase (py, px), tap
+    // (iy, ix) reads the input at (py - iy, px - ix)) whose caller supplied the F(3x3, 2x2) operands; bias / activation / second
+    // residual only.  Cost model as below: a round of workgroups (each the four phases of a block x channel group, all of K)
+    // costs 17 (nine exchange rounds instead of four) + 2.55 per K step (profiles/r02/unet_layer_table.md: 37.4 us for 230
+    // workgroups x 8 steps, 54.6 us for 455 x 4).
+    {
+        bool t3 = d.wino && nphase == 4 && d.ntaps == 4 && d.in_stride == 1 && d.out_stride == 2 && nbatch == 1 && d.Cin % 8 == 0 &&
+                  !d.res1 && !d.scale && d.OH == d.IH && d.OW == d.IW && d.OHf == 2 * d.IH && d.OWf == 2 * d.IW && d.kind != USC_CONV_HEAD;
+        for (int t = 0; t3 && t < 16; t++) t3 = d.dy[t] == (t >> 3) - ((t >> 1) & 1) && d.dx[t] == ((t >> 2) & 1) - (t & 1);
+        static thread_local int force_t3 = -1;
+        if (const char* e = getenv("USC_WINO_T3")) force_t3 = atoi(e);              // tests / A-B timing: 0 never, 1 wherever admissible
+        if (t3 && g_force_wino != 0 && force_t3 != 0) {
+            const int TH = (d.IH + 2) / 3, TW = (d.IW + 2) / 3;
+            const int nbt = TW < 11 ? (32 / TW < 4 ? 32 / TW : 4) * TW : 32;
+            const long long blk = ((long long)TH * TW + nbt - 1) / nbt;
+            const long long wgs = blk * (d.Cout / 32);             // a workgroup = the four phases of a block x channel group
+            const int nsteps = d.Cin / 8;
+            const double wino_us = (double)((wgs + 255) / 256) * (17.0 + nsteps * 2.55);
+            const double direct_us = 6.0 + 2.0 * (double)M * 4 * d.Cout * 4.0 * d.Cin / 118e6 + (double)M * 4 * d.Cout * 4.0 / 3e6;
+            if (wino_us < direct_us || g_force_wino == 1 || force_t3 == 1) {
+                p.wino = true;
+                p.lin = true;
+                p.t3 = true;
+                p.kw = 1;
+                p.d.ksplit = 1;
+                p.grid = dim3((unsigned)wgs);
+                p.block = dim3(512);
+                p.fn = d.in_relu ? (void*)conv_wino_kernel<1, true, 2> : (void*)conv_wino_kernel<1, false, 2>;
+                return USC_OK;
+            }
+        }
+    }
     // Winograd form (conv_wino_kernel): the standard 3x3 / stride 1 / pad 1 layer whose caller supplied the transformed weights.
     // The choice and the K groups are functions of the per-image shape and plan_batch only.
     {
@@ -1117,8 +1317,8 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
                 const long long waves = wt * kw;
                 p.grid = dim3((unsigned)((waves + 3) / 4 * ws));
                 p.block = dim3(512);                              // 4 units x 2 position halves
-#define USC_PICKW(KWV) (lin ? (d.in_relu ? (void*)conv_wino_kernel<KWV, true, true> : (void*)conv_wino_kernel<KWV, false, true>) \
-                           : (d.in_relu ? (void*)conv_wino_kernel<KWV, true, false> : (void*)conv_wino_kernel<KWV, false, false>))
+#define USC_PICKW(KWV) (lin ? (d.in_relu ? (void*)conv_wino_kernel<KWV, true, 1> : (void*)conv_wino_kernel<KWV, false, 1>) \
+                           : (d.in_relu ? (void*)conv_wino_kernel<KWV, true, 0> : (void*)conv_wino_kernel<KWV, false, 0>))
                 p.fn = kw == 4 ? USC_PICKW(4) : kw == 2 ? USC_PICKW(2) : USC_PICKW(1);
 #undef USC_PICKW
                 return USC_OK;
@@ -1226,7 +1426,7 @@ extern "C" int usc_conv_plan_query(const usc_conv_desc* desc, usc_conv_plan_info
     int rc = plan_layer(*desc, p);
     if (rc) return rc;
     out->nt = p.nt; out->rowgroups = p.rg; out->kgroups = p.kw; out->ksplit = p.d.kind == USC_CONV_HEAD ? 1 : p.d.ksplit;
-    out->winograd = p.wino ? (p.lin ? 2 : 1) : 0;                 // 2: blocks of 32 consecutive tiles
+    out->winograd = p.wino ? (p.t3 ? 3 : p.lin ? 2 : 1) : 0;      // 2: blocks of 32 consecutive tiles, 3: transposed form
     out->workgroups = (int)(p.grid.x * p.grid.y * p.grid.z);
     out->threads = (int)p.block.x;
     out->launches = p.reduce ? 2 : 1;

@@ -60,6 +60,28 @@ def pack_wino(w):
     return U.permute(1, 0, 2, 4, 3).contiguous()                                         # [c][p][h][n][q]
 
 
+_WINO_GT = torch.tensor([[1., 0.], [.5, .5], [.5, -.5], [0., -1.]], dtype=torch.float64)
+
+
+def pack_wino_t(w):
+    """ConvTranspose2d(k 4, s 2, p 1) weight (Cin, Cout, 4, 4), Cin % 8 == 0 -> the Winograd F(3x3, 2x2) operands of
+    conv_wino_kernel's transposed form, one per output phase (py, px): along each axis phase 0 is the correlation of
+    (in[y - 1], in[y]) with (w[3], w[1]), phase 1 of (in[y], in[y + 1]) with (w[2], w[0]) (convt_phase_taps); U = G g G^T with
+    G = [1 0; 1/2 1/2; 1/2 -1/2; 0 -1] - the last row negated, so that the kernel's input transform is F(2x2, 3x3)'s own.
+    Layout [phase][Cin/8][16 positions][2][Cout][4] (pack_wino's, per phase)."""
+    ci, co, kh, kw = w.shape
+    assert (kh, kw) == (4, 4) and ci % 8 == 0
+    sel = {0: [3, 1], 1: [2, 0]}
+    out = []
+    for py in (0, 1):
+        for px in (0, 1):
+            g = w.double()[:, :, sel[py], :][:, :, :, sel[px]]                          # (Cin, Cout, 2, 2)
+            U = torch.einsum('ai,coij,bj->abco', _WINO_GT, g, _WINO_GT).float()        # (4, 4, Cin, Cout)
+            U = U.reshape(16, ci // 8, 2, 4, co)
+            out.append(U.permute(1, 0, 2, 4, 3).contiguous())
+    return torch.stack(out, 0)
+
+
 def conv_taps(w, pad):
     """Conv2d weight (Cout, Cin, kh, kw) -> (taps [(dy, dx)], (K, Cout) matrix)."""
     co, ci, kh, kw = w.shape
@@ -126,7 +148,7 @@ class HipMattingNet:
 
     def _add(self, x, out, taps, wk, bias, IH, IW, Cin, OH, OW, Cout, in_stride=1, out_stride=1, py=0, px=0,
              res1=None, res1_shift=0, act="none", scale=None, shift=None, res2=None, kind=0, OHf=None, OWf=None,
-             phases=None, wino=None):
+             phases=None, wino=None, wino_t=None):
         """phases: optional list of 4 (taps, wk) pairs (transposed conv); then `taps` / `wk` are ignored."""
         d = ConvDesc()
         d.inp, d.out = x.data_ptr(), out.data_ptr()
@@ -143,6 +165,8 @@ class HipMattingNet:
         d.wpk = wp.data_ptr()
         if wino is not None:                                   # 3x3 / stride 1: the Winograd operand of the same weights
             d.wino = self._dev(pack_wino(wino)).data_ptr()
+        if wino_t is not None:                                 # transposed conv: the F(3x3, 2x2) operands of the four phases
+            d.wino = self._dev(pack_wino_t(wino_t)).data_ptr()
         # every layer gets its own 16-slice region of the split-K scratch, so layers on different graph branches
         # never share partial-sum memory
         tiles = ((OH * OW + 127) // 128) * max(Cout // 32, 1) * (4 if phases is not None else 1)
@@ -185,7 +209,8 @@ class HipMattingNet:
         ci, co = c.w.shape[0], c.w.shape[1]
         out = self._buf(2 * IH, 2 * IW, co)
         phases = [convt_phase_taps(c.w, py, px) for py in (0, 1) for px in (0, 1)]       # phase index = 2*py + px
-        self._add(x, out, None, None, c.b, IH, IW, ci, IH, IW, co, out_stride=2, act=c.act, res2=res2, phases=phases)
+        self._add(x, out, None, None, c.b, IH, IW, ci, IH, IW, co, out_stride=2, act=c.act, res2=res2, phases=phases,
+                  wino_t=c.w if ci % 8 == 0 else None)
         return out
 
     # ------------------------------------------------------------------ graph
