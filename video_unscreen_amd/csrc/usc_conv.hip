@@ -818,8 +818,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         q_fl[q] = (t < cnt ? 1 : 0) | (ty3 + 1 < H ? 2 : 0) | (ty3 + 2 < H ? 4 : 0) | (tx3 + 1 < W ? 8 : 0) | (tx3 + 2 < W ? 16 : 0);
     }
     auto t3_ok = [](int fl, int i, int j) { return (fl & 1) && (i == 0 || (fl & (1 << i))) && (j == 0 || (fl & (4 << j))); };
-    auto t3_rounds = [&](auto edge_c) {
-        constexpr bool EDGE = decltype(edge_c)::value;
+    // (two variants, with and without a second residual: in a common one the waits for the residual loads sit on the path
+    // without loads too, where all they find in flight are the stores of the round before - every round then lasts a store's round trip)
+    auto t3_rounds = [&](auto edge_c, auto r2_c) {
+        constexpr bool EDGE = decltype(edge_c)::value, R2 = decltype(r2_c)::value;
         auto r2_request = [&](int rd, float (&dst)[NR]) {
             const int i = rd % 3, j = rd / 3;
             const int so = __builtin_amdgcn_readfirstlane((2 * i * OW2 + 2 * j) * d.Cout * 4);
@@ -830,7 +832,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         float r2c[NR], r2n[NR];
 #pragma unroll
         for (int q = 0; q < NR; q++) { r2c[q] = 0.f; r2n[q] = 0.f; }
-        if (has_r2) r2_request(0, r2c);
+        if (R2) r2_request(0, r2c);
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const f32x16 s0 = j == 0 ? acc[0] + acc[1] + acc[2] : j == 1 ? acc[1] - acc[2] : acc[1] + acc[2] + acc[3];
@@ -865,23 +867,26 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                         v[0] += u.x; v[1] += u.y;
                     }
                 }
-                if (has_r2 && rd + 1 < 9) r2_request(rd + 1, r2n);
+                if (R2 && rd + 1 < 9) r2_request(rd + 1, r2n);
                 const int so = __builtin_amdgcn_readfirstlane(((2 * i * OW2 + 2 * j) * out_ld + d.out_c0) * 4);
 #pragma unroll
                 for (int q = 0; q < NR; q++) {
                     float x = v[q] + bias;
                     x = fmaxf(x, x * slope);
-                    x += r2c[q];
+                    if (R2) x += r2c[q];
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), out_rsrc,
                                                           (EDGE ? t3_ok(q_fl[q], i, j) : true) ? (q_pb[q] * out_ld + n) * 4 : INVALID, so, 0);
                 }
+                if (R2) {
 #pragma unroll
-                for (int q = 0; q < NR; q++) r2c[q] = r2n[q];
+                    for (int q = 0; q < NR; q++) r2c[q] = r2n[q];
+                }
                 if (rd == 0) WINO_STAMP(5);
             }
         }
     };
-    if (interior) t3_rounds(no); else t3_rounds(yes);
+    if (has_r2) { if (interior) t3_rounds(no, yes); else t3_rounds(yes, yes); }
+    else { if (interior) t3_rounds(no, no); else t3_rounds(yes, no); }
 #ifdef USC_WINO_NO_PAIR_EPILOGUE
     } else if constexpr (false) {
 #else
