@@ -334,7 +334,10 @@ typedef struct usc_conv_desc {
     int wphase_stride;             /* floats between the packed weights of consecutive phases */
     int ksplit;                    /* set by the library */
     int in_relu;                   /* 1: the layer computes conv(relu(in)) (pre-activation residual blocks, stm/model.py:25-30) */
-    float* slab;                   /* optional scratch for split-K partial sums (small-M layers), may be NULL */
+    float* slab;                   /* optional scratch for split-K partial sums (small-M layers), may be NULL.  Its LAST 64 KB hold
+                                      arrival counters (Winograd layers that split K over two workgroups): the library zeroes
+                                      them when it plans such a layer, kernels leave them even; partial sums never reach them.
+                                      Layers that may run concurrently must not share a slab. */
     size_t slab_bytes;
     int out_ld, out_c0;            /* 0 / 0: `out` is a dense [pixel][Cout] tensor; otherwise `out` has out_ld channels per pixel
                                       and this layer writes channels [out_c0, out_c0 + Cout) (concat buffers) */
@@ -348,7 +351,11 @@ typedef struct usc_conv_desc {
                                       U = G g G^T of the same weights, floats [Cin/8][16][2][Cout][4] with cin = 8c + 4h + q
                                       (vmatting/net_hip.py pack_wino).  When given, the library may run the layer as 16 per-position
                                       products on transformed 4x4 patches (2.25x fewer multiplications; results equal to the
-                                      direct form up to float rounding, ~2e-7 relative).  NULL: direct form. */
+                                      direct form up to float rounding, ~2e-7 relative).  NULL: direct form.
+                                      Four-phase layers (nphase = 4: ConvTranspose2d(k4, s2, p1)) with Cin % 8 == 0, no first
+                                      residual and no affine: the Winograd F(3x3, 2x2) operands of the four phases instead,
+                                      floats [4][Cin/8][16][2][Cout][4] (vmatting/net_hip.py pack_wino_t: G = [1 0; 1/2 1/2;
+                                      1/2 -1/2; 0 -1], phase (py, px) = index 2 py + px). */
 } usc_conv_desc;
 
 /* Tuning hook (tools/dev/tune_convs.py): force the tile width (1 | 2 x 32 columns), the row groups per workgroup (4 | 2 | 1
@@ -360,7 +367,8 @@ void usc_conv_force_winograd(int mode);
 
 /* The launch plan the library chooses for one layer (no device work): tile width in 32-column units, row groups and K groups
  * per workgroup, grid K split, workgroups and threads of the main launch, launches per layer (2 when the grid splits K),
- * winograd = 1 when the layer runs in the Winograd form (then nt = rowgroups = 0).
+ * winograd = 1 | 2 | 3 when the layer runs in the Winograd form (8 x 4 blocks | blocks of 32 consecutive tiles | transposed
+ * form; then nt = rowgroups = 0 and ksplit = 2 means K halves on two workgroups of the SAME launch).
  * Used by the profiling tools to label kernel traces (tools/dev/layer_table.py). */
 typedef struct usc_conv_plan_info { int nt, rowgroups, ksplit, kgroups, workgroups, threads, launches, winograd; } usc_conv_plan_info;
 int usc_conv_plan_query(const usc_conv_desc* desc, usc_conv_plan_info* out);
