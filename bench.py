@@ -300,10 +300,11 @@ def main():
         else:
             pipe.run(io.inputs(frames_h[first:first + n], bg_always), on_result=io.collect(alpha_h, fg_h))
 
-    def spin_up(seconds=0.25):
+    def spin_up(seconds=1.0):
         """The clip is generated and pinned on the CPU for seconds while the GPU idles in a low power state, and W warm-up frames
         (30 ms at W = 10) do not bring its clocks back: untimed matting forwards on a scratch input do (measured: the same 300
-        timed frames run 3.5 % slower without; nothing here touches the pipeline's state or the frames)."""
+        timed frames run 3.5 % slower without, and 1 - 2 % slower after 0.25 s than after 1.5 s; nothing here touches the
+        pipeline's state or the frames)."""
         if args.no_spin_up:
             return
         x = torch.zeros_like(pipe.x7)
