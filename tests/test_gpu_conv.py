@@ -178,6 +178,42 @@ def test_full_network_matches_torch_plan_and_golden(hipnet, H, W):
     assert torch.equal(again, got)
 
 
+def test_full_network_with_every_winograd_form_forced_matches_golden(hipnet):
+    """The same 64 x 96 network with the Winograd form forced on every layer that admits one - standard (both block forms), K
+    halves on two workgroups, and the transposed F(3x3, 2x2) form on all five upsampling layers (the planner only picks them for
+    large layers) - against the reference module's own output (tests/golden/unet_64x96.npz) and the torch plan."""
+    from video_unscreen_amd import _native as nv
+    sys.path.insert(0, GOLD)
+    from gen_golden import unet_input
+    from video_unscreen_amd.vmatting.net import MattingNet, synthetic_state_dict
+    H, W = 64, 96
+    sd = synthetic_state_dict(0)
+    x = unet_input(H, W, 1234)
+    x8 = torch.cat([x, torch.zeros(1, 1, H, W)], 1)[0].permute(1, 2, 0).contiguous().cuda()
+    want = MattingNet(sd, device="cpu")(x)
+    z = np.load(os.path.join(GOLD, "unet_64x96.npz"))
+    lib = nv.load()
+    for split in ("1", "2"):
+        os.environ["USC_WINO_T3"], os.environ["USC_WINO_SPLIT"] = "1", split
+        lib.usc_conv_force_winograd(1)
+        try:
+            net = hipnet.HipMattingNet(sd, H, W)                      # plans are made here
+            plans = [p["plan"] for p in nv.conv_plans(net._arr, len(net._descs))]
+        finally:
+            lib.usc_conv_force_winograd(-1)
+            os.environ["USC_WINO_T3"], os.environ["USC_WINO_SPLIT"] = "-1", "0"
+        assert sum("winograd-t3" in p for p in plans) == 5, plans
+        assert sum(p.startswith("winograd") for p in plans) >= 35, plans
+        if split == "2":
+            assert any("S=2" in p for p in plans), plans
+        got = net(x8).cpu()
+        torch.cuda.synchronize()
+        assert float((got - want).abs().max()) < 1e-4
+        assert np.abs(got.numpy() - z["y"]).max() < 1e-4
+        assert torch.equal(net(x8).cpu(), got)
+        net.close()
+
+
 @pytest.mark.parametrize("in_relu", [False, True])
 def test_conv_every_plan_gives_the_same_layer(hipnet, in_relu):
     """All kernel variants on one layer: tile width (32 / 64 columns) x pixels per workgroup (128 / 64 / 32) x grid K split x
