@@ -1,0 +1,40 @@
+"""Where do the transposed Winograd form's outputs differ from the direct kernel's?  (debug aid)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from video_unscreen_amd import _native as nv
+if os.environ.get("USC_DBG_LIB"): nv.LIB_PATH = os.environ["USC_DBG_LIB"]
+from video_unscreen_amd.vmatting import net_hip as m
+lib = nv.load()
+cin, cout, h, w = [int(a) for a in sys.argv[1:5]] if len(sys.argv) > 4 else (32, 32, 12, 36)
+g = torch.Generator().manual_seed(1)
+x = torch.randn(h, w, cin, generator=g).cuda()
+wt = torch.randn(cin, cout, 4, 4, generator=g) * 0.05
+phases = [m.convt_phase_taps(wt, py, px) for py in (0, 1) for px in (0, 1)]
+wp = torch.stack([m.pack_k_major(k.float()) for _, k in phases], 0).cuda(); wn = m.pack_wino_t(wt).cuda()
+taps = [t for tp, _ in phases for t in tp]
+outs = []
+for mode in ("1", "0", "1"):
+    os.environ["USC_WINO_T3"] = mode
+    out = torch.full((2 * h, 2 * w, cout), float("nan"), device="cuda")
+    d = m.ConvDesc()
+    d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = h, w, cin, h, w, 2 * h, 2 * w, cout
+    d.in_stride, d.out_stride, d.ntaps, d.nphase, d.wphase_stride = 1, 2, 4, 4, wp[0].numel()
+    d.inp, d.out, d.wpk, d.wino = x.data_ptr(), out.data_ptr(), wp.data_ptr(), wn.data_ptr()
+    for i, (dy, dx) in enumerate(taps): d.dy[i], d.dx[i] = dy, dx
+    arr = (m.ConvDesc * 1)(d)
+    print(nv.conv_plans(arr, 1)[0]["plan"])
+    lib.usc_conv_sequence_f32(arr, 1, torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+    outs.append(out.cpu())
+a, ref, b = outs
+bad = ((a - ref).abs() > 1e-3) | torch.isnan(a)
+print("bad", int(bad.sum()), "of", bad.numel(), "; run-to-run differing", int((a != b).sum()))
+ys, xs, cs = bad.nonzero(as_tuple=True)
+if len(ys):
+    print("rows", sorted(set(ys.tolist()))[:40]); print("cols", sorted(set(xs.tolist()))[:60]); print("chans", sorted(set(cs.tolist()))[:40])
+    print("row%6", sorted(set((ys % 6).tolist())), "col%6", sorted(set((xs % 6).tolist())))
+for k in range(min(12, len(ys))):
+    y_, x_, c_ = int(ys[k]), int(xs[k]), int(cs[k])
+    va, vr = float(a[y_, x_, c_]), float(ref[y_, x_, c_])
+    near = (ref[y_, x_] - va).abs()
+    print(f"({y_},{x_},{c_}) got {va:+.5f} want {vr:+.5f}; same pixel channel with that value: {int(near.argmin())} ({float(near.min()):.1e}); second run {float(b[y_, x_, c_]):+.5f}")
