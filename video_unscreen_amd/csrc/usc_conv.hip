@@ -806,32 +806,43 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     // registers [m NR, (m + 1) NR) of every phase); the second residual of round rd + 1 is requested BEFORE the stores of round rd
     // (loads and stores share one in-order counter: waiting for a load issued after a store would wait for the store).
     // The planner admits layers with bias / activation / second residual only.
+    // Stores are 16 bytes per lane: a `buffer_store_dword` of 64 lanes costs the memory pipeline as many cycles (~20) as a
+    // `buffer_store_dwordx4`, and with 72 dword stores per wave the nine rounds were bound by exactly that (11.5 k cycles, the same
+    // with the stores sent out of range).  The exchange region is laid out [wave][register][lane]: read linearly, 16 bytes per
+    // lane, it hands lane t (+ 64 u) FOUR CONSECUTIVE CHANNELS 4 (t & 7) .. + 3 of the pixel of register me NR + (t >> 4) + 4 u,
+    // half-wave (t >> 3) & 1 - the transposition costs nothing but 16 ds_write_b32 instead of 4 ds_write_b128.
     const int OW2 = d.OWf;
-    int q_pb[NR], q_fl[NR];
+    constexpr int NTK = NR / 4;                                    // 16-byte tasks per lane and round (KW = 1: 2)
+    static_assert(NTK >= 1, "the transposed form runs with KW = 1");
+    const int ch = nb0 + 4 * (lane & 7);
+    int tk_pb[NTK], tk_fl[NTK];
 #pragma unroll
-    for (int q = 0; q < NR; q++) {
+    for (int u = 0; u < NTK; u++) {
         int row, a, L, s0, pp;
-        const int r = me * NR + q, t = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int r = me * NR + (lane >> 4) + 4 * u, t = (r & 3) + 8 * (r >> 2) + 4 * ((lane >> 3) & 1);
         lin_seg(t, row, a, L, s0, pp);
         const int ty3 = 3 * row, tx3 = 3 * (a + pp);
-        q_pb[q] = (imr * 2 * H + 2 * ty3 + pary) * OW2 + 2 * tx3 + parx;
-        q_fl[q] = (t < cnt ? 1 : 0) | (ty3 + 1 < H ? 2 : 0) | (ty3 + 2 < H ? 4 : 0) | (tx3 + 1 < W ? 8 : 0) | (tx3 + 2 < W ? 16 : 0);
+        tk_pb[u] = (imr * 2 * H + 2 * ty3 + pary) * OW2 + 2 * tx3 + parx;
+        tk_fl[u] = (t < cnt ? 1 : 0) | (ty3 + 1 < H ? 2 : 0) | (ty3 + 2 < H ? 4 : 0) | (tx3 + 1 < W ? 8 : 0) | (tx3 + 2 < W ? 16 : 0);
     }
+    const f32x4 bias4 = d.bias ? *reinterpret_cast<const f32x4*>(d.bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
     auto t3_ok = [](int fl, int i, int j) { return (fl & 1) && (i == 0 || (fl & (1 << i))) && (j == 0 || (fl & (4 << j))); };
     // (two variants, with and without a second residual: in a common one the waits for the residual loads sit on the path
-    // without loads too, where all they find in flight are the stores of the round before - every round then lasts a store's round trip)
+    // without loads too, where all they find in flight are the stores of the round before)
     auto t3_rounds = [&](auto edge_c, auto r2_c) {
         constexpr bool EDGE = decltype(edge_c)::value, R2 = decltype(r2_c)::value;
-        auto r2_request = [&](int rd, float (&dst)[NR]) {
+        auto r2_request = [&](int rd, f32x4 (&dst)[NTK]) {
             const int i = rd % 3, j = rd / 3;
             const int so = __builtin_amdgcn_readfirstlane((2 * i * OW2 + 2 * j) * d.Cout * 4);
 #pragma unroll
-            for (int q = 0; q < NR; q++)
-                dst[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2_rsrc, t3_ok(q_fl[q], i, j) ? (q_pb[q] * d.Cout + n) * 4 : INVALID, so, 0));
+            for (int u = 0; u < NTK; u++) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, t3_ok(tk_fl[u], i, j) ? (tk_pb[u] * d.Cout + ch) * 4 : INVALID, so, 0);
+                dst[u] = *reinterpret_cast<const f32x4*>(&v);
+            }
         };
-        float r2c[NR], r2n[NR];
+        f32x4 r2c[NTK], r2n[NTK];
 #pragma unroll
-        for (int q = 0; q < NR; q++) { r2c[q] = 0.f; r2n[q] = 0.f; }
+        for (int u = 0; u < NTK; u++) { r2c[u] = f32x4{0.f, 0.f, 0.f, 0.f}; r2n[u] = r2c[u]; }
         if (R2) r2_request(0, r2c);
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -847,39 +858,40 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                 else y = h == 0 ? s1 : t01;
                 float* const reg = Ls + (rd & 1) * WREGION;
 #pragma unroll
-                for (int qd = 0; qd < 4; qd++)
-                    *reinterpret_cast<float4*>(&reg[((wave * 4 + qd) * 64 + lane) * 4]) = make_float4(y[4 * qd], y[4 * qd + 1], y[4 * qd + 2], y[4 * qd + 3]);
+                for (int r = 0; r < 16; r++) reg[(wave * 16 + r) * 64 + lane] = y[r];
                 __syncthreads();
-                float v[NR];
+                float v[NTK][4];
 #pragma unroll
-                for (int q = 0; q < NR; q++) v[q] = 0.f;
+                for (int u = 0; u < NTK; u++) {
 #pragma unroll
-                for (int m = 0; m < G; m++) {                     // fixed order: K group major, position half minor
-                    const int w2 = (m & 1) * 4 + ubase + (m >> 1);
-                    if constexpr (NR >= 4) {
-#pragma unroll
-                        for (int blk = 0; blk < NR / 4; blk++) {
-                            const float4 u = *reinterpret_cast<const float4*>(&reg[((w2 * 4 + me * (NR / 4) + blk) * 64 + lane) * 4]);
-                            v[4 * blk] += u.x; v[4 * blk + 1] += u.y; v[4 * blk + 2] += u.z; v[4 * blk + 3] += u.w;
-                        }
-                    } else {
-                        const float2 u = *reinterpret_cast<const float2*>(&reg[((w2 * 4 + (me >> 1)) * 64 + lane) * 4 + 2 * (me & 1)]);
-                        v[0] += u.x; v[1] += u.y;
+                    for (int m = 0; m < G; m++) {                 // fixed order: K group major, position half minor
+                        const int w2 = (m & 1) * 4 + ubase + (m >> 1);
+                        const float4 e = *reinterpret_cast<const float4*>(&reg[(w2 * 16 + me * NR + 4 * u) * 64 + 4 * lane]);
+                        if (m == 0) { v[u][0] = e.x; v[u][1] = e.y; v[u][2] = e.z; v[u][3] = e.w; }
+                        else { v[u][0] += e.x; v[u][1] += e.y; v[u][2] += e.z; v[u][3] += e.w; }
                     }
                 }
                 if (R2 && rd + 1 < 9) r2_request(rd + 1, r2n);
                 const int so = __builtin_amdgcn_readfirstlane(((2 * i * OW2 + 2 * j) * out_ld + d.out_c0) * 4);
 #pragma unroll
-                for (int q = 0; q < NR; q++) {
-                    float x = v[q] + bias;
-                    x = fmaxf(x, x * slope);
-                    if (R2) x += r2c[q];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), out_rsrc,
-                                                          (EDGE ? t3_ok(q_fl[q], i, j) : true) ? (q_pb[q] * out_ld + n) * 4 : INVALID, so, 0);
+                for (int u = 0; u < NTK; u++) {
+                    float x[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        x[k] = v[u][k] + bias4[k];
+                        x[k] = fmaxf(x[k], x[k] * slope);
+                        if (R2) x[k] += r2c[u][k];
+                    }
+                    const u32x4 xs = {__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]), __builtin_bit_cast(unsigned, x[2]), __builtin_bit_cast(unsigned, x[3])};
+                    // (the round's offset goes into the VECTOR offset, the scalar one stays the constant 0: with a register there the
+                    // compiler assumes a 16-byte store has read its data when it issues and lets the next instruction overwrite the
+                    // registers - on this part it has not: single components of some lanes then carry the next value, found with a
+                    // pattern pushed through the exchange, tools/dev/t3_debug.py.  With a constant it inserts the wait state itself.)
+                    __builtin_amdgcn_raw_buffer_store_b128(xs, out_rsrc, (EDGE ? t3_ok(tk_fl[u], i, j) : true) ? (tk_pb[u] * out_ld + ch) * 4 + so : INVALID, 0, 0);
                 }
                 if (R2) {
 #pragma unroll
-                    for (int q = 0; q < NR; q++) r2c[q] = r2n[q];
+                    for (int u = 0; u < NTK; u++) r2c[u] = r2n[u];
                 }
                 if (rd == 0) WINO_STAMP(5);
             }
