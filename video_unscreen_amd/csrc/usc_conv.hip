@@ -1244,8 +1244,8 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     // Transposed Winograd form (conv_wino_kernel, MODE 2): the four-phase ConvTranspose2d(k 4, s 2, p 1) layer (phase (py, px), tap
     // (iy, ix) reads the input at (py - iy, px - ix)) whose caller supplied the F(3x3, 2x2) operands; bias / activation / second
     // residual only.  Cost model as below: a round of workgroups (each the four phases of a block x channel group, all of K)
-    // costs 17 (nine exchange rounds instead of four) + 2.55 per K step (profiles/r02/unet_layer_table.md: 37.4 us for 230
-    // workgroups x 8 steps, 54.6 us for 455 x 4).
+    // costs 14.5 (nine exchange rounds instead of four) + 2.55 per K step (profiles/r02/unet_layer_table.md: 34.1 us for 230
+    // workgroups x 8 steps, 51.7 us for 455 x 4).
     {
         bool t3 = d.wino && nphase == 4 && d.ntaps == 4 && d.in_stride == 1 && d.out_stride == 2 && nbatch == 1 && d.Cin % 8 == 0 &&
                   !d.res1 && !d.scale && d.OH == d.IH && d.OW == d.IW && d.OHf == 2 * d.IH && d.OWf == 2 * d.IW && d.kind != USC_CONV_HEAD;
@@ -1258,7 +1258,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
             const long long blk = ((long long)TH * TW + nbt - 1) / nbt;
             const long long wgs = blk * (d.Cout / 32);             // a workgroup = the four phases of a block x channel group
             const int nsteps = d.Cin / 8;
-            const double wino_us = (double)((wgs + 255) / 256) * (17.0 + nsteps * 2.55);
+            const double wino_us = (double)((wgs + 255) / 256) * (14.5 + nsteps * 2.55);
             const double direct_us = 6.0 + 2.0 * (double)M * 4 * d.Cout * 4.0 * d.Cin / 118e6 + (double)M * 4 * d.Cout * 4.0 / 3e6;
             if (wino_us < direct_us || g_force_wino == 1 || force_t3 == 1) {
                 p.wino = true;
