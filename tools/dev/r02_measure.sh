@@ -24,3 +24,4 @@ timeout -k 10 300 rocprofv3 --kernel-trace -d $R/$o/layer_trace -o lt --output-f
 cd $R
 f=$(find $o/layer_trace -name '*kernel_trace.csv' | head -1)
 python tools/dev/layer_table.py table $o/layers.json $f > $o/unet_layer_table.md && tail -4 $o/unet_layer_table.md
+rm -rf $o/layer_trace
