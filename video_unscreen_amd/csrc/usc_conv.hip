@@ -983,6 +983,91 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         if (h == 0) dispatch(std::integral_constant<int, 0>());
         else dispatch(std::integral_constant<int, 1>());
     } else {
+    bool finished = false;
+    if constexpr (KW == 2) {
+    if (S == 1) {
+    // ---- two K groups, one workgroup per unit: the four rounds with 16-byte accesses (see the transposed form above: what bounds
+    // an epilogue is the NUMBER of loads and stores, a dword one costs as much as a dwordx4).  The exchange region is laid out
+    // [wave][register][lane]; read back linearly, 16 bytes per lane, it hands lane l four consecutive channels 4 (l & 7) .. + 3 of
+    // the pixel of register me NR + (l >> 4), half-wave (l >> 3) & 1: one residual load per tensor and ONE store per lane and round
+    // instead of four.  Same summation order as the dword rounds below (K group major, position half minor): same bits.
+    finished = true;
+    const int r4 = me * NR + (lane >> 4), hf4 = (lane >> 3) & 1, ch = nb0 + 4 * (lane & 7);
+    int oy0, ox0;
+    bool tile_ok;
+    if (LIN) {
+        int row, a, L, s0, pp;
+        const int t = (r4 & 3) + 8 * (r4 >> 2) + 4 * hf4;
+        lin_seg(t, row, a, L, s0, pp);
+        oy0 = 2 * row; ox0 = 2 * (a + pp); tile_ok = t < cnt;
+    } else {
+        oy0 = 2 * (4 * by + (r4 >> 2)); ox0 = 16 * bx + 2 * ((r4 & 3) + 4 * hf4); tile_ok = live;
+    }
+    const int rs = d.res1_shift;
+    auto pix4 = [&](int i, int j) { return pix(oy0 + i, ox0 + j); };                         // real pixel index of output phase (i, j)
+    auto ok4 = [&](int i, int j) { return tile_ok && oy0 + i < H && ox0 + j < W; };
+    auto r1_off = [&](int i, int j) {                                                        // (a half-resolution residual only exists for D = 1)
+        const int Yg = imr * d.IH + oy0 + i, Xg = ox0 + j;
+        return rs ? (((Yg >> rs) * (d.OWf >> rs) + (Xg >> rs)) * d.Cout + ch) * 4 : (pix4(i, j) * d.Cout + ch) * 4;
+    };
+    auto ld4 = [&](const float* p) { return *reinterpret_cast<const float4*>(p + ch); };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 bias4 = d.bias ? ld4(d.bias) : zero4, sc4 = has_aff ? ld4(d.scale) : one4, sh4 = has_aff ? ld4(d.shift) : zero4;
+    float4 r1q[4], r2q[4];
+#pragma unroll
+    for (int rd = 0; rd < 4; rd++) { r1q[rd] = zero4; r2q[rd] = zero4; }
+    if (has_r1) {
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r1_rsrc, ok4(rd >> 1, rd & 1) ? r1_off(rd >> 1, rd & 1) : INVALID, 0, 0);
+            r1q[rd] = *reinterpret_cast<const float4*>(&v);
+        }
+    }
+    if (has_r2) {
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, ok4(rd >> 1, rd & 1) ? (pix4(rd >> 1, rd & 1) * d.Cout + ch) * 4 : INVALID, 0, 0);
+            r2q[rd] = *reinterpret_cast<const float4*>(&v);
+        }
+    }
+    auto rounds4 = [&](auto full_c, auto edge_c) {
+        constexpr bool FULL = decltype(full_c)::value, EDGE = decltype(edge_c)::value;
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++) {
+            float* const reg = Ls + (rd & 1) * WREGION;
+#pragma unroll
+            for (int r = 0; r < 16; r++) reg[(wave * 16 + r) * 64 + lane] = Yp[rd][r];
+            __syncthreads();
+            float v[4];
+#pragma unroll
+            for (int m = 0; m < G; m++) {                         // fixed order: K group major, position half minor
+                const int w2 = (m & 1) * 4 + ubase + (m >> 1);
+                const float4 e = *reinterpret_cast<const float4*>(&reg[(w2 * 16 + me * NR) * 64 + 4 * lane]);
+                if (m == 0) { v[0] = 0.f + e.x; v[1] = 0.f + e.y; v[2] = 0.f + e.z; v[3] = 0.f + e.w; }
+                else { v[0] += e.x; v[1] += e.y; v[2] += e.z; v[3] += e.w; }
+            }
+            const float b4[4] = {bias4.x, bias4.y, bias4.z, bias4.w}, s4[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, t4[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+            const float p1[4] = {r1q[rd].x, r1q[rd].y, r1q[rd].z, r1q[rd].w}, p2[4] = {r2q[rd].x, r2q[rd].y, r2q[rd].z, r2q[rd].w};
+            float x[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                x[k] = v[k] + b4[k];
+                if (FULL) x[k] += p1[k];
+                x[k] = fmaxf(x[k], x[k] * slope);
+                if (FULL) { x[k] = x[k] * s4[k] + t4[k]; x[k] += p2[k]; }
+            }
+            const u32x4 xs = {__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]), __builtin_bit_cast(unsigned, x[2]), __builtin_bit_cast(unsigned, x[3])};
+            // (scalar offset = the constant 0: with a register there the next instruction may overwrite the data registers of a
+            // 16-byte store before it has read them - see the transposed form)
+            __builtin_amdgcn_raw_buffer_store_b128(xs, out_rsrc, (!EDGE || ok4(rd >> 1, rd & 1)) ? (pix4(rd >> 1, rd & 1) * out_ld + d.out_c0 + ch) * 4 : INVALID, 0, 0);
+            if (rd == 0) WINO_STAMP(5);
+        }
+    };
+    if (plain) { if (interior) rounds4(no, no); else rounds4(no, yes); }
+    else { if (interior) rounds4(yes, no); else rounds4(yes, yes); }
+    }
+    }
+    if (!finished) {
     // ---- K groups: G = 2 KW waves (member m = 2 kg + h); member m finishes registers [m NR, (m + 1) NR) of every phase, in four
     // rounds (one per phase) through two alternating exchange regions.
     // ALL residual values of the four rounds are requested before the first store is issued: loads and stores share one
@@ -1089,6 +1174,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     };
     if (plain) { if (interior) rounds(no, no); else rounds(no, yes); }
     else { if (interior) rounds(yes, no); else rounds(yes, yes); }
+    }
     }
     WINO_STAMP(6);
     WINO_PH(15);
