@@ -984,24 +984,26 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         else dispatch(std::integral_constant<int, 1>());
     } else {
     bool finished = false;
-    if constexpr (KW == 2) {
-    if (S == 1) {
-    // ---- two K groups, one workgroup per unit: the four rounds with 16-byte accesses (see the transposed form above: what bounds
+    {
+    {
+    // ---- K groups: the four rounds with 16-byte accesses (see the transposed form above: what bounds
     // an epilogue is the NUMBER of loads and stores, a dword one costs as much as a dwordx4).  The exchange region is laid out
     // [wave][register][lane]; read back linearly, 16 bytes per lane, it hands lane l four consecutive channels 4 (l & 7) .. + 3 of
     // the pixel of register me NR + (l >> 4), half-wave (l >> 3) & 1: one residual load per tensor and ONE store per lane and round
-    // instead of four.  Same summation order as the dword rounds below (K group major, position half minor): same bits.
+    // instead of four (four K groups: NR = 2 registers per wave and phase are 32 such tasks - the upper half-wave idles).
+    // Same summation order as the dword rounds below (K group major, position half minor): same bits.
     finished = true;
-    const int r4 = me * NR + (lane >> 4), hf4 = (lane >> 3) & 1, ch = nb0 + 4 * (lane & 7);
+    const bool task = NR >= 4 || lane < 32;
+    const int r4 = me * NR + (task ? lane >> 4 : 0), hf4 = (lane >> 3) & 1, ch = nb0 + 4 * (lane & 7);
     int oy0, ox0;
     bool tile_ok;
     if (LIN) {
         int row, a, L, s0, pp;
         const int t = (r4 & 3) + 8 * (r4 >> 2) + 4 * hf4;
         lin_seg(t, row, a, L, s0, pp);
-        oy0 = 2 * row; ox0 = 2 * (a + pp); tile_ok = t < cnt;
+        oy0 = 2 * row; ox0 = 2 * (a + pp); tile_ok = task && t < cnt;
     } else {
-        oy0 = 2 * (4 * by + (r4 >> 2)); ox0 = 16 * bx + 2 * ((r4 & 3) + 4 * hf4); tile_ok = live;
+        oy0 = 2 * (4 * by + (r4 >> 2)); ox0 = 16 * bx + 2 * ((r4 & 3) + 4 * hf4); tile_ok = task && live;
     }
     const int rs = d.res1_shift;
     auto pix4 = [&](int i, int j) { return pix(oy0 + i, ox0 + j); };                         // real pixel index of output phase (i, j)
@@ -1032,6 +1034,31 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     }
     auto rounds4 = [&](auto full_c, auto edge_c) {
         constexpr bool FULL = decltype(full_c)::value, EDGE = decltype(edge_c)::value;
+        // bias, residual, activation, affine, second residual, one 16-byte store.  The interior variant still needs the lane
+        // mask when the upper half-wave has no task.
+        auto finish4 = [&](const float (&v)[4], int rd) {
+            const float b4[4] = {bias4.x, bias4.y, bias4.z, bias4.w}, s4[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, t4[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+            const float p1[4] = {r1q[rd].x, r1q[rd].y, r1q[rd].z, r1q[rd].w}, p2[4] = {r2q[rd].x, r2q[rd].y, r2q[rd].z, r2q[rd].w};
+            float x[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                x[k] = v[k] + b4[k];
+                if (FULL) x[k] += p1[k];
+                x[k] = fmaxf(x[k], x[k] * slope);
+                if (FULL) { x[k] = x[k] * s4[k] + t4[k]; x[k] += p2[k]; }
+            }
+            const u32x4 xs = {__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]), __builtin_bit_cast(unsigned, x[2]), __builtin_bit_cast(unsigned, x[3])};
+            // (scalar offset = the constant 0: with a register there the next instruction may overwrite the data registers of a
+            // 16-byte store before it has read them - see the transposed form)
+            const bool st_ok = EDGE ? ok4(rd >> 1, rd & 1) : (NR >= 4 || task);
+            __builtin_amdgcn_raw_buffer_store_b128(xs, out_rsrc, st_ok ? (pix4(rd >> 1, rd & 1) * out_ld + d.out_c0 + ch) * 4 : INVALID, 0, 0);
+        };
+        float vs[4][4];
+        constexpr int SC = 0x11;                                  // sc0 | sc1 (two workgroups per unit, below)
+        const __amdgpu_buffer_rsrc_t sl_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.slab, 0, S == 2 ? (int)d.slab_bytes : 0, 0x00020000);
+        // slab: [unit][half][phase][member wave][task lane][4] floats = 16 KB per unit and half (16 NR task lanes per member)
+        constexpr int TL = NR >= 4 ? 64 : 32;
+        auto slab_off = [&](int half, int rd) { return (((wt * 2 + half) * 4 + rd) * G + me) * TL * 16 + lane * 16; };
 #pragma unroll
         for (int rd = 0; rd < 4; rd++) {
             float* const reg = Ls + (rd & 1) * WREGION;
@@ -1046,21 +1073,35 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
                 if (m == 0) { v[0] = 0.f + e.x; v[1] = 0.f + e.y; v[2] = 0.f + e.z; v[3] = 0.f + e.w; }
                 else { v[0] += e.x; v[1] += e.y; v[2] += e.z; v[3] += e.w; }
             }
-            const float b4[4] = {bias4.x, bias4.y, bias4.z, bias4.w}, s4[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, t4[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
-            const float p1[4] = {r1q[rd].x, r1q[rd].y, r1q[rd].z, r1q[rd].w}, p2[4] = {r2q[rd].x, r2q[rd].y, r2q[rd].z, r2q[rd].w};
-            float x[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                x[k] = v[k] + b4[k];
-                if (FULL) x[k] += p1[k];
-                x[k] = fmaxf(x[k], x[k] * slope);
-                if (FULL) { x[k] = x[k] * s4[k] + t4[k]; x[k] += p2[k]; }
+            for (int k = 0; k < 4; k++) vs[rd][k] = v[k];
+            if (S == 1) finish4(v, rd);
+            else {
+                const u32x4 raw = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(raw, sl_rsrc, task && live ? slab_off(ks, rd) : INVALID, 0, SC);
             }
-            const u32x4 xs = {__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]), __builtin_bit_cast(unsigned, x[2]), __builtin_bit_cast(unsigned, x[3])};
-            // (scalar offset = the constant 0: with a register there the next instruction may overwrite the data registers of a
-            // 16-byte store before it has read them - see the transposed form)
-            __builtin_amdgcn_raw_buffer_store_b128(xs, out_rsrc, (!EDGE || ok4(rd >> 1, rd & 1)) ? (pix4(rd >> 1, rd & 1) * out_ld + d.out_c0 + ch) * 4 : INVALID, 0, 0);
             if (rd == 0) WINO_STAMP(5);
+        }
+        if (S == 1) return;
+        // ---- two workgroups per unit (see the dword rounds below for the protocol): sums to the slab with system-scope
+        // write-through stores, one relaxed atomic per workgroup counts arrivals, the second to arrive adds and finishes.
+        int* const counter = reinterpret_cast<int*>(reinterpret_cast<char*>(d.slab) + d.slab_bytes - WSLAB_TAIL) + wt;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the stores have been acknowledged
+        __syncthreads();
+        int* const s_flag = reinterpret_cast<int*>(Ls);           // (the exchange regions are free: every wave is past its last read)
+        if ((wave & 3) == ubase && h == 0 && kg == 0 && lane == 0)
+            s_flag[sub / KW] = live ? (__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) : 0;
+        __syncthreads();
+        if (s_flag[sub / KW] == 0) return;                        // first to arrive (even count): the partner finishes
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++) {
+            const u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(sl_rsrc, task ? slab_off(1 - ks, rd) : INVALID, 0, SC);
+            const float4 of4 = *reinterpret_cast<const float4*>(&o);
+            const float of[4] = {of4.x, of4.y, of4.z, of4.w};
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = ks == 0 ? vs[rd][k] + of[k] : of[k] + vs[rd][k];
+            finish4(v, rd);
         }
     };
     if (plain) { if (interior) rounds4(no, no); else rounds4(no, yes); }
