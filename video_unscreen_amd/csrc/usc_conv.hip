@@ -798,6 +798,150 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         }
         return v;
     };
+    // ---- Epilogue in four rounds with 16-byte accesses (all K-group layers; KW = 1 layers with residual tensors).  The group of a
+    // block x channel group is G = 2 KW waves (member m = 2 kg + h); member m finishes registers [m NR, (m + 1) NR) of every output
+    // phase, one phase per round, through two alternating exchange regions.  What bounds an epilogue is the NUMBER of loads and
+    // stores (a dword one costs the memory pipeline as much as a dwordx4: see the transposed form below), and the accumulator
+    // layout puts one channel in a lane - so the exchange region is laid out [wave][register][lane]: read back linearly, 16 bytes
+    // per lane, it hands lane l four consecutive channels 4 (l & 7) .. + 3 of the pixel of register me NR + (l >> 4) + 4 u,
+    // half-wave (l >> 3) & 1 (u < NR / 4 tasks per lane; four K groups: NR = 2 registers are 32 tasks, the upper half-wave idles):
+    // one load per residual tensor and ONE store per task and round.  Summation order: K group major, position half minor (fixed:
+    // run-to-run and batch-to-batch identical results).  ALL residual values of the four rounds are requested before the first
+    // store is issued: loads and stores share one in-order counter, a load waited for after a store would wait for that store.
+    auto epilogue4 = [&]() {
+    constexpr int NTK = NR >= 4 ? NR / 4 : 1;
+    const bool task = NR >= 4 || lane < 32;
+    const int hf4 = (lane >> 3) & 1, ch = nb0 + 4 * (lane & 7);
+    int oy0[NTK], ox0[NTK];
+    bool tile_ok[NTK];
+#pragma unroll
+    for (int u = 0; u < NTK; u++) {
+        const int r4 = me * NR + (task ? lane >> 4 : 0) + 4 * u;
+        if (LIN) {
+            int row, a, L, s0, pp;
+            const int t = (r4 & 3) + 8 * (r4 >> 2) + 4 * hf4;
+            lin_seg(t, row, a, L, s0, pp);
+            oy0[u] = 2 * row; ox0[u] = 2 * (a + pp); tile_ok[u] = task && t < cnt;
+        } else {
+            oy0[u] = 2 * (4 * by + (r4 >> 2)); ox0[u] = 16 * bx + 2 * ((r4 & 3) + 4 * hf4); tile_ok[u] = task && live;
+        }
+    }
+    const int rs = d.res1_shift;
+    auto pix4 = [&](int u, int i, int j) { return pix(oy0[u] + i, ox0[u] + j); };              // real pixel index of output phase (i, j)
+    auto ok4 = [&](int u, int i, int j) { return tile_ok[u] && oy0[u] + i < H && ox0[u] + j < W; };
+    auto r1_off = [&](int u, int i, int j) {                                                   // (a half-resolution residual only exists for D = 1)
+        const int Yg = imr * d.IH + oy0[u] + i, Xg = ox0[u] + j;
+        return rs ? (((Yg >> rs) * (d.OWf >> rs) + (Xg >> rs)) * d.Cout + ch) * 4 : (pix4(u, i, j) * d.Cout + ch) * 4;
+    };
+    auto ld4 = [&](const float* p) { return *reinterpret_cast<const float4*>(p + ch); };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 bias4 = d.bias ? ld4(d.bias) : zero4, sc4 = has_aff ? ld4(d.scale) : one4, sh4 = has_aff ? ld4(d.shift) : zero4;
+    float4 r1q[4][NTK], r2q[4][NTK];
+#pragma unroll
+    for (int rd = 0; rd < 4; rd++)
+#pragma unroll
+        for (int u = 0; u < NTK; u++) { r1q[rd][u] = zero4; r2q[rd][u] = zero4; }
+    if (has_r1) {
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++)
+#pragma unroll
+            for (int u = 0; u < NTK; u++) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r1_rsrc, ok4(u, rd >> 1, rd & 1) ? r1_off(u, rd >> 1, rd & 1) : INVALID, 0, 0);
+                r1q[rd][u] = *reinterpret_cast<const float4*>(&v);
+            }
+    }
+    if (has_r2) {
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++)
+#pragma unroll
+            for (int u = 0; u < NTK; u++) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, ok4(u, rd >> 1, rd & 1) ? (pix4(u, rd >> 1, rd & 1) * d.Cout + ch) * 4 : INVALID, 0, 0);
+                r2q[rd][u] = *reinterpret_cast<const float4*>(&v);
+            }
+    }
+    auto rounds4 = [&](auto full_c, auto edge_c) {
+        constexpr bool FULL = decltype(full_c)::value, EDGE = decltype(edge_c)::value;
+        // bias, residual, activation, affine, second residual, one 16-byte store.  (The interior variant still needs the lane
+        // mask when the upper half-wave has no task.)
+        auto finish4 = [&](const float (&v)[4], int rd, int u) {
+            const float b4[4] = {bias4.x, bias4.y, bias4.z, bias4.w}, s4[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, t4[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+            const float p1[4] = {r1q[rd][u].x, r1q[rd][u].y, r1q[rd][u].z, r1q[rd][u].w}, p2[4] = {r2q[rd][u].x, r2q[rd][u].y, r2q[rd][u].z, r2q[rd][u].w};
+            float x[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                x[k] = v[k] + b4[k];
+                if (FULL) x[k] += p1[k];
+                x[k] = fmaxf(x[k], x[k] * slope);
+                if (FULL) { x[k] = x[k] * s4[k] + t4[k]; x[k] += p2[k]; }
+            }
+            const u32x4 xs = {__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]), __builtin_bit_cast(unsigned, x[2]), __builtin_bit_cast(unsigned, x[3])};
+            // (scalar offset = the constant 0: with a register there the next instruction may overwrite the data registers of a
+            // 16-byte store before it has read them - see the transposed form)
+            const bool st_ok = EDGE ? ok4(u, rd >> 1, rd & 1) : (NR >= 4 || task);
+            __builtin_amdgcn_raw_buffer_store_b128(xs, out_rsrc, st_ok ? (pix4(u, rd >> 1, rd & 1) * out_ld + d.out_c0 + ch) * 4 : INVALID, 0, 0);
+        };
+        float vs[4][NTK][4];
+        constexpr int SC = 0x11;                                  // sc0 | sc1 (two workgroups per unit, below)
+        const __amdgpu_buffer_rsrc_t sl_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.slab, 0, S == 2 ? (int)d.slab_bytes : 0, 0x00020000);
+        // slab: [unit][half][phase][member wave][task][4] floats = 16 KB per unit and half (16 NR tasks per member and phase)
+        constexpr int TL = NR >= 4 ? 16 * NR : 32;
+        auto slab_off = [&](int half, int rd, int u) { return (((wt * 2 + half) * 4 + rd) * G + me) * TL * 16 + (u * 64 + lane) * 16; };
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++) {
+            float* const reg = Ls + (rd & 1) * WREGION;
+#pragma unroll
+            for (int r = 0; r < 16; r++) reg[(wave * 16 + r) * 64 + lane] = Yp[rd][r];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < NTK; u++) {
+                float v[4];
+#pragma unroll
+                for (int m = 0; m < G; m++) {                     // fixed order: K group major, position half minor
+                    const int w2 = (m & 1) * 4 + ubase + (m >> 1);
+                    const float4 e = *reinterpret_cast<const float4*>(&reg[(w2 * 16 + me * NR + 4 * u) * 64 + 4 * lane]);
+                    if (m == 0) { v[0] = 0.f + e.x; v[1] = 0.f + e.y; v[2] = 0.f + e.z; v[3] = 0.f + e.w; }
+                    else { v[0] += e.x; v[1] += e.y; v[2] += e.z; v[3] += e.w; }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) vs[rd][u][k] = v[k];
+                if (S == 1) finish4(v, rd, u);
+                else {
+                    const u32x4 raw = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(raw, sl_rsrc, task && live ? slab_off(ks, rd, u) : INVALID, 0, SC);
+                }
+            }
+            if (rd == 0) WINO_STAMP(5);
+        }
+        if (S == 1) return;
+        // ---- two workgroups per unit: this one's sums went to the slab with system-scope write-through stores (the partner may sit
+        // on another XCD, whose L2 is not coherent with ours: sc0 sc1 on both sides instead of a release that writes the whole L2
+        // back), then one relaxed atomic per workgroup counts arrivals; the second to arrive adds the first one's sums to its own
+        // (half 0 + half 1: addition commutes) and finishes.  The counters (last WSLAB_TAIL bytes of the slab, zeroed by the host
+        // once) only ever matter modulo 2.
+        int* const counter = reinterpret_cast<int*>(reinterpret_cast<char*>(d.slab) + d.slab_bytes - WSLAB_TAIL) + wt;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the stores have been acknowledged
+        __syncthreads();
+        int* const s_flag = reinterpret_cast<int*>(Ls);           // (the exchange regions are free: every wave is past its last read)
+        if ((wave & 3) == ubase && h == 0 && kg == 0 && lane == 0)
+            s_flag[sub / KW] = live ? (__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) : 0;
+        __syncthreads();
+        if (s_flag[sub / KW] == 0) return;                        // first to arrive (even count): the partner finishes
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++)
+#pragma unroll
+            for (int u = 0; u < NTK; u++) {
+                const u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(sl_rsrc, task ? slab_off(1 - ks, rd, u) : INVALID, 0, SC);
+                const float4 of4 = *reinterpret_cast<const float4*>(&o);
+                const float of[4] = {of4.x, of4.y, of4.z, of4.w};
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = ks == 0 ? vs[rd][u][k] + of[k] : of[k] + vs[rd][u][k];
+                finish4(v, rd, u);
+            }
+    };
+    if (plain) { if (interior) rounds4(no, no); else rounds4(no, yes); }
+    else { if (interior) rounds4(yes, no); else rounds4(yes, yes); }
+    };
     if constexpr (T3) {
     // ---- transposed form: nine output phases (i, j) -> pixel (2 (3 ty + i) + py, 2 (3 tx + j) + px) of the doubled map.  With
     // C_j(a) = sum_b A^T[j][b] M[a][b] (C_0 = M0 + M1 + M2, C_1 = M1 - M2, C_2 = M1 + M2 + M3) this wave's partial sums are
@@ -980,242 +1124,12 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
             else if (!has_r1) { if (interior) finish_pair(hh, no, yes, no); else finish_pair(hh, no, yes, yes); }
             else { if (interior) finish_pair(hh, yes, yes, no); else finish_pair(hh, yes, yes, yes); }
         };
-        if (h == 0) dispatch(std::integral_constant<int, 0>());
+        // (with residual tensors the 16-byte rounds win: the pair path loads them dword by dword, 32 per wave and tensor)
+        if (has_r1 || has_r2) epilogue4();
+        else if (h == 0) dispatch(std::integral_constant<int, 0>());
         else dispatch(std::integral_constant<int, 1>());
     } else {
-    bool finished = false;
-    {
-    {
-    // ---- K groups: the four rounds with 16-byte accesses (see the transposed form above: what bounds
-    // an epilogue is the NUMBER of loads and stores, a dword one costs as much as a dwordx4).  The exchange region is laid out
-    // [wave][register][lane]; read back linearly, 16 bytes per lane, it hands lane l four consecutive channels 4 (l & 7) .. + 3 of
-    // the pixel of register me NR + (l >> 4), half-wave (l >> 3) & 1: one residual load per tensor and ONE store per lane and round
-    // instead of four (four K groups: NR = 2 registers per wave and phase are 32 such tasks - the upper half-wave idles).
-    // Same summation order as the dword rounds below (K group major, position half minor): same bits.
-    finished = true;
-    const bool task = NR >= 4 || lane < 32;
-    const int r4 = me * NR + (task ? lane >> 4 : 0), hf4 = (lane >> 3) & 1, ch = nb0 + 4 * (lane & 7);
-    int oy0, ox0;
-    bool tile_ok;
-    if (LIN) {
-        int row, a, L, s0, pp;
-        const int t = (r4 & 3) + 8 * (r4 >> 2) + 4 * hf4;
-        lin_seg(t, row, a, L, s0, pp);
-        oy0 = 2 * row; ox0 = 2 * (a + pp); tile_ok = task && t < cnt;
-    } else {
-        oy0 = 2 * (4 * by + (r4 >> 2)); ox0 = 16 * bx + 2 * ((r4 & 3) + 4 * hf4); tile_ok = task && live;
-    }
-    const int rs = d.res1_shift;
-    auto pix4 = [&](int i, int j) { return pix(oy0 + i, ox0 + j); };                         // real pixel index of output phase (i, j)
-    auto ok4 = [&](int i, int j) { return tile_ok && oy0 + i < H && ox0 + j < W; };
-    auto r1_off = [&](int i, int j) {                                                        // (a half-resolution residual only exists for D = 1)
-        const int Yg = imr * d.IH + oy0 + i, Xg = ox0 + j;
-        return rs ? (((Yg >> rs) * (d.OWf >> rs) + (Xg >> rs)) * d.Cout + ch) * 4 : (pix4(i, j) * d.Cout + ch) * 4;
-    };
-    auto ld4 = [&](const float* p) { return *reinterpret_cast<const float4*>(p + ch); };
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    const float4 bias4 = d.bias ? ld4(d.bias) : zero4, sc4 = has_aff ? ld4(d.scale) : one4, sh4 = has_aff ? ld4(d.shift) : zero4;
-    float4 r1q[4], r2q[4];
-#pragma unroll
-    for (int rd = 0; rd < 4; rd++) { r1q[rd] = zero4; r2q[rd] = zero4; }
-    if (has_r1) {
-#pragma unroll
-        for (int rd = 0; rd < 4; rd++) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r1_rsrc, ok4(rd >> 1, rd & 1) ? r1_off(rd >> 1, rd & 1) : INVALID, 0, 0);
-            r1q[rd] = *reinterpret_cast<const float4*>(&v);
-        }
-    }
-    if (has_r2) {
-#pragma unroll
-        for (int rd = 0; rd < 4; rd++) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, ok4(rd >> 1, rd & 1) ? (pix4(rd >> 1, rd & 1) * d.Cout + ch) * 4 : INVALID, 0, 0);
-            r2q[rd] = *reinterpret_cast<const float4*>(&v);
-        }
-    }
-    auto rounds4 = [&](auto full_c, auto edge_c) {
-        constexpr bool FULL = decltype(full_c)::value, EDGE = decltype(edge_c)::value;
-        // bias, residual, activation, affine, second residual, one 16-byte store.  The interior variant still needs the lane
-        // mask when the upper half-wave has no task.
-        auto finish4 = [&](const float (&v)[4], int rd) {
-            const float b4[4] = {bias4.x, bias4.y, bias4.z, bias4.w}, s4[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, t4[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
-            const float p1[4] = {r1q[rd].x, r1q[rd].y, r1q[rd].z, r1q[rd].w}, p2[4] = {r2q[rd].x, r2q[rd].y, r2q[rd].z, r2q[rd].w};
-            float x[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                x[k] = v[k] + b4[k];
-                if (FULL) x[k] += p1[k];
-                x[k] = fmaxf(x[k], x[k] * slope);
-                if (FULL) { x[k] = x[k] * s4[k] + t4[k]; x[k] += p2[k]; }
-            }
-            const u32x4 xs = {__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]), __builtin_bit_cast(unsigned, x[2]), __builtin_bit_cast(unsigned, x[3])};
-            // (scalar offset = the constant 0: with a register there the next instruction may overwrite the data registers of a
-            // 16-byte store before it has read them - see the transposed form)
-            const bool st_ok = EDGE ? ok4(rd >> 1, rd & 1) : (NR >= 4 || task);
-            __builtin_amdgcn_raw_buffer_store_b128(xs, out_rsrc, st_ok ? (pix4(rd >> 1, rd & 1) * out_ld + d.out_c0 + ch) * 4 : INVALID, 0, 0);
-        };
-        float vs[4][4];
-        constexpr int SC = 0x11;                                  // sc0 | sc1 (two workgroups per unit, below)
-        const __amdgpu_buffer_rsrc_t sl_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.slab, 0, S == 2 ? (int)d.slab_bytes : 0, 0x00020000);
-        // slab: [unit][half][phase][member wave][task lane][4] floats = 16 KB per unit and half (16 NR task lanes per member)
-        constexpr int TL = NR >= 4 ? 64 : 32;
-        auto slab_off = [&](int half, int rd) { return (((wt * 2 + half) * 4 + rd) * G + me) * TL * 16 + lane * 16; };
-#pragma unroll
-        for (int rd = 0; rd < 4; rd++) {
-            float* const reg = Ls + (rd & 1) * WREGION;
-#pragma unroll
-            for (int r = 0; r < 16; r++) reg[(wave * 16 + r) * 64 + lane] = Yp[rd][r];
-            __syncthreads();
-            float v[4];
-#pragma unroll
-            for (int m = 0; m < G; m++) {                         // fixed order: K group major, position half minor
-                const int w2 = (m & 1) * 4 + ubase + (m >> 1);
-                const float4 e = *reinterpret_cast<const float4*>(&reg[(w2 * 16 + me * NR) * 64 + 4 * lane]);
-                if (m == 0) { v[0] = 0.f + e.x; v[1] = 0.f + e.y; v[2] = 0.f + e.z; v[3] = 0.f + e.w; }
-                else { v[0] += e.x; v[1] += e.y; v[2] += e.z; v[3] += e.w; }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) vs[rd][k] = v[k];
-            if (S == 1) finish4(v, rd);
-            else {
-                const u32x4 raw = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(raw, sl_rsrc, task && live ? slab_off(ks, rd) : INVALID, 0, SC);
-            }
-            if (rd == 0) WINO_STAMP(5);
-        }
-        if (S == 1) return;
-        // ---- two workgroups per unit (see the dword rounds below for the protocol): sums to the slab with system-scope
-        // write-through stores, one relaxed atomic per workgroup counts arrivals, the second to arrive adds and finishes.
-        int* const counter = reinterpret_cast<int*>(reinterpret_cast<char*>(d.slab) + d.slab_bytes - WSLAB_TAIL) + wt;
-        __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the stores have been acknowledged
-        __syncthreads();
-        int* const s_flag = reinterpret_cast<int*>(Ls);           // (the exchange regions are free: every wave is past its last read)
-        if ((wave & 3) == ubase && h == 0 && kg == 0 && lane == 0)
-            s_flag[sub / KW] = live ? (__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) : 0;
-        __syncthreads();
-        if (s_flag[sub / KW] == 0) return;                        // first to arrive (even count): the partner finishes
-#pragma unroll
-        for (int rd = 0; rd < 4; rd++) {
-            const u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(sl_rsrc, task ? slab_off(1 - ks, rd) : INVALID, 0, SC);
-            const float4 of4 = *reinterpret_cast<const float4*>(&o);
-            const float of[4] = {of4.x, of4.y, of4.z, of4.w};
-            float v[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = ks == 0 ? vs[rd][k] + of[k] : of[k] + vs[rd][k];
-            finish4(v, rd);
-        }
-    };
-    if (plain) { if (interior) rounds4(no, no); else rounds4(no, yes); }
-    else { if (interior) rounds4(yes, no); else rounds4(yes, yes); }
-    }
-    }
-    if (!finished) {
-    // ---- K groups: G = 2 KW waves (member m = 2 kg + h); member m finishes registers [m NR, (m + 1) NR) of every phase, in four
-    // rounds (one per phase) through two alternating exchange regions.
-    // ALL residual values of the four rounds are requested before the first store is issued: loads and stores share one
-    // in-order counter, a load waited for after a store would wait for that store's round trip.
-    int q_pb[NR], q_fl[NR];
-    float r1v[4][NR], r2v[4][NR];
-#pragma unroll
-    for (int q = 0; q < NR; q++) {
-        q_pb[q] = 0; q_fl[q] = 0;
-        if (LIN) lin_geom(me * NR + q, q_pb[q], q_fl[q]);
-#pragma unroll
-        for (int rd = 0; rd < 4; rd++) { r1v[rd][q] = 0.f; r2v[rd][q] = 0.f; }
-    }
-    if (has_r1) {
-#pragma unroll
-        for (int q = 0; q < NR; q++)
-#pragma unroll
-            for (int rd = 0; rd < 4; rd++) {
-                const VA v = a_r1(me * NR + q, q_pb[q], q_fl[q], rd >> 1, rd & 1);
-                r1v[rd][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1_rsrc, v.ok ? v.vo : INVALID, v.so, 0));
-            }
-    }
-    if (has_r2) {
-#pragma unroll
-        for (int q = 0; q < NR; q++)
-#pragma unroll
-            for (int rd = 0; rd < 4; rd++) {
-                const VA v = a_r2(me * NR + q, q_pb[q], q_fl[q], rd >> 1, rd & 1);
-                r2v[rd][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2_rsrc, v.ok ? v.vo : INVALID, v.so, 0));
-            }
-    }
-    // Exchange layout of a round: [wave][quad of registers][lane][4] floats - b128 writes and reads, lane-contiguous.  The
-    // rounds exist in four variants: with / without the residual + affine arithmetic, and for blocks that lie wholly inside the
-    // image (no per-lane validity) or not - ~7 instead of ~18 instructions per stored value in the common case.
-    auto rounds = [&](auto full_c, auto edge_c) {
-        constexpr bool FULL = decltype(full_c)::value, EDGE = decltype(edge_c)::value;
-        auto finish = [&](float x, int rd, int q) {               // bias, residual, activation, affine, second residual, store
-            x += bias;
-            if (FULL) x += r1v[rd][q];
-            x = fmaxf(x, x * slope);
-            if (FULL) { x = x * sc + sh; x += r2v[rd][q]; }
-            const VA a = a_out(me * NR + q, q_pb[q], q_fl[q], rd >> 1, rd & 1);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), out_rsrc, (!EDGE || a.ok) ? a.vo : INVALID, a.so, 0);
-        };
-        float vs[4][NR];
-        constexpr int SC = 0x11;                                  // sc0 | sc1 (two workgroups per unit, below)
-        const __amdgpu_buffer_rsrc_t sl_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.slab, 0, S == 2 ? (int)d.slab_bytes : 0, 0x00020000);
-#pragma unroll
-        for (int rd = 0; rd < 4; rd++) {
-            float* const reg = Ls + (rd & 1) * WREGION;
-#pragma unroll
-            for (int qd = 0; qd < 4; qd++)
-                *reinterpret_cast<float4*>(&reg[((wave * 4 + qd) * 64 + lane) * 4]) =
-                    make_float4(Yp[rd][4 * qd], Yp[rd][4 * qd + 1], Yp[rd][4 * qd + 2], Yp[rd][4 * qd + 3]);
-            __syncthreads();
-            float v[NR];
-#pragma unroll
-            for (int q = 0; q < NR; q++) v[q] = 0.f;
-#pragma unroll
-            for (int m = 0; m < G; m++) {                         // fixed order: K group major, position half minor
-                const int w2 = (m & 1) * 4 + ubase + (m >> 1);
-                if constexpr (NR >= 4) {
-#pragma unroll
-                    for (int blk = 0; blk < NR / 4; blk++) {
-                        const float4 u = *reinterpret_cast<const float4*>(&reg[((w2 * 4 + me * (NR / 4) + blk) * 64 + lane) * 4]);
-                        v[4 * blk] += u.x; v[4 * blk + 1] += u.y; v[4 * blk + 2] += u.z; v[4 * blk + 3] += u.w;
-                    }
-                } else {
-                    const float2 u = *reinterpret_cast<const float2*>(&reg[((w2 * 4 + (me >> 1)) * 64 + lane) * 4 + 2 * (me & 1)]);
-                    v[0] += u.x; v[1] += u.y;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < NR; q++) {
-                vs[rd][q] = v[q];
-                if (S == 1) finish(v[q], rd, q);
-                else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[q]), sl_rsrc, ((rd * 16 + me * NR + q) * 64 + lane) * 4,
-                                                           (wt * 2 + ks) * 16384, SC);
-            }
-            if (rd == 0) WINO_STAMP(5);
-        }
-        if (S == 1) return;
-        // ---- two workgroups per unit: this one's sums went to the slab ([unit][half][phase][register][lane]) with system-scope
-        // write-through stores (the partner may sit on another XCD, whose L2 is not coherent with ours: sc0 sc1 on both sides instead
-        // of a release that writes the whole L2 back), then one relaxed atomic per workgroup counts arrivals; the second to arrive
-        // adds the first one's sums to its own (half 0 + half 1: addition commutes) and finishes.  The counters (last WSLAB_TAIL bytes of
-        // the slab, zeroed by the host once) only ever matter modulo 2.
-        int* const counter = reinterpret_cast<int*>(reinterpret_cast<char*>(d.slab) + d.slab_bytes - WSLAB_TAIL) + wt;
-        __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the stores have been acknowledged
-        __syncthreads();
-        int* const s_flag = reinterpret_cast<int*>(Ls);           // (the exchange regions are free: every wave is past its last read)
-        if ((wave & 3) == ubase && h == 0 && kg == 0 && lane == 0)
-            s_flag[sub / KW] = live ? (__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) : 0;
-        __syncthreads();
-        if (s_flag[sub / KW] == 0) return;                        // first to arrive (even count): the partner finishes
-#pragma unroll
-        for (int rd = 0; rd < 4; rd++)
-#pragma unroll
-            for (int q = 0; q < NR; q++) {
-                const float o = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sl_rsrc, ((rd * 16 + me * NR + q) * 64 + lane) * 4,
-                                                                                               (wt * 2 + (1 - ks)) * 16384, SC));
-                finish(ks == 0 ? vs[rd][q] + o : o + vs[rd][q], rd, q);
-            }
-    };
-    if (plain) { if (interior) rounds(no, no); else rounds(no, yes); }
-    else { if (interior) rounds(yes, no); else rounds(yes, yes); }
-    }
+    epilogue4();
     }
     WINO_STAMP(6);
     WINO_PH(15);
