@@ -317,9 +317,11 @@ __global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d
 //     [cout][4], read straight from global memory, one float4 per position and step, re-requested (for the next step) into the
 //     registers a row of positions has just consumed;
 //   * epilogue: each wave output-transforms its two rows into partial sums of the four 2x2 output phases; per phase the partial
-//     tiles of all waves of the unit's group (2 position halves x KW K groups) meet in LDS in accumulator layout, every wave of
-//     the group sums (fixed order) and finishes 16 / (2 KW) of the 16 accumulator registers: bias, residuals, activation,
-//     per-channel affine, 128-byte runs of channels stored straight from the accumulator layout.
+//     tiles of all waves of the unit's group (2 position halves x KW K groups) meet in LDS laid out [wave][register][lane]; read
+//     back 16 bytes per lane every lane holds four consecutive channels of a pixel: the group's waves sum (fixed order) and
+//     finish 16 / (2 KW) of the 16 accumulator registers each - bias, residuals, activation, per-channel affine - with one
+//     16-byte load per residual tensor and one 16-byte store per task (epilogue4; KW = 1 layers without residual tensors keep a
+//     one-barrier pair exchange with dword stores, finish_pair).
 // Summation order depends on the shape (and KW) only: run-to-run and batch-to-batch identical results.  Results differ from
 // the direct kernel's by float rounding (relative 2e-7 per layer): the planner's choice is a function of the shape alone.
 constexpr int WSUBROW = 19, WSUB = 5 * WSUBROW;     // parity sub-image: 5 rows of 9 pixels x 2 halves, row pitch 19 slots
