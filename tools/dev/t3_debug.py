@@ -38,17 +38,3 @@ for k in range(min(12, len(ys))):
     va, vr = float(a[y_, x_, c_]), float(ref[y_, x_, c_])
     near = (ref[y_, x_] - va).abs()
     print(f"({y_},{x_},{c_}) got {va:+.5f} want {vr:+.5f}; same pixel channel with that value: {int(near.argmin())} ({float(near.min()):.1e}); second run {float(b[y_, x_, c_]):+.5f}")
-if os.environ.get("PATTERN"):
-    TW = (w + 2) // 3
-    n_bad = 0
-    for Y in range(2 * h):
-        for X in range(2 * w):
-            sub = 2 * (Y & 1) + (X & 1); oy, ox = Y >> 1, X >> 1
-            t = ((oy // 3) * TW + ox // 3) % 32
-            r, hf = (t & 3) + 4 * (t >> 3), (t >> 2) & 1
-            for c in range(cout):
-                v = int(a[Y, X, c]); W_, R_, L_ = v // 10000, (v % 10000) // 100, v % 100
-                if (W_, R_, L_) != (sub, r, 32 * hf + c):
-                    n_bad += 1
-                    if n_bad <= 24: print(f"pixel ({Y},{X}) ch {c}: want (wave {sub}, row {r}, lane {32*hf+c}) got (wave {W_}, row {R_}, lane {L_})")
-    print("pattern mismatches", n_bad)
