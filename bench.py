@@ -59,6 +59,11 @@ def parse():
     ap.add_argument("--mode", default="bg_step", choices=["bg_step", "green", "bg_online"],
                     help="bg_step (default, BASELINE.json configs[1] / [3]); green (configs[0]: SegAgent / colour filtering loop) and "
                          "bg_online (configs[2]: STM tracking + inpainting loop) time the other frame loops the same way")
+    ap.add_argument("--clip-frames", type=int, default=0,
+                    help="strong-scaling form: ONE clip of that many frames, sharded into contiguous frame ranges over the ranks exactly as "
+                         "the reference's --range runs cut it (tools/unscreen/bg_offline.py:34-35, 184-192); `steps` becomes the clip "
+                         "length, `value` = clip frames / max-over-ranks time, \"scaling\": \"strong\".  BASELINE.json configs[3] = "
+                         "--height 2160 --width 3840 --clip-frames 300")
     ap.add_argument("--net", default="hip", choices=["hip", "miopen"],
                     help="conv stack: hand-written f32-MFMA kernels (default) or PyTorch-ROCm / MIOpen")
     return ap.parse_args()
@@ -207,11 +212,39 @@ def other_mode(args, rank, world, dev):
         dist.destroy_process_group()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves - one child `torch.distributed.run`
+    (the command line the driver uses), one process per GPU - and pass rank 0's JSON line through.  This process has made no GPU
+    call (importing torch and counting devices do not initialise HIP), and it starts a CHILD and waits: it never replaces itself.
+    The reference's analogue is tools/unscreen.sh:3-17, which takes the GPU list on its command line."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus and not os.environ.get("USC_BENCH_SHARE_GPU"):
+        print(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to report a line "
+                  f"whose n_gpus would not be what was asked for", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -244,9 +277,20 @@ def main():
 
     H, W, K, Wm = args.height, args.width, args.steps, args.warmup
     cfg = default_config()
+    strong = args.clip_frames > 0
+    if strong:
+        # ONE clip of F frames cut into contiguous ranges (the reference's --range, bg_offline.py:34-35): this rank times its own
+        # range [lo, hi) from a fresh alpha_pre, after Wm untimed warm-up frames (the head of its range, run and discarded)
+        F_clip = args.clip_frames
+        if F_clip < world:
+            print(f"bench.py: --clip-frames {F_clip} < {world} ranks", file=sys.stderr)
+            sys.exit(2)
+        lo, hi = shard_range(F_clip, rank, world)
+        K = hi - lo                                          # this rank's timed frames
+        Wm = min(Wm, K)
 
     # weights + overall background: rank 0 owns them, everyone else receives them over RCCL / xGMI
-    clip = SyntheticClip(H, W, (K + Wm) * world, config_id=2, device=dev)
+    clip = SyntheticClip(H, W, F_clip if strong else (K + Wm) * world, config_id=2, device=dev)
     sd = synthetic_state_dict(0) if rank == 0 else None
     extra = {}
     if not args.no_seg:
@@ -257,15 +301,22 @@ def main():
     if not args.no_seg:
         from video_unscreen_amd.binseg import HumanSegAgent
         seg_agent = HumanSegAgent(model_path=None, cuda_device=local, state_dict=extra["schp"])
-    seg_batch = args.seg_batch if args.seg_batch > 0 else next((b for b in (12, 8, 6, 4) if K % b == 0), 8)
+    if args.seg_batch > 0:
+        seg_batch = args.seg_batch
+    elif strong:
+        seg_batch = 12            # every rank plans for the same batch whatever its range length (a short last group rides in a full forward)
+    else:
+        seg_batch = next((b for b in (12, 8, 6, 4) if K % b == 0), 8)
     pipe = BgStepPipeline(cfg, H, W, device=dev, state_dict=sd, net_backend=args.net, seg_agent=seg_agent,
                           seg_batch=1 if args.sync_loop else seg_batch, object_filter=args.object_filter)
 
     # this rank's contiguous frame range (not timed).  Host boundary (default): each frame + its per-frame background (+ its
     # mask with --no-seg) sit in pinned host memory, and pinned host buffers receive alpha + fg.
     from video_unscreen_amd.hostio import HostFrameIO
-    lo, hi = shard_range((K + Wm) * world, rank, world)
+    if not strong:
+        lo, hi = shard_range((K + Wm) * world, rank, world)
     clip.gen.manual_seed(20260002 + 7919 * rank)
+    first = 0 if strong else Wm                              # index of the first timed frame in this rank's list
     host_io = not args.device_resident
     frames, frames_h = [], []
     for t in range(lo, hi):
@@ -273,7 +324,7 @@ def main():
         if host_io:
             frames_h.append((f["frame"].cpu().pin_memory(), f["seg"].cpu().pin_memory() if seg_agent is None else None,
                              f["bg"].cpu().pin_memory()))
-        if not host_io or (rank == 0 and t - lo < Wm + K):
+        if not host_io or (rank == 0 and t - lo < first + K):
             frames.append((f["frame"], f["seg"], f["bg"], bg_always))
     alpha_h = fg_h = io = None
     if host_io:
@@ -319,6 +370,8 @@ def main():
         spin_up()
         fn_warm()
         torch.cuda.synchronize()
+        if strong:
+            pipe.reset()                                     # the timed range starts like a reference --range run: alpha_pre = its first gate
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -331,25 +384,28 @@ def main():
         return time.perf_counter() - t0
 
     if host_io:
-        dt = timed(lambda: run_host(0, Wm), lambda: run_host(Wm, K))
+        dt = timed(lambda: run_host(0, Wm), lambda: run_host(first, K))
     else:
-        dt = timed(lambda: run(frames[:Wm]), lambda: run(frames[Wm:Wm + K]))
+        dt = timed(lambda: run(frames[:Wm]), lambda: run(frames[first:first + K]))
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    total = F_clip if strong else world * K                 # frames all ranks processed inside the timed region
 
     result = None
     if rank == 0:
-        fps = world * K / dt
+        fps = total / dt
+        K_line = total if strong else K
         result = {
             "metric": "frames/sec end-to-end unscreen (bg_step, 1080p)" if (H, W) == (1080, 1920) else f"frames/sec end-to-end unscreen (bg_step, {W}x{H})",
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K_line, "warmup": Wm,
+            "ms_per_step": round(dt / K_line * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("bg_step: " + ("human-parsing segmentation (SCHP ResNet-101) + " if seg_agent is not None else "")
                                     + "stage-3 loop (bgdiff mask + object filter + trimap + matting UNet-18 + get_fg), "
-                                    + f"{W}x{H}, {K} frames/GPU, frame-sharded x{world}"),
+                                    + (f"{W}x{H}, ONE clip of {F_clip} frames cut into {world} contiguous frame range(s) (rank 0: {K} frames)"
+                                       if strong else f"{W}x{H}, {K} frames/GPU, frame-sharded x{world}")),
                        "boundary": ("pinned host -> pinned host: frame + per-frame background" + (" + mask" if seg_agent is None else "")
                                     + " uploaded, alpha + fg downloaded per frame inside the timed region (SURVEY.md 8d)") if host_io
                                    else "device resident: inputs in HBM when the timed region starts, outputs left in HBM",
@@ -366,7 +422,7 @@ def main():
             result["pcie_bytes_per_frame"] = {"up": 6 * nb + (nb if seg_agent is None else 0), "down": 4 * nb}
         if world == 1 and host_io:
             # the same loop with inputs resident in HBM and outputs left there (round 1's figure), for the record (not `value`)
-            t1 = timed(lambda: run(frames[:Wm]), lambda: run(frames[Wm:Wm + K]))
+            t1 = timed(lambda: run(frames[:Wm]), lambda: run(frames[first:first + K]))
             result["device_resident"] = {"value": round(K / t1, 2), "unit": "frames/s",
                                          "note": "same loop, frames already in HBM, alpha / fg not copied out"}
         if world == 1 and not args.sync_loop and args.object_filter != "host":
@@ -374,14 +430,14 @@ def main():
             chosen_f, chosen_c = pipe.object_filter, pipe._filter_choice
             pipe.object_filter, pipe._filter_choice = "host", "host"
             if host_io:
-                t1 = timed(lambda: run_host(0, Wm), lambda: run_host(Wm, K))
+                t1 = timed(lambda: run_host(0, Wm), lambda: run_host(first, K))
             else:
-                t1 = timed(lambda: run(frames[:Wm]), lambda: run(frames[Wm:Wm + K]))
+                t1 = timed(lambda: run(frames[:Wm]), lambda: run(frames[first:first + K]))
             result["host_object_filter"] = {"value": round(K / t1, 2), "unit": "frames/s",
                                             "note": "same loop and boundary as `value` with remove_invalid_objects on two host worker threads"}
             pipe.object_filter, pipe._filter_choice = chosen_f, chosen_c
         if not args.no_kernel_table:                         # (other ranks wait at the final barrier: not inside the timed region)
-            rows, t_net, t_graph = kernel_table(pipe, frames[Wm], H, W)
+            rows, t_net, t_graph = kernel_table(pipe, frames[first], H, W)
             dom = max(rows, key=lambda r: r["us"])
             scale = (pipe.in_h * pipe.in_w) / (544 * 960)
             gflop = UNET_GFLOP_544x960 * scale

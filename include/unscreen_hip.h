@@ -51,6 +51,28 @@ void usc_get_target_size(int h, int w, int long_side, int division, int* target_
 void usc_pad_resize_geometry(int h, int w, int target_h, int target_w, int* new_h, int* new_w);
 void usc_inv_pad_geometry(int h, int w, int ori_h, int ori_w, int* resized_h, int* resized_w);
 
+/* The NumPy-level forms of the same helpers, behind the names the reference's tools and agents import from unscreen.utils
+ * (tools/unscreen/bg_offline.py:16, tools/replace/replace.py:14, unscreen/iseg/agent.py:5); the frame loops use the fused
+ * kernels further down.
+ * usc_pad_resize_u8: unscreen/utils/imgprocess.py:67-97 pad_resize on uint8, cn = 1 | 3: cv2.resize (default INTER_LINEAR, incl.
+ *   OpenCV's same-size copy and exact-2x box reroute) to the aspect-preserving size, cv2.copyMakeBorder(BORDER_REFLECT) at the
+ *   bottom / right up to (target_h, target_w) - one kernel.
+ * usc_inv_pad_resize: imgprocess.py:100-132 inv_pad_resize: the bottom / right pad is cut, the rest resized to (ori_h, ori_w);
+ *   elem = USC_ELEM_U8 (fixed point), USC_ELEM_F32 / USC_ELEM_F64 (float weights; the float32 alpha of vmatting/agent.py:127 and
+ *   probability of iseg/agent.py:117, the float64 scores of binseg/agent.py:233), cn = 1..4 interleaved channels.
+ * usc_imnormalize_u8: imgprocess.py:135-161 imnormalize on n pixels: BGR -> RGB IN PLACE on `img` when to_rgb (as the reference
+ *   does to its argument, :157), out = ((float32(img) / 255) - mean) * (1 / std), float32 operations; mean / std: host, 3 doubles.
+ * usc_gray_moments_u8: imgprocess.py:7-14 get_center (rgb_order = 1: cv2.COLOR_RGB2GRAY; moments3 = m00, m10, m01 of the gray
+ *   image as exact integers) and :17-30 get_mask (rgb_order = 0, mask = 255 where gray > thr); either output may be NULL. */
+#define USC_ELEM_U8  0
+#define USC_ELEM_F32 1
+#define USC_ELEM_F64 2
+int usc_pad_resize_u8(const uint8_t* src, int h, int w, int cn, uint8_t* dst, int target_h, int target_w, usc_stream_t stream);
+int usc_inv_pad_resize(const void* src, int h, int w, int cn, int elem, void* dst, int ori_h, int ori_w, usc_stream_t stream);
+int usc_imnormalize_u8(uint8_t* img, size_t n, const double* mean3_host, const double* std3_host, int to_rgb, float* out, usc_stream_t stream);
+int usc_gray_moments_u8(const uint8_t* img, int H, int W, int rgb_order, int thr, uint8_t* mask, unsigned long long* moments3,
+                        usc_stream_t stream);
+
 /* unscreen/utils/maskprocess.py:7-34 dilate_mask / erode_mask: grey-level max / min filter with
  * cv2.getStructuringElement(MORPH_ELLIPSE, (ksize, ksize)), `iters` passes, out-of-image taps ignored.
  * src and dst may not alias. */
@@ -364,6 +386,12 @@ typedef struct usc_conv_desc {
 void usc_conv_force_plan(int nt, int rowgroups, int ksplit, int kgroups);
 /* Tests / tuning: -1 = the library decides per layer (default), 0 = never use the Winograd form, 1 = use it wherever it applies. */
 void usc_conv_force_winograd(int mode);
+/* Tests / tuning: which Winograd FORM layers planned from the calling thread may take.  t3 (transposed F(3x3, 2x2) form of the
+ * four-phase layers) and lin (blocks of 32 consecutive tiles instead of 8 x 4 rectangles): -1 = cost model (default), 0 = never,
+ * 1 = wherever admissible; split (K halves of a unit on two workgroups): 0 = cost model (default), 1 = never, 2 = wherever
+ * admissible.  Like the two hooks above this is per-thread planner state, not process state: the library reads no environment
+ * variable, and a plan is a function of the layer shape and these arguments only. */
+void usc_conv_force_winograd_form(int t3, int lin, int split);
 
 /* The launch plan the library chooses for one layer (no device work): tile width in 32-column units, row groups and K groups
  * per workgroup, grid K split, workgroups and threads of the main launch, launches per layer (2 when the grid splits K),

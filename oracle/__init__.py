@@ -61,6 +61,14 @@ def lib():
         _lib.orc_cf_threshold.argtypes = [u8p, u8p, C.c_size_t, C.c_double]
         _lib.orc_color_correct.argtypes = [u8p, u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_double, u8p, C.POINTER(C.c_int)]
         _lib.orc_box_filter_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+        _lib.orc_pad_resize_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
+        _lib.orc_inv_pad_resize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        _lib.orc_resize_linear_f32c.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_size_t, f32p, C.c_int, C.c_int]
+        _lib.orc_resize_linear_f64c.argtypes = [f64p, C.c_int, C.c_int, C.c_int, C.c_size_t, f64p, C.c_int, C.c_int]
+        _lib.orc_imnormalize.argtypes = [u8p, C.c_size_t, f64p, f64p, C.c_int, f32p]
+        _lib.orc_moments_u8.argtypes = [u8p, C.c_int, C.c_int, f64p]
+        _lib.orc_get_center.argtypes = [u8p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _lib.orc_get_mask.argtypes = [u8p, C.c_size_t, C.c_int, u8p]
         for name in ("orc_bgr2gray_u8", "orc_bgr2hsv_u8", "orc_hsv2bgr_u8", "orc_bgr2lab_u8", "orc_lab2bgr_u8"):
             getattr(_lib, name).argtypes = [u8p, u8p, C.c_size_t]
     return _lib
@@ -97,16 +105,81 @@ def resize_nearest(img, dh, dw):
 
 
 def resize_linear(img, dh, dw):
+    """cv2.resize(img, (dw, dh)) with the default INTER_LINEAR: uint8 (fixed point), float32 / float64 (float weights), 1..n
+    interleaved channels."""
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    shape = (dh, dw) if img.ndim == 2 else (dh, dw, cn)
     if img.dtype == np.uint8:
         img, p = _u8(img)
-        cn = 1 if img.ndim == 2 else img.shape[2]
-        out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
+        out = np.empty(shape, np.uint8)
         lib().orc_resize_linear_u8(p, img.shape[0], img.shape[1], cn, out.ctypes.data_as(u8p), dh, dw)
         return out
+    if img.dtype == np.float64:
+        img = np.ascontiguousarray(img)
+        out = np.empty(shape, np.float64)
+        lib().orc_resize_linear_f64c(img.ctypes.data_as(f64p), img.shape[0], img.shape[1], cn, img.shape[1] * cn, out.ctypes.data_as(f64p), dh, dw)
+        return out
     img, p = _f32(img)
-    out = np.empty((dh, dw), np.float32)
-    lib().orc_resize_linear_f32(p, img.shape[0], img.shape[1], img.shape[1], out.ctypes.data_as(f32p), dh, dw)
+    out = np.empty(shape, np.float32)
+    lib().orc_resize_linear_f32c(p, img.shape[0], img.shape[1], cn, img.shape[1] * cn, out.ctypes.data_as(f32p), dh, dw)
     return out
+
+
+def pad_resize(img, target_size):
+    """imgprocess.py:67-97 on uint8 -> (image, ratio)."""
+    img, p = _u8(img)
+    th, tw = int(target_size[0]), int(target_size[1])
+    h, w = img.shape[:2]
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty((th, tw) if img.ndim == 2 else (th, tw, cn), np.uint8)
+    lib().orc_pad_resize_u8(p, h, w, cn, out.ctypes.data_as(u8p), th, tw)
+    ratio = float(th) / h if float(h) / w > float(th) / tw else float(tw) / w
+    return out, ratio
+
+
+def inv_pad_resize(img, ori_size):
+    """imgprocess.py:100-132 on uint8 / float32 / float64."""
+    img = np.ascontiguousarray(img)
+    elem = {np.dtype(np.uint8): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}[img.dtype]
+    oh, ow = int(ori_size[0]), int(ori_size[1])
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty((oh, ow) if img.ndim == 2 else (oh, ow, cn), img.dtype)
+    lib().orc_inv_pad_resize(img.ctypes.data, img.shape[0], img.shape[1], cn, elem, out.ctypes.data, oh, ow)
+    return out
+
+
+def imnormalize(img, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), to_rgb=True):
+    """imgprocess.py:135-161: converts `img` BGR -> RGB in place when to_rgb, returns the float32 result."""
+    assert img.dtype == np.uint8 and img.flags.c_contiguous and img.shape[-1] == 3
+    mean, std = np.ascontiguousarray(mean, np.float64), np.ascontiguousarray(std, np.float64)
+    out = np.empty(img.shape, np.float32)
+    lib().orc_imnormalize(img.ctypes.data_as(u8p), img.size // 3, mean.ctypes.data_as(f64p), std.ctypes.data_as(f64p), int(bool(to_rgb)),
+                          out.ctypes.data_as(f32p))
+    return out
+
+
+def moments(gray):
+    """cv2.moments of a uint8 image: {'m00', 'm10', 'm01'}."""
+    g, p = _u8(gray)
+    m = np.empty(3, np.float64)
+    lib().orc_moments_u8(p, g.shape[0], g.shape[1], m.ctypes.data_as(f64p))
+    return {"m00": float(m[0]), "m10": float(m[1]), "m01": float(m[2])}
+
+
+def get_center(img):
+    """imgprocess.py:7-14."""
+    img, p = _u8(img)
+    cx, cy = C.c_int(), C.c_int()
+    lib().orc_get_center(p, img.shape[0], img.shape[1], C.byref(cx), C.byref(cy))
+    return cx.value, cy.value
+
+
+def get_mask(img):
+    """imgprocess.py:17-30 -> (thresh (h, w, 1) uint8, binary (h, w, 1) float64)."""
+    img, p = _u8(img)
+    out = np.empty(img.shape[:2], np.uint8)
+    lib().orc_get_mask(p, out.size, 25, out.ctypes.data_as(u8p))
+    return out[..., None], (out / 255)[..., None]
 
 
 def resize_cubic(img, dh, dw):

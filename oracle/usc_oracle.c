@@ -281,12 +281,19 @@ ORC_API void orc_composite_fgbg(const uint8_t* fg, const uint8_t* alpha, int fh,
 
 /* cv2.copyMakeBorder(img, 0, pad_h, 0, pad_w, cv2.BORDER_REFLECT)  (unscreen/utils/imgprocess.py:96):
  * fedcba|abcdefgh|hgfedcb - the edge sample is repeated. */
+static inline int orc_reflect_past_end(int p, int n)          /* cv::borderInterpolate(BORDER_REFLECT): bounces until inside */
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p - 1 : 2 * n - 1 - p;
+    return p;
+}
+
 ORC_API void orc_pad_reflect_u8(const uint8_t* src, int h, int w, int cn, uint8_t* dst, int dh, int dw)
 {
     for (int y = 0; y < dh; y++) {
-        int sy = y < h ? y : 2 * h - 1 - y;
+        int sy = orc_reflect_past_end(y, h);
         for (int x = 0; x < dw; x++) {
-            int sx = x < w ? x : 2 * w - 1 - x;
+            int sx = orc_reflect_past_end(x, w);
             memcpy(dst + ((size_t)y * dw + x) * cn, src + ((size_t)sy * w + sx) * cn, cn);
         }
     }
@@ -1746,4 +1753,170 @@ ORC_API void orc_stm_post(const float* p2, int lh, int lw, int cbuf, int in_h, i
     }
     free(tx); free(ty); free(up);
     if (!prob_out) free(prob);
+}
+
+/* ============================================================================================
+ * NumPy-level helpers of unscreen/utils/imgprocess.py that the reference's tools and agents import
+ * (tools/unscreen/bg_offline.py:16, tools/replace/replace.py:14, unscreen/iseg/agent.py:5)
+ * ============================================================================================ */
+
+/* unscreen/utils/imgprocess.py:67-97 pad_resize on uint8 (1 or 3 channels): cv2.resize (default INTER_LINEAR) to the
+ * aspect-preserving size, then cv2.copyMakeBorder(0, pad_h, 0, pad_w, BORDER_REFLECT). */
+ORC_API void orc_pad_resize_u8(const uint8_t* src, int h, int w, int cn, uint8_t* dst, int th, int tw)
+{
+    int nh, nw;
+    orc_pad_resize_geometry(h, w, th, tw, &nh, &nw);
+    uint8_t* tmp = (uint8_t*)malloc((size_t)nh * nw * cn);
+    orc_resize_linear_u8(src, h, w, cn, tmp, nh, nw);
+    orc_pad_reflect_u8(tmp, nh, nw, cn, dst, th, tw);
+    free(tmp);
+}
+
+/* cv2.resize (INTER_LINEAR) on float32 / float64 images with cn interleaved channels and a source row pitch (in elements):
+ * same size -> copy; exact 2x decimation -> the 2x2 INTER_AREA average (generic path: ((S00 + S01) + S10) + S11, times the
+ * float 0.25); otherwise float weights in both passes (cv::HResizeLinear / VResizeLinear with AT = float; WT = float for
+ * float32 data, double for float64 data), each product and sum rounded once. */
+ORC_API void orc_resize_linear_f32c(const float* src, int sh, int sw, int cn, size_t pitch, float* dst, int dh, int dw)
+{
+    if (sh == dh && sw == dw) {
+        for (int y = 0; y < dh; y++) memcpy(dst + (size_t)y * dw * cn, src + (size_t)y * pitch, sizeof(float) * (size_t)dw * cn);
+        return;
+    }
+    if (orc_is_area_fast_2x(sh, sw, dh, dw)) {
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++)
+                for (int c = 0; c < cn; c++) {
+                    const float* p = src + (size_t)(2 * y) * pitch + (size_t)(2 * x) * cn + c;
+                    float s = p[0] + p[cn];
+                    s = s + p[pitch];
+                    s = s + p[pitch + cn];
+                    dst[((size_t)y * dw + x) * cn + c] = s * 0.25f;
+                }
+        return;
+    }
+    orc_tap* tx = (orc_tap*)malloc(sizeof(orc_tap) * dw);
+    orc_tap* ty = (orc_tap*)malloc(sizeof(orc_tap) * dh);
+    orc_linear_taps(dw, sw, tx, 1);
+    orc_linear_taps(dh, sh, ty, 0);
+    for (int y = 0; y < dh; y++) {
+        int y0 = orc_clampi(ty[y].ofs, 0, sh - 1), y1 = orc_clampi(ty[y].ofs + 1, 0, sh - 1);
+        float b0 = ty[y].f0, b1 = ty[y].f1;
+        for (int x = 0; x < dw; x++) {
+            int x0 = tx[x].ofs, x1 = x0 + 1 < sw ? x0 + 1 : x0;
+            float a0 = tx[x].f0, a1 = tx[x].f1;
+            for (int c = 0; c < cn; c++) {
+                float r0 = src[(size_t)y0 * pitch + (size_t)x0 * cn + c] * a0 + src[(size_t)y0 * pitch + (size_t)x1 * cn + c] * a1;
+                float r1 = src[(size_t)y1 * pitch + (size_t)x0 * cn + c] * a0 + src[(size_t)y1 * pitch + (size_t)x1 * cn + c] * a1;
+                dst[((size_t)y * dw + x) * cn + c] = r0 * b0 + r1 * b1;
+            }
+        }
+    }
+    free(tx); free(ty);
+}
+
+ORC_API void orc_resize_linear_f64c(const double* src, int sh, int sw, int cn, size_t pitch, double* dst, int dh, int dw)
+{
+    if (sh == dh && sw == dw) {
+        for (int y = 0; y < dh; y++) memcpy(dst + (size_t)y * dw * cn, src + (size_t)y * pitch, sizeof(double) * (size_t)dw * cn);
+        return;
+    }
+    if (orc_is_area_fast_2x(sh, sw, dh, dw)) {
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++)
+                for (int c = 0; c < cn; c++) {
+                    const double* p = src + (size_t)(2 * y) * pitch + (size_t)(2 * x) * cn + c;
+                    double s = p[0] + p[cn];
+                    s = s + p[pitch];
+                    s = s + p[pitch + cn];
+                    dst[((size_t)y * dw + x) * cn + c] = s * (double)0.25f;
+                }
+        return;
+    }
+    orc_tap* tx = (orc_tap*)malloc(sizeof(orc_tap) * dw);
+    orc_tap* ty = (orc_tap*)malloc(sizeof(orc_tap) * dh);
+    orc_linear_taps(dw, sw, tx, 1);
+    orc_linear_taps(dh, sh, ty, 0);
+    for (int y = 0; y < dh; y++) {
+        int y0 = orc_clampi(ty[y].ofs, 0, sh - 1), y1 = orc_clampi(ty[y].ofs + 1, 0, sh - 1);
+        double b0 = ty[y].f0, b1 = ty[y].f1;
+        for (int x = 0; x < dw; x++) {
+            int x0 = tx[x].ofs, x1 = x0 + 1 < sw ? x0 + 1 : x0;
+            double a0 = tx[x].f0, a1 = tx[x].f1;
+            for (int c = 0; c < cn; c++) {
+                double r0 = src[(size_t)y0 * pitch + (size_t)x0 * cn + c] * a0 + src[(size_t)y0 * pitch + (size_t)x1 * cn + c] * a1;
+                double r1 = src[(size_t)y1 * pitch + (size_t)x0 * cn + c] * a0 + src[(size_t)y1 * pitch + (size_t)x1 * cn + c] * a1;
+                dst[((size_t)y * dw + x) * cn + c] = r0 * b0 + r1 * b1;
+            }
+        }
+    }
+    free(tx); free(ty);
+}
+
+/* unscreen/utils/imgprocess.py:100-132 inv_pad_resize: cut the bottom / right pad of an (h, w) canvas, cv2.resize the rest to
+ * (ori_h, ori_w).  elem: 0 = uint8, 1 = float32, 2 = float64 (the reference passes uint8 masks, the float32 alpha of
+ * vmatting/agent.py:127 and iseg/agent.py:117, and the float64 scores of binseg/agent.py:233). */
+ORC_API void orc_inv_pad_resize(const void* src, int h, int w, int cn, int elem, void* dst, int oh, int ow)
+{
+    int rh, rw;
+    orc_inv_pad_geometry(h, w, oh, ow, &rh, &rw);
+    if (elem == 0) {
+        uint8_t* crop = (uint8_t*)malloc((size_t)rh * rw * cn);
+        for (int y = 0; y < rh; y++) memcpy(crop + (size_t)y * rw * cn, (const uint8_t*)src + (size_t)y * w * cn, (size_t)rw * cn);
+        orc_resize_linear_u8(crop, rh, rw, cn, (uint8_t*)dst, oh, ow);
+        free(crop);
+    } else if (elem == 1) {
+        orc_resize_linear_f32c((const float*)src, rh, rw, cn, (size_t)w * cn, (float*)dst, oh, ow);
+    } else {
+        orc_resize_linear_f64c((const double*)src, rh, rw, cn, (size_t)w * cn, (double*)dst, oh, ow);
+    }
+}
+
+/* unscreen/utils/imgprocess.py:135-161 imnormalize: cv2.cvtColor(BGR2RGB) IN PLACE on the argument when to_rgb, then
+ * float32(img) / 255., cv2.subtract(img, mean) and cv2.multiply(img, 1 / std) - OpenCV turns the float64 scalars into float32
+ * for a float32 array, so all three steps are float32 operations; 1 / std is evaluated in float64 first. */
+ORC_API void orc_imnormalize(uint8_t* img, size_t n, const double* mean, const double* std, int to_rgb, float* out)
+{
+    float meanf[3], stdinvf[3];
+    for (int c = 0; c < 3; c++) { meanf[c] = (float)mean[c]; stdinvf[c] = (float)(1 / std[c]); }
+    for (size_t i = 0; i < n; i++) {
+        if (to_rgb) { uint8_t t = img[3 * i]; img[3 * i] = img[3 * i + 2]; img[3 * i + 2] = t; }
+        for (int c = 0; c < 3; c++) {
+            float x = (float)img[3 * i + c] / 255.f;
+            x = x - meanf[c];
+            out[3 * i + c] = x * stdinvf[c];
+        }
+    }
+}
+
+/* cv2.moments of an 8-bit single-channel image, spatial moments up to order 1 (m00, m10, m01): exact integer sums
+ * sum(I), sum(x I), sum(y I) returned as doubles (OpenCV accumulates 8-bit rows in integers). */
+ORC_API void orc_moments_u8(const uint8_t* img, int h, int w, double* m)
+{
+    unsigned long long m00 = 0, m10 = 0, m01 = 0;
+    for (int y = 0; y < h; y++) {
+        unsigned long long r0 = 0, r1 = 0;
+        for (int x = 0; x < w; x++) { r0 += img[(size_t)y * w + x]; r1 += (unsigned long long)x * img[(size_t)y * w + x]; }
+        m00 += r0; m10 += r1; m01 += r0 * (unsigned long long)y;
+    }
+    m[0] = (double)m00; m[1] = (double)m10; m[2] = (double)m01;
+}
+
+/* unscreen/utils/imgprocess.py:7-14 get_center: cv2.cvtColor(img, COLOR_RGB2GRAY) - the first channel gets the red weight -,
+ * cv2.moments, cX = int(m10 / (m00 + 1e-6)), cY = int(m01 / (m00 + 1e-6)). */
+ORC_API void orc_get_center(const uint8_t* img3, int h, int w, int* cx, int* cy)
+{
+    size_t n = (size_t)h * w;
+    uint8_t* g = (uint8_t*)malloc(n);
+    for (size_t i = 0; i < n; i++) g[i] = orc_gray(img3[3 * i + 2], img3[3 * i + 1], img3[3 * i]);
+    double m[3];
+    orc_moments_u8(g, h, w, m);
+    *cx = (int)(m[1] / (m[0] + 1e-6));
+    *cy = (int)(m[2] / (m[0] + 1e-6));
+    free(g);
+}
+
+/* unscreen/utils/imgprocess.py:17-30 get_mask: BGR2GRAY, cv2.threshold(25, 255, THRESH_BINARY): 255 where gray > 25. */
+ORC_API void orc_get_mask(const uint8_t* img3, size_t n, int thr, uint8_t* out)
+{
+    for (size_t i = 0; i < n; i++) out[i] = orc_gray(img3[3 * i], img3[3 * i + 1], img3[3 * i + 2]) > thr ? 255 : 0;
 }

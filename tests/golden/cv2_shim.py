@@ -35,7 +35,7 @@ def resize(src, dsize, dst=None, fx=0, fy=0, interpolation=INTER_LINEAR):
     if src.dtype == np.uint8:
         fn = {INTER_NEAREST: oracle.resize_nearest, INTER_LINEAR: oracle.resize_linear, INTER_CUBIC: oracle.resize_cubic}[interpolation]
         return fn(np.ascontiguousarray(src), dh, dw)
-    if src.dtype == np.float32 and src.ndim == 2 and interpolation == INTER_LINEAR:
+    if src.dtype in (np.float32, np.float64) and interpolation == INTER_LINEAR:
         return oracle.resize_linear(np.ascontiguousarray(src), dh, dw)
     raise NotImplementedError(f"cv2_shim.resize: {src.dtype} {src.shape} interpolation {interpolation}")
 
@@ -63,6 +63,21 @@ def cvtColor(src, code, dst=None, dstCn=0):
         return oracle.bgr2gray(np.ascontiguousarray(flat[..., ::-1])).reshape(shape[:-1])
     fn = {COLOR_BGR2HSV: oracle.bgr2hsv, COLOR_HSV2BGR: oracle.hsv2bgr, COLOR_BGR2Lab: oracle.bgr2lab, COLOR_Lab2BGR: oracle.lab2bgr}[code]
     return fn(flat).reshape(shape)
+
+
+THRESH_BINARY = 0
+
+
+def threshold(src, thresh, maxval, type):
+    assert type == THRESH_BINARY and src.dtype == np.uint8
+    _log("threshold")
+    return float(thresh), np.where(src > thresh, maxval, 0).astype(np.uint8)
+
+
+def moments(array, binaryImage=False):
+    assert array.dtype == np.uint8 and array.ndim == 2 and not binaryImage
+    _log("moments")
+    return oracle.moments(array)
 
 
 def boxFilter(src, ddepth, ksize, dst=None, anchor=None, normalize=True, borderType=None):

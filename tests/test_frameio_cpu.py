@@ -49,3 +49,50 @@ def test_writer_round_trip(tmp_path):
         assert np.array_equal(np.load(tmp_path / f"alphamask_{i:06d}.npy"), a)
         assert np.array_equal(np.load(tmp_path / f"fg_{i:06d}.npy"), f)
     assert not [p for p in os.listdir("/dev/shm") if p.startswith("psm_") and False]      # rings are unlinked on close
+
+
+def _npy_groups(tmp_path, n, H=8, W=12):
+    groups = []
+    for i in range(n):
+        p = str(tmp_path / f"{i:06d}.npy")
+        np.save(p, np.full((H, W, 3), i, np.uint8))
+        groups.append((p,))
+    return groups
+
+
+def test_reader_out_of_slots_waits_for_a_release_instead_of_hanging(tmp_path):
+    """A consumer that runs ahead (every slot delivered, none released, no decode in flight) used to block for ever in done.get():
+    with a wait_release callback the reader asks for a slot back; without one it raises."""
+    import pytest
+    groups = _npy_groups(tmp_path, 7)
+    rd = FrameReader(groups, [(8, 12, 3)], workers=2, depth=2, pin=False)
+    next(rd), next(rd)
+    with pytest.raises(RuntimeError, match="none was released"):
+        next(rd)
+    rd.close()
+    held, calls = [], []
+    rd = FrameReader(groups, [(8, 12, 3)], workers=2, depth=2, pin=False)
+
+    def wait_release():
+        calls.append(len(held))
+        rd.release(held.pop(0))                               # e.g. after synchronising on the oldest upload
+
+    rd.wait_release = wait_release
+    seen = []
+    for slot, (t,) in rd:
+        seen.append(int(t[0, 0, 0]))
+        held.append(slot)
+    rd.close()
+    assert seen == list(range(7)) and len(calls) == 5 and all(c == 2 for c in calls)
+
+
+def test_reader_reports_a_dead_decoder(tmp_path):
+    import pytest
+    groups = _npy_groups(tmp_path, 4) + [(str(tmp_path / "missing.npy"),)]
+    rd = FrameReader(groups[:4], [(8, 12, 3)], workers=1, depth=1, pin=False)
+    slot, _ = next(rd)
+    rd.procs[0].terminate()
+    rd.procs[0].join()
+    rd.release(slot)                                          # a task goes to a worker that no longer exists
+    with pytest.raises(RuntimeError, match="died"):
+        next(rd)

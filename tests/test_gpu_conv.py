@@ -194,14 +194,14 @@ def test_full_network_with_every_winograd_form_forced_matches_golden(hipnet):
     z = np.load(os.path.join(GOLD, "unet_64x96.npz"))
     lib = nv.load()
     for split in ("1", "2"):
-        os.environ["USC_WINO_T3"], os.environ["USC_WINO_SPLIT"] = "1", split
+        lib.usc_conv_force_winograd_form(1, -1, int(split))
         lib.usc_conv_force_winograd(1)
         try:
             net = hipnet.HipMattingNet(sd, H, W)                      # plans are made here
             plans = [p["plan"] for p in nv.conv_plans(net._arr, len(net._descs))]
         finally:
             lib.usc_conv_force_winograd(-1)
-            os.environ["USC_WINO_T3"], os.environ["USC_WINO_SPLIT"] = "-1", "0"
+            lib.usc_conv_force_winograd_form(-1, -1, 0)
         assert sum("winograd-t3" in p for p in plans) == 5, plans
         assert sum(p.startswith("winograd") for p in plans) >= 35, plans
         if split == "2":
@@ -335,8 +335,7 @@ def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw, dil, l
             d.slab, d.slab_bytes = slab.data_ptr(), slab.numel() * 4
         lib.usc_conv_force_winograd(1)
         lib.usc_conv_force_plan(0, 0, 0, kw)
-        os.environ["USC_WINO_LIN"] = str(lin)
-        os.environ["USC_WINO_SPLIT"] = str(split)
+        lib.usc_conv_force_winograd_form(-1, int(lin), int(split))
         try:
             arr = (hipnet.ConvDesc * 1)(d)
             plan = nv.conv_plans(arr, 1)[0]
@@ -349,8 +348,7 @@ def test_winograd_layer_matches_torch(hipnet, cin, cout, h, w, batch, kw, dil, l
                     L.run([d])
                     assert torch.equal(out, first)
         finally:
-            os.environ["USC_WINO_LIN"] = "-1"
-            os.environ["USC_WINO_SPLIT"] = "0"
+            lib.usc_conv_force_winograd_form(-1, -1, 0)
             lib.usc_conv_force_winograd(-1)
             lib.usc_conv_force_plan(0, 0, 0, 0)
         y = F.conv2d(x.double(), wt.double(), b.double(), padding=dil, dilation=dil)
@@ -391,7 +389,7 @@ def test_winograd_transposed_layer_matches_torch(hipnet, cin, cout, h, w):
         for i, (dy, dx) in enumerate([t for tp, _ in phases for t in tp]):
             d.dy[i], d.dx[i] = dy, dx
         d.wino = wino.data_ptr()
-        os.environ["USC_WINO_T3"] = "1"
+        lib.usc_conv_force_winograd_form(1, -1, 0)
         try:
             plan = nv.conv_plans((hipnet.ConvDesc * 1)(d), 1)[0]
             assert "winograd-t3" in plan["plan"], plan
@@ -399,13 +397,13 @@ def test_winograd_transposed_layer_matches_torch(hipnet, cin, cout, h, w):
             first = out.clone()
             L.run([d])
             assert torch.equal(out, first)
-            os.environ["USC_WINO_T3"] = "0"                       # the direct kernel on the same descriptor
+            lib.usc_conv_force_winograd_form(0, -1, 0)            # the direct kernel on the same descriptor
             ref = torch.full_like(out, float("nan"))
             d.out = ref.data_ptr()
             assert "winograd" not in nv.conv_plans((hipnet.ConvDesc * 1)(d), 1)[0]["plan"]
             L.run([d])
         finally:
-            os.environ["USC_WINO_T3"] = "-1"
+            lib.usc_conv_force_winograd_form(-1, -1, 0)
         y = F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=2, padding=1)
         if fused:
             y = torch.where(y > 0, y, y * 0.2) + r2.double()

@@ -100,7 +100,7 @@ def test_structured_masks(nv, oracle_lib):
             _check(nv, oracle_lib, flt, al, ((ndi.gaussian_filter(rng.random((H, W)), 2) > 0.5) * 255).astype(np.uint8), thr)
 
 
-@pytest.mark.parametrize("H,W", [(1080, 1920), (1920, 1080), (540, 960)])
+@pytest.mark.parametrize("H,W", [(1080, 1920), (1920, 1080), (540, 960), (2160, 3840)])
 def test_clip_masks_full_size(nv, oracle_lib, H, W):
     from video_unscreen_amd.synth import SyntheticClip
     flt = nv.DeviceObjectFilter()

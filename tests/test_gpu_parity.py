@@ -176,7 +176,7 @@ def test_agents_numpy_api(nv, oracle_lib, cfg):
     assert np.array_equal(get_bg(m, bg), oracle_lib.get_bg(m, bg))
 
 
-@pytest.mark.parametrize("H,W", [(270, 480), (1080, 1920)])
+@pytest.mark.parametrize("H,W", [(270, 480), (1080, 1920), (2160, 3840)])      # 3840 x 2160: BASELINE.json configs[3] as a whole path
 def test_matting_agent_and_pipeline_vs_oracle(nv, oracle_lib, cfg, H, W):
     """Whole frames: the device-resident loop against the oracle loop (bg_offline.py:145-176).  Index masks
     bit-exact; float alpha within ALPHA_TOL of the CPU path; uint8 alpha within 1 LSB (a truncation can flip)."""

@@ -62,6 +62,23 @@ def test_schp_hip_convs_match_torch_plan(nv, H, W):
     assert torch.equal(again, got)                                       # deterministic
 
 
+def test_schp_hip_net_matches_reference_golden(nv):
+    """HipSchpNet on the device against the output of the REFERENCE module itself (unscreen/binseg/human_parse.py:248-265, run by
+    tests/golden/gen_golden.py on keyed-deterministic weights): same input seed, same tolerance as the CPU plan's test
+    (tests/test_oracle_cpu.py::test_schp_plan_matches_reference_golden)."""
+    import os
+    from video_unscreen_amd.binseg.schp_net import HipSchpNet, schp_synthetic_state_dict
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "schp_97x129.npz"))
+    g = torch.Generator().manual_seed(int(z["seed"]))
+    x = torch.randn(1, 3, 97, 129, generator=g)
+    net = HipSchpNet(schp_synthetic_state_dict(0), 97, 129)
+    x4 = torch.cat([x, torch.zeros(1, 1, 97, 129)], 1)[0].permute(1, 2, 0).contiguous().cuda()
+    got = net(x4).cpu().numpy()[..., :20].transpose(2, 0, 1)[None]
+    assert got.shape == z["y"].shape
+    err = np.abs(got - z["y"]).max() / np.abs(z["y"]).max()
+    assert err < 1e-4, err                                               # CPU plan vs reference: 2e-5; + the HIP summation order
+
+
 @pytest.mark.parametrize("H,W", [(270, 480), (1080, 1920)])
 def test_humanseg_agent_vs_oracle_chain(nv, oracle_lib, H, W):
     """Whole agent vs oracle pre -> folded plan on torch-CPU -> oracle post.  The mask is an argmax of float logits (person iff

@@ -104,6 +104,26 @@ def test_deeplab_hip_convs_match_torch_plan(nv):
         assert np.array_equal(got, got2)              # fixed accumulation order: run-to-run identical
 
 
+def test_deeplab_hip_net_matches_reference_golden(nv):
+    """HipDeepLabNet + the device's align_corners=False upsample against the output of the REFERENCE model itself
+    (unscreen/binseg/deeplab/_deeplab.py:29-60 incl. its final F.interpolate; tests/golden/gen_golden.py, keyed-deterministic
+    weights), same seed as tests/test_oracle_cpu.py::test_deeplab_plan_and_segagent_geometry_match_reference_golden."""
+    import os
+    from video_unscreen_amd.binseg.deeplab_net import HipDeepLabNet, deeplab_synthetic_state_dict
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "deeplab_97x129.npz"))
+    g = torch.Generator().manual_seed(int(z["seed"]))
+    x = torch.randn(1, 3, 97, 129, generator=g)
+    net = HipDeepLabNet(deeplab_synthetic_state_dict(0), 97, 129)
+    x4 = torch.cat([x[0].permute(1, 2, 0), torch.zeros(97, 129, 1)], -1).contiguous().cuda()
+    low = net(x4)                                                       # (h/4, w/4, 32) logits, classes in channels 0, 1
+    up = torch.zeros((97, 129, low.shape[2]), device="cuda")
+    nv.upsample_nc(low.contiguous(), up, 0)
+    got = up.cpu().numpy()[..., :2].transpose(2, 0, 1)[None]
+    assert got.shape == z["y"].shape
+    err = np.abs(got - z["y"]).max() / np.abs(z["y"]).max()
+    assert err < 1e-4, err
+
+
 @pytest.mark.parametrize("H,W", [(270, 480), (256, 256)])
 def test_segagent_vs_oracle_chain(nv, oracle_lib, H, W):
     """Whole agent vs oracle pre -> folded plan on torch-CPU -> oracle post (mask flips only where the two class scores are

@@ -125,6 +125,39 @@ def test_stm_hip_net_matches_torch_plan(nv, H, W):
         assert np.array_equal(got, got2)                                              # run-to-run identical
 
 
+def test_stm_hip_net_matches_reference_golden(nv):
+    """HipStmNet on the device against the REFERENCE model's own memorize() / segment() outputs (unscreen/stm/model.py:185-219;
+    tests/golden/gen_golden.py, keyed-deterministic weights): key / value of the memorised frame, and the class probabilities of
+    segment() for one and for two memory frames (the second entry built from the first exactly as the generator did), through
+    the device's own post stage (usc_stm_post: x4 upsample, softmax, soft aggregation).  Tolerances as in
+    tests/test_oracle_cpu.py::test_stm_plan_matches_reference_golden."""
+    import os
+    from video_unscreen_amd.stm.net import stm_synthetic_state_dict
+    from video_unscreen_amd.stm.net_hip import HipStmNet
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "stm_64x96.npz"))
+    g = torch.Generator().manual_seed(int(z["seed"]))
+    f0, f1 = torch.randn(1, 3, 64, 96, generator=g), torch.randn(1, 3, 64, 96, generator=g)
+    m = (torch.rand(1, 1, 64, 96, generator=g) > 0.5).float()
+    net = HipStmNet(stm_synthetic_state_dict(0), 64, 96, capacity=3)
+    net.x8.copy_(_x8(f0, torch.cat([1 - m, m], 1)))
+    net.memorize(0)
+    hw = net.hw
+    gk = net.kbank[:hw].cpu().numpy().reshape(net.h16, net.w16, -1).transpose(2, 0, 1)[None]
+    gv = net.vbank[:hw].cpu().numpy().reshape(net.h16, net.w16, -1).transpose(2, 0, 1)[None]
+    assert np.abs(gk - z["k4"]).max() < 1e-4 * np.abs(z["k4"]).max()
+    assert np.abs(gv - z["v4"]).max() < 1e-4 * np.abs(z["v4"]).max()
+    # second memory entry: keys * 0.5 + 0.1, values flipped along y - dim 3 of (1, C, T, h, w) - (gen_golden.py builds logit2 from exactly this)
+    net.kbank[hw:2 * hw].copy_(net.kbank[:hw] * 0.5 + 0.1)
+    net.vbank[hw:2 * hw].copy_(net.vbank[:hw].view(net.h16, net.w16, -1).flip(0).reshape(hw, -1))
+    for T, name in ((1, "logit1"), (2, "logit2")):
+        net.x8.copy_(_x8(f1))
+        p2 = net.segment(T)
+        mask, prob = nv.stm_post(p2, 64, 96, 64, 96)
+        ref = torch.softmax(torch.from_numpy(z[name]), 1)[0].permute(1, 2, 0).numpy()
+        assert np.abs(prob.cpu().numpy() - ref).max() < 2e-4, (T, float(np.abs(prob.cpu().numpy() - ref).max()))
+        assert (mask.cpu().numpy() != (ref[..., 1] > ref[..., 0]) * 255).mean() < 1e-3
+
+
 @pytest.mark.parametrize("H,W", [(270, 480)])
 def test_stm_agent_vs_oracle_chain(nv, oracle_lib, H, W):
     """STMAgent.forward on 3 frames vs oracle pre -> folded plan on torch-CPU -> oracle post, step by step (the mask may flip

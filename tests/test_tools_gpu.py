@@ -54,20 +54,39 @@ def test_bg_step_tool_end_to_end(tmp_path, oracle_lib):
         assert np.abs(a - out["alpha"].cpu().numpy().astype(int)).mean() < 1.0
 
 
-def test_bench_two_ranks_rehearsal():
-    """bench.py launched exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), with the
-    two ranks sharing this box's single GPU and gloo instead of RCCL: exercises the broadcast of weights / background, the
-    frame sharding, the barrier-bracketed timing, the MAX over ranks and the single JSON line."""
-    env = dict(os.environ, USC_BENCH_BACKEND="gloo", USC_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-                        "--no-cpu-baseline", "--no-kernel-table"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+def _bench(args, env, launcher=True, port="29533"):
+    pre = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", port] if launcher else [sys.executable])
+    return subprocess.run(pre + [os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+
+
+def _one_line(r):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout                         # rank 0 prints ONE line
-    out = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py for N = 2, with the two ranks sharing this box's single GPU and gloo instead of RCCL: (a) launched exactly as the
+    driver launches it (torch.distributed.run, one process per rank), (b) as the bare `python bench.py --gpus 2`, which must start
+    the two ranks itself, (c) the strong-scaling form: ONE clip of 31 frames (no segmentation batch divides either range) cut into
+    two contiguous ranges.  Exercises the broadcast of weights / background, the frame sharding, the barrier-bracketed timing, the
+    MAX over ranks and the single JSON line; (d) a launcher whose world size is not --gpus is refused."""
+    env = dict(os.environ, USC_BENCH_BACKEND="gloo", USC_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    common = ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-table"]
+    out = _one_line(_bench(["--gpus", "2"] + common, env))
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["value"] > 0 and abs(out["value"] - 2 * 6 / (out["ms_per_step"] * 6 / 1e3)) < 1e-2 * out["value"]
+    out = _one_line(_bench(["--gpus", "2"] + common, env, launcher=False))           # the form the driver's N = 1 command has
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "weak" and out["value"] > 0
+    out = _one_line(_bench(["--gpus", "2", "--clip-frames", "31", "--height", "270", "--width", "480"] + common[2:], env, launcher=False))
+    assert out["n_gpus"] == 2 and out["steps"] == 31 and out["scaling"] == "strong"
+    assert abs(out["value"] - 31 / (out["ms_per_step"] * 31 / 1e3)) < 1e-2 * out["value"]
+    assert "rank 0: 16 frames" in out["config"]["workload"]
+    r = _bench(["--gpus", "4"] + common, env, port="29534")                          # 2 ranks started, 4 claimed
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_bg_step_tool_raw_files_are_bit_exact(tmp_path):

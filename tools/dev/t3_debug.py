@@ -14,8 +14,8 @@ phases = [m.convt_phase_taps(wt, py, px) for py in (0, 1) for px in (0, 1)]
 wp = torch.stack([m.pack_k_major(k.float()) for _, k in phases], 0).cuda(); wn = m.pack_wino_t(wt).cuda()
 taps = [t for tp, _ in phases for t in tp]
 outs = []
-for mode in ("1", "0", "1"):
-    os.environ["USC_WINO_T3"] = mode
+for mode in (1, 0, 1):
+    lib.usc_conv_force_winograd_form(mode, -1, 0)
     out = torch.full((2 * h, 2 * w, cout), float("nan"), device="cuda")
     d = m.ConvDesc()
     d.IH, d.IW, d.Cin, d.OH, d.OW, d.OHf, d.OWf, d.Cout = h, w, cin, h, w, 2 * h, 2 * w, cout

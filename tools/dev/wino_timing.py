@@ -8,7 +8,7 @@ nv.LIB_PATH = os.environ["USC_TIMING_LIB"]
 from video_unscreen_amd.vmatting import net_hip as m
 lib = nv.load()
 T3 = os.environ.get("T3", "0") == "1"          # the transposed form (ConvTranspose2d k4 s2 p1) on the matting net's decoder shapes
-if T3: os.environ["USC_WINO_T3"] = "1"
+if T3: lib.usc_conv_force_winograd_form(1, -1, 0)
 cases = ((128, 128, 68, 120, 1), (64, 64, 136, 240, 1), (32, 32, 272, 480, 1)) if T3 else \
         ((32, 32, 272, 480, 1), (64, 32, 272, 480, 1), (64, 64, 136, 240, 2), (128, 128, 68, 120, 4), (32, 32, 544, 960, 1))
 for (cin, cout, h, w, kw) in cases:

@@ -63,7 +63,7 @@ def main(cfg):
     lo, hi = shard_range(len(frame_paths), rank, world)          # this rank's contiguous range
     # stages 1 and 2 walk the clip in memory like the reference (bg_offline.py:36); stage 3 streams it (below)
     frames = parallel_read_img(frame_paths[lo:hi]) if ("1" in stages or "2" in stages) else None
-    h, w = (frames[0] if frames else read_img(frame_paths[lo])).shape[:2]
+    h, w = (frames[0] if frames else read_img(frame_paths[min(lo, len(frame_paths) - 1)])).shape[:2]   # (a rank may own no frame)
     print('{} frames. Reading Data Done! {:.2f}s'.format(hi - lo, time.time() - st))
     masks, bgs = [], []
 
@@ -94,12 +94,24 @@ def main(cfg):
         del pipe1
         print('stage 1: {} frames in {:.2f}s on rank {}'.format(len(frames), time.time() - st, rank))
 
-    def shard_of(pattern):
-        paths = sorted(glob(osp.join(dst_img_dir, pattern)))
-        assert len(paths) >= first + len(frame_paths), "frames and {} must pair up".format(pattern)
-        if len(paths) != len(frame_paths):
-            paths = paths[first:first + len(frame_paths)]
-        return parallel_read_img(paths[lo:hi])
+    def shard_files(prefix):
+        """This rank's intermediate files of one kind, selected BY FRAME ID ('<prefix>_<fid:06d>.<ext>' for the frame ids of its
+        range - what stage 1 of this tool writes, whatever --range was), in the run's format or as the reference's JPEGs; a
+        directory that holds exactly one file per frame of the (ranged) clip, or of the whole clip, under other numbers is paired
+        positionally like the reference does (bg_offline.py:134-141)."""
+        exts = list(dict.fromkeys((ext, 'jpg')))
+        for e in exts:
+            named = [osp.join(dst_img_dir, '{}_{:06d}.{}'.format(prefix, first + lo + i, e)) for i in range(hi - lo)]
+            if all(osp.exists(q) for q in named):
+                return named
+        for e in exts:
+            paths = sorted(glob(osp.join(dst_img_dir, '{}_*.{}'.format(prefix, e))))
+            if len(paths) == len(frame_paths):
+                return paths[lo:hi]
+            if paths and len(paths) >= first + len(frame_paths):
+                return paths[first:first + len(frame_paths)][lo:hi]
+        raise FileNotFoundError("no {}_<frame id>.{{{}}} files for frames {}..{} in {} (run stage 1 first, or with the same --range)".format(
+            prefix, ",".join(exts), first + lo, first + hi - 1, dst_img_dir))
 
     if world > 1:
         dist.barrier()
@@ -107,7 +119,7 @@ def main(cfg):
         print("calculate overall bg image according to video segmentation and temporal constraints")
         st = time.time()
         if not masks:
-            masks = shard_of('segmask_*.' + ext)
+            masks = parallel_read_img(shard_files('segmask'))
         acc = OverallBackground(h, w, device=dev)
         for f, m in zip(frames, masks):
             acc.add(torch.from_numpy(f).to(dev), torch.from_numpy(np.ascontiguousarray(m[..., 0])).to(dev))
@@ -136,14 +148,8 @@ def main(cfg):
     # Stage 3 streams: decoder processes -> page-locked ring -> uploads -> the pipelined frame loop -> downloads -> encoder
     # processes (utils/frameio.py, hostio.stream_clip).  Nothing is held but the rings; the lossy JPEG round trip of the masks
     # and backgrounds (bg_offline.py:134-141) happens only when those files are JPEGs (--io jpg, the reference's layout).
-    def shard_paths(pattern):
-        paths = sorted(glob(osp.join(dst_img_dir, pattern)))
-        assert len(paths) >= first + len(frame_paths), "frames and {} must pair up".format(pattern)
-        if len(paths) != len(frame_paths):
-            paths = paths[first:first + len(frame_paths)]
-        return paths[lo:hi]
-    mask_paths = shard_paths('segmask_*.' + ext) or shard_paths('segmask_*.jpg')
-    bg_paths = shard_paths('bg_*.' + ext) or shard_paths('bg_*.jpg')
+    mask_paths = shard_files('segmask')
+    bg_paths = shard_files('bg')
     groups = list(zip(frame_paths[lo:hi], mask_paths, bg_paths))
     workers = int(cfg["data"].get("io_workers", 6))
     print("calculate fg image according to bg image")

@@ -26,6 +26,10 @@ _SIGNATURES = {
     "usc_get_target_size": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "usc_pad_resize_geometry": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "usc_inv_pad_geometry": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "usc_pad_resize_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp]),
+    "usc_inv_pad_resize": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp]),
+    "usc_imnormalize_u8": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, _vp, _vp]),
+    "usc_gray_moments_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "usc_morph_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "usc_morph_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
     "usc_trimap_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -82,6 +86,7 @@ _SIGNATURES = {
     "usc_upsample_taps_accum_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "usc_conv_force_plan": (None, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "usc_conv_force_winograd": (None, [C.c_int]),
+    "usc_conv_force_winograd_form": (None, [C.c_int, C.c_int, C.c_int]),
     "usc_bg_accumulate_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "usc_bg_finalize_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "usc_remove_invalid_objects_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
@@ -341,6 +346,72 @@ def resize(img, dh, dw, interp=1, out=None):
     out = torch.empty((dh, dw) if img.dim() == 2 else (dh, dw, cn), dtype=torch.uint8, device=img.device) if out is None else out
     _check(load().usc_resize_u8(_dev_u8(img, "resize.img"), sh, sw, cn, _dev_u8(out, "resize.out"), int(dh), int(dw), int(interp), _stream()),
            "usc_resize_u8")
+    return out
+
+
+_ELEM = {torch.uint8: 0, torch.float32: 1, torch.float64: 2}
+
+
+def _dev_any(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()):
+        raise NativeError(f"{name}: expected a contiguous CUDA tensor (the HIP path has no CPU fallback)")
+    return t.data_ptr()
+
+
+def pad_resize(img, target_h, target_w, out=None):
+    """imgprocess.py:67-97 on a uint8 CUDA image (H, W) or (H, W, 3): resize + reflect pad to (target_h, target_w), one kernel."""
+    h, w, cn = _img_dims(img)
+    shape = (target_h, target_w) if img.dim() == 2 else (target_h, target_w, cn)
+    out = torch.empty(shape, dtype=torch.uint8, device=img.device) if out is None else out
+    _check(load().usc_pad_resize_u8(_dev_u8(img, "pad_resize.img"), h, w, cn, _dev_u8(out, "pad_resize.out", shape), int(target_h), int(target_w),
+                                    _stream()), "usc_pad_resize_u8")
+    return out
+
+
+def inv_pad_resize(img, ori_h, ori_w, out=None):
+    """imgprocess.py:100-132 on a uint8 / float32 / float64 CUDA image (H, W) or (H, W, C <= 4)."""
+    if img.dtype not in _ELEM:
+        raise NativeError(f"inv_pad_resize: dtype {img.dtype} (uint8, float32 or float64)")
+    h, w = img.shape[:2]
+    cn = 1 if img.dim() == 2 else img.shape[2]
+    shape = (ori_h, ori_w) if img.dim() == 2 else (ori_h, ori_w, cn)
+    out = torch.empty(shape, dtype=img.dtype, device=img.device) if out is None else out
+    if out.dtype != img.dtype or tuple(out.shape) != tuple(shape):
+        raise NativeError("inv_pad_resize: out has the wrong dtype / shape")
+    _check(load().usc_inv_pad_resize(_dev_any(img, "inv_pad_resize.img"), h, w, cn, _ELEM[img.dtype], _dev_any(out, "inv_pad_resize.out"),
+                                     int(ori_h), int(ori_w), _stream()), "usc_inv_pad_resize")
+    return out
+
+
+def imnormalize(img, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), to_rgb=True, out=None):
+    """imgprocess.py:135-161 on a (H, W, 3) uint8 CUDA image: img becomes RGB IN PLACE when to_rgb; returns float32 (H, W, 3)."""
+    H, W, _ = img.shape
+    out = torch.empty((H, W, 3), dtype=torch.float32, device=img.device) if out is None else out
+    m = (C.c_double * 3)(*[float(v) for v in np.asarray(mean).reshape(-1)])
+    sd = (C.c_double * 3)(*[float(v) for v in np.asarray(std).reshape(-1)])
+    _check(load().usc_imnormalize_u8(_dev_u8(img, "imnormalize.img", (H, W, 3)), H * W, m, sd, int(bool(to_rgb)), _dev_any(out, "imnormalize.out"),
+                                     _stream()), "usc_imnormalize_u8")
+    return out
+
+
+def gray_moments(img, rgb_order=False, thr=None, want_moments=True):
+    """Gray of a (H, W, 3) uint8 CUDA image (rgb_order: cv2.COLOR_RGB2GRAY): -> (mask | None, moments | None); mask = 255 where
+    gray > thr (thr given), moments = int64 CUDA tensor (m00, m10, m01)."""
+    H, W, _ = img.shape
+    mask = torch.empty((H, W), dtype=torch.uint8, device=img.device) if thr is not None else None
+    mom = torch.empty(3, dtype=torch.int64, device=img.device) if want_moments else None
+    _check(load().usc_gray_moments_u8(_dev_u8(img, "gray_moments.img", (H, W, 3)), H, W, int(bool(rgb_order)), int(thr if thr is not None else 0),
+                                      mask.data_ptr() if mask is not None else None, mom.data_ptr() if mom is not None else None, _stream()),
+           "usc_gray_moments_u8")
+    return mask, mom
+
+
+def score_map(H, W, center, device):
+    """maskprocess.py:155-178 get_score_map as a float64 (H, W) CUDA table."""
+    out = torch.empty((H, W), dtype=torch.float64, device=device)
+    ws8 = torch.zeros(8, dtype=torch.uint8, device=device)
+    _check(load().usc_score_map_f64(int(H), int(W), float(center[0]), float(center[1]), out.data_ptr(), ws8.data_ptr(), _stream()),
+           "usc_score_map_f64")
     return out
 
 

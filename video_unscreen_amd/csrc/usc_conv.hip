@@ -538,10 +538,12 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
             // addresses, would put a wait for the newest of them in front of every fragment phase.  Its own waits for ordinary
             // loads stay correct with loads it does not know of in flight: the counter is in order, it can only wait longer.)
             const int m0v = lds_base + dst * 4, so = c * 32;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, %5 offen lds\n\t"
-                         "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %5 offen lds\n\t"
-                         "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %5 offen lds"
-                         :: "s"(m0v), "v"(g0), "v"(g1), "v"(g2), "s"(in_v4), "s"(so) : "memory", "scc");       // (m0 is reserved: nothing else in this form uses it)
+            int m0_keep;                                          // m0 is saved and put back inside the statement: whatever the compiler keeps in it survives
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"
+                         "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
+                         "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(m0_keep) : "s"(m0v), "v"(g0), "v"(g1), "v"(g2), "s"(in_v4), "s"(so) : "memory", "scc");
             return;
         }
         const int dst = img0 + ((c - c_begin) & 1) * IMGF + NG * h * 256;
@@ -918,8 +920,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         // ---- two workgroups per unit: this one's sums went to the slab with system-scope write-through stores (the partner may sit
         // on another XCD, whose L2 is not coherent with ours: sc0 sc1 on both sides instead of a release that writes the whole L2
         // back), then one relaxed atomic per workgroup counts arrivals; the second to arrive adds the first one's sums to its own
-        // (half 0 + half 1: addition commutes) and finishes.  The counters (last WSLAB_TAIL bytes of the slab, zeroed by the host
-        // once) only ever matter modulo 2.
+        // (half 0 + half 1: addition commutes) and finishes.  The counters (last WSLAB_TAIL bytes of the slab, zeroed on the launch stream
+        // at the head of every forward) only ever matter modulo 2.
         int* const counter = reinterpret_cast<int*>(reinterpret_cast<char*>(d.slab) + d.slab_bytes - WSLAB_TAIL) + wt;
         __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the stores have been acknowledged
         __syncthreads();
@@ -1236,6 +1238,14 @@ extern "C" void usc_conv_force_plan(int nt, int rowgroups, int ksplit, int kgrou
 }
 static thread_local int g_force_wino = -1;
 extern "C" void usc_conv_force_winograd(int mode) { g_force_wino = mode; }
+// which Winograd form the planner may / must take (tests and A/B timing; thread-local like the hooks above, no environment):
+// t3: transposed form -1 cost model | 0 never | 1 wherever admissible; lin: blocks of 32 consecutive tiles, same coding;
+// split: K halves on two workgroups 0 cost model | 1 never | 2 wherever admissible
+static thread_local int g_force_t3 = -1, g_force_lin = -1, g_force_ws = 0;
+extern "C" void usc_conv_force_winograd_form(int t3, int lin, int split) { g_force_t3 = t3; g_force_lin = lin; g_force_ws = split; }
+// cost-model constants of the direct kernel's planner (microseconds; fitted on the device with tools/dev/tune_convs.py)
+static constexpr int kNt2Min = 512, kMinSteps = 9, kKwSteps = 4, kRgMin = 1;
+static constexpr double kTStep = 0.43, kTLone = 1.5, kTFixed = 3.0, kTReduce = 8.0;
 
 // One layer = one main launch (+ one reduce launch when K is split).
 struct LayerPlan {
@@ -1293,8 +1303,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
         bool t3 = d.wino && nphase == 4 && d.ntaps == 4 && d.in_stride == 1 && d.out_stride == 2 && nbatch == 1 && d.Cin % 8 == 0 &&
                   !d.res1 && !d.scale && d.OH == d.IH && d.OW == d.IW && d.OHf == 2 * d.IH && d.OWf == 2 * d.IW && d.kind != USC_CONV_HEAD;
         for (int t = 0; t3 && t < 16; t++) t3 = d.dy[t] == (t >> 3) - ((t >> 1) & 1) && d.dx[t] == ((t >> 2) & 1) - (t & 1);
-        static thread_local int force_t3 = -1;
-        if (const char* e = getenv("USC_WINO_T3")) force_t3 = atoi(e);              // tests / A-B timing: 0 never, 1 wherever admissible
+        const int force_t3 = g_force_t3;
         if (t3 && g_force_wino != 0 && force_t3 != 0) {
             const int TH = (d.IH + 2) / 3, TW = (d.IW + 2) / 3;
             const int nbt = TW < 11 ? (32 / TW < 4 ? 32 / TW : 4) * TW : 32;
@@ -1336,14 +1345,12 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
             // 6 + flops / 118 TFLOP/s + output bytes / 3 TB/s (its epilogue is exposed when K is short).  All inputs are plan
             // quantities.
             const long long blk_rect = (long long)((TH + 3) / 4) * ((TW + 7) / 8), blk_lin = ((long long)TH * TW + 31) / 32;
-            static thread_local int force_lin = -1;
-            if (const char* e = getenv("USC_WINO_LIN")) force_lin = atoi(e);        // tests / A-B timing: 0 never, 1 wherever admissible
+            const int force_lin = g_force_lin;
             const int nsteps = d.Cin / 8;
             int kw = 1, ws = 1;
             bool lin = false;
             double wino_us = 1e30;
-            static thread_local int force_ws = 0;
-            if (const char* e = getenv("USC_WINO_SPLIT")) force_ws = atoi(e);       // tests / A-B timing: 1 never, 2 wherever admissible
+            const int force_ws = g_force_ws;
             for (int l = 0; l < 2; l++) {
                 if (l == 1 && (TW < 11 || force_lin == 0)) continue;
                 if (l == 0 && force_lin == 1 && TW >= 11) continue;
@@ -1385,7 +1392,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
             }
         }
     }
-    static const int nt2_min = getenv("USC_NT2_MIN") ? atoi(getenv("USC_NT2_MIN")) : 512;
+    constexpr int nt2_min = kNt2Min;
     bool nt2 = (d.Cout % 64 == 0) && ((m_plan + 127) / 128 * (d.Cout / 64) * nphase >= nt2_min);
     if (g_force_nt) nt2 = g_force_nt == 2 && d.Cout % 64 == 0;
     const int nblocks = nt2 ? d.Cout / 64 : d.Cout / 32;
@@ -1394,9 +1401,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     // KW groups of RG waves that split its K range (partial sums meet in LDS, no HBM traffic), and the grid may split K into
     // S slices (partial sums through the slab and splitk_reduce_kernel).  Chosen by a cost model; tools/dev/tune_convs.py
     // times every admissible plan of every layer shape of the path's networks on the device.
-    static const int min_steps = getenv("USC_MIN_STEPS") ? atoi(getenv("USC_MIN_STEPS")) : 9;           // tuning knobs
-    static const int kw_steps = getenv("USC_KW_STEPS") ? atoi(getenv("USC_KW_STEPS")) : 4;
-    static const int rg_min = getenv("USC_RG_MIN") ? atoi(getenv("USC_RG_MIN")) : 1;                    // 4: 128-pixel workgroups only
+    constexpr int min_steps = kMinSteps, kw_steps = kKwSteps, rg_min = kRgMin;
     int RG = 4, KW = 1, S = 1;
     // slab capacity is checked for the planned batch (or the actual one if larger): the same S at every batch <= plan_batch
     const size_t plane_actual = (size_t)d.OHf * d.OWf * d.Cout * sizeof(float);
@@ -1423,10 +1428,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
         //   SIMD, but never less than the ~1.5 us a lone wave needs per step (load latency it cannot hide on its own);
         //   a workgroup puts RG KW / 4 waves on each SIMD; W = that x the workgroups on the busiest CU, in rounds when they
         //   exceed the CU's wave slots; a grid split adds the reduce launch and the slab round trip.
-        static const double t_step = getenv("USC_T_STEP") ? atof(getenv("USC_T_STEP")) : 0.43;
-        static const double t_lone = getenv("USC_T_LONE") ? atof(getenv("USC_T_LONE")) : 1.5;
-        static const double t_fixed = getenv("USC_T_FIXED") ? atof(getenv("USC_T_FIXED")) : 3.0;
-        static const double t_reduce = getenv("USC_T_REDUCE") ? atof(getenv("USC_T_REDUCE")) : 8.0;
+        constexpr double t_step = kTStep, t_lone = kTLone, t_fixed = kTFixed, t_reduce = kTReduce;
         const double plane_mb = (double)m_plan * d.Cout * 4e-6 * nphase;
         const double slots = nt2 ? 3. : 4.;                          // waves per SIMD the register file admits
         double best = 1e30;
@@ -1525,6 +1527,7 @@ struct ConvGraph {
     std::vector<LayerPlan> plans;          // kernel arguments must outlive the graph
     int device = -1;                       // the device the graph was created (and is launched) on
     int mode = USC_CONV_LAUNCH_STREAM;     // how usc_conv_graph_launch enqueues the layers
+    void* counters = nullptr;              // arrival counters (slab tail) of the layers that split K over two workgroups, if any
 };
 
 extern "C" int usc_conv_graph_create(const usc_conv_desc* descs, int n, void** handle) {
@@ -1535,18 +1538,28 @@ extern "C" int usc_conv_graph_create(const usc_conv_desc* descs, int n, void** h
     for (int i = 0; i < n; i++) {
         int rc = plan_layer(descs[i], g->plans[i]);
         if (rc) { delete g; return rc; }
-        // arrival counters of Winograd layers split over two workgroups: zero once, every launch leaves them even
-        if (g->plans[i].wsplit && hipMemset(wslab_counters(g->plans[i].d), 0, WSLAB_TAIL) != hipSuccess) {
-            delete g; return conv_fail(USC_E_LAUNCH, "hipMemset (arrival counters) failed");
-        }
+        // arrival counters of Winograd layers split over two workgroups: zeroed on the launch stream at the head of EVERY launch
+        // (below), so a launch never inherits a counter that an aborted launch, or another handle sharing the slab, left odd
+        if (g->plans[i].wsplit && !g->counters) g->counters = wslab_counters(g->plans[i].d);
     }
     if (hipGraphCreate(&g->graph, 0) != hipSuccess) { delete g; return conv_fail(USC_E_LAUNCH, "hipGraphCreate failed"); }
     std::vector<hipGraphNode_t> last(n);                     // node that completes layer i
     std::vector<void*> kargs(n);
+    hipGraphNode_t head = nullptr;                           // chain head: the counters' memset, when the net has split layers
+    if (g->counters) {
+        hipMemsetParams mp;
+        memset(&mp, 0, sizeof(mp));
+        mp.dst = g->counters; mp.value = 0; mp.elementSize = 4; mp.width = WSLAB_TAIL / 4; mp.height = 1; mp.pitch = WSLAB_TAIL;
+        if (hipGraphAddMemsetNode(&head, g->graph, nullptr, 0, &mp) != hipSuccess) {
+            (void)hipGraphDestroy(g->graph); delete g;
+            return conv_fail(USC_E_LAUNCH, "hipGraphAddMemsetNode (arrival counters) failed");
+        }
+    }
     for (int i = 0; i < n; i++) {
         LayerPlan& p = g->plans[i];
         std::vector<hipGraphNode_t> deps;
         if (i > 0) deps.push_back(last[i - 1]);              // linear chain (see above)
+        else if (head) deps.push_back(head);
         kargs[i] = &p.d;
         hipKernelNodeParams kp;
         memset(&kp, 0, sizeof(kp));
@@ -1580,6 +1593,7 @@ extern "C" int usc_conv_graph_launch(void* handle, usc_stream_t stream) {
     ConvGraph* g = (ConvGraph*)handle;
     hipStream_t st = (hipStream_t)stream;
     if (g->mode == USC_CONV_LAUNCH_STREAM) {                // the planned launches, one after the other on the stream
+        if (g->counters && hipMemsetAsync(g->counters, 0, WSLAB_TAIL, st) != hipSuccess) return conv_fail(USC_E_LAUNCH, "hipMemsetAsync (arrival counters) failed");
         for (LayerPlan& p : g->plans) {
             void* args[] = {&p.d};
             hipError_t e = hipLaunchKernel(p.fn, p.grid, p.block, args, 0, st);
@@ -1616,7 +1630,8 @@ extern "C" void usc_conv_graph_destroy(void* handle) {
     int cur = -1;
     (void)hipGetDevice(&cur);
     if (g->device >= 0 && g->device != cur) (void)hipSetDevice(g->device);
-    if (!g->execs.empty()) (void)hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();          // both launch modes: stream launches of this handle may still be queued on any stream, and the
+                                           // caller releases the layers' buffers right after this call (ConvGraphNet.close())
     for (auto& se : g->execs) (void)hipGraphExecDestroy(se.second);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     if (g->device >= 0 && g->device != cur && cur >= 0) (void)hipSetDevice(cur);

@@ -114,6 +114,17 @@ def stream_clip(pipe, reader, writer, out_paths, bg_always, depth=None):
         while uploaded and uploaded[0][0].query():
             reader.release(uploaded.popleft()[1])
 
+    def wait_release():
+        # the reader has no free slot and no decode in flight (the host ran ahead of the GPU: nothing in the loop synchronises
+        # since the object filter moved to the device): block on the OLDEST upload, then hand its slot back
+        if not uploaded:
+            raise RuntimeError("stream_clip: the reader is out of slots but no upload is pending (reader depth %d is smaller than "
+                               "the frames the pipeline looks ahead)" % reader.ring.depth)
+        uploaded[0][0].synchronize()
+        reap()
+
+    reader.wait_release = wait_release
+
     def host_frames():
         for slot, (f, m, b) in reader:
             reap()

@@ -86,8 +86,13 @@ class FrameReader:
     shapes: the array shape of each element of a tuple ((H, W, 3), (H, W), (H, W, 3)); a 2-D shape takes channel 0 of a
     3-channel file.  workers decoder processes, `depth` slots."""
 
-    def __init__(self, groups, shapes, workers=8, depth=32, pin=True):
+    def __init__(self, groups, shapes, workers=8, depth=32, pin=True, wait_release=None):
+        """wait_release: called (no arguments) when the consumer asks for the next group while every slot has been delivered and
+        none handed back - it must block until it has release()d at least one slot (hostio.stream_clip waits for the oldest
+        upload).  Without it that state raises instead of waiting for ever."""
         self.groups = list(groups)
+        self.wait_release = wait_release
+        self.outstanding = 0                               # decode tasks handed to the workers and not reported back yet
         self.ring = _Ring(shapes, depth, pin)
         self.tasks, self.done = _CTX.Queue(), _CTX.Queue()
         gray = [len(s) == 2 for s in self.ring.shapes]
@@ -108,6 +113,7 @@ class FrameReader:
             slot = self.free.pop()
             self.tasks.put((self.next_submit, slot, self.groups[self.next_submit]))
             self.next_submit += 1
+            self.outstanding += 1
 
     def __iter__(self):
         return self
@@ -116,7 +122,25 @@ class FrameReader:
         if self.next_deliver >= len(self.groups):
             raise StopIteration
         while self.next_deliver not in self.ready:
-            seq, slot, err = self.done.get()
+            if self.outstanding == 0:
+                # nothing is being decoded: every slot sits with the consumer.  Only a release() can make progress.
+                if self.wait_release is None:
+                    raise RuntimeError("FrameReader: all %d slots are delivered and none was released - release() a slot before "
+                                       "asking for the next group (or pass wait_release=)" % self.ring.depth)
+                before = self.outstanding
+                self.wait_release()
+                if self.outstanding == before:
+                    raise RuntimeError("FrameReader: wait_release() returned without releasing a slot")
+                continue
+            try:
+                seq, slot, err = self.done.get(timeout=2.0)
+            except queue.Empty:
+                dead = [p.pid for p in self.procs if not p.is_alive()]
+                if dead:                                   # a decoder that died (e.g. killed for memory) will never report its task
+                    self.close()
+                    raise RuntimeError("FrameReader: decoder process(es) %s died with %d task(s) outstanding" % (dead, self.outstanding))
+                continue
+            self.outstanding -= 1
             if err:
                 self.close()
                 raise RuntimeError("FrameReader: " + err)

@@ -22,6 +22,50 @@ def inv_pad_resize_size(h, w, ori_size):
     return nv.inv_pad_geometry(h, w, ori_size[0], ori_size[1])
 
 
+def get_center(img):
+    """Centre of mass of the gray image, (cX, cY) (reference imgprocess.py:7-14: COLOR_RGB2GRAY, cv2.moments, int())."""
+    _, mom = nv.gray_moments(to_dev(img), rgb_order=True)
+    m00, m10, m01 = (float(v) for v in mom.tolist())            # exact integer sums, as cv2.moments reports them for 8-bit data
+    return (int(m10 / (m00 + 1e-6)), int(m01 / (m00 + 1e-6)))
+
+
+def get_mask(img):
+    """(mask (h, w, 1) uint8 0 / 255, binary mask (h, w, 1) float64 0 / 1): BGR2GRAY > 25 (reference imgprocess.py:17-30)."""
+    assert img.shape[2] == 3
+    thresh = to_host(nv.gray_moments(to_dev(img), rgb_order=False, thr=25, want_moments=False)[0])
+    binary_mask = thresh / 255
+    return thresh[..., np.newaxis], binary_mask[..., np.newaxis]
+
+
+def pad_resize(img, target_size):
+    """Aspect-preserving cv2.resize + bottom / right BORDER_REFLECT pad to target_size -> (image, ratio)
+    (reference imgprocess.py:67-97; uint8 images, as every caller passes)."""
+    target_h, target_w = target_size
+    h, w = img.shape[:2]
+    ratio = float(target_h) / h if float(h) / w > float(target_h) / target_w else float(target_w) / w
+    if img.dtype != np.uint8:
+        raise TypeError("pad_resize: uint8 images only (the reference's callers pass frames, trimaps and masks)")
+    return to_host(nv.pad_resize(to_dev(img), int(target_h), int(target_w))), ratio
+
+
+def inv_pad_resize(img, ori_size):
+    """Inverse of pad_resize: cut the pad, cv2.resize to ori_size (reference imgprocess.py:100-132); uint8, float32 or float64,
+    (h, w) or (h, w, c)."""
+    if img.dtype not in (np.uint8, np.float32, np.float64):
+        raise TypeError(f"inv_pad_resize: dtype {img.dtype}")
+    return to_host(nv.inv_pad_resize(to_dev(img), int(ori_size[0]), int(ori_size[1])))
+
+
+def imnormalize(img, mean=np.array([0.485, 0.456, 0.406]), std=np.array([0.229, 0.224, 0.225]), to_rgb=True):
+    """((img / 255) - mean) / std in float32; like the reference (imgprocess.py:135-161, :157) the ARGUMENT is converted from BGR
+    to RGB in place when to_rgb."""
+    d = to_dev(img)
+    out = nv.imnormalize(d, mean, std, to_rgb)
+    if to_rgb:
+        img[...] = to_host(d)
+    return to_host(out)
+
+
 def adaptive_resize(img, img_target):
     """cv2.resize(img, size of img_target), default bilinear (reference imgprocess.py:33-37)."""
     return to_host(nv.resize(to_dev(img), img_target.shape[0], img_target.shape[1], 1))

@@ -30,6 +30,18 @@ def get_outer_boundary(mask, kernelsize=7, iters=10):
     return np.clip(dilated - mask, 0, 255)
 
 
+def get_score_map(map_size, center):
+    """Normalised inverted distance to `center` (ratios), float64 (reference maskprocess.py:155-178)."""
+    from ._dev import device
+    h, w = map_size
+    return to_host(nv.score_map(h, w, center, device()))
+
+
+def build_score_map(h, w, config):
+    """Score map for the object filter: landscape / portrait centre from the config (reference maskprocess.py:181-189)."""
+    return get_score_map((h, w), score_map_center(h, w, config))
+
+
 def score_map_center(h, w, config):
     centers = config['objectremoval']['score_map_center']
     return centers['landscape'] if w > h else centers['portrait']
