@@ -73,6 +73,27 @@ int usc_imnormalize_u8(uint8_t* img, size_t n, const double* mean3_host, const d
 int usc_gray_moments_u8(const uint8_t* img, int H, int W, int rgb_order, int thr, uint8_t* mask, unsigned long long* moments3,
                         usc_stream_t stream);
 
+/* ISegAgent, no-BRS predictor (unscreen/iseg/agent.py:92-119, iseg/brs/brs_predictor.py:35-106).  The network's dense layers run
+ * on usc_conv_* (video_unscreen_amd/iseg/net_hip.py); these are its pixel stages and the one non-dense layer type.
+ * usc_iseg_pre: agent.py:92-104 preprocess + the model's input stage (iseg/brs/models/distmap.py:16-22, 30-34, 70-124): pad_resize of
+ *   the uint8 BGR frame to (in_h, in_w), imnormalize, the two click distance maps tanh(2 sqrt(min_p |x - p|^2) / 260) and rgb_conv
+ *   (Conv 5->8, LeakyReLU 0.2, BN, Conv 8->3).  points_yx_host: 2 P (y, x) float pairs in NETWORK-INPUT coordinates, first the P
+ *   positive slots then the P negative ones, (-1, -1) = empty slot (brs_predictor.py:64-99 get_points_nd; 1 <= P <=
+ *   USC_ISEG_MAX_CLICKS = its net_clicks_limit).  rgb_params_host: 75 floats w1[8][5], b1[8], w2[3][8], b2[3] with the BatchNorm
+ *   folded into the second layer.  out: (in_h, in_w, 4) float32 NHWC (R', G', B', 0); with flip a second image follows, the
+ *   mirror of the first (transforms.py:34-58 AddHorizontalFlip mirrors image and clicks: the same values, mirrored).
+ * usc_dwconv3x3_nhwc_f32: the depthwise 3x3 (padding 1, no bias) of SeparableConv2d (iseg/brs/models/basic_blocks.py:101-113) on
+ *   `batch` stacked NHWC images; w9c = weights [9][C] tap-major.  Not a dense contraction: a direct kernel, off the matrix cores.
+ * usc_iseg_post: brs_predictor.py:46-51 (bilinear align_corners up to the input size, flip pair averaged on the logits, sigmoid)
+ *   -> prob (in_h, in_w) float32; then, when mask != NULL, agent.py:116-119: inv_pad_resize of prob to (H, W), > prob_thresh -> 255 / 0.
+ *   logits: channel 0 of (nimg * lh, lw, cbuf) float32, nimg = 2 with flip. */
+#define USC_ISEG_MAX_CLICKS 20
+int usc_iseg_pre(const uint8_t* frame, int H, int W, int in_h, int in_w, const float* points_yx_host, int P,
+                 const float* rgb_params_host, int flip, float* out, usc_stream_t stream);
+int usc_dwconv3x3_nhwc_f32(const float* src, int h, int w, int C, int batch, const float* w9c, float* dst, usc_stream_t stream);
+int usc_iseg_post(const float* logits, int lh, int lw, int cbuf, int in_h, int in_w, int flip, int H, int W, double prob_thresh,
+                  float* prob, uint8_t* mask, usc_stream_t stream);
+
 /* unscreen/utils/maskprocess.py:7-34 dilate_mask / erode_mask: grey-level max / min filter with
  * cv2.getStructuringElement(MORPH_ELLIPSE, (ksize, ksize)), `iters` passes, out-of-image taps ignored.
  * src and dst may not alias. */

@@ -69,6 +69,8 @@ def lib():
         _lib.orc_moments_u8.argtypes = [u8p, C.c_int, C.c_int, f64p]
         _lib.orc_get_center.argtypes = [u8p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib.orc_get_mask.argtypes = [u8p, C.c_size_t, C.c_int, u8p]
+        _lib.orc_iseg_pre.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_int, f32p]
+        _lib.orc_iseg_post.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p, u8p]
         for name in ("orc_bgr2gray_u8", "orc_bgr2hsv_u8", "orc_hsv2bgr_u8", "orc_bgr2lab_u8", "orc_lab2bgr_u8"):
             getattr(_lib, name).argtypes = [u8p, u8p, C.c_size_t]
     return _lib
@@ -653,6 +655,27 @@ def draw_contour_filled(img, pts, value=255):
     fn.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, u8p, C.c_int]
     fn(pts.ctypes.data_as(C.POINTER(C.c_int)), len(pts), img.shape[0], img.shape[1], img.ctypes.data_as(u8p), int(value))
     return img
+
+
+def iseg_pre(frame, in_h, in_w, points_yx, rgb_params, flip=True):
+    """ISegAgent.preprocess + DistMaps + rgb_conv -> ((1 + flip) * in_h, in_w, 4) float32 (see orc_iseg_pre)."""
+    frame, p = _u8(frame)
+    pts, pp = _f32(np.asarray(points_yx, np.float32).reshape(-1, 2))
+    prm, pr = _f32(np.asarray(rgb_params, np.float32).reshape(-1))
+    assert prm.size == 75
+    out = np.empty(((2 if flip else 1) * in_h, in_w, 4), np.float32)
+    lib().orc_iseg_pre(p, frame.shape[0], frame.shape[1], int(in_h), int(in_w), pp, pts.shape[0] // 2, pr, int(bool(flip)), out.ctypes.data_as(f32p))
+    return out
+
+
+def iseg_post(logits, in_h, in_w, flip, H, W, prob_thresh=0.5):
+    """logits ((1 + flip) * lh, lw, cbuf) float32 -> (prob (in_h, in_w) float32, mask (H, W) uint8) (see orc_iseg_post)."""
+    lg, p = _f32(logits)
+    nimg = 2 if flip else 1
+    prob, mask = np.empty((in_h, in_w), np.float32), np.empty((H, W), np.uint8)
+    lib().orc_iseg_post(p, lg.shape[0] // nimg, lg.shape[1], lg.shape[2], int(in_h), int(in_w), int(bool(flip)), int(H), int(W), float(prob_thresh),
+                        prob.ctypes.data_as(f32p), mask.ctypes.data_as(u8p))
+    return prob, mask
 
 
 def version():

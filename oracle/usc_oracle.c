@@ -1920,3 +1920,95 @@ ORC_API void orc_get_mask(const uint8_t* img3, size_t n, int thr, uint8_t* out)
 {
     for (size_t i = 0; i < n; i++) out[i] = orc_gray(img3[3 * i], img3[3 * i + 1], img3[3 * i + 2]) > thr ? 255 : 0;
 }
+
+/* ============================================================================================
+ * ISegAgent, no-BRS predictor (unscreen/iseg/agent.py, iseg/brs/brs_predictor.py, iseg/brs/models/distmap.py): pixel stages
+ * ============================================================================================ */
+
+/* agent.py:92-104 preprocess (pad_resize to (in_h, in_w), imnormalize) + the model's input stage: DistMaps (distmap.py:80-114,
+ * spatial_scale 1, norm_radius 260: tanh(2 sqrt(min over the clicks of ((y - py)^2 + (x - px)^2) / 260^2)), absent clicks (-1, -1)
+ * count as distance^2 = 1e6) and rgb_conv (distmap.py:16-22: Conv 5 -> 8, LeakyReLU(0.2), BatchNorm, Conv 8 -> 3; the BatchNorm is
+ * folded into the second layer by the caller).  points: 2 P (y, x) pairs in network-input coordinates, positive slots first.
+ * tanh is restated with orc_det_expf (1 - 2 / (exp(2u) + 1), u clamped at 20) so that the HIP kernel agrees bit for bit; it is
+ * within float rounding of torch.tanh.  out: (in_h, in_w, 4) float32 NHWC (R', G', B', 0); with flip a second, mirrored image. */
+ORC_API void orc_iseg_pre(const uint8_t* frame, int H, int W, int in_h, int in_w, const float* points, int P, const float* rgb_params,
+                          int flip, float* out)
+{
+    static const double mean[3] = {0.485, 0.456, 0.406}, std[3] = {0.229, 0.224, 0.225};
+    size_t n = (size_t)in_h * in_w;
+    uint8_t* img = (uint8_t*)malloc(n * 3);
+    orc_pad_resize_u8(frame, H, W, 3, img, in_h, in_w);
+    float meanf[3], stdinvf[3];
+    for (int c = 0; c < 3; c++) { meanf[c] = (float)mean[c]; stdinvf[c] = (float)(1 / std[c]); }
+    const float* w1 = rgb_params; const float* b1 = w1 + 40; const float* w2 = b1 + 8; const float* b2 = w2 + 24;
+    for (int y = 0; y < in_h; y++)
+        for (int x = 0; x < in_w; x++) {
+            size_t i = (size_t)y * in_w + x;
+            float v[5];
+            for (int c = 0; c < 3; c++) {
+                float f = (float)img[3 * i + (2 - c)] / 255.f;
+                f = f - meanf[c];
+                v[c] = f * stdinvf[c];
+            }
+            for (int g = 0; g < 2; g++) {
+                float best = 1e6f;
+                for (int k = 0; k < P; k++) {
+                    float qy = points[2 * (g * P + k)], qx = points[2 * (g * P + k) + 1];
+                    float d = 1e6f;
+                    if (!((qy > qx ? qy : qx) < 0.f)) {
+                        float dy = ((float)y - qy) / 260.f, dx = ((float)x - qx) / 260.f;
+                        d = dy * dy + dx * dx;
+                    }
+                    best = d < best ? d : best;
+                }
+                float u = sqrtf(best) * 2.f;
+                u = u > 20.f ? 20.f : u;
+                v[3 + g] = 1.f - 2.f / (orc_det_expf(2.f * u) + 1.f);
+            }
+            float h[8], r[3];
+            for (int j = 0; j < 8; j++) {
+                float s = b1[j];
+                for (int c = 0; c < 5; c++) s = s + w1[j * 5 + c] * v[c];
+                h[j] = s > 0.f ? s : s * 0.2f;
+            }
+            for (int k = 0; k < 3; k++) {
+                float s = b2[k];
+                for (int j = 0; j < 8; j++) s = s + w2[k * 8 + j] * h[j];
+                r[k] = s;
+            }
+            float* o = out + 4 * i;
+            o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = 0.f;
+            if (flip) {
+                float* m = out + 4 * (n + (size_t)y * in_w + (in_w - 1 - x));
+                m[0] = r[0]; m[1] = r[1]; m[2] = r[2]; m[3] = 0.f;
+            }
+        }
+    free(img);
+}
+
+/* brs_predictor.py:46-51 + transforms.py:28-29, 61-66 + agent.py:116-119: channel 0 of the (nimg, lh, lw, cbuf) logits is upsampled
+ * (bilinear, align_corners) to (in_h, in_w); with flip the second image is mirrored back and the pair averaged ON THE LOGITS (the
+ * transforms are undone in reverse order), then the sigmoid (restated with orc_det_expf); prob_out (in_h, in_w).  mask (may be
+ * NULL): inv_pad_resize of prob to (H, W) (cv2.resize on float32), > thr (float32 compare) -> 255 / 0. */
+ORC_API void orc_iseg_post(const float* logits, int lh, int lw, int cbuf, int in_h, int in_w, int flip, int H, int W, double thr,
+                           float* prob_out, uint8_t* mask)
+{
+    size_t n = (size_t)in_h * in_w;
+    float* up0 = (float*)malloc(sizeof(float) * n);
+    float* up1 = flip ? (float*)malloc(sizeof(float) * n) : NULL;
+    orc_upsample_ac_f32(logits, 1, lh, lw, 0, (size_t)cbuf, up0, in_h, in_w);
+    if (flip) orc_upsample_ac_f32(logits + (size_t)lh * lw * cbuf, 1, lh, lw, 0, (size_t)cbuf, up1, in_h, in_w);
+    for (int y = 0; y < in_h; y++)
+        for (int x = 0; x < in_w; x++) {
+            float v = up0[(size_t)y * in_w + x];
+            if (flip) v = 0.5f * (v + up1[(size_t)y * in_w + (in_w - 1 - x)]);
+            prob_out[(size_t)y * in_w + x] = 1.f / (1.f + orc_det_expf(-v));
+        }
+    free(up0); free(up1);
+    if (!mask) return;
+    float* full = (float*)malloc(sizeof(float) * (size_t)H * W);
+    orc_inv_pad_resize(prob_out, in_h, in_w, 1, 1, full, H, W);
+    float t = (float)thr;
+    for (size_t i = 0; i < (size_t)H * W; i++) mask[i] = full[i] > t ? 255 : 0;
+    free(full);
+}

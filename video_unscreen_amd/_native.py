@@ -30,6 +30,9 @@ _SIGNATURES = {
     "usc_inv_pad_resize": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "usc_imnormalize_u8": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, _vp, _vp]),
     "usc_gray_moments_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "usc_iseg_pre": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, _vp, _vp]),
+    "usc_dwconv3x3_nhwc_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "usc_iseg_post": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp]),
     "usc_morph_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "usc_morph_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
     "usc_trimap_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -413,6 +416,47 @@ def score_map(H, W, center, device):
     _check(load().usc_score_map_f64(int(H), int(W), float(center[0]), float(center[1]), out.data_ptr(), ws8.data_ptr(), _stream()),
            "usc_score_map_f64")
     return out
+
+
+ISEG_MAX_CLICKS = 20
+
+
+def iseg_pre(frame, in_h, in_w, points_yx, rgb_params, flip=True, out=None):
+    """ISegAgent.preprocess + DistMaps + rgb_conv: frame (H, W, 3) uint8 CUDA -> ((1 + flip) * in_h, in_w, 4) float32 NHWC.
+    points_yx: (2 P, 2) float array in network-input coordinates (positive slots, then negative; (-1, -1) = empty);
+    rgb_params: 75 floats (w1 8x5, b1 8, w2 3x8, b2 3; BatchNorm folded into the second layer)."""
+    H, W, _ = frame.shape
+    pts = np.ascontiguousarray(points_yx, np.float32).reshape(-1, 2)
+    P = pts.shape[0] // 2
+    prm = np.ascontiguousarray(rgb_params, np.float32).reshape(-1)
+    if prm.size != 75 or pts.shape[0] != 2 * P:
+        raise NativeError("iseg_pre: rgb_params must hold 75 floats and points an even number of (y, x) rows")
+    nimg = 2 if flip else 1
+    out = torch.empty((nimg * in_h, in_w, 4), dtype=torch.float32, device=frame.device) if out is None else out
+    _check(load().usc_iseg_pre(_dev_u8(frame, "iseg_pre.frame", (H, W, 3)), H, W, int(in_h), int(in_w), pts.ctypes.data_as(C.POINTER(C.c_float)), P,
+                               prm.ctypes.data_as(C.POINTER(C.c_float)), int(bool(flip)), _dev_any(out, "iseg_pre.out"), _stream()), "usc_iseg_pre")
+    return out
+
+
+def dwconv3x3(src, w9c, dst, batch=1):
+    """Depthwise 3x3 (padding 1): src (batch * h, w, C) float32 NHWC CUDA, w9c (9, C) -> dst like src."""
+    bh, w, Cn = src.shape
+    _check(load().usc_dwconv3x3_nhwc_f32(_dev_any(src, "dwconv3x3.src"), bh // batch, w, Cn, int(batch), _dev_any(w9c, "dwconv3x3.w"),
+                                         _dev_any(dst, "dwconv3x3.dst"), _stream()), "usc_dwconv3x3_nhwc_f32")
+    return dst
+
+
+def iseg_post(logits, in_h, in_w, flip, H=None, W=None, prob_thresh=0.5, prob=None, mask=None, want_mask=True):
+    """logits ((1 + flip) * lh, lw, cbuf) float32 CUDA (channel 0) -> (prob (in_h, in_w) float32, mask (H, W) uint8 | None)."""
+    nimg = 2 if flip else 1
+    bh, lw, cbuf = logits.shape
+    prob = torch.empty((in_h, in_w), dtype=torch.float32, device=logits.device) if prob is None else prob
+    if want_mask and mask is None:
+        mask = torch.empty((H, W), dtype=torch.uint8, device=logits.device)
+    _check(load().usc_iseg_post(_dev_any(logits, "iseg_post.logits"), bh // nimg, lw, cbuf, int(in_h), int(in_w), int(bool(flip)), int(H or 0), int(W or 0),
+                                float(prob_thresh), _dev_any(prob, "iseg_post.prob"), _dev_u8(mask, "iseg_post.mask", (H, W)) if want_mask else None,
+                                _stream()), "usc_iseg_post")
+    return prob, (mask if want_mask else None)
 
 
 def rescale_fg(img, scale_factor=1.1, out=None):
