@@ -124,7 +124,9 @@ int usc_trimap_withbg_u8(const uint8_t* mask, const uint8_t* img, const uint8_t*
 /* tools/unscreen/bg_offline.py:150-160 (same arithmetic: tools/unscreen/bg.py:85-92): background fusion
  * bg = u8(bg_i*beta + (1-beta)*bg_always) and the background-difference gate
  * alpha = gray(seg) * (dilate4x4x2(gray(|frame - bg|) > thr) // 255).
- * bg_always may be NULL with beta = 1 (bg.py: a single background image).  seg_cn is 1 or 3. */
+ * bg_always may be NULL with beta = 1 (bg.py: a single background image).  seg_cn is 1 or 3.  One kernel (bgdiff_gate_kernel):
+ * the difference image lives as bits in LDS; ws may be NULL (usc_bgdiff_ws_bytes returns 0 since round 3 and stays for callers
+ * that size a buffer with it).  out_bg must not alias an input. */
 size_t usc_bgdiff_ws_bytes(int H, int W);
 int usc_bgdiff_mask_u8(const uint8_t* frame, const uint8_t* bg_i, const uint8_t* bg_always,
                        const uint8_t* seg, int seg_cn, double beta, int thr, int H, int W,
@@ -310,7 +312,8 @@ int usc_remove_invalid_objects_host(uint8_t* alpha, const uint8_t* seg, int H, i
  * usc_humanseg_pre: :277-294 cv2.warpAffine(frame -> in_h x in_w, LINEAR, zero border) + imnormalize; writes NHWC
  *   float32 with 4 channels (R, G, B, 0).
  * usc_humanseg_post: :296-311 + transform_logits :58-73: logits (lh x lw, NHWC with Cbuf >= C channels per pixel)
- *   -> bilinear align_corners to in_h x in_w -> inverse affine warp of every class to H x W -> argmax > 0 -> 255. */
+ *   -> bilinear align_corners to in_h x in_w -> inverse affine warp of every class to H x W -> argmax > 0 -> 255.  One kernel
+ *   since round 3 (the upsampled tensor is staged per tile in LDS); ws may be NULL, usc_humanseg_post_ws_bytes returns 0. */
 void   usc_humanseg_affine(int w, int h, int in_w, int in_h, int inv, double* M2x3);
 int    usc_humanseg_pre(const uint8_t* frame, int H, int W, int in_h, int in_w, float* out_nhwc4, usc_stream_t stream);
 size_t usc_humanseg_post_ws_bytes(int C, int in_h, int in_w);

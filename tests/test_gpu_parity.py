@@ -71,7 +71,7 @@ def test_morph_bit_exact(nv, oracle_lib, H, W, k, it):
         assert np.array_equal(host(nv.morph(dev(g), k, it, op)), oracle_lib.morph(g, k, it, name))   # bit-exact
 
 
-@pytest.mark.parametrize("H,W", [(1080, 1920), (2160, 3840), (270, 480), (135, 241), (33, 47), (2, 3)])
+@pytest.mark.parametrize("H,W", [(1080, 1920), (2160, 3840), (270, 480), (135, 241), (33, 47), (2, 3), (70, 501), (40, 249), (17, 248), (50, 1000)])
 def test_bgdiff_mask_bit_exact(nv, oracle_lib, H, W):
     frame = rand_img(H, W, 1)
     bg_always = rand_img(H, W, 2)
@@ -86,6 +86,9 @@ def test_bgdiff_mask_bit_exact(nv, oracle_lib, H, W):
             gb, ga = nv.bgdiff_mask(dev(frame), dev(bg_i), dev(bg_always), dev(seg), beta, thr)
             assert np.array_equal(host(gb), wb)            # fused background: bit-exact (f32 blend, truncation)
             assert np.array_equal(host(ga), wa)            # gated alpha: bit-exact
+    wb, wa = oracle_lib.bgdiff_mask(frame, bg_i, None, seg1, 1.0, 25)          # bg.py:85-92: one background image, no fusion
+    gb, ga = nv.bgdiff_mask(dev(frame), dev(bg_i), None, dev(seg1), 1.0, 25)
+    assert np.array_equal(host(gb), wb) and np.array_equal(host(ga), wa)
 
 
 @pytest.mark.parametrize("H,W,L", [(1080, 1920, 960), (2160, 3840, 960), (256, 256, 960), (270, 480, 960),

@@ -86,6 +86,8 @@ def main():
         return best
 
     io = hostio.HostFrameIO(pipe)
+    io_p = hostio.HostFrameIO(pipe, down_mode="primed")
+    io_s = hostio.HostFrameIO(pipe, down_mode="shared")
 
     def mark_consumed():                         # frees the staging slot like collect(), downloads nothing
         main = torch.cuda.current_stream(dev)
@@ -108,12 +110,16 @@ def main():
         ("downloads only", lambda: pipe.run(iter(dev_frames), on_result=io.collect(alpha_h, fg_h))),
         ("uploads + downloads", lambda: pipe.run(io.inputs(host_frames, bga), on_result=io.collect(alpha_h, fg_h))),
         ("events + waits, no copies", lambda: pipe.run(nio.inputs(host_frames, bga), on_result=nio.collect())),
+        ("up + down, primed", lambda: pipe.run(io_p.inputs(host_frames, bga), on_result=io_p.collect(alpha_h, fg_h))),
+        ("up + down, one copy stream", lambda: pipe.run(io_s.inputs(host_frames, bga), on_result=io_s.collect(alpha_h, fg_h))),
+        ("uploads + downloads again", lambda: pipe.run(io.inputs(host_frames, bga), on_result=io.collect(alpha_h, fg_h))),
         ("device-resident again", lambda: pipe.run(iter(dev_frames))),
     ]
     for name, fn in cases:
         t, n = timed(fn), K
-        io.drain()
-        io.done = [None] * io.depth
+        for q in (io, io_p, io_s):
+            q.drain()
+            q.done = [None] * q.depth
         print(f"{name:28s} {n / t:7.1f} frames/s  {t / n * 1e3:.3f} ms/frame", flush=True)
 
 

@@ -268,12 +268,12 @@ def bgdiff_mask(frame, bg_i, bg_always, seg, beta, thr, out_bg=None, out_alpha=N
     ps = _dev_u8(seg, "bgdiff.seg", (H, W, 3) if seg_cn == 3 else (H, W))
     out_bg = torch.empty_like(frame) if out_bg is None else out_bg
     out_alpha = torch.empty((H, W), dtype=torch.uint8, device=frame.device) if out_alpha is None else out_alpha
-    need = load().usc_bgdiff_ws_bytes(H, W)
-    if ws is None or ws.numel() < need:
+    need = load().usc_bgdiff_ws_bytes(H, W)                # 0 since the two kernels became one; `ws` stays accepted
+    if need and (ws is None or ws.numel() < need):
         ws = _ws(need, frame.device)
     _check(load().usc_bgdiff_mask_u8(pf, pi, pa, ps, seg_cn, float(beta), int(thr), H, W,
                                      _dev_u8(out_bg, "bgdiff.out_bg", (H, W, 3)), _dev_u8(out_alpha, "bgdiff.out_alpha", (H, W)),
-                                     ws.data_ptr(), ws.numel(), _stream()), "usc_bgdiff_mask_u8")
+                                     ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream()), "usc_bgdiff_mask_u8")
     return out_bg, out_alpha
 
 
@@ -803,11 +803,12 @@ def humanseg_post(logits, C_classes, H, W, in_h=473, in_w=473, out=None, ws=None
         raise NativeError("humanseg_post.logits: expected a contiguous (lh, lw, C) float32 CUDA tensor")
     lh, lw, cbuf = logits.shape
     out = torch.empty((H, W), dtype=torch.uint8, device=logits.device) if out is None else out
-    need = load().usc_humanseg_post_ws_bytes(int(C_classes), int(in_h), int(in_w))
-    if ws is None or ws.numel() < need:
+    need = load().usc_humanseg_post_ws_bytes(int(C_classes), int(in_h), int(in_w))      # 0 since round 3; `ws` stays accepted
+    if need and (ws is None or ws.numel() < need):
         ws = _ws(need, logits.device)
     rc = load().usc_humanseg_post(logits.data_ptr(), int(C_classes), cbuf, lh, lw, int(in_h), int(in_w), H, W,
-                                  _dev_u8(out, "humanseg_post.out", (H, W)), ws.data_ptr(), ws.numel(), _stream())
+                                  _dev_u8(out, "humanseg_post.out", (H, W)), ws.data_ptr() if ws is not None else None,
+                                  ws.numel() if ws is not None else 0, _stream())
     if rc != 0:
         raise NativeError(f"usc_humanseg_post failed ({rc}): {load().usc_seg_last_error().decode()}")
     return out

@@ -233,9 +233,10 @@ static bool bit_se_fits(int ksize, int iters) { return iters * (ksize / 2) <= 32
 
 // `iters` passes over the LDS bit tile.  D accumulates OR (dilation, outside = 0), E accumulates AND (erosion,
 // outside = 1); positions outside the image are forced back to the identity after every pass.
-template <bool WITH_ERODE>
+template <bool WITH_ERODE, int EWW = kBitEWW>
 __device__ void bit_morph_passes(uint32_t*& d, uint32_t*& d2, uint32_t*& e, uint32_t*& e2, const uint32_t* inimg,
                                  int ER, const BitSE& se, int iters) {
+    constexpr int kBitEWW = EWW;              // words per extended row of THIS tile shape (shadows the default)
     for (int it = 0; it < iters; it++) {
         for (int idx = threadIdx.x; idx < ER * kBitEWW; idx += blockDim.x) {
             const int r = idx / kBitEWW, w = idx - r * kBitEWW;
@@ -283,22 +284,38 @@ __global__ __launch_bounds__(kBitThreads) void trimap_small_kernel(const uint8_t
     const int y0 = blockIdx.y * kBitH, x0 = blockIdx.x * (kBitWW * 32);
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
     const int chunks_per_row = kBitEWW / 2;                      // 64 pixels = 2 words per wave-instruction
-    for (int c = wave; c < ER * chunks_per_row; c += nwaves) {
-        const int r = c / chunks_per_row, cx = c - r * chunks_per_row;
-        const int ly = y0 - se.top + r, lx = x0 - 32 + cx * 64 + lane;
-        const bool in = ly >= 0 && ly < h && lx >= 0 && lx < w;
-        bool b = false;
-        if (in) {
-            const int sy = min((int)floor(ly * ify), H - 1);     // cv::resizeNN
-            const int sx = min((int)floor(lx * ifx), W - 1);
-            b = mask[(size_t)sy * W + sx] > 127;
+    // kLoadBatch chunks per round: their byte loads are all issued before the first ballot needs one (a wave has ~20 chunks; one
+    // memory round trip per chunk was most of this kernel's duration)
+    constexpr int kLoadBatch = 5;
+    for (int c0 = wave; c0 < ER * chunks_per_row; c0 += nwaves * kLoadBatch) {
+        uint8_t val[kLoadBatch];
+        bool inside[kLoadBatch];
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; u++) {
+            const int c = c0 + u * nwaves;
+            const int r = c / chunks_per_row, cx = c - r * chunks_per_row;
+            const int ly = y0 - se.top + r, lx = x0 - 32 + cx * 64 + lane;
+            inside[u] = c < ER * chunks_per_row && ly >= 0 && ly < h && lx >= 0 && lx < w;
+            val[u] = 0;
+            if (inside[u]) {
+                const int sy = min((int)floor(ly * ify), H - 1);     // cv::resizeNN
+                const int sx = min((int)floor(lx * ifx), W - 1);
+                val[u] = mask[(size_t)sy * W + sx];
+            }
         }
-        const unsigned long long bal = __ballot(b), inb = __ballot(in);
-        if (lane == 0) {
-            const int o = r * kBitEWW + 2 * cx;
-            d[o] = (uint32_t)bal; d[o + 1] = (uint32_t)(bal >> 32);
-            e[o] = (uint32_t)(bal | ~inb); e[o + 1] = (uint32_t)((bal | ~inb) >> 32);
-            inimg[o] = (uint32_t)inb; inimg[o + 1] = (uint32_t)(inb >> 32);
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; u++) {
+            const int c = c0 + u * nwaves;
+            if (c >= ER * chunks_per_row) continue;              // (uniform per wave)
+            const int r = c / chunks_per_row, cx = c - r * chunks_per_row;
+            const bool in = inside[u], b = in && val[u] > 127;
+            const unsigned long long bal = __ballot(b), inb = __ballot(in);
+            if (lane == 0) {
+                const int o = r * kBitEWW + 2 * cx;
+                d[o] = (uint32_t)bal; d[o + 1] = (uint32_t)(bal >> 32);
+                e[o] = (uint32_t)(bal | ~inb); e[o + 1] = (uint32_t)((bal | ~inb) >> 32);
+                inimg[o] = (uint32_t)inb; inimg[o + 1] = (uint32_t)(inb >> 32);
+            }
         }
     }
     __syncthreads();
@@ -320,71 +337,6 @@ __global__ __launch_bounds__(kBitThreads) void trimap_small_kernel(const uint8_t
             v.y = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
             *reinterpret_cast<uint2*>(dst) = v;
         } else for (int k = 0; k < 8 && lx + k < w; k++) dst[k] = (uint8_t)out[k];
-    }
-}
-
-// Difference gate (bg_offline.py:158-160): binary dilation of (diff == 255) by the 4x4 ellipse x2, then
-// alpha = gray(seg) where the dilation reached, else 0.
-__global__ __launch_bounds__(kBitThreads) void gate_kernel(const uint8_t* __restrict__ diff, int H, int W,
-                                                           const uint8_t* __restrict__ seg, int seg_cn,
-                                                           uint8_t* __restrict__ alpha, BitSE se, int iters) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const int ER = kBitH + se.top + se.bottom;
-    const int plane = ER * kBitEWW;
-    uint32_t* lds = reinterpret_cast<uint32_t*>(lds_raw);
-    uint32_t *d = lds, *d2 = lds + plane, *inimg = lds + 2 * plane, *unused = nullptr, *unused2 = nullptr;
-    const int y0 = blockIdx.y * kBitH, x0 = blockIdx.x * (kBitWW * 32);
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
-    const int chunks_per_row = kBitEWW / 2;
-    for (int c = wave; c < ER * chunks_per_row; c += nwaves) {
-        const int r = c / chunks_per_row, cx = c - r * chunks_per_row;
-        const int gy = y0 - se.top + r, gx = x0 - 32 + cx * 64 + lane;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const bool b = in && diff[(size_t)gy * W + gx] == 255;
-        const unsigned long long bal = __ballot(b), inb = __ballot(in);
-        if (lane == 0) {
-            const int o = r * kBitEWW + 2 * cx;
-            d[o] = (uint32_t)bal; d[o + 1] = (uint32_t)(bal >> 32);
-            inimg[o] = (uint32_t)inb; inimg[o + 1] = (uint32_t)(inb >> 32);
-        }
-    }
-    __syncthreads();
-    bit_morph_passes<false>(d, d2, unused, unused2, inimg, ER, se, iters);
-    for (int idx = threadIdx.x; idx < kBitH * kBitWW * 4; idx += blockDim.x) {
-        const int row = idx / (kBitWW * 4), sg = idx - row * (kBitWW * 4);
-        const int gy = y0 + row, gx = x0 + sg * 8;
-        if (gy >= H || gx >= W) continue;
-        const int o = (row + se.top) * kBitEWW + 1 + (sg >> 2), sh = (sg & 3) * 8;
-        const uint32_t db = (d[o] >> sh) & 0xff;
-        const size_t p = (size_t)gy * W + gx;
-        uint32_t out[8];
-        if (gx + 8 <= W && (p & 3) == 0) {
-            if (seg_cn == 3) {
-                int c0[12], c1[12];
-                unpack12(*reinterpret_cast<const Px4*>(seg + 3 * p), c0);
-                unpack12(*reinterpret_cast<const Px4*>(seg + 3 * p + 12), c1);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    out[k] = ((db >> k) & 1) ? (uint32_t)gray_u8(c0[3 * k], c0[3 * k + 1], c0[3 * k + 2]) : 0u;
-                    out[4 + k] = ((db >> (4 + k)) & 1) ? (uint32_t)gray_u8(c1[3 * k], c1[3 * k + 1], c1[3 * k + 2]) : 0u;
-                }
-            } else {
-                const uint32_t s0 = *reinterpret_cast<const uint32_t*>(seg + p), s1 = *reinterpret_cast<const uint32_t*>(seg + p + 4);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    out[k] = ((db >> k) & 1) ? ((s0 >> (8 * k)) & 0xffu) : 0u;
-                    out[4 + k] = ((db >> (4 + k)) & 1) ? ((s1 >> (8 * k)) & 0xffu) : 0u;
-                }
-            }
-            *reinterpret_cast<uint32_t*>(alpha + p) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
-            *reinterpret_cast<uint32_t*>(alpha + p + 4) = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
-        } else {
-            for (int k = 0; k < 8 && gx + k < W; k++) {
-                const size_t q = p + k;
-                const int sv = seg_cn == 3 ? gray_u8(seg[3 * q], seg[3 * q + 1], seg[3 * q + 2]) : seg[q];
-                alpha[q] = ((db >> k) & 1) ? (uint8_t)sv : 0;
-            }
-        }
     }
 }
 
@@ -602,80 +554,150 @@ extern "C" int usc_trimap_withbg_u8(const uint8_t* mask, const uint8_t* img, con
 // background fusion + difference mask
 // --------------------------------------------------------------------------------------------
 
-// Pointwise half: fused background and the thresholded grey difference, 4 pixels per lane.
-__global__ __launch_bounds__(256) void bgdiff_point_kernel(const uint8_t* __restrict__ frame, const uint8_t* __restrict__ bg_i,
-                                                           const uint8_t* __restrict__ bg_always, float beta, float beta1, int thr,
-                                                           size_t n, uint8_t* __restrict__ out_bg, uint8_t* __restrict__ diff) {
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += (size_t)gridDim.x * blockDim.x) {
-        size_t i0 = q * 4;
-        if (i0 + 4 <= n) {
+// Background fusion, difference threshold, 4x4-ellipse dilation x2 and the gate (bg_offline.py:150-160) in ONE launch (rounds 1-2 ran a
+// pointwise kernel that wrote a 1 byte / pixel difference image and a tile kernel that read it back): a workgroup owns 16 rows x 248 pixels.
+// It loads 22 rows x 256 pixels (halo: 4 rows / pixels before, 2 after - the reach of the 4x4 ellipse applied twice) of frame, bg_i
+// and bg_always as 12-byte groups (lane l of a wave = pixels 4l .. 4l + 3 of the row: 768 contiguous bytes per wave and image),
+// computes the fused background and the thresholded grey difference in registers, writes the background of its core pixels,
+// packs the 4 difference bits of every lane into 32-pixel words with three lane exchanges, dilates the bit tile in LDS and
+// finishes alpha = gray(seg) where the dilation reached.  The 1 byte / pixel difference image never exists.
+constexpr int kFgRows = 16, kFgCoreLanes = 62, kFgEWW = 8, kFgThreads = 256;
+
+__device__ __forceinline__ int fuse_bg_px(int bi, int ba, bool has_always, float beta, float beta1) {
+    if (!has_always) return bi;
+    const float p0 = (float)bi * beta;
+    const float p1 = beta1 * (float)ba;
+    return (int)(p0 + p1);
+}
+
+__global__ __launch_bounds__(kFgThreads) void bgdiff_gate_kernel(const uint8_t* __restrict__ frame, const uint8_t* __restrict__ bg_i,
+                                                                 const uint8_t* __restrict__ bg_always, float beta, float beta1, int thr,
+                                                                 const uint8_t* __restrict__ seg, int seg_cn, int H, int W,
+                                                                 uint8_t* __restrict__ out_bg, uint8_t* __restrict__ alpha, BitSE se, int iters) {
+    __shared__ uint32_t lds[3 * (kFgRows + 2 * kMaxK) * kFgEWW];
+    const int ER = kFgRows + se.top + se.bottom;
+    const int plane = ER * kFgEWW;
+    uint32_t *d = lds, *d2 = lds + plane, *inimg = lds + 2 * plane, *unused = nullptr, *unused2 = nullptr;
+    const int y0 = blockIdx.y * kFgRows, x0 = blockIdx.x * (kFgCoreLanes * 4);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
+    const int gx0 = x0 - 4 + 4 * lane;                          // first pixel of this lane's group (may be < 0 in the first tile)
+    const bool core_lane = lane >= 1 && lane <= kFgCoreLanes;
+    const bool has_always = bg_always != nullptr;
+    // Every wave owns the rows r = wave, wave + 4, ...: all of their 12-byte loads are issued before the first is used (one
+    // memory round trip per wave instead of one per row: at 2 workgroups per CU nothing else would hide the latency).
+    constexpr int kRowsPerWave = (kFgRows + 6 + 3) / 4;        // ER = 16 + 4 + 2 rows (the 4x4 ellipse applied twice): checked by the host
+    Px4 F[kRowsPerWave], BI[kRowsPerWave], BA[kRowsPerWave];
+    bool fast[kRowsPerWave];
+#pragma unroll
+    for (int j = 0; j < kRowsPerWave; j++) {
+        const int r = wave + nwaves * j, gy = y0 - se.top + r;
+        const size_t p = (size_t)gy * W + gx0;
+        fast[j] = r < ER && gy >= 0 && gy < H && gx0 >= 0 && gx0 + 4 <= W && (p & 3) == 0;
+        if (fast[j]) {
+            F[j] = *reinterpret_cast<const Px4*>(frame + 3 * p);
+            BI[j] = *reinterpret_cast<const Px4*>(bg_i + 3 * p);
+            if (has_always) BA[j] = *reinterpret_cast<const Px4*>(bg_always + 3 * p);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kRowsPerWave; j++) {
+        const int r = wave + nwaves * j;
+        if (r >= ER) continue;
+        const int gy = y0 - se.top + r;
+        uint32_t nib = 0, inb = 0;
+        const bool core = core_lane && gy >= y0 && gy < y0 + kFgRows;
+        if (fast[j]) {
+            const size_t p = (size_t)gy * W + gx0;
             int f[12], bi[12], ba[12], o[12];
-            unpack12(*reinterpret_cast<const Px4*>(frame + 3 * i0), f);
-            unpack12(*reinterpret_cast<const Px4*>(bg_i + 3 * i0), bi);
-            if (bg_always) unpack12(*reinterpret_cast<const Px4*>(bg_always + 3 * i0), ba);
-            uint32_t m = 0;
+            unpack12(F[j], f);
+            unpack12(BI[j], bi);
+            if (has_always) unpack12(BA[j], ba);
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
-                int d[3];
+            for (int q = 0; q < 4; q++) {
+                int dd[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    int k = 3 * p + c;
-                    int b;
-                    if (bg_always) {
-                        float p0 = (float)bi[k] * beta;
-                        float p1 = beta1 * (float)ba[k];
-                        b = (int)(p0 + p1);
-                    } else b = bi[k];
+                    const int k = 3 * q + c;
+                    const int b = fuse_bg_px(bi[k], has_always ? ba[k] : 0, has_always, beta, beta1);
                     o[k] = b;
-                    d[c] = abs(f[k] - b);
+                    dd[c] = abs(f[k] - b);
                 }
-                int g = gray_u8(d[0], d[1], d[2]);
+                int g = gray_u8(dd[0], dd[1], dd[2]);
                 if (g > thr) g = 255;
-                m |= (uint32_t)g << (8 * p);
+                nib |= (uint32_t)(g == 255) << q;
             }
-            *reinterpret_cast<Px4*>(out_bg + 3 * i0) = pack12(o);
-            *reinterpret_cast<uint32_t*>(diff + i0) = m;
-        } else {
-            for (size_t i = i0; i < n; i++) {
-                int d[3];
+            inb = 0xf;
+            if (core) *reinterpret_cast<Px4*>(out_bg + 3 * p) = pack12(o);
+        } else if (gy >= 0 && gy < H && gx0 + 3 >= 0 && gx0 < W) {
+            for (int q = 0; q < 4; q++) {
+                const int gx = gx0 + q;
+                if (gx < 0 || gx >= W) continue;
+                const size_t i = (size_t)gy * W + gx;
+                int dd[3];
                 for (int c = 0; c < 3; c++) {
-                    int b;
-                    if (bg_always) {
-                        float p0 = (float)bg_i[3 * i + c] * beta;
-                        float p1 = beta1 * (float)bg_always[3 * i + c];
-                        b = (int)(p0 + p1);
-                    } else b = bg_i[3 * i + c];
-                    out_bg[3 * i + c] = (uint8_t)b;
-                    d[c] = abs((int)frame[3 * i + c] - b);
+                    const int b = fuse_bg_px(bg_i[3 * i + c], has_always ? bg_always[3 * i + c] : 0, has_always, beta, beta1);
+                    if (core) out_bg[3 * i + c] = (uint8_t)b;
+                    dd[c] = abs((int)frame[3 * i + c] - b);
                 }
-                int g = gray_u8(d[0], d[1], d[2]);
-                diff[i] = (uint8_t)(g > thr ? 255 : g);
+                int g = gray_u8(dd[0], dd[1], dd[2]);
+                if (g > thr) g = 255;
+                nib |= (uint32_t)(g == 255) << q;
+                inb |= 1u << q;
+            }
+        }
+        uint32_t vd = nib << (4 * (lane & 7)), vi = inb << (4 * (lane & 7));
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) { vd |= __shfl_xor(vd, m, kWave); vi |= __shfl_xor(vi, m, kWave); }
+        if ((lane & 7) == 0) { d[r * kFgEWW + (lane >> 3)] = vd; inimg[r * kFgEWW + (lane >> 3)] = vi; }
+    }
+    __syncthreads();
+    bit_morph_passes<false, kFgEWW>(d, d2, unused, unused2, inimg, ER, se, iters);
+    if (!core_lane) return;
+    for (int r = se.top + wave; r < se.top + kFgRows; r += nwaves) {
+        const int gy = y0 - se.top + r;
+        if (gy >= H || gx0 >= W) continue;
+        const uint32_t db = (d[r * kFgEWW + (lane >> 3)] >> (4 * (lane & 7))) & 0xf;
+        const size_t p = (size_t)gy * W + gx0;
+        if (gx0 + 4 <= W && (p & 3) == 0) {
+            uint32_t out = 0;
+            if (seg_cn == 3) {
+                int c0[12];
+                unpack12(*reinterpret_cast<const Px4*>(seg + 3 * p), c0);
+#pragma unroll
+                for (int k = 0; k < 4; k++) out |= (((db >> k) & 1) ? (uint32_t)gray_u8(c0[3 * k], c0[3 * k + 1], c0[3 * k + 2]) : 0u) << (8 * k);
+            } else {
+                const uint32_t s0 = *reinterpret_cast<const uint32_t*>(seg + p);
+#pragma unroll
+                for (int k = 0; k < 4; k++) out |= (((db >> k) & 1) ? ((s0 >> (8 * k)) & 0xffu) : 0u) << (8 * k);
+            }
+            *reinterpret_cast<uint32_t*>(alpha + p) = out;
+        } else {
+            for (int k = 0; k < 4 && gx0 + k < W; k++) {
+                const size_t q = p + k;
+                const int sv = seg_cn == 3 ? gray_u8(seg[3 * q], seg[3 * q + 1], seg[3 * q + 2]) : seg[q];
+                alpha[q] = ((db >> k) & 1) ? (uint8_t)sv : 0;
             }
         }
     }
 }
 
-extern "C" size_t usc_bgdiff_ws_bytes(int H, int W) { return (((size_t)H * W) + 255) & ~(size_t)255; }
+extern "C" size_t usc_bgdiff_ws_bytes(int, int) { return 0; }            // (kept in the ABI: the fused kernel needs no scratch)
 
 extern "C" int usc_bgdiff_mask_u8(const uint8_t* frame, const uint8_t* bg_i, const uint8_t* bg_always,
                                   const uint8_t* seg, int seg_cn, double beta, int thr, int H, int W,
                                   uint8_t* out_bg, uint8_t* out_alpha, void* ws, size_t ws_bytes, usc_stream_t stream) {
     if (!frame || !bg_i || !seg || !out_bg || !out_alpha || H <= 0 || W <= 0) return fail(USC_E_ARG, "usc_bgdiff_mask_u8: bad argument");
     if (seg_cn != 1 && seg_cn != 3) return fail(USC_E_ARG, "usc_bgdiff_mask_u8: seg_cn %d", seg_cn);
-    size_t n = (size_t)H * W;
-    if (!ws || ws_bytes < n) return fail(USC_E_WORKSPACE, "usc_bgdiff_mask_u8: workspace %zu < %zu", ws_bytes, n);
+    if (too_big(H, W)) return fail(USC_E_UNSUPPORTED, "usc_bgdiff_mask_u8: image too large");
     hipStream_t st = (hipStream_t)stream;
-    uint8_t* diff = (uint8_t*)ws;
+    (void)ws; (void)ws_bytes;                                              // (the 1 byte / pixel difference image of the two-kernel form is gone)
     // `1 - beta` is formed in double by the reference and only then meets the float32 image.
-    hipLaunchKernelGGL(bgdiff_point_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, st,
-                       frame, bg_i, bg_always, (float)beta, (float)(1 - beta), thr, n, out_bg, diff);
-    int rc = check_launch("bgdiff_point_kernel");
-    if (rc) return rc;
     BitSE se = make_bit_se(4, 2);
-    size_t lds = 3 * (size_t)(kBitH + se.top + se.bottom) * kBitEWW * sizeof(uint32_t);
-    dim3 grid((W + kBitWW * 32 - 1) / (kBitWW * 32), (H + kBitH - 1) / kBitH);
-    hipLaunchKernelGGL(gate_kernel, grid, dim3(kBitThreads), lds, st, diff, H, W, seg, seg_cn, out_alpha, se, 2);
-    return check_launch("gate_kernel");
+    if (se.top + se.bottom != 6 || se.top > 4) return fail(USC_E_UNSUPPORTED, "usc_bgdiff_mask_u8: structuring element reach");
+    dim3 grid((W + kFgCoreLanes * 4 - 1) / (kFgCoreLanes * 4), (H + kFgRows - 1) / kFgRows);
+    hipLaunchKernelGGL(bgdiff_gate_kernel, grid, dim3(kFgThreads), 0, st, frame, bg_i, bg_always, (float)beta, (float)(1 - beta), thr, seg, seg_cn,
+                       H, W, out_bg, out_alpha, se, 2);
+    return check_launch("bgdiff_gate_kernel");
 }
 
 // --------------------------------------------------------------------------------------------

@@ -107,50 +107,87 @@ __global__ __launch_bounds__(256) void seg_pre_kernel(const uint8_t* __restrict_
     }
 }
 
-// torch upsample_bilinear2d (align_corners = True): src = dst * (in-1)/(out-1) in float.
-__global__ __launch_bounds__(256) void seg_up_kernel(const float* __restrict__ logits, int C, int Cbuf, int lh, int lw,
-                                                     float* __restrict__ up, int oh, int ow, float rh, float rw) {
-    const int n = oh * ow * C;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int c = i % C, p = i / C;
-        const int y = p / ow, x = p - y * ow;
-        const float h1r = rh * y, w1r = rw * x;
-        const int h1 = (int)h1r, w1 = (int)w1r;
-        const int h1p = h1 < lh - 1 ? 1 : 0, w1p = w1 < lw - 1 ? 1 : 0;
-        const float h1l = h1r - h1, h0l = 1.f - h1l, w1l = w1r - w1, w0l = 1.f - w1l;
-        const float v00 = logits[((size_t)h1 * lw + w1) * Cbuf + c], v01 = logits[((size_t)h1 * lw + w1 + w1p) * Cbuf + c];
-        const float v10 = logits[((size_t)(h1 + h1p) * lw + w1) * Cbuf + c], v11 = logits[((size_t)(h1 + h1p) * lw + w1 + w1p) * Cbuf + c];
-        const float top = w0l * v00 + w1l * v01, bot = w0l * v10 + w1l * v11;
-        up[i] = h0l * top + h1l * bot;
-    }
+// torch upsample_bilinear2d (align_corners = True) of class c at (y, x) of the (in_h, in_w) network-input grid: src = dst * (in - 1) /
+// (out - 1) in float, weights and sums exactly as ATen's CPU kernel forms them.
+__device__ __forceinline__ float up_ac_value(const float* __restrict__ logits, int Cbuf, int lh, int lw, int c, int y, int x, float rh, float rw) {
+    const float h1r = rh * y, w1r = rw * x;
+    const int h1 = (int)h1r, w1 = (int)w1r;
+    const int h1p = h1 < lh - 1 ? 1 : 0, w1p = w1 < lw - 1 ? 1 : 0;
+    const float h1l = h1r - h1, h0l = 1.f - h1l, w1l = w1r - w1, w0l = 1.f - w1l;
+    const float v00 = logits[((size_t)h1 * lw + w1) * Cbuf + c], v01 = logits[((size_t)h1 * lw + w1 + w1p) * Cbuf + c];
+    const float v10 = logits[((size_t)(h1 + h1p) * lw + w1) * Cbuf + c], v11 = logits[((size_t)(h1 + h1p) * lw + w1 + w1p) * Cbuf + c];
+    const float top = w0l * v00 + w1l * v01, bot = w0l * v10 + w1l * v11;
+    return h0l * top + h1l * bot;
 }
 
+// The whole post stage in one launch (agent_human.py:58-73, 296-310): a workgroup owns 16 x 64 frame pixels.  It finds the box of
+// network-input pixels its inverse-warp taps touch, evaluates the align_corners upsample of the C class logits for that box into
+// LDS (at 1080p: ~6 x 18 pixels x 20 classes = 8.6 KB, pixel stride 80 B: the 16 lanes of a ds_read_b128 phase hit 64 distinct
+// banks), then every lane warps its 4 pixels from LDS (float bilinear, zero border) and takes the argmax.  Rounds 1-2 wrote the
+// upsampled 473 x 473 x 20 tensor (17.9 MB) to HBM in a first kernel and gathered from it in a second (62 MB fetched per frame).
+// When the box does not fit the LDS budget (frames smaller than the network input are magnified) the taps are evaluated on the fly.
+constexpr int kSpTileH = 16, kSpGroups = 16, kSpCap = 320;
+
 template <int C>
-__global__ __launch_bounds__(256) void seg_warp_argmax_kernel(const float* __restrict__ up, int in_h, int in_w, Affine A,
-                                                              uint8_t* __restrict__ out, int H, int W) {
-    const uint32_t n = (uint32_t)H * (uint32_t)W;
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += gridDim.x * blockDim.x) {
-        const uint32_t i0 = q * 4;
-        uint32_t y = i0 / (uint32_t)W, x = i0 - y * (uint32_t)W;
-        const int cnt = (int)min(4u, n - i0);
-        uint32_t packed = 0;
-        for (int k = 0; k < cnt; k++) {
-            int sx, sy, fx, fy;
-            warp_coord(A, (int)x, (int)y, sx, sy, fx, fy);
-            const float ax = fx * (1.f / 32), ay = fy * (1.f / 32);
-            const float wx0 = 1.f - ax, wx1 = ax, wy0 = 1.f - ay, wy1 = ay;
-            const float w0 = wy0 * wx0, w1 = wy0 * wx1, w2 = wy1 * wx0, w3 = wy1 * wx1;
-            const bool in0 = sx >= 0 && sx < in_w, in1 = sx + 1 >= 0 && sx + 1 < in_w;
-            const bool jn0 = sy >= 0 && sy < in_h, jn1 = sy + 1 >= 0 && sy + 1 < in_h;
-            const int cx0 = min(max(sx, 0), in_w - 1), cx1 = min(max(sx + 1, 0), in_w - 1);
-            const int cy0 = min(max(sy, 0), in_h - 1), cy1 = min(max(sy + 1, 0), in_h - 1);
-            const float4* p00 = reinterpret_cast<const float4*>(up + ((size_t)cy0 * in_w + cx0) * C);
-            const float4* p01 = reinterpret_cast<const float4*>(up + ((size_t)cy0 * in_w + cx1) * C);
-            const float4* p10 = reinterpret_cast<const float4*>(up + ((size_t)cy1 * in_w + cx0) * C);
-            const float4* p11 = reinterpret_cast<const float4*>(up + ((size_t)cy1 * in_w + cx1) * C);
-            const float m00 = (in0 && jn0) ? 1.f : 0.f, m01 = (in1 && jn0) ? 1.f : 0.f, m10 = (in0 && jn1) ? 1.f : 0.f, m11 = (in1 && jn1) ? 1.f : 0.f;
-            float best = 0.f;
-            int besti = 0;
+__global__ __launch_bounds__(256) void seg_post_fused_kernel(const float* __restrict__ logits, int Cbuf, int lh, int lw, int in_h, int in_w,
+                                                             float rh, float rw, Affine A, uint8_t* __restrict__ out, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float s_up[kSpCap * C];
+    __shared__ int s_box[4];
+    const int t = threadIdx.x;
+    const int y = blockIdx.y * kSpTileH + (t >> 4), x0 = blockIdx.x * (kSpGroups * 4) + (t & 15) * 4;
+    if (t < 4) s_box[t] = (t & 1) ? -0x7fffffff : 0x7fffffff;
+    __syncthreads();
+    int sx[4], sy[4], fx[4], fy[4];
+    int bx0 = 0x7fffffff, bx1 = -0x7fffffff, by0 = 0x7fffffff, by1 = -0x7fffffff;
+    const int cnt = (y < H && x0 < W) ? min(4, W - x0) : 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        sx[k] = sy[k] = fx[k] = fy[k] = 0;
+        if (k < cnt) {
+            warp_coord(A, x0 + k, y, sx[k], sy[k], fx[k], fy[k]);
+            bx0 = min(bx0, min(max(sx[k], 0), in_w - 1)); bx1 = max(bx1, min(max(sx[k] + 1, 0), in_w - 1));
+            by0 = min(by0, min(max(sy[k], 0), in_h - 1)); by1 = max(by1, min(max(sy[k] + 1, 0), in_h - 1));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, off, 64)); bx1 = max(bx1, __shfl_xor(bx1, off, 64));
+        by0 = min(by0, __shfl_xor(by0, off, 64)); by1 = max(by1, __shfl_xor(by1, off, 64));
+    }
+    if ((t & 63) == 0) { atomicMin(&s_box[0], bx0); atomicMax(&s_box[1], bx1); atomicMin(&s_box[2], by0); atomicMax(&s_box[3], by1); }
+    __syncthreads();
+    bx0 = s_box[0]; bx1 = s_box[1]; by0 = s_box[2]; by1 = s_box[3];
+    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+    const bool staged = bx1 >= bx0 && by1 >= by0 && (long long)bw * bh <= kSpCap;
+    if (staged) {
+        const int total = bw * bh * C;
+        for (int idx = t; idx < total; idx += 256) {
+            const int c = idx % C, p = idx / C;
+            const int py = p / bw, px = p - py * bw;
+            s_up[idx] = up_ac_value(logits, Cbuf, lh, lw, c, by0 + py, bx0 + px, rh, rw);
+        }
+    }
+    __syncthreads();
+    if (cnt == 0) return;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (k >= cnt) continue;
+        const float ax = fx[k] * (1.f / 32), ay = fy[k] * (1.f / 32);
+        const float wx0 = 1.f - ax, wx1 = ax, wy0 = 1.f - ay, wy1 = ay;
+        const float w0 = wy0 * wx0, w1 = wy0 * wx1, w2 = wy1 * wx0, w3 = wy1 * wx1;
+        const bool in0 = sx[k] >= 0 && sx[k] < in_w, in1 = sx[k] + 1 >= 0 && sx[k] + 1 < in_w;
+        const bool jn0 = sy[k] >= 0 && sy[k] < in_h, jn1 = sy[k] + 1 >= 0 && sy[k] + 1 < in_h;
+        const int cx0 = min(max(sx[k], 0), in_w - 1), cx1 = min(max(sx[k] + 1, 0), in_w - 1);
+        const int cy0 = min(max(sy[k], 0), in_h - 1), cy1 = min(max(sy[k] + 1, 0), in_h - 1);
+        const bool m00 = in0 && jn0, m01 = in1 && jn0, m10 = in0 && jn1, m11 = in1 && jn1;
+        float best = 0.f;
+        int besti = 0;
+        if (staged) {
+            const float4* p00 = reinterpret_cast<const float4*>(s_up + ((cy0 - by0) * bw + (cx0 - bx0)) * C);
+            const float4* p01 = reinterpret_cast<const float4*>(s_up + ((cy0 - by0) * bw + (cx1 - bx0)) * C);
+            const float4* p10 = reinterpret_cast<const float4*>(s_up + ((cy1 - by0) * bw + (cx0 - bx0)) * C);
+            const float4* p11 = reinterpret_cast<const float4*>(s_up + ((cy1 - by0) * bw + (cx1 - bx0)) * C);
 #pragma unroll
             for (int c4 = 0; c4 < C / 4; c4++) {
                 const float4 a = p00[c4], b = p01[c4], c = p10[c4], d = p11[c4];
@@ -158,8 +195,7 @@ __global__ __launch_bounds__(256) void seg_warp_argmax_kernel(const float* __res
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     // out-of-image taps read the border value 0 (select, not multiply: -0 / NaN safe)
-                    const float t0 = m00 != 0.f ? va[e] : 0.f, t1 = m01 != 0.f ? vb[e] : 0.f;
-                    const float t2 = m10 != 0.f ? vc[e] : 0.f, t3 = m11 != 0.f ? vd[e] : 0.f;
+                    const float t0 = m00 ? va[e] : 0.f, t1 = m01 ? vb[e] : 0.f, t2 = m10 ? vc[e] : 0.f, t3 = m11 ? vd[e] : 0.f;
                     float r = t0 * w0;
                     r = r + t1 * w1;
                     r = r + t2 * w2;
@@ -168,12 +204,24 @@ __global__ __launch_bounds__(256) void seg_warp_argmax_kernel(const float* __res
                     if (ci == 0 || r > best) { best = r; besti = ci; }       // np.argmax: the first maximum wins
                 }
             }
-            packed |= (uint32_t)(besti > 0 ? 255 : 0) << (8 * k);
-            if (++x == (uint32_t)W) { x = 0; y++; }
+        } else {
+            for (int ci = 0; ci < C; ci++) {
+                const float t0 = m00 ? up_ac_value(logits, Cbuf, lh, lw, ci, cy0, cx0, rh, rw) : 0.f;
+                const float t1 = m01 ? up_ac_value(logits, Cbuf, lh, lw, ci, cy0, cx1, rh, rw) : 0.f;
+                const float t2 = m10 ? up_ac_value(logits, Cbuf, lh, lw, ci, cy1, cx0, rh, rw) : 0.f;
+                const float t3 = m11 ? up_ac_value(logits, Cbuf, lh, lw, ci, cy1, cx1, rh, rw) : 0.f;
+                float r = t0 * w0;
+                r = r + t1 * w1;
+                r = r + t2 * w2;
+                r = r + t3 * w3;
+                if (ci == 0 || r > best) { best = r; besti = ci; }
+            }
         }
-        if (cnt == 4) *reinterpret_cast<uint32_t*>(out + i0) = packed;
-        else for (int k = 0; k < cnt; k++) out[i0 + k] = (packed >> (8 * k)) & 0xff;
+        packed |= (uint32_t)(besti > 0 ? 255 : 0) << (8 * k);
     }
+    const size_t i0 = (size_t)y * W + x0;
+    if (cnt == 4 && (i0 & 3) == 0) *reinterpret_cast<uint32_t*>(out + i0) = packed;
+    else for (int k = 0; k < cnt; k++) out[i0 + k] = (packed >> (8 * k)) & 0xff;
 }
 
 // F.interpolate(mode='bilinear', align_corners=True) on NHWC float32, 4 channels per lane, written into channels
@@ -315,26 +363,23 @@ extern "C" int usc_humanseg_pre(const uint8_t* frame, int H, int W, int in_h, in
     return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "seg_pre_kernel launch failed");
 }
 
-extern "C" size_t usc_humanseg_post_ws_bytes(int C, int in_h, int in_w) { return (size_t)in_h * in_w * C * sizeof(float); }
+extern "C" size_t usc_humanseg_post_ws_bytes(int, int, int) { return 0; }      // (kept in the ABI: the fused kernel stages in LDS)
 
 extern "C" int usc_humanseg_post(const float* logits, int C, int Cbuf, int lh, int lw, int in_h, int in_w, int H, int W,
                                  uint8_t* out, void* ws, size_t ws_bytes, usc_stream_t stream) {
-    if (!logits || !out || !ws || lh <= 0 || lw <= 0 || H <= 0 || W <= 0 || in_h <= 1 || in_w <= 1 || Cbuf < C)
+    (void)ws; (void)ws_bytes;
+    if (!logits || !out || lh <= 0 || lw <= 0 || H <= 0 || W <= 0 || in_h <= 1 || in_w <= 1 || Cbuf < C)
         return seg_fail(USC_E_ARG, "usc_humanseg_post: bad argument");
     if (C != 20) return seg_fail(USC_E_UNSUPPORTED, "usc_humanseg_post: built for the 20 LIP classes");
-    if (ws_bytes < usc_humanseg_post_ws_bytes(C, in_h, in_w)) return seg_fail(USC_E_WORKSPACE, "usc_humanseg_post: workspace too small");
     if ((long long)H * W >= (1ll << 31)) return seg_fail(USC_E_UNSUPPORTED, "usc_humanseg_post: image too large");
-    hipStream_t st = (hipStream_t)stream;
-    float* up = (float*)ws;
     const float rh = (float)(lh - 1) / (in_h - 1), rw = (float)(lw - 1) / (in_w - 1);
-    hipLaunchKernelGGL(seg_up_kernel, dim3(grid_for((long long)in_h * in_w * C, 256)), dim3(256), 0, st, logits, C, Cbuf, lh, lw, up, in_h, in_w, rh, rw);
-    if (hipGetLastError() != hipSuccess) return seg_fail(USC_E_LAUNCH, "seg_up_kernel launch failed");
     double M[6];
     Affine A;
     usc_humanseg_affine(W, H, in_w, in_h, 1, M);
     invert_affine(M, A.m);
-    hipLaunchKernelGGL(seg_warp_argmax_kernel<20>, dim3(grid_for(((long long)H * W + 3) / 4, 256)), dim3(256), 0, st, up, in_h, in_w, A, out, H, W);
-    return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "seg_warp_argmax_kernel launch failed");
+    const dim3 grid((W + kSpGroups * 4 - 1) / (kSpGroups * 4), (H + kSpTileH - 1) / kSpTileH);
+    hipLaunchKernelGGL(seg_post_fused_kernel<20>, grid, dim3(256), 0, (hipStream_t)stream, logits, Cbuf, lh, lw, in_h, in_w, rh, rw, A, out, H, W);
+    return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "seg_post_fused_kernel launch failed");
 }
 
 extern "C" int usc_upsample_ac_nhwc_batch_f32(const float* src, int sh, int sw, int C, float* dst, int dh, int dw, int ld, int c0,

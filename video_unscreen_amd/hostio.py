@@ -27,8 +27,14 @@ class HostFrameIO:
     alpha_host[i] / fg_host[i] are pinned CPU tensors that receive frame i's outputs.  depth must exceed the number of
     frames the pipeline holds in flight (run() looks two segmentation groups + two frames ahead)."""
 
-    def __init__(self, pipe, depth=None):
+    def __init__(self, pipe, depth=None, down_mode="own"):
+        """down_mode: how the two device -> host copies of a frame are enqueued (tools/dev/hostio_ablate.py measures them):
+        "own" = on the download stream behind the compute event; "primed" = the same with a 64-byte host -> device copy in front of
+        them; "shared" = on the upload stream (one copy stream for both directions)."""
         self.pipe = pipe
+        self.down_mode = down_mode
+        self._tiny_h = torch.zeros(64, dtype=torch.uint8).pin_memory()
+        self._tiny_d = torch.zeros(64, dtype=torch.uint8, device=pipe.device)
         dev = pipe.device
         H, W = pipe.H, pipe.W
         self.depth = depth if depth is not None else 2 * pipe.seg_batch + 6
@@ -79,16 +85,19 @@ class HostFrameIO:
             ev = torch.cuda.Event()
             ev.record(main)
             self.done[(base + n) % self.depth] = ev  # frames are consumed in order: the slot input n was staged in
-            self.down.wait_event(ev)
+            down = self.up if self.down_mode == "shared" else self.down
+            down.wait_event(ev)
             if target is not None:
                 a_h, f_h, token = target(n)
             else:
                 a_h, f_h, token = alpha_host[n], fg_host[n], None
-            with torch.cuda.stream(self.down):
+            with torch.cuda.stream(down):
+                if self.down_mode == "primed":
+                    self._tiny_d.copy_(self._tiny_h, non_blocking=True)
                 a_h.copy_(out["alpha"], non_blocking=True)
                 f_h.copy_(out["fg"], non_blocking=True)
                 dn = torch.cuda.Event()
-                dn.record(self.down)
+                dn.record(down)
             self.pipe.note_output_consumed(out, dn)
             self._last_down = dn
             if on_downloaded is not None:
