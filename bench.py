@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--device-resident", action="store_true",
                     help="time the loop with inputs already in HBM and outputs left there (round 1's figure) as `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-single-thread", action="store_true", help="skip the one-frame single-thread leg of the CPU baseline")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-spin-up", action="store_true", help="skip the untimed clock spin-up in front of the warm-up frames (counter-collecting profile runs)")
     ap.add_argument("--sync-loop", action="store_true", help="use the synchronous step() instead of the pipelined run()")
@@ -124,8 +125,39 @@ def kernel_table(pipe, sample, H, W):
     return rows, t_net, t_graph
 
 
-def cpu_baseline(cfg, pipe, clip_cpu_frames, bg_always, nframes):
-    """The CPU oracle (C restatement, 1 thread) + the same networks on torch-CPU, on a bounded sample."""
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def usable_cpus():
+    """CPUs this process may really use: its affinity mask, capped by the cgroup CPU quota when there is one (a GPU box hands a
+    rank a share of the host: 128 torch threads on a 16-CPU share run slower than 16)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_baseline(cfg, pipe, clip_cpu_frames, bg_always, nframes, threads=None):
+    """The CPU oracle (C restatement, 1 thread) + the same networks on torch-CPU with `threads` threads (None = torch's default = all
+    cores the process may use), on a bounded sample; every call restarts the alpha_pre chain."""
     import __graft_entry__ as ge
     import oracle
     oracle.build()
@@ -134,12 +166,18 @@ def cpu_baseline(cfg, pipe, clip_cpu_frames, bg_always, nframes):
         from video_unscreen_amd.binseg.schp_net import SchpNetTorch
         seg_cpu = SchpNetTorch(pipe.seg_agent.state_dict)
     pipe.cpu_net()
-    alpha_pre = None
-    t0 = time.time()
-    for f in clip_cpu_frames[:nframes]:
-        o = ge.oracle_frame(oracle, cfg, pipe, f["frame"], f["seg"], f["bg"], bg_always, alpha_pre, seg_net_cpu=seg_cpu)
-        alpha_pre = o["alpha"]
-    dt = time.time() - t0
+    saved = torch.get_num_threads()
+    if threads is not None:
+        torch.set_num_threads(int(threads))
+    try:
+        alpha_pre = None
+        t0 = time.time()
+        for f in clip_cpu_frames[:nframes]:
+            o = ge.oracle_frame(oracle, cfg, pipe, f["frame"], f["seg"], f["bg"], bg_always, alpha_pre, seg_net_cpu=seg_cpu)
+            alpha_pre = o["alpha"]
+        dt = time.time() - t0
+    finally:
+        torch.set_num_threads(saved)
     return nframes / dt, dt
 
 
@@ -212,6 +250,30 @@ def other_mode(args, rank, world, dev):
         dist.destroy_process_group()
 
 
+def bind_near_gpu(local):
+    """Multi-rank runs: keep this rank's host threads (and so its pinned staging memory, first-touched by them) on the NUMA node its
+    GPU's PCIe root hangs off - uploads and downloads then do not cross the socket interconnect.  Best effort: any missing piece
+    (no NUMA information, a cpuset that excludes the node) leaves the affinity as it is.  Returns a short description."""
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        dom, bus, devid = getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id
+        sysdev = f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{devid:02x}.0"
+        node = int(open(os.path.join(sysdev, "numa_node")).read())
+        if node < 0:
+            return "no NUMA node reported"
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return f"node {node}: outside this process's cpuset"
+        os.sched_setaffinity(0, cpus)
+        return f"node {node}: {len(cpus)} cpus"
+    except Exception as e:      # noqa: BLE001 - placement is an optimisation, never a reason to fail
+        return f"unchanged ({type(e).__name__})"
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves - one child `torch.distributed.run`
     (the command line the driver uses), one process per GPU - and pass rank 0's JSON line through.  This process has made no GPU
@@ -256,6 +318,7 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    numa = bind_near_gpu(local) if world > 1 and not os.environ.get("USC_BENCH_SHARE_GPU") else "not bound (single rank)"
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -429,7 +492,7 @@ def main():
                        "object_filter": ("host worker threads (border-following C++ in libunscreen_hip.so; same masks as the device kernels)"
                                          if args.object_filter == "host" and not args.sync_loop else
                                          "device (label-based HIP kernels inside the foreground's bounding box, usc_objects.hip): no CPU stage in the loop"),
-                       "weights": "keyed-deterministic synthetic (no checkpoint offline)"},
+                       "weights": "keyed-deterministic synthetic (no checkpoint offline)", "host_numa_rank0": numa},
         }
         if host_io:
             nb = H * W
@@ -488,12 +551,17 @@ def main():
             for t in range(args.cpu_frames):
                 f = clip_cpu.frame(t)
                 cf.append({k: f[k].numpy() for k in ("frame", "seg", "bg")})
-            cpu_fps, cpu_dt = cpu_baseline(cfg, pipe, cf, clip_cpu.bg_always.numpy(), args.cpu_frames)
-            result["cpu_baseline"] = {"value": round(cpu_fps, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
+            nthr = min(torch.get_num_threads(), usable_cpus())
+            cpu_fps, cpu_dt = cpu_baseline(cfg, pipe, cf, clip_cpu.bg_always.numpy(), args.cpu_frames, threads=nthr)
+            result["cpu_baseline"] = {"value": round(cpu_fps, 4), "unit": "frames/s", "cores": nthr,
                                       "kind": "port",
                                       "sample": f"{args.cpu_frames} frames {W}x{H}: C oracle (1 thread) for the pixel stages + the same "
-                                                f"network(s) on torch-CPU ({torch.get_num_threads()} threads), {cpu_dt:.1f} s",
-                                      "host_cpus": os.cpu_count()}
+                                                f"network(s) on torch-CPU ({nthr} threads), {cpu_dt:.1f} s",
+                                      "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
+            if not args.no_cpu_single_thread:                # single-thread next to all-core (one frame: ~10 - 25 s)
+                fps1, dt1 = cpu_baseline(cfg, pipe, cf, clip_cpu.bg_always.numpy(), 1, threads=1)
+                result["cpu_baseline"]["single_thread"] = {"value": round(fps1, 4), "unit": "frames/s", "cores": 1,
+                                                           "sample": f"1 frame {W}x{H}, everything on one thread, {dt1:.1f} s"}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

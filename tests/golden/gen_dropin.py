@@ -68,6 +68,40 @@ def main():
     for name, (h, w) in (("land", (54, 96)), ("port", (96, 54)), ("sq", (50, 50))):
         out[f"sm_{name}"] = utils.build_score_map(h, w, go.CFG)
     out["sm_custom"] = utils.get_score_map((40, 70), (0.3, 0.8))
+    # ---- options of fgfuncs.py that no reference tool reaches ("dead-branch options"): is_pixel_inrange with
+    # long_side_input > 0 (both background forms), get_fg_naive, get_fg_with_colorremove (modifies its alpha), composite_fgbg(extend)
+    h, w = 54, 96
+    bg_color = np.array([60, 200, 60], np.uint8)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    near = rng.random((h, w)) < 0.4
+    img[near] = np.clip(bg_color.astype(int) + rng.integers(-4, 5, (int(near.sum()), 3)), 0, 255).astype(np.uint8)
+    bgimg = np.clip(img.astype(int) + rng.integers(-30, 31, img.shape), 0, 255).astype(np.uint8)
+    out["ir_img"], out["ir_bgimg"], out["ir_color"] = img, bgimg, bg_color
+    out["ir_color_L48"] = utils.is_pixel_inrange(img.copy(), bg_color.copy(), (10, 100, 180), long_side_input=48).astype(np.uint8)
+    out["ir_color_L144"] = utils.is_pixel_inrange(img.copy(), bg_color.copy(), (10, 100, 180), long_side_input=144).astype(np.uint8)
+    out["ir_img_L48"] = utils.is_pixel_inrange(img.copy(), bgimg.copy(), (20, 20, 120), long_side_input=48).astype(np.uint8)
+    alpha = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    out["fgn_alpha"], out["fgn_out"] = alpha, utils.get_fg_naive(img.copy(), alpha.copy())
+    a_arg = alpha.copy()
+    out["fgcr_out"] = utils.get_fg_with_colorremove(img.copy(), a_arg, bgimg.copy(), winsize=(10, 100, 120), long_side_input=48)
+    out["fgcr_alpha_after"] = a_arg
+    fg = rng.integers(0, 256, (40, 64, 3), dtype=np.uint8)
+    fa = rng.integers(0, 256, (40, 64), dtype=np.uint8)
+    for name, bshape in (("wide", (50, 120, 3)), ("tall", (90, 70, 3))):
+        cbg = rng.integers(0, 256, bshape, dtype=np.uint8)
+        out[f"comp_{name}_bg"] = cbg
+        out[f"comp_{name}_plain"] = utils.composite_fgbg(fg.copy(), fa.copy(), cbg.copy())
+        out[f"comp_{name}_extend"] = utils.composite_fgbg(fg.copy(), fa.copy(), cbg.copy(), extend=True)
+    out["comp_fg"], out["comp_alpha"] = fg, fa
+    # ---- index helpers: get_fgbox, remove_blackborder / add_blackborder
+    m = np.zeros((40, 60), np.uint8)
+    m[12:30, 20:41] = 255
+    out["box_mask"], out["box_out"] = m, np.array(utils.get_fgbox(m, 5), np.int64)
+    bb = np.zeros((30, 44, 3), np.uint8)
+    bb[4:25, 6:40] = rng.integers(1, 256, (21, 34, 3), dtype=np.uint8)
+    cropped, loc = utils.remove_blackborder(bb.copy())
+    out["bb_img"], out["bb_cropped"], out["bb_loc"] = bb, cropped, np.array(loc, np.int64)
+    out["bb_restored"] = utils.add_blackborder(cropped.copy(), (30, 44), loc)
     np.savez_compressed(os.path.join(HERE, "dropin.npz"), **out)
     rows = tool_imports()
     json.dump([list(r) for r in rows], open(os.path.join(HERE, "tool_imports.json"), "w"), indent=0)

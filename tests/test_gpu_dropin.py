@@ -70,3 +70,23 @@ def test_score_maps_vs_reference(z, cfg):
         got = build_score_map(h, w, cfg)
         assert got.dtype == np.float64 and np.array_equal(got, z[f"sm_{name}"])
     assert np.array_equal(get_score_map((40, 70), (0.3, 0.8)), z["sm_custom"])
+
+
+def test_fgfuncs_options_no_tool_reaches_vs_reference(z):
+    """is_pixel_inrange(long_side_input > 0) in both background forms, get_fg_naive, get_fg_with_colorremove (alpha modified in place),
+    composite_fgbg(extend=True): outputs of the reference's own functions (fgfuncs.py:9-81, 140-214)."""
+    from unscreen.utils import composite_fgbg, get_fg_naive, get_fg_with_colorremove, is_pixel_inrange
+    img, bgimg, color = z["ir_img"], z["ir_bgimg"], z["ir_color"]
+    for L in (48, 144):
+        got = is_pixel_inrange(img.copy(), color.copy(), (10, 100, 180), long_side_input=L)
+        assert got.dtype == bool and np.array_equal(got.astype(np.uint8), z[f"ir_color_L{L}"]), L
+    assert np.array_equal(is_pixel_inrange(img.copy(), bgimg.copy(), (20, 20, 120), long_side_input=48).astype(np.uint8), z["ir_img_L48"])
+    assert np.array_equal(get_fg_naive(img.copy(), z["fgn_alpha"].copy()), z["fgn_out"])
+    a = z["fgn_alpha"].copy()
+    assert np.array_equal(get_fg_with_colorremove(img.copy(), a, bgimg.copy(), winsize=(10, 100, 120), long_side_input=48), z["fgcr_out"])
+    assert np.array_equal(a, z["fgcr_alpha_after"]) and not np.array_equal(a, z["fgn_alpha"])
+    for name in ("wide", "tall"):
+        bg = z[f"comp_{name}_bg"]
+        assert np.array_equal(composite_fgbg(z["comp_fg"].copy(), z["comp_alpha"].copy(), bg.copy()), z[f"comp_{name}_plain"])
+        ext = composite_fgbg(z["comp_fg"].copy(), z["comp_alpha"].copy(), bg.copy(), extend=True)
+        assert ext.shape == z[f"comp_{name}_extend"].shape and np.array_equal(ext, z[f"comp_{name}_extend"]), name

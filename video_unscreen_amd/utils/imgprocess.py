@@ -82,6 +82,32 @@ def shift_fg(img, dx=0, dy=0):
     return to_host(nv.warp_affine(to_dev(img), M, img.shape[0], img.shape[1]))
 
 
+def remove_blackborder(img, location=None):
+    """Crop all-zero border rows / columns (reference imgprocess.py:195-232: every all-zero row or column COUNTS, wherever it is);
+    without a location -> (image, (top, left, bottom, right)), with one -> the cropped image.  Index bookkeeping only."""
+    h, w = img.shape[:2]
+    if location is not None:
+        t, left, b, r = location
+        return img[t:b, left:r]
+    zero_rows = int((img.reshape(h, -1).sum(axis=1) == 0).sum())
+    zero_cols = int((np.moveaxis(img, 1, 0).reshape(w, -1).sum(axis=1) == 0).sum())
+    t, left, b, r = zero_rows, zero_cols, h - zero_rows, w - zero_cols
+    if left >= r or t >= b:
+        return img, (0, 0, h, w)
+    return img[t:b, left:r], (t, left, b, r)
+
+
+def add_blackborder(img, ori_size, location):
+    """Inverse of remove_blackborder (reference imgprocess.py:235-260, including its `t == ori_w` comparison)."""
+    t, left, b, r = location
+    ori_h, ori_w = ori_size
+    if t == 0 and left == 0 and b == ori_h and t == ori_w:
+        return img
+    out = np.zeros((ori_h, ori_w, img.shape[-1]) if img.ndim == 3 else (ori_h, ori_w), np.uint8)
+    out[t:b, left:r] = img
+    return out
+
+
 def color_correct(img, alpha, bg_color, target_long_side=960, mean_exp=0.95):
     """Scale alpha by the (min-max normalised, repeatedly square-rooted) Lab a/b distance to the screen colour
     (reference imgprocess.py:263-300): three kernels, the data-dependent sqrt loop resolved on the device."""

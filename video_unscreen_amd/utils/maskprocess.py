@@ -18,6 +18,17 @@ def erode_mask(mask, kernelsize=5, iters=10):
     return to_host(nv.morph(to_dev(mask), kernelsize, iters, nv.ERODE))
 
 
+def get_fgbox(fgmask, padsize=5):
+    """Padded bounding box of mask > 0, in the reference's naming (left / right index ROWS, top / bottom index COLUMNS:
+    reference maskprocess.py:37-53)."""
+    h, w = fgmask.shape
+    x, y = np.where(fgmask > 0)
+    left, right, top, bottom = np.min(x), np.max(x), np.min(y), np.max(y)
+    left, right = max(left - padsize, 0), min(right + padsize, h)
+    top, bottom = max(top - padsize, 0), min(bottom + padsize, w)
+    return left, right, top, bottom
+
+
 def exist_foreground(mask, fg_exist_thr):
     """count(mask >= 128) > thr*h*w (reference maskprocess.py:56-60)."""
     h, w = mask.shape
