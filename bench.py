@@ -375,7 +375,7 @@ def main():
 
     # this rank's contiguous frame range (not timed).  Host boundary (default): each frame + its per-frame background (+ its
     # mask with --no-seg) sit in pinned host memory, and pinned host buffers receive alpha + fg.
-    from video_unscreen_amd.hostio import HostFrameIO
+    from video_unscreen_amd.hostio import HostFrameIO, pack_host_group, packed_outputs
     if not strong:
         lo, hi = shard_range((K + Wm) * world, rank, world)
     clip.gen.manual_seed(20260002 + 7919 * rank)
@@ -384,15 +384,13 @@ def main():
     frames, frames_h = [], []
     for t in range(lo, hi):
         f = clip.frame(t)
-        if host_io:
-            frames_h.append((f["frame"].cpu().pin_memory(), f["seg"].cpu().pin_memory() if seg_agent is None else None,
-                             f["bg"].cpu().pin_memory()))
+        if host_io:      # one page-locked buffer per frame, laid out like the upload staging slot: the group goes up with ONE copy
+            frames_h.append(pack_host_group(f["frame"].cpu(), f["bg"].cpu(), f["seg"].cpu() if seg_agent is None else None))
         if not host_io or (rank == 0 and t - lo < first + K):
             frames.append((f["frame"], f["seg"], f["bg"], bg_always))
     alpha_h = fg_h = io = None
     if host_io:
-        alpha_h = torch.empty((K, H, W), dtype=torch.uint8).pin_memory()
-        fg_h = torch.empty((K, H, W, 3), dtype=torch.uint8).pin_memory()
+        alpha_h, fg_h = packed_outputs(K, H, W)               # frame k's alpha and fg are neighbours: ONE download per frame
         io = HostFrameIO(pipe)
     torch.cuda.synchronize()
 

@@ -42,9 +42,10 @@ def main():
     for t in range(K):
         f = clip.frame(t)
         dev_frames.append((f["frame"], f["seg"] if seg_agent is None else None, f["bg"], bga))
-        host_frames.append((f["frame"].cpu().pin_memory(), f["seg"].cpu().pin_memory() if seg_agent is None else None, f["bg"].cpu().pin_memory()))
-    alpha_h = torch.empty((K, H, W), dtype=torch.uint8).pin_memory()
-    fg_h = torch.empty((K, H, W, 3), dtype=torch.uint8).pin_memory()
+        host_frames.append(hostio.pack_host_group(f["frame"].cpu(), f["bg"].cpu(), f["seg"].cpu() if seg_agent is None else None))
+    alpha_h, fg_h = hostio.packed_outputs(K, H, W)
+    alpha_s = torch.empty((K, H, W), dtype=torch.uint8).pin_memory()          # separate buffers: two downloads per frame (rounds 1 - 2)
+    fg_s = torch.empty((K, H, W, 3), dtype=torch.uint8).pin_memory()
 
     class NoCopyIO(hostio.HostFrameIO):
         """events + waits as HostFrameIO, the copies themselves left out (staging slots are pre-filled once)"""
@@ -112,6 +113,7 @@ def main():
         ("events + waits, no copies", lambda: pipe.run(nio.inputs(host_frames, bga), on_result=nio.collect())),
         ("up + down, primed", lambda: pipe.run(io_p.inputs(host_frames, bga), on_result=io_p.collect(alpha_h, fg_h))),
         ("up + down, one copy stream", lambda: pipe.run(io_s.inputs(host_frames, bga), on_result=io_s.collect(alpha_h, fg_h))),
+        ("up + down, alpha / fg as two copies", lambda: pipe.run(io.inputs(host_frames, bga), on_result=io.collect(alpha_s, fg_s))),
         ("uploads + downloads again", lambda: pipe.run(io.inputs(host_frames, bga), on_result=io.collect(alpha_h, fg_h))),
         ("device-resident again", lambda: pipe.run(iter(dev_frames))),
     ]

@@ -150,11 +150,11 @@ def main(cfg):
     # and backgrounds (bg_offline.py:134-141) happens only when those files are JPEGs (--io jpg, the reference's layout).
     mask_paths = shard_files('segmask')
     bg_paths = shard_files('bg')
-    groups = list(zip(frame_paths[lo:hi], mask_paths, bg_paths))
+    groups = list(zip(frame_paths[lo:hi], bg_paths, mask_paths))        # (frame, bg, mask): the upload staging order (hostio.in_layout)
     workers = int(cfg["data"].get("io_workers", 6))
     print("calculate fg image according to bg image")
     st = time.time()                                   # the files -> files figure includes starting the codec processes
-    reader = FrameReader(groups, [(h, w, 3), (h, w), (h, w, 3)], workers=workers, depth=16)
+    reader = FrameReader(groups, [(h, w, 3), (h, w, 3), (h, w)], workers=workers, depth=16)
     writer = FrameWriter([(h, w), (h, w, 3)], workers=workers, depth=16)
 
     def out_paths(i):

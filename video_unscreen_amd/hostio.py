@@ -16,6 +16,70 @@ def pinned_like(shape, dtype=torch.uint8):
     return torch.empty(shape, dtype=dtype).pin_memory()
 
 
+def _a16(v):
+    return (v + 15) & ~15
+
+
+def in_layout(H, W):
+    """Byte offsets of one staged input group [frame | bg_i | seg]: (bg offset, seg offset, total); every part starts on a 16-byte
+    boundary (the kernels read 12- and 16-byte groups)."""
+    n = H * W
+    bg = _a16(3 * n)
+    seg = _a16(bg + 3 * n)
+    return bg, seg, _a16(seg + n)
+
+
+def out_layout(H, W):
+    """Byte offsets of one output group [alpha | fg]: (fg offset, total) - the layout of BgStepPipeline's output ring."""
+    n = H * W
+    fg = _a16(n)
+    return fg, _a16(fg + 3 * n)
+
+
+def _host_span(parts, offsets):
+    """parts: contiguous uint8 CPU tensors, offsets: where each should start relative to the first.  If they are views of ONE
+    storage at exactly those distances, the flat view from the first to the end of the last (one copy moves the group); else None."""
+    try:
+        base = parts[0].untyped_storage().data_ptr()
+        p0 = parts[0].data_ptr()
+        for t, o in zip(parts, offsets):
+            if t.dtype != torch.uint8 or not t.is_contiguous() or t.untyped_storage().data_ptr() != base or t.data_ptr() != p0 + o:
+                return None
+        return parts[0].as_strided((offsets[len(parts) - 1] + parts[-1].numel(),), (1,))
+    except (RuntimeError, AttributeError):
+        return None
+
+
+def pack_host_group(frame, bg, seg=None, pin=True):
+    """One page-locked buffer laid out as in_layout() holding copies of the given uint8 tensors -> (frame, seg | None, bg) views of
+    it: HostFrameIO uploads such a group with a single copy."""
+    H, W = frame.shape[:2]
+    bg_off, seg_off, total = in_layout(H, W)
+    buf = torch.zeros(total, dtype=torch.uint8)
+    if pin:
+        buf = buf.pin_memory()
+    n = H * W
+    fv, bv = buf[:3 * n].view(H, W, 3), buf[bg_off:bg_off + 3 * n].view(H, W, 3)
+    fv.copy_(frame)
+    bv.copy_(bg)
+    sv = None
+    if seg is not None:
+        sv = buf[seg_off:seg_off + n].view(H, W)
+        sv.copy_(seg)
+    return fv, sv, bv
+
+
+def packed_outputs(K, H, W, pin=True):
+    """(alpha (K, H, W), fg (K, H, W, 3)) views of one page-locked (K, out_layout total) buffer: frame k's alpha and fg sit as in the
+    pipeline's output ring, so HostFrameIO.collect() fetches them with a single copy."""
+    fg_off, total = out_layout(H, W)
+    buf = torch.empty((K, total), dtype=torch.uint8)
+    if pin:
+        buf = buf.pin_memory()
+    n = H * W
+    return buf[:, :n].unflatten(1, (H, W)), buf[:, fg_off:fg_off + 3 * n].unflatten(1, (H, W, 3))
+
+
 class HostFrameIO:
     """Ring of device staging slots + copy streams around a pipeline's run().
 
@@ -38,10 +102,14 @@ class HostFrameIO:
         dev = pipe.device
         H, W = pipe.H, pipe.W
         self.depth = depth if depth is not None else 2 * pipe.seg_batch + 6
-        u8 = dict(dtype=torch.uint8, device=dev)
-        self.frames = [torch.empty((H, W, 3), **u8) for _ in range(self.depth)]
-        self.bgs = [torch.empty((H, W, 3), **u8) for _ in range(self.depth)]
-        self.segs = [torch.empty((H, W), **u8) for _ in range(self.depth)]
+        n = H * W
+        # one staging buffer per slot, [frame | bg_i | seg] (in_layout): host groups laid out the same way (pack_host_group) arrive
+        # with ONE copy
+        self._bg_off, self._seg_off, total = in_layout(H, W)
+        self.stage = [torch.empty(total, dtype=torch.uint8, device=dev) for _ in range(self.depth)]
+        self.frames = [t[:3 * n].view(H, W, 3) for t in self.stage]
+        self.bgs = [t[self._bg_off:self._bg_off + 3 * n].view(H, W, 3) for t in self.stage]
+        self.segs = [t[self._seg_off:self._seg_off + n].view(H, W) for t in self.stage]
         self.done = [None] * self.depth              # event: the frame staged in this slot has left the pipeline
         self.up = torch.cuda.Stream(dev)
         self.down = torch.cuda.Stream(dev)
@@ -62,11 +130,15 @@ class HostFrameIO:
             if self.done[i] is not None:
                 self.up.wait_event(self.done[i])     # the slot's previous frame has been consumed
             self.done[i] = _BUSY
+            span = _host_span([frame_h, bg_h] + ([seg_h] if seg_h is not None else []), [0, self._bg_off, self._seg_off])
             with torch.cuda.stream(self.up):
-                self.frames[i].copy_(frame_h, non_blocking=True)
-                self.bgs[i].copy_(bg_h, non_blocking=True)
-                if seg_h is not None:
-                    self.segs[i].copy_(seg_h, non_blocking=True)
+                if span is not None:                 # the group is one contiguous run of host memory in the staging order
+                    self.stage[i][:span.numel()].copy_(span, non_blocking=True)
+                else:
+                    self.frames[i].copy_(frame_h, non_blocking=True)
+                    self.bgs[i].copy_(bg_h, non_blocking=True)
+                    if seg_h is not None:
+                        self.segs[i].copy_(seg_h, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.up)
             if on_uploaded is not None:
@@ -91,11 +163,15 @@ class HostFrameIO:
                 a_h, f_h, token = target(n)
             else:
                 a_h, f_h, token = alpha_host[n], fg_host[n], None
+            span = _host_span([a_h, f_h], [0, out["fg"].data_ptr() - out["alpha"].data_ptr()]) if "packed" in out else None
             with torch.cuda.stream(down):
                 if self.down_mode == "primed":
                     self._tiny_d.copy_(self._tiny_h, non_blocking=True)
-                a_h.copy_(out["alpha"], non_blocking=True)
-                f_h.copy_(out["fg"], non_blocking=True)
+                if span is not None:                 # alpha and fg are neighbours on the host as they are in the pipeline's ring entry
+                    span.copy_(out["packed"][:span.numel()], non_blocking=True)
+                else:
+                    a_h.copy_(out["alpha"], non_blocking=True)
+                    f_h.copy_(out["fg"], non_blocking=True)
                 dn = torch.cuda.Event()
                 dn.record(down)
             self.pipe.note_output_consumed(out, dn)
@@ -112,7 +188,8 @@ class HostFrameIO:
 def stream_clip(pipe, reader, writer, out_paths, bg_always, depth=None):
     """bg_step stage 3 over files: FrameReader (decoder processes -> page-locked shared-memory slots) -> uploads -> the pipelined
     frame loop -> downloads -> FrameWriter (encoder processes), all bounded and overlapped; nothing but queue bookkeeping runs on
-    the loop's thread.  reader yields (frame, segmask, bg_i) groups; out_paths(n) -> (alpha path, fg path).  Returns the frame count."""
+    the loop's thread.  reader yields (frame, bg_i, segmask) groups - the order of the staging layout, so a reader slot goes up with
+    one copy and a writer slot [alpha | fg] comes down with one; out_paths(n) -> (alpha path, fg path).  Returns the frame count."""
     import collections
     from .utils.frameio import DeferredSubmit
     io = HostFrameIO(pipe, depth)
@@ -135,7 +212,7 @@ def stream_clip(pipe, reader, writer, out_paths, bg_always, depth=None):
     reader.wait_release = wait_release
 
     def host_frames():
-        for slot, (f, m, b) in reader:
+        for slot, (f, b, m) in reader:
             reap()
             yield f, m, b, slot
 

@@ -120,9 +120,14 @@ class BgStepPipeline:
             seg_agent.set_plan_batch(self.seg_batch)       # step() and run() then segment a frame to the same bits
         self._seg_ring = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in range(3 * self.seg_batch)] if seg_agent is not None else []
         # outputs live in a ring of 4 (alpha of frame t is alpha_pre of frame t + 1; a consumer on another stream - the
-        # download stream of hostio.HostFrameIO - may still be reading frame t - 1): no allocation inside the frame loop
-        self._out_ring = [{"alpha": torch.empty((H, W), dtype=torch.uint8, device=dev),
-                           "fg": torch.empty((H, W, 3), dtype=torch.uint8, device=dev), "consumed": None} for _ in range(4)]
+        # download stream of hostio.HostFrameIO - may still be reading frame t - 1): no allocation inside the frame loop.  A ring
+        # entry is ONE buffer [alpha (H W) | fg (H W 3)]: a consumer that wants both on the host fetches them with one copy (two
+        # device -> host copies per frame cost the conv stream 0.24 ms per frame, one packed copy 0.05: tools/dev/d2h_batch_probe.py)
+        from .hostio import out_layout
+        fg_off, total = out_layout(H, W)                     # both parts on 16-byte boundaries
+        self._out_buf = torch.empty((4, total), dtype=torch.uint8, device=dev)
+        self._out_ring = [{"alpha": self._out_buf[i, :H * W].view(H, W), "fg": self._out_buf[i, fg_off:fg_off + 3 * H * W].view(H, W, 3),
+                           "packed": self._out_buf[i], "consumed": None} for i in range(4)]
         self._out_i = 0
         self.alpha_pre = None
 
@@ -175,7 +180,7 @@ class BgStepPipeline:
         fg = nv.get_fg(frame, alpha, slot.bg, paste_thr=1, out_fg=ring["fg"])
         self.alpha_pre = alpha
         return {"alpha": alpha, "alpha_f32": alpha_f, "fg": fg, "trimap": slot.trimap, "bg": slot.bg,
-                "gate": slot.gate, "alphaor": slot.alphaor, "pred": pred, "seg": slot.seg, "_ring": ring}
+                "gate": slot.gate, "alphaor": slot.alphaor, "pred": pred, "seg": slot.seg, "packed": ring["packed"], "_ring": ring}
 
     def note_output_consumed(self, out, event):
         """A consumer that reads out["alpha"] / out["fg"] on another stream hands back the event that ends its reads; the

@@ -20,7 +20,7 @@ from multiprocessing import shared_memory
 import numpy as np
 import torch
 
-from .._io_workers import decode_worker as _decode_worker, encode_worker as _encode_worker
+from .._io_workers import decode_worker as _decode_worker, encode_worker as _encode_worker, part_offsets
 
 _CTX = mp.get_context("spawn")         # no fork: the parent may hold a HIP context
 
@@ -47,7 +47,7 @@ class _light_children:
 class _Ring:
     def __init__(self, shapes, depth, pin):
         self.shapes = [tuple(s) for s in shapes]
-        self.slot_bytes = int(sum(int(np.prod(s)) for s in self.shapes))
+        self.offsets, self.slot_bytes = part_offsets(self.shapes)         # every array of a slot on a 16-byte boundary
         self.depth = depth
         self.nbytes = self.slot_bytes * depth
         self.shm = shared_memory.SharedMemory(create=True, size=self.nbytes)
@@ -59,11 +59,10 @@ class _Ring:
             self.pinned = int(rc) == 0
 
     def views(self, slot):
-        out, off = [], slot * self.slot_bytes
-        for s in self.shapes:
-            n = int(np.prod(s))
+        out = []
+        for s, o in zip(self.shapes, self.offsets):
+            off, n = slot * self.slot_bytes + o, int(np.prod(s))
             out.append(self.t[off:off + n].view(s))
-            off += n
         return out
 
     def close(self):
