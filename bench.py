@@ -238,16 +238,85 @@ def other_mode(args, rank, world, dev):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if rank == 0:
+        roof, extra = mode_roofline(args, pipe, frames[-1])
         print(json.dumps({
             "metric": f"frames/sec end-to-end unscreen ({args.mode}, {W}x{H})", "value": round(world * K / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{what}, {W}x{H}, {K} frames/GPU, one independent clip per GPU", "tracked_frames_rank0": tracked,
                        "weights": "keyed-deterministic synthetic (no checkpoint offline)"},
-            "roofline": None, "cpu_baseline": None}), flush=True)
+            "roofline": roof, **extra,
+            "cpu_baseline": None, "cpu_baseline_note": "not measured for this mode: the oracle chain of this loop lives in the tests "
+                                                         "(tests/test_gpu_green.py, tests/test_gpu_bgonline.py), the headline mode carries the CPU baseline"}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _net_time(run, iters=10, warm=2):
+    for _ in range(warm):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def mode_roofline(args, pipe, frame):
+    """green / bg_online: the dominant kernels of those loops are the same conv kernels (usc_conv.hip) on other networks - DeepLabv3+
+    over the crops of an untracked green frame, the space-time memory network's three graphs for a tracked bg-online frame - plus, in
+    the bg-online loop, the float64 Laplace solver (HBM-bound).  Each is timed here with HIP events on the stream it runs on;
+    flops = 2 M N K of the planned layers (ConvGraphNet.plan_gflop), bytes of the solver = its vector traffic per iteration (see
+    DESIGN.md section 6)."""
+    extra = {}
+    if args.mode == "green":
+        agent = pipe.segagent
+        net = agent.model_for(agent.crop_batch)
+        t = _net_time(lambda: net.forward(None))
+        gf = net.plan_gflop()
+        tf = gf / t / 1e3
+        roof = {"bound": "mfma", "kernel": f"conv_mfma_kernel + conv_wino_kernel (DeepLabv3+/R50, {agent.crop_batch} crops of 513 x 513 per forward, {net.n_layers()} launches)",
+                "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "alg_gflop_per_forward": round(gf, 1), "ms_per_forward": round(t * 1e3, 3)}
+        mnet = next(iter(getattr(pipe.vmatagent, "_nets", {}).values()), None)
+        if mnet is not None:                            # the matting net of the tracked frames (the headline mode's roofline kernel)
+            tm = _net_time(lambda: mnet())
+            gm = UNET_GFLOP_544x960 * (mnet.H * mnet.W) / (544 * 960)
+            extra["roofline_matting"] = {"bound": "mfma", "achieved": round(gm / tm / 1e3, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                                         "unit": "TFLOP/s", "frac": round(gm / tm / 1e3 / MFMA_F32_PEAK_TFLOPS, 4), "ms_per_forward": round(tm * 1e3, 3)}
+        return roof, extra
+    stm = next(iter(getattr(pipe.stmagent, "_nets", {}).values()), None)
+    roof = None
+    if stm is not None:
+        def step():
+            stm.mem.run()
+            stm.qry.run()
+            stm._read_for(1).run()
+            stm.dec.run()
+        t = _net_time(step)
+        gf = stm.mem.plan_gflop() + stm.qry.plan_gflop() + stm._read_for(1).plan_gflop() + stm.dec.plan_gflop()
+        tf = gf / t / 1e3
+        roof = {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_wino_kernel (space-time memory network: memorize + query trunk + memory read + decoder)",
+                "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "alg_gflop_per_forward": round(gf, 1), "ms_per_forward": round(t * 1e3, 3)}
+    # the Laplace fill of the frame's own hole: bytes = iterations x unknowns x 195 B (21 vector passes of 8 B on the fine level per
+    # preconditioned CG iteration + the coarser levels' third), time = HIP events around one converged solve
+    from video_unscreen_amd import _native as nv
+    out = pipe.step(frame)
+    if "bg_holes" in out and "hole" in out:
+        bg, hole = out["bg_holes"], out["hole"]
+        _, iters = nv.regionfill(bg, hole, want_iters=True)
+        t = _net_time(lambda: nv.regionfill(bg, hole), iters=3, warm=1)
+        unknowns = 3 * int((hole > 0).sum().item())
+        nbytes = iters * unknowns * 195
+        extra["roofline_fill"] = {"bound": "hbm", "kernel": "usc_regionfill.hip (multigrid-preconditioned CG, float64)", "achieved": round(nbytes / t / 1e9, 1),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                  "iterations": iters, "unknowns": unknowns, "ms_per_solve": round(t * 1e3, 3)}
+    return roof, extra
 
 
 def bind_near_gpu(local):

@@ -89,6 +89,7 @@ def main():
     io = hostio.HostFrameIO(pipe)
     io_p = hostio.HostFrameIO(pipe, down_mode="primed")
     io_s = hostio.HostFrameIO(pipe, down_mode="shared")
+    io_x = hostio.HostFrameIO(pipe, down_mode="exclusive")
 
     def mark_consumed():                         # frees the staging slot like collect(), downloads nothing
         main = torch.cuda.current_stream(dev)
@@ -112,6 +113,7 @@ def main():
         ("uploads + downloads", lambda: pipe.run(io.inputs(host_frames, bga), on_result=io.collect(alpha_h, fg_h))),
         ("events + waits, no copies", lambda: pipe.run(nio.inputs(host_frames, bga), on_result=nio.collect())),
         ("up + down, primed", lambda: pipe.run(io_p.inputs(host_frames, bga), on_result=io_p.collect(alpha_h, fg_h))),
+        ("up + down, exclusive", lambda: pipe.run(io_x.inputs(host_frames, bga), on_result=io_x.collect(alpha_h, fg_h))),
         ("up + down, one copy stream", lambda: pipe.run(io_s.inputs(host_frames, bga), on_result=io_s.collect(alpha_h, fg_h))),
         ("up + down, alpha / fg as two copies", lambda: pipe.run(io.inputs(host_frames, bga), on_result=io.collect(alpha_s, fg_s))),
         ("uploads + downloads again", lambda: pipe.run(io.inputs(host_frames, bga), on_result=io.collect(alpha_h, fg_h))),
@@ -119,7 +121,7 @@ def main():
     ]
     for name, fn in cases:
         t, n = timed(fn), K
-        for q in (io, io_p, io_s):
+        for q in (io, io_p, io_s, io_x):
             q.drain()
             q.done = [None] * q.depth
         print(f"{name:28s} {n / t:7.1f} frames/s  {t / n * 1e3:.3f} ms/frame", flush=True)

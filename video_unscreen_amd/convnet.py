@@ -131,6 +131,17 @@ class ConvGraphNet:
             if kind == "conv":
                 self.nv.load().usc_conv_graph_set_mode(a, {"stream": 0, "graph": 1}[mode])
 
+    def plan_gflop(self):
+        """2 * M * N * K over every conv launch of the plan (GFLOP per run(), padded channels included; a Winograd layer counts its
+        algorithmic multiplications, not the 2.25x fewer it issues): the numerator of a roofline figure for this network."""
+        total = 0
+        for kind, _, arr in self._segments:
+            if kind != "conv":
+                continue
+            for d in arr:
+                total += 2 * d.OH * d.OW * max(1, d.nphase) * d.Cout * d.ntaps * d.Cin
+        return total / 1e9
+
     def n_layers(self):
         return sum(len(arr) for kind, _, arr in self._segments if kind == "conv")
 

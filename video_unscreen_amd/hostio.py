@@ -94,7 +94,8 @@ class HostFrameIO:
     def __init__(self, pipe, depth=None, down_mode="own"):
         """down_mode: how the two device -> host copies of a frame are enqueued (tools/dev/hostio_ablate.py measures them):
         "own" = on the download stream behind the compute event; "primed" = the same with a 64-byte host -> device copy in front of
-        them; "shared" = on the upload stream (one copy stream for both directions)."""
+        them; "shared" = on the upload stream (one copy stream for both directions); "exclusive" = two streams, but a download waits
+        for the last upload issued and the next upload for the last download (one PCIe direction at a time)."""
         self.pipe = pipe
         self.down_mode = down_mode
         self._tiny_h = torch.zeros(64, dtype=torch.uint8).pin_memory()
@@ -129,6 +130,8 @@ class HostFrameIO:
                 raise RuntimeError("HostFrameIO: depth %d is smaller than the number of frames the pipeline holds in flight" % self.depth)
             if self.done[i] is not None:
                 self.up.wait_event(self.done[i])     # the slot's previous frame has been consumed
+            if self.down_mode == "exclusive" and self._last_down is not None:
+                self.up.wait_event(self._last_down)  # never an upload beside a download (one PCIe direction at a time)
             self.done[i] = _BUSY
             span = _host_span([frame_h, bg_h] + ([seg_h] if seg_h is not None else []), [0, self._bg_off, self._seg_off])
             with torch.cuda.stream(self.up):
@@ -141,6 +144,7 @@ class HostFrameIO:
                         self.segs[i].copy_(seg_h, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.up)
+            self._last_up = ev
             if on_uploaded is not None:
                 on_uploaded(ev, item[3] if len(item) > 3 else None)
             yield (self.frames[i], self.segs[i] if seg_h is not None else None, self.bgs[i], bg_always, ev)
@@ -159,6 +163,8 @@ class HostFrameIO:
             self.done[(base + n) % self.depth] = ev  # frames are consumed in order: the slot input n was staged in
             down = self.up if self.down_mode == "shared" else self.down
             down.wait_event(ev)
+            if self.down_mode == "exclusive" and getattr(self, "_last_up", None) is not None:
+                down.wait_event(self._last_up)
             if target is not None:
                 a_h, f_h, token = target(n)
             else:
