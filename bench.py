@@ -182,12 +182,12 @@ def cpu_baseline(cfg, pipe, clip_cpu_frames, bg_always, nframes, threads=None):
 
 
 def pmc_traffic(H, W):
-    """Fabric bytes of the conv stack per forward from the committed rocprofv3 PMC passes (profiles/r02/pmc_conv_traffic.json, else r01's,
+    """Fabric bytes of the conv stack per forward from the committed rocprofv3 PMC passes (profiles/r03/pmc_conv_traffic.json, else an earlier round's,
     produced by tools/dev/run_profiles.sh + summarize_profiles.py on this workload): FETCH_SIZE x 2 (gfx950 reports half the bytes of
     16-B/lane streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE.  Counters cannot be collected inside this process; null for any
     other frame size or when the file is absent."""
     root = os.path.dirname(os.path.abspath(__file__))
-    path = next((q for q in (os.path.join(root, "profiles", r, "pmc_conv_traffic.json") for r in ("r02", "r01")) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(root, "profiles", r, "pmc_conv_traffic.json") for r in ("r03", "r02", "r01")) if os.path.exists(q)), None)
     if (H, W) != (1080, 1920) or path is None:
         return None
     z = json.load(open(path))

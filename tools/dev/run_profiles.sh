@@ -1,9 +1,10 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): rocprofv3 kernel-trace + two PMC passes of bench.py (default and --no-seg), outputs under
-# gpurun_out/prof_r02/.  Summaries are made afterwards with tools/dev/summarize_profiles.py and committed under profiles/r02/.
+# gpurun_out/prof_<round>/ (ROUND=r03 by default).  Summaries are made afterwards with tools/dev/summarize_profiles.py and committed under profiles/<round>/.
 set -e
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/prof_r02
+ROUND=${ROUND:-r03}
+OUT=$ROOT/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for mode in default no_seg; do
