@@ -920,8 +920,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         // ---- two workgroups per unit: this one's sums went to the slab with system-scope write-through stores (the partner may sit
         // on another XCD, whose L2 is not coherent with ours: sc0 sc1 on both sides instead of a release that writes the whole L2
         // back), then one relaxed atomic per workgroup counts arrivals; the second to arrive adds the first one's sums to its own
-        // (half 0 + half 1: addition commutes) and finishes.  The counters (last WSLAB_TAIL bytes of the slab, zeroed on the launch stream
-        // at the head of every forward) only ever matter modulo 2.
+        // (half 0 + half 1: addition commutes) and finishes.  The counters (last WSLAB_TAIL bytes of the slab) are zeroed when a plan is
+        // made and put back to zero by every second arriver: between launches they are always zero.
         int* const counter = reinterpret_cast<int*>(reinterpret_cast<char*>(d.slab) + d.slab_bytes - WSLAB_TAIL) + wt;
         __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the stores have been acknowledged
         __syncthreads();
@@ -930,6 +930,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
             s_flag[sub / KW] = live ? (__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) : 0;
         __syncthreads();
         if (s_flag[sub / KW] == 0) return;                        // first to arrive (even count): the partner finishes
+        // second to arrive: put the counter back to zero (both arrivals have happened, nobody else touches it in this launch), so the
+        // protocol does not depend on the parity a previous - possibly aborted - launch left behind
+        if ((wave & 3) == ubase && h == 0 && kg == 0 && lane == 0 && live) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int rd = 0; rd < 4; rd++)
 #pragma unroll
@@ -1538,28 +1541,21 @@ extern "C" int usc_conv_graph_create(const usc_conv_desc* descs, int n, void** h
     for (int i = 0; i < n; i++) {
         int rc = plan_layer(descs[i], g->plans[i]);
         if (rc) { delete g; return rc; }
-        // arrival counters of Winograd layers split over two workgroups: zeroed on the launch stream at the head of EVERY launch
-        // (below), so a launch never inherits a counter that an aborted launch, or another handle sharing the slab, left odd
-        if (g->plans[i].wsplit && !g->counters) g->counters = wslab_counters(g->plans[i].d);
+        // arrival counters of Winograd layers split over two workgroups: zeroed here once; every launch leaves them zero (the second
+        // arriver of a pair resets its counter), so no launch inherits a counter left odd and no memset sits in the launch path.
+        // Handles that share a slab (the space-time memory network's parts) are created before any of them runs.
+        if (g->plans[i].wsplit && !g->counters) {
+            g->counters = wslab_counters(g->plans[i].d);
+            if (hipMemset(g->counters, 0, WSLAB_TAIL) != hipSuccess) { delete g; return conv_fail(USC_E_LAUNCH, "hipMemset (arrival counters) failed"); }
+        }
     }
     if (hipGraphCreate(&g->graph, 0) != hipSuccess) { delete g; return conv_fail(USC_E_LAUNCH, "hipGraphCreate failed"); }
     std::vector<hipGraphNode_t> last(n);                     // node that completes layer i
     std::vector<void*> kargs(n);
-    hipGraphNode_t head = nullptr;                           // chain head: the counters' memset, when the net has split layers
-    if (g->counters) {
-        hipMemsetParams mp;
-        memset(&mp, 0, sizeof(mp));
-        mp.dst = g->counters; mp.value = 0; mp.elementSize = 4; mp.width = WSLAB_TAIL / 4; mp.height = 1; mp.pitch = WSLAB_TAIL;
-        if (hipGraphAddMemsetNode(&head, g->graph, nullptr, 0, &mp) != hipSuccess) {
-            (void)hipGraphDestroy(g->graph); delete g;
-            return conv_fail(USC_E_LAUNCH, "hipGraphAddMemsetNode (arrival counters) failed");
-        }
-    }
     for (int i = 0; i < n; i++) {
         LayerPlan& p = g->plans[i];
         std::vector<hipGraphNode_t> deps;
         if (i > 0) deps.push_back(last[i - 1]);              // linear chain (see above)
-        else if (head) deps.push_back(head);
         kargs[i] = &p.d;
         hipKernelNodeParams kp;
         memset(&kp, 0, sizeof(kp));
@@ -1593,7 +1589,6 @@ extern "C" int usc_conv_graph_launch(void* handle, usc_stream_t stream) {
     ConvGraph* g = (ConvGraph*)handle;
     hipStream_t st = (hipStream_t)stream;
     if (g->mode == USC_CONV_LAUNCH_STREAM) {                // the planned launches, one after the other on the stream
-        if (g->counters && hipMemsetAsync(g->counters, 0, WSLAB_TAIL, st) != hipSuccess) return conv_fail(USC_E_LAUNCH, "hipMemsetAsync (arrival counters) failed");
         for (LayerPlan& p : g->plans) {
             void* args[] = {&p.d};
             hipError_t e = hipLaunchKernel(p.fn, p.grid, p.block, args, 0, st);
