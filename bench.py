@@ -246,8 +246,7 @@ def other_mode(args, rank, world, dev):
             "config": {"workload": f"{what}, {W}x{H}, {K} frames/GPU, one independent clip per GPU", "tracked_frames_rank0": tracked,
                        "weights": "keyed-deterministic synthetic (no checkpoint offline)"},
             "roofline": roof, **extra,
-            "cpu_baseline": None, "cpu_baseline_note": "not measured for this mode: the oracle chain of this loop lives in the tests "
-                                                         "(tests/test_gpu_green.py, tests/test_gpu_bgonline.py), the headline mode carries the CPU baseline"}), flush=True)
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else mode_cpu_baseline(args, cfg, H, W)}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -264,6 +263,49 @@ def _net_time(run, iters=10, warm=2):
     e1.record()
     e1.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def mode_cpu_baseline(args, cfg, H, W):
+    """green / bg_online: the loop body restated on the CPU oracle (oracle/chains.py) with the same networks on torch-CPU, on a
+    bounded sample of the same synthetic clip: one untracked frame (the segmentation network runs) + the tracked frames after it."""
+    import oracle
+    from oracle import chains
+    from video_unscreen_amd.synth import SyntheticClip
+    from video_unscreen_amd.vmatting.net import MattingNet, synthetic_state_dict
+    oracle.build()
+    nthr = min(torch.get_num_threads(), usable_cpus())
+    saved = torch.get_num_threads()
+    torch.set_num_threads(nthr)
+    try:
+        mat = MattingNet(synthetic_state_dict(0), device="cpu", dtype=torch.float32)
+        st = {}
+        if args.mode == "green":
+            from video_unscreen_amd.binseg.deeplab_net import DeepLabNetTorch, deeplab_synthetic_state_dict
+            n = 3
+            clip = SyntheticClip(H, W, n, config_id=1, device="cpu")
+            cc = cfg["colorfiltering"]
+            cf = chains.OracleColorFilter(oracle, cc["input_long_side"], tuple(cc["bg_ncomp"]), tuple(cc["fg_ncomp"]), cc["max_num_samples"],
+                                          cc["color_prior_winsize"], random_state=0)
+            seg = DeepLabNetTorch(deeplab_synthetic_state_dict(0))
+            frames = [clip.frame(t)["frame"].numpy() for t in range(n)]
+            t0 = time.time()
+            tracked = sum(int(chains.green_frame(oracle, cfg, st, f, cf, seg, mat)["tracking"]) for f in frames)
+        else:
+            from video_unscreen_amd.binseg.schp_net import SchpNetTorch, schp_synthetic_state_dict
+            from video_unscreen_amd.stm.net import StmNetTorch, stm_synthetic_state_dict
+            n = 2
+            clip = SyntheticClip(H, W, n, config_id=2, device="cpu")
+            schp, stm = SchpNetTorch(schp_synthetic_state_dict(0)), StmNetTorch(stm_synthetic_state_dict(0))
+            frames = [clip.frame(t)["frame"].numpy() for t in range(n)]
+            t0 = time.time()
+            tracked = sum(int(chains.bg_online_frame(oracle, cfg, st, f, schp, stm, mat)["tracking"]) for f in frames)
+        dt = time.time() - t0
+    finally:
+        torch.set_num_threads(saved)
+    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": nthr, "kind": "port",
+            "sample": f"{n} frames {W}x{H} ({n - tracked} untracked + {tracked} tracked): C oracle (1 thread; sklearn EM / scipy sparse solve where the "
+                      f"reference calls them) + the same networks on torch-CPU ({nthr} threads), {dt:.1f} s",
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
 
 
 def mode_roofline(args, pipe, frame):
