@@ -224,3 +224,18 @@ def test_shard_start_semantics(oracle_lib):
         assert not d[a["trimap"] != 128].any()
         differs |= bool(d.any())
     assert differs, "the cut must be visible somewhere, or this test pins nothing"
+
+
+def test_bench_gpus_flag_is_not_ignored():
+    """bench.py --gpus N means N ranks (the flag used to be parsed and never read).  Without a launcher it starts them
+    itself - here, on a box without N GPUs, that is refused with a message instead of silently running one rank; under a launcher whose
+    WORLD_SIZE differs from --gpus it exits non-zero before touching a GPU and prints no JSON line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "USC_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "2", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "--gpus 64" in r.stderr and "{" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr and "{" not in r.stdout
