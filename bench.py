@@ -478,7 +478,10 @@ def main():
     if args.seg_batch > 0:
         seg_batch = args.seg_batch
     elif strong:
-        seg_batch = 12            # every rank plans for the same batch whatever its range length (a short last group rides in a full forward)
+        # every rank plans for the same batch: the largest range (ceil(F / world)) cut into the fewest groups of <= 12 frames, evenly -
+        # a 38-frame range runs as 10 + 10 + 10 + 8, not 12 + 12 + 12 + 2 (a short last group rides in a full forward)
+        kmax = -(-F_clip // world)
+        seg_batch = -(-kmax // -(-kmax // 12))
     else:
         seg_batch = next((b for b in (12, 8, 6, 4) if K % b == 0), 8)
     pipe = BgStepPipeline(cfg, H, W, device=dev, state_dict=sd, net_backend=args.net, seg_agent=seg_agent,

@@ -96,3 +96,45 @@ def test_reader_reports_a_dead_decoder(tmp_path):
     rd.release(slot)                                          # a task goes to a worker that no longer exists
     with pytest.raises(RuntimeError, match="died"):
         next(rd)
+
+
+def test_packed_host_layouts():
+    """hostio's packed layouts: a host group / output pair laid out as the device staging slot / output-ring entry is recognised as ONE
+    contiguous span (one copy per frame and direction); anything else falls back to per-array copies.  Odd sizes keep 16-byte starts."""
+    import torch
+    from video_unscreen_amd.hostio import _host_span, in_layout, out_layout, pack_host_group, packed_outputs
+    for H, W in ((33, 47), (270, 480)):
+        n = H * W
+        f = torch.randint(0, 255, (H, W, 3), dtype=torch.uint8)
+        b = torch.randint(0, 255, (H, W, 3), dtype=torch.uint8)
+        m = torch.randint(0, 255, (H, W), dtype=torch.uint8)
+        bg_off, seg_off, total = in_layout(H, W)
+        assert bg_off % 16 == 0 and seg_off % 16 == 0 and total % 16 == 0 and bg_off >= 3 * n and seg_off >= bg_off + 3 * n
+        F, S, B = pack_host_group(f, b, m, pin=False)
+        assert torch.equal(F, f) and torch.equal(B, b) and torch.equal(S, m)
+        span = _host_span([F, B, S], [0, bg_off, seg_off])
+        assert span is not None and span.numel() == seg_off + n and torch.equal(span[bg_off:bg_off + 3 * n].view(H, W, 3), b)
+        F2, S2, B2 = pack_host_group(f, b, None, pin=False)
+        assert S2 is None and _host_span([F2, B2], [0, bg_off, seg_off]).numel() == bg_off + 3 * n
+        assert _host_span([f, b], [0, bg_off, seg_off]) is None                      # separate allocations: two copies
+        assert _host_span([F, S, B], [0, bg_off, seg_off]) is None                   # wrong order
+        a, g = packed_outputs(3, H, W, pin=False)
+        fg_off, tot = out_layout(H, W)
+        assert a.shape == (3, H, W) and g.shape == (3, H, W, 3) and a[1].is_contiguous() and g[1].is_contiguous() and fg_off % 16 == 0
+        assert _host_span([a[1], g[1]], [0, fg_off]).numel() == fg_off + 3 * n
+        assert _host_span([a[1], g[2]], [0, fg_off]) is None
+        g[1].fill_(7)
+        a[1].fill_(9)
+        assert int(_host_span([a[1], g[1]], [0, fg_off])[:n].sum()) == 9 * n and not bool((a[0] == 9).all() and (g[2] == 7).all())
+
+
+def test_ring_slots_share_the_staging_layout(tmp_path):
+    """A reader slot (frame, bg, mask) and a writer slot (alpha, fg) are laid out like hostio.in_layout / out_layout: whole slots move
+    with one copy."""
+    from video_unscreen_amd._io_workers import part_offsets
+    from video_unscreen_amd.hostio import in_layout, out_layout
+    for H, W in ((33, 47), (1080, 1920)):
+        offs, total = part_offsets([(H, W, 3), (H, W, 3), (H, W)])
+        assert (offs[1], offs[2], total) == in_layout(H, W)
+        offs, total = part_offsets([(H, W), (H, W, 3)])
+        assert (offs[1], total) == out_layout(H, W)
