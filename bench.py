@@ -117,13 +117,12 @@ def kernel_table(pipe, sample, H, W):
     cnt = torch.empty(1, dtype=torch.int64, device=frame.device)
     add("count_ge", lambda: nv.count_ge(alpha, 128, out=cnt), N)
     t_net = time_kernel(lambda: pipe.net(pipe.x7), iters=20, warm=3)           # the product path: planned stream launches
-    t_serial = time_kernel(pipe.net.forward_serial, iters=20, warm=3) if hasattr(pipe.net, "forward_serial") else t_net
     t_graph = t_net
     if hasattr(pipe.net, "set_launch_mode"):
         pipe.net.set_launch_mode("graph")
         t_graph = time_kernel(lambda: pipe.net(pipe.x7), iters=20, warm=3)     # the same layers as one hipGraph replay
         pipe.net.set_launch_mode("stream")
-    return rows, t_net, t_graph, t_serial
+    return rows, t_net, t_graph
 
 
 def cpu_model():
@@ -627,7 +626,7 @@ def main():
                                             "note": "same loop and boundary as `value` with remove_invalid_objects on two host worker threads"}
             pipe.object_filter, pipe._filter_choice = chosen_f, chosen_c
         if not args.no_kernel_table:                         # (other ranks wait at the final barrier: not inside the timed region)
-            rows, t_net, t_graph, t_serial = kernel_table(pipe, frames[first], H, W)
+            rows, t_net, t_graph = kernel_table(pipe, frames[first], H, W)
             dom = max(rows, key=lambda r: r["us"])
             scale = (pipe.in_h * pipe.in_w) / (544 * 960)
             gflop = UNET_GFLOP_544x960 * scale
@@ -635,18 +634,16 @@ def main():
             if args.net == "hip":
                 # dominant kernels of the frame: conv_mfma_kernel / conv_wino_kernel (usc_conv.hip).  One "launch" here is one network
                 # forward = num_layers conv launches; flops are the algorithmic 2*M*N*K of the reference module (torch flop counter,
-                # SURVEY.md section 6) - the Winograd layers execute 2.25x fewer.  Time: HIP events around forwards launched on ONE
-                # stream with nothing beside them, the product's launch mode.  profiles/r03/unet_layer_table.md (rocprofv3 kernel trace,
-                # tools/dev/layer_table.py) lists the per-layer kernel durations of strictly serial launches and both HIP-event times.
-                # ms_per_forward_graph: the same layers as one hipGraph replay.
+                # SURVEY.md section 6) - the Winograd layers execute 2.25x fewer.  Time: HIP events around forwards whose layers are
+                # launched one after the other on ONE stream with nothing beside them (the product's launch mode) - the quantity
+                # profiles/r02/unet_layer_table.md (rocprofv3 kernel trace of the same launches, tools/dev/layer_table.py) sums per
+                # layer.  ms_per_forward_graph: the same layers as one hipGraph replay (slower on this runtime).
                 result["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_wino_kernel (all %d conv launches of one forward)" % pipe.net.num_layers,
                                       "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(H, W),
                                       "alg_gflop_per_forward": round(gflop, 2), "ms_per_forward": round(t_net * 1e3, 3),
-                                      "ms_per_forward_graph": round(t_graph * 1e3, 3), "ms_per_forward_strictly_serial": round(t_serial * 1e3, 3),
-                                      "timing": "HIP events around forwards launched as the product launches them (one stream; the layers that are "
-                                                "independent of the launch before them go out without the in-order barrier); strictly serial launches "
-                                                "of the same layers beside it; see profiles/r03/unet_layer_table.md"}
+                                      "ms_per_forward_graph": round(t_graph * 1e3, 3),
+                                      "timing": "serial single-stream launches, HIP events; see profiles/r02/unet_layer_table.md"}
                 result["roofline_pixel"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
                                             "unit": "GB/s", "frac": dom["frac_hbm_peak"], "traffic": None,
                                             "alg_bytes_per_launch": dom["alg_bytes"], "us_per_launch": dom["us"]}

@@ -382,7 +382,7 @@ typedef struct usc_conv_desc {
     int in_relu;                   /* 1: the layer computes conv(relu(in)) (pre-activation residual blocks, stm/model.py:25-30) */
     float* slab;                   /* optional scratch for split-K partial sums (small-M layers), may be NULL.  Its LAST 64 KB hold
                                       arrival counters (Winograd layers that split K over two workgroups): the library zeroes
-                                      them when it plans such a layer, every launch leaves them zero; partial sums never reach them.
+                                      them when it plans such a layer, kernels leave them even; partial sums never reach them.
                                       Layers that may run concurrently must not share a slab. */
     size_t slab_bytes;
     int out_ld, out_c0;            /* 0 / 0: `out` is a dense [pixel][Cout] tensor; otherwise `out` has out_ld channels per pixel
@@ -402,11 +402,6 @@ typedef struct usc_conv_desc {
                                       residual and no affine: the Winograd F(3x3, 2x2) operands of the four phases instead,
                                       floats [4][Cin/8][16][2][Cout][4] (vmatting/net_hip.py pack_wino_t: G = [1 0; 1/2 1/2;
                                       1/2 -1/2; 0 -1], phase (py, px) = index 2 py + px). */
-    int concurrent_with_prev;      /* 1: this layer neither reads nor overwrites anything the layer(s) before it in the list write
-                                      (back to the last layer with 0 here), nor shares a slab with them: usc_conv_graph_launch (stream
-                                      mode) enqueues it without the in-order barrier, so its workgroups start on the CUs the previous
-                                      launch frees instead of after its last wave (a shortcut branch beside the main branch).  The next
-                                      layer with 0 waits for all of them.  Ignored by usc_conv_sequence_f32 and in graph mode. */
 } usc_conv_desc;
 
 /* Tuning hook (tools/dev/tune_convs.py): force the tile width (1 | 2 x 32 columns), the row groups per workgroup (4 | 2 | 1
@@ -447,8 +442,6 @@ const char* usc_conv_last_error(void);
 #define USC_CONV_LAUNCH_STREAM 0   /* default: the planned launches are enqueued one by one on the stream (no re-planning, ~3 us of host
                                     * time per layer; measured 1.49 ms per matting forward against 1.67 ms for the graph replay) */
 #define USC_CONV_LAUNCH_GRAPH  1   /* one hipGraphLaunch per call: least host time (one call per forward) */
-#define USC_CONV_LAUNCH_STREAM_SERIAL 2   /* as STREAM, every launch behind the in-order barrier (concurrent_with_prev ignored): the
-                                           * reference point for measuring what the barrier-free launches buy (tools/dev/layer_table.py) */
 int  usc_conv_graph_create(const usc_conv_desc* descs, int n, void** handle);
 int  usc_conv_graph_set_mode(void* handle, int mode);
 int  usc_conv_graph_launch(void* handle, usc_stream_t stream);

@@ -2,10 +2,8 @@
 `roofline`): shape, algorithmic GFLOP, average kernel duration, TFLOP/s, fraction of the f32-MFMA peak.
 
   1. rocprofv3 --kernel-trace -d <dir> -o lt -- python3 tools/dev/layer_table.py run [forwards] > <dir>/layers.json
-       launches every layer of `forwards` forwards strictly one after the other on ONE stream (usc_conv_sequence_f32: no graph,
-       no barrier-free launches, nothing else on the device) and prints the layer list (shape, flops, launches per layer) as JSON,
-       with the HIP-event time per forward of those serial launches AND of the product's launch path (usc_conv_graph_launch,
-       stream mode: the layers marked concurrent_with_prev go out without the in-order barrier);
+       launches every layer of `forwards` forwards one after the other on ONE stream (usc_conv_sequence_f32: no graph, no
+       branch overlap, nothing else on the device) and prints the layer list (shape, flops, launches per layer) as JSON;
   2. python3 tools/dev/layer_table.py table <dir>/layers.json <kernel_trace.csv> > profiles/rNN/unet_layer_table.md
        orders the trace's conv dispatches by start time, drops the warm-up forwards, folds them modulo the launches of one
        forward and averages per layer.
@@ -31,22 +29,15 @@ def run(forwards):
     net = HipMattingNet(synthetic_state_dict(0), 544, 960)        # launch mode "stream": the product's
     net.x8.normal_()
     torch.cuda.synchronize()
-    def timed(fn):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(forwards):
-            fn()
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / forwards
-
     for _ in range(WARM + forwards):
-        net.forward_serial()
-    torch.cuda.synchronize()
-    ms_serial = timed(net.forward_serial)
-    for _ in range(WARM):                                         # (untraced by the table: it folds the FIRST 5 + 2 x forwards only)
         net()
-    ms_product = timed(net)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(forwards):
+        net()
+    e1.record()
+    e1.synchronize()
     layers = []
     plans = nv.conv_plans(net._arr, len(net._descs))
     for i, (d, p) in enumerate(zip(net._descs, plans)):
@@ -55,9 +46,8 @@ def run(forwards):
         layers.append({"i": i, "M": M * nph, "Cin": d.Cin, "Cout": d.Cout, "taps": d.ntaps, "in_stride": d.in_stride,
                        "out_stride": d.out_stride, "kind": d.kind, "gflop": 2.0 * M * d.Cout * d.ntaps * d.Cin * nph / 1e9,
                        "launches": p["launches"], "plan": p["plan"], "workgroups": p["workgroups"]})
-    json.dump({"forwards_traced": WARM + 2 * forwards, "warm": WARM, "layers": layers, "hip_event_ms_per_forward": ms_serial,
-               "hip_event_ms_per_forward_product_path": ms_product,
-               "barrier_free_launches": int(sum(d.concurrent_with_prev for d in net._descs))}, sys.stdout)
+    json.dump({"forwards_traced": WARM + 2 * forwards, "warm": WARM, "layers": layers,
+               "hip_event_ms_per_forward": e0.elapsed_time(e1) / forwards}, sys.stdout)
 
 
 def table(layers_json, trace_csv):
@@ -70,7 +60,6 @@ def table(layers_json, trace_csv):
         if any(k in name for k in ("conv_mfma_kernel", "conv_wino_kernel", "splitk_reduce_kernel", "head_conv_kernel")):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     rows.sort()
-    rows = rows[:meta["forwards_traced"] * per_fwd]               # the serial forwards; the product-path forwards after them are timed, not tabled
     assert len(rows) % per_fwd == 0, (len(rows), per_fwd)
     nf = len(rows) // per_fwd
     rows = rows[meta["warm"] * per_fwd:]
@@ -100,11 +89,6 @@ def table(layers_json, trace_csv):
           f"**{132.75 / tot_us * 1e3:.1f} TFLOP/s = {132.75 / tot_us * 1e3 / PEAK:.3f} of the f32-MFMA peak**.")
     print(f"\nHIP events around the same serial launches in the same (traced) process: {meta['hip_event_ms_per_forward']:.3f} ms per forward "
           "(kernel time + the gaps between consecutive launches on the stream).")
-    if "hip_event_ms_per_forward_product_path" in meta:
-        pp = meta["hip_event_ms_per_forward_product_path"]
-        print(f"\nThe product's launch path (usc_conv_graph_launch, stream mode: {meta['barrier_free_launches']} of the {len(layers)} launches - layers that "
-              f"are independent of the launch before them - go out without the in-order barrier), HIP events, same process: **{pp:.3f} ms per "
-              f"forward = {132.75 / pp:.1f} TFLOP/s = {132.75 / pp / PEAK:.3f} of the peak** (what bench.py's `roofline` reports).")
 
 
 if __name__ == "__main__":

@@ -22,7 +22,6 @@
 // f32 MFMA is an exact k-ordered fmaf chain; the K partition and the order partial sums are added in depend only on the
 // layer's shape (and the caller's plan_batch), so results are run-to-run and batch-to-batch identical.
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -1589,18 +1588,10 @@ extern "C" int usc_conv_graph_launch(void* handle, usc_stream_t stream) {
     usc_debug_arm_segv_backtrace();
     ConvGraph* g = (ConvGraph*)handle;
     hipStream_t st = (hipStream_t)stream;
-    if (g->mode == USC_CONV_LAUNCH_STREAM || g->mode == USC_CONV_LAUNCH_STREAM_SERIAL) {   // the planned launches, one after the other on the stream
-        const bool allow_concurrent = g->mode == USC_CONV_LAUNCH_STREAM;
-        bool first = true;
+    if (g->mode == USC_CONV_LAUNCH_STREAM) {                // the planned launches, one after the other on the stream
         for (LayerPlan& p : g->plans) {
             void* args[] = {&p.d};
-            // a layer that declares itself independent of the launches before it goes out without the in-order barrier
-            // (hipExtAnyOrderLaunch): its workgroups take the CUs the previous launch frees, its ramp and prologue overlap that
-            // launch's tail; the next ordinary launch waits for everything before it
-            hipError_t e = (allow_concurrent && p.d.concurrent_with_prev && !first && !p.reduce)
-                               ? hipExtLaunchKernel(p.fn, p.grid, p.block, args, 0, st, nullptr, nullptr, 1 /* hipExtAnyOrderLaunch */)
-                               : hipLaunchKernel(p.fn, p.grid, p.block, args, 0, st);
-            first = false;
+            hipError_t e = hipLaunchKernel(p.fn, p.grid, p.block, args, 0, st);
             if (e == hipSuccess && p.reduce) e = hipLaunchKernel((void*)splitk_reduce_kernel, p.rgrid, dim3(256), args, 0, st);
             if (e != hipSuccess) return conv_fail(USC_E_LAUNCH, hipGetErrorString(e));
         }
@@ -1619,8 +1610,7 @@ extern "C" int usc_conv_graph_launch(void* handle, usc_stream_t stream) {
 }
 
 extern "C" int usc_conv_graph_set_mode(void* handle, int mode) {
-    if (!handle || (mode != USC_CONV_LAUNCH_STREAM && mode != USC_CONV_LAUNCH_GRAPH && mode != USC_CONV_LAUNCH_STREAM_SERIAL))
-        return conv_fail(USC_E_ARG, "usc_conv_graph_set_mode: bad argument");
+    if (!handle || (mode != USC_CONV_LAUNCH_STREAM && mode != USC_CONV_LAUNCH_GRAPH)) return conv_fail(USC_E_ARG, "usc_conv_graph_set_mode: bad argument");
     ((ConvGraph*)handle)->mode = mode;
     return USC_OK;
 }

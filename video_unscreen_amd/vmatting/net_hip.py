@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
                 ("dy", C.c_byte * 16), ("dx", C.c_byte * 16),
                 ("nphase", C.c_int), ("wphase_stride", C.c_int), ("ksplit", C.c_int), ("in_relu", C.c_int),
                 ("slab", C.c_void_p), ("slab_bytes", C.c_size_t), ("out_ld", C.c_int), ("out_c0", C.c_int),
-                ("batch", C.c_int), ("plan_batch", C.c_int), ("wino", C.c_void_p), ("concurrent_with_prev", C.c_int)]
+                ("batch", C.c_int), ("plan_batch", C.c_int), ("wino", C.c_void_p)]
 
 
 def d_out_elems(OH, OW, out_stride, OHf, OWf, Cout):
@@ -148,12 +148,9 @@ class HipMattingNet:
 
     def _add(self, x, out, taps, wk, bias, IH, IW, Cin, OH, OW, Cout, in_stride=1, out_stride=1, py=0, px=0,
              res1=None, res1_shift=0, act="none", scale=None, shift=None, res2=None, kind=0, OHf=None, OWf=None,
-             phases=None, wino=None, wino_t=None, concurrent=False):
-        """phases: optional list of 4 (taps, wk) pairs (transposed conv); then `taps` / `wk` are ignored.
-        concurrent: the layer is independent of the launches before it, back to the last layer without the flag (usc_conv_desc.
-        concurrent_with_prev): it is enqueued without the in-order barrier."""
+             phases=None, wino=None, wino_t=None):
+        """phases: optional list of 4 (taps, wk) pairs (transposed conv); then `taps` / `wk` are ignored."""
         d = ConvDesc()
-        d.concurrent_with_prev = 1 if concurrent else 0
         d.inp, d.out = x.data_ptr(), out.data_ptr()
         if phases is not None:
             packed = [pack_k_major(w.float()) for _, w in phases]
@@ -207,13 +204,13 @@ class HipMattingNet:
         self._add(x, out, taps, wk, c.b, IH, IW, ci, OH, OW, co, in_stride=c.stride, act=kw.pop("act", c.act), wino=wino, **kw)
         return out
 
-    def _convt(self, c, x, IH, IW, res2=None, concurrent=False):
+    def _convt(self, c, x, IH, IW, res2=None):
         """ConvTranspose2d(k4, s2, p1) as four phase convolutions writing one (2 IH, 2 IW) tensor."""
         ci, co = c.w.shape[0], c.w.shape[1]
         out = self._buf(2 * IH, 2 * IW, co)
         phases = [convt_phase_taps(c.w, py, px) for py in (0, 1) for px in (0, 1)]       # phase index = 2*py + px
         self._add(x, out, None, None, c.b, IH, IW, ci, IH, IW, co, out_stride=2, act=c.act, res2=res2, phases=phases,
-                  wino_t=c.w if ci % 8 == 0 else None, concurrent=concurrent)
+                  wino_t=c.w if ci % 8 == 0 else None)
         return out
 
     # ------------------------------------------------------------------ graph
@@ -238,25 +235,22 @@ class HipMattingNet:
                               wd.shape[1], in_stride=2)
                 else:
                     idt = t
-                y = self._conv(blk["conv1"], t, h, w, concurrent=blk["down"] is not None)     # beside the shortcut conv: same input
+                y = self._conv(blk["conv1"], t, h, w)
                 h, w = h // s, w // s
                 t = self._conv(blk["conv2"], y, h, w, res1=idt, act="relu")
             feats.append((t, h, w))
         (x2, h2, w2), (x3, h3, w3), (x4, h4, w4), (out, h5, w5) = feats
         # shortcut branches: conv -> ReLU -> BN twice (model.py:452-456)
-        # The five branches read x, x1 .. x4 (never the last stage's output) and nothing of each other: their first convs are
-        # enqueued as one run of independent launches beside the last encoder layer, their second convs as a second run - each
-        # launch's workgroups start on the CUs the launch before it frees (usc_conv_desc.concurrent_with_prev)
-        srcs = ((x, H, W), (x1, H // 2, W // 2), (x2, h2, w2), (x3, h3, w3), (x4, h4, w4))
-        mids = [self._conv(s["c1"], z, zh, zw, scale=s["s1"], shift=s["t1"], concurrent=True) for s, (z, zh, zw) in zip(p["shortcut"], srcs)]
-        fea = [self._conv(s["c2"], y, zh, zw, scale=s["s2"], shift=s["t2"], concurrent=i > 0)
-               for i, (s, y, (_, zh, zw)) in enumerate(zip(p["shortcut"], mids, srcs))]
+        fea = []
+        for s, (z, zh, zw) in zip(p["shortcut"], ((x, H, W), (x1, H // 2, W // 2), (x2, h2, w2), (x3, h3, w3), (x4, h4, w4))):
+            y = self._conv(s["c1"], z, zh, zw, scale=s["s1"], shift=s["t1"])
+            fea.append(self._conv(s["c2"], y, zh, zw, scale=s["s2"], shift=s["t2"]))
         # decoder (model.py:274-324, 505-515)
         t, h, w = out, h5, w5
         for blocks, skip in zip(p["dec"], (fea[4], fea[3], fea[2], fea[1])):
             b0, b1 = blocks
             up = self._conv(b0["up"], t, h, w)                  # 1x1 at low resolution; nearest x2 happens in the read
-            y = self._convt(b0["conv1"], t, h, w, concurrent=True)      # beside the 1x1 shortcut: same input
+            y = self._convt(b0["conv1"], t, h, w)
             h, w = 2 * h, 2 * w
             t = self._conv(b0["conv2"], y, h, w, res1=up, res1_shift=1, act="leaky")
             y = self._conv(b1["conv1"], t, h, w)
@@ -290,20 +284,14 @@ class HipMattingNet:
 
     def set_launch_mode(self, mode):
         """"stream" (default: the planned launches one by one on the stream) or "graph" (one hipGraphLaunch per forward)."""
-        rc = nv.load().usc_conv_graph_set_mode(self._graph, {"stream": 0, "graph": 1, "stream_serial": 2}[mode])
+        rc = nv.load().usc_conv_graph_set_mode(self._graph, {"stream": 0, "graph": 1}[mode])
         if rc != 0:
             raise nv.NativeError(f"usc_conv_graph_set_mode failed ({rc})")
 
     def forward_serial(self):
-        """The same planned launches strictly one after the other on the current stream (every launch behind the in-order barrier:
-        concurrent_with_prev ignored): what the per-layer profile table lists, and the reference point of the barrier-free launches."""
-        if not self._graph:
-            rc = nv.load().usc_conv_sequence_f32(self._arr, len(self._descs), torch.cuda.current_stream().cuda_stream)
-            if rc != 0:
-                raise nv.NativeError(f"conv launch failed ({rc}): {nv.load().usc_conv_last_error().decode()}")
-            return self.pred
-        self.set_launch_mode("stream_serial")
-        try:
-            return self.forward(None)
-        finally:
-            self.set_launch_mode("stream")
+        """The same layers launched one after the other on the current stream (no graph, no branch overlap): what the per-layer
+        profile table and bench.py's roofline time."""
+        rc = nv.load().usc_conv_sequence_f32(self._arr, len(self._descs), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise nv.NativeError(f"conv launch failed ({rc}): {nv.load().usc_conv_last_error().decode()}")
+        return self.pred
