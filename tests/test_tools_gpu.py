@@ -150,3 +150,52 @@ dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group(); print("r
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=600,
                        env=dict(os.environ, PYTHONPATH=ROOT))
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_replace_tool_end_to_end(tmp_path, oracle_lib):
+    """tools/replace/replace.py (BASELINE.json configs[4], the compositing half) on a small dataset on disk: the correspondence mean it
+    prints equals the reference's comp_dx_dy flow (replace.py:28-41) on the oracle, and its composites equal the oracle chain
+    (shift_fg, rescale_fg 1.2, float64 blend: replace.py:59-76) on the same decoded inputs up to the JPEG of the output."""
+    from video_unscreen_amd.synth import SyntheticClip
+    from video_unscreen_amd.utils.fileio import read_img, save_img
+    H, W, n = 120, 200, 3
+    root = tmp_path / "replace"
+    src, tgt, bgd = root / "unscreen_img" / "test7", root / "unscreenbg_img" / "out7", root / "unscreen_img" / "bg"
+    for d in (src, tgt, bgd):
+        d.mkdir(parents=True)
+    clip = SyntheticClip(H, W, n, config_id=2, device="cpu")
+    clip2 = SyntheticClip(H + 30, W + 40, n, config_id=3, device="cpu")
+    save_img(clip2.bg_always.numpy(), str(bgd / "test5_case.jpg"))
+    for t in range(n):
+        f, g = clip.frame(t), clip2.frame(t)
+        a = (f["alpha_true"].numpy() * 255).astype(np.uint8)
+        save_img((f["frame"].numpy() * (a[..., None] / 255.)).astype(np.uint8), str(tgt / f"fg_{t:06d}.jpg"))
+        save_img(np.stack([a] * 3, -1), str(tgt / f"alphamask_{t:06d}.jpg"))
+        save_img(g["frame"].numpy(), str(src / f"frame_{t:06d}.jpg"))
+        save_img(np.stack([(g["alpha_true"].numpy() * 255).astype(np.uint8)] * 3, -1), str(src / f"alphamask_{t:06d}.jpg"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "replace", "replace.py"), "--src", "test7", "--data_root", str(root)],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # the reference's comp_dx_dy on the oracle
+    dxs, dys = [], []
+    for t in range(n):
+        dm = read_img(str(tgt / f"alphamask_{t:06d}.jpg"))
+        sm = oracle_lib.resize_linear(read_img(str(src / f"alphamask_{t:06d}.jpg")), dm.shape[0], dm.shape[1])
+        dc, sc = oracle_lib.get_center(dm), oracle_lib.get_center(sm)
+        dxs.append(sc[0] - dc[0])
+        dys.append(sc[1] - dc[1])
+    dx, dy = float(np.mean(dxs)), float(np.mean(dys))
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("Correspondence mean")][0]
+    got_dx, got_dy = (float(v) for v in line.split(":")[1].split())
+    assert abs(got_dx - dx) < 1e-9 and abs(got_dy - dy) < 1e-9, (line, dx, dy)
+    out = root / "merge_test_img" / "test7_out7"
+    bg = oracle_lib.resize_linear(read_img(str(bgd / "test5_case.jpg")), H, W)
+    for t in range(n):
+        fg, m = read_img(str(tgt / f"fg_{t:06d}.jpg")), read_img(str(tgt / f"alphamask_{t:06d}.jpg"))
+        fs = oracle_lib.rescale_fg(oracle_lib.shift_fg(fg, dx, dy), 1.2)
+        ms = oracle_lib.rescale_fg(oracle_lib.shift_fg(m, dx, dy), 1.2)
+        want = oracle_lib.blend(fs, ms, bg)
+        got = read_img(str(out / f"res_{t:06d}.jpg"))
+        assert got.shape == want.shape and np.abs(got.astype(int) - want.astype(int)).mean() < 1.5      # the output JPEG is lossy
+        cmp_img = read_img(str(out / f"compare_{t:06d}.jpg"))
+        assert cmp_img.shape == (H, 2 * W, 3)

@@ -25,12 +25,12 @@ from video_unscreen_amd.dist import shard_range
 from video_unscreen_amd.utils.fileio import read_img, save_img
 
 
-def centroid(mask_gray):
-    """get_center (reference utils/imgprocess.py:7-14): integer centroid of a grey image via raw moments."""
-    m = mask_gray.astype(np.float64)
-    m00 = m.sum()
-    ys, xs = np.mgrid[0:m.shape[0], 0:m.shape[1]]
-    return int((m * xs).sum() / (m00 + 1e-6)), int((m * ys).sum() / (m00 + 1e-6))
+def centroid(mask_dev):
+    """get_center (reference utils/imgprocess.py:7-14, as replace.py:32,35 call it on the 3-channel mask): COLOR_RGB2GRAY, integer
+    moments on the device (usc_gray_moments_u8), int(m10 / (m00 + 1e-6)), int(m01 / (m00 + 1e-6))."""
+    _, mom = nv.gray_moments(mask_dev, rgb_order=True)
+    m00, m10, m01 = (float(v) for v in mom.tolist())
+    return int(m10 / (m00 + 1e-6)), int(m01 / (m00 + 1e-6))
 
 
 def run(args):
@@ -48,10 +48,10 @@ def run(args):
     if args.dx is None or args.dy is None:
         acc = torch.zeros(3, dtype=torch.float64, device=dev)
         for fid in range(lo, hi):
-            dst_mask = read_img(osp.join(args.tgt_data_dir, "alphamask_{:06d}.jpg".format(fid)))
-            src_mask = read_img(osp.join(args.src_data_dir, "alphamask_{:06d}.jpg".format(fid)))
-            src_mask = nv.resize(torch.from_numpy(src_mask).to(dev), dst_mask.shape[0], dst_mask.shape[1], 1).cpu().numpy()
-            dc, sc = centroid(dst_mask[..., 0]), centroid(src_mask[..., 0])
+            dst_mask = torch.from_numpy(read_img(osp.join(args.tgt_data_dir, "alphamask_{:06d}.jpg".format(fid)))).to(dev)
+            src_mask = torch.from_numpy(read_img(osp.join(args.src_data_dir, "alphamask_{:06d}.jpg".format(fid)))).to(dev)
+            src_mask = nv.resize(src_mask, dst_mask.shape[0], dst_mask.shape[1], 1)        # adaptive_resize (replace.py:34)
+            dc, sc = centroid(dst_mask), centroid(src_mask)
             acc += torch.tensor([sc[0] - dc[0], sc[1] - dc[1], 1.0], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(acc)
