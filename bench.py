@@ -525,6 +525,7 @@ def main():
                 fg_h[j].copy_(out["fg"], non_blocking=True)
         else:
             pipe.run(io.inputs(frames_h[first:first + n], bg_always), on_result=io.collect(alpha_h, fg_h))
+            io.drain()                                       # every download enqueued and finished (the copy thread may trail the loop)
 
     def spin_up(seconds=1.0):
         """The clip is generated and pinned on the CPU for seconds while the GPU idles in a low power state, and W warm-up frames
@@ -625,6 +626,24 @@ def main():
             result["host_object_filter"] = {"value": round(K / t1, 2), "unit": "frames/s",
                                             "note": "same loop and boundary as `value` with remove_invalid_objects on two host worker threads"}
             pipe.object_filter, pipe._filter_choice = chosen_f, chosen_c
+        if world == 1 and host_io and not args.sync_loop:
+            # not timed: the host -> host loop must deliver the bytes of the loop over HBM-resident inputs (copy streams, the download
+            # thread and the side streams may not overtake each other into buffers still in use) - two segmentation groups and a
+            # ragged tail, compared byte for byte
+            nchk = min(K, 2 * pipe.seg_batch + 3)
+            kept = []
+            pipe.reset()
+            pipe.run(iter(frames[first:first + nchk]), on_result=lambda n, o: kept.append((o["alpha"].clone(), o["fg"].clone())))
+            torch.cuda.synchronize()
+            alpha_h[:nchk].zero_()
+            pipe.reset()
+            run_host(first, nchk)
+            torch.cuda.synchronize()
+            bad = [n for n in range(nchk) if not (torch.equal(alpha_h[n], kept[n][0].cpu()) and torch.equal(fg_h[n], kept[n][1].cpu()))]
+            result["self_check"] = {"frames": nchk, "host_loop_equals_device_loop": not bad}
+            if bad:
+                print("bench.py: the host -> host loop and the device-resident loop disagree on frames %s" % bad[:8], file=sys.stderr, flush=True)
+                sys.exit(1)
         if not args.no_kernel_table:                         # (other ranks wait at the final barrier: not inside the timed region)
             rows, t_net, t_graph = kernel_table(pipe, frames[first], H, W)
             dom = max(rows, key=lambda r: r["us"])

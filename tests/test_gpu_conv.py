@@ -437,3 +437,44 @@ def test_winograd_is_batch_invariant_and_deterministic(hipnet):
             nv.load().usc_conv_force_winograd(-1)
         outs.append(out.cpu())
     assert torch.equal(outs[0], outs[1][:h]) and torch.equal(outs[1], outs[2])
+
+
+def test_two_conv_stacks_on_two_streams_give_the_bits_of_one():
+    """The frame loop runs the matting net, the human-parsing net and the pixel stages on three streams at once.  A conv launch must
+    not depend on having the GPU to itself: the Winograd kernel hands staged patch images from one wave of a pair to the other, and
+    until round 3 the hand-over of a pair's second image rested on its requests landing within a phase and a half (fine on an idle
+    GPU; beside another stream's kernels a unit now and then multiplied one K step of stale values - about one launch in 20 000).
+    Here: 40 parsing forwards (12 frames each) beside 400 matting forwards, every output compared with the one computed alone."""
+    from video_unscreen_amd.binseg import HumanSegAgent
+    from video_unscreen_amd.binseg.schp_net import schp_synthetic_state_dict
+    from video_unscreen_amd.synth import SyntheticClip
+    from video_unscreen_amd.vmatting.net import synthetic_state_dict
+    from video_unscreen_amd.vmatting.net_hip import HipMattingNet
+    dev = torch.device("cuda", 0)
+    net = HipMattingNet(synthetic_state_dict(0), 544, 960, device=dev)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(5)
+    x = torch.rand((544, 960, 8), generator=g)
+    x[..., 7] = 0
+    net.x8.copy_(x.to(dev))
+    seg = HumanSegAgent(model_path=None, cuda_device=0, state_dict=schp_synthetic_state_dict(0))
+    seg.set_plan_batch(12)
+    clip = SyntheticClip(1080, 1920, 12, config_id=2, device=dev)
+    frames = [clip.frame(t)["frame"] for t in range(12)]
+    masks = [torch.empty((1080, 1920), dtype=torch.uint8, device=dev) for _ in range(12)]
+    ref = net().clone()
+    seg.forward_device_batch(frames, outs=masks)
+    torch.cuda.synchronize()
+    mref = torch.stack(masks).clone()
+    s2 = torch.cuda.Stream(dev)
+    bad, mbad = [], []
+    for _ in range(40):
+        with torch.cuda.stream(s2):
+            seg.forward_device_batch(frames, outs=masks)
+            mbad.append((torch.stack(masks) != mref).sum())
+        for _ in range(10):
+            bad.append((net() != ref).sum())
+    torch.cuda.synchronize()
+    assert sum(int(b) for b in bad) == 0, [i for i, b in enumerate(bad) if int(b)]
+    assert sum(int(b) for b in mbad) == 0, [i for i, b in enumerate(mbad) if int(b)]
+    net.close()

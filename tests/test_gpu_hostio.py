@@ -1,0 +1,112 @@
+"""Host boundary of the frame loop (video_unscreen_amd/hostio.py): every way of ordering the copies gives the bytes of the device-resident
+loop - the default "hostwait" (a helper thread waits for the compute event, then enqueues the download) and the event-ordered "own"."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _clip(H, W, K):
+    from video_unscreen_amd.synth import SyntheticClip
+    clip = SyntheticClip(H, W, K, config_id=2, device="cuda")
+    clip.gen.manual_seed(77)
+    return clip, [clip.frame(t) for t in range(K)]
+
+
+# (135, 241): odd sizes, the parts of a group sit on padded 16-byte offsets; with_seg: the masks come from the human-parsing network,
+# 4 frames per forward, into the pipeline's three sets of mask buffers (21 frames: a ragged last group)
+@pytest.mark.parametrize("H,W,with_seg", [(270, 480, False), (135, 241, False), (270, 480, True)])
+def test_host_loop_equals_device_loop(H, W, with_seg):
+    """Inputs staged by copy streams must not let the front / segmentation streams run ahead of the back half into buffers it still
+    reads (pipeline slots, mask sets): the staged loop gives the bytes of the loop over device-resident inputs, in every mode."""
+    from video_unscreen_amd import hostio
+    from video_unscreen_amd.pipeline import BgStepPipeline, default_config
+    from video_unscreen_amd.vmatting.net import synthetic_state_dict
+    K = 21                                                      # more frames than the output ring (8) and the staging ring
+    seg_agent = None
+    if with_seg:
+        from video_unscreen_amd.binseg import HumanSegAgent
+        from video_unscreen_amd.binseg.schp_net import schp_synthetic_state_dict
+        seg_agent = HumanSegAgent(model_path=None, cuda_device=0, state_dict=schp_synthetic_state_dict(0))
+    pipe = BgStepPipeline(default_config(), H, W, state_dict=synthetic_state_dict(0), seg_agent=seg_agent, seg_batch=4 if with_seg else 1)
+    clip, fr = _clip(H, W, K)
+    want = []
+    pipe.run(iter([(f["frame"], None if with_seg else f["seg"], f["bg"], clip.bg_always) for f in fr]),
+             on_result=lambda n, out: want.append((out["alpha"].clone(), out["fg"].clone())))
+    torch.cuda.synchronize()
+    assert len(want) == K
+    packed = [hostio.pack_host_group(f["frame"].cpu(), f["bg"].cpu(), None if with_seg else f["seg"].cpu()) for f in fr]
+    loose = [(f["frame"].cpu().pin_memory(), None if with_seg else f["seg"].cpu().pin_memory(), f["bg"].cpu().pin_memory()) for f in fr]
+    depth = 14 if with_seg else 9
+    for mode in ("hostwait", "own"):
+        for groups, outs in ((packed, hostio.packed_outputs(K, H, W)),
+                             (loose, (torch.zeros((K, H, W), dtype=torch.uint8).pin_memory(), torch.zeros((K, H, W, 3), dtype=torch.uint8).pin_memory()))):
+            io = hostio.HostFrameIO(pipe, depth=depth, down_mode=mode)
+            outs[0].zero_(); outs[1].zero_()
+            pipe.reset()
+            n = pipe.run(io.inputs(groups, clip.bg_always), on_result=io.collect(*outs))
+            io.drain()
+            io.close()
+            assert n == K
+            for t in range(K):
+                assert torch.equal(outs[0][t], want[t][0].cpu()), (mode, t)
+                assert torch.equal(outs[1][t], want[t][1].cpu()), (mode, t)
+
+
+def test_download_thread_failure_reaches_the_loop():
+    """A copy the helper thread cannot enqueue (here: a destination of the wrong size) fails whoever waits on it - the frame loop, when
+    it wants the output ring entry back - instead of leaving it waiting."""
+    from video_unscreen_amd import hostio
+    from video_unscreen_amd.pipeline import BgStepPipeline, default_config
+    from video_unscreen_amd.vmatting.net import synthetic_state_dict
+    H, W, K = 135, 240, 12
+    pipe = BgStepPipeline(default_config(), H, W, state_dict=synthetic_state_dict(0))
+    clip, fr = _clip(H, W, K)
+    groups = [hostio.pack_host_group(f["frame"].cpu(), f["bg"].cpu(), f["seg"].cpu()) for f in fr]
+    io = hostio.HostFrameIO(pipe)
+    bad_alpha = torch.zeros((K, H, W + 1), dtype=torch.uint8).pin_memory()
+    fg = torch.zeros((K, H, W, 3), dtype=torch.uint8).pin_memory()
+    with pytest.raises(RuntimeError, match="download thread"):
+        pipe.run(io.inputs(groups, clip.bg_always), on_result=io.collect(bad_alpha, fg))
+        io.drain()
+        for p in (io._last_down,):
+            p.synchronize()
+    io.close()
+    torch.cuda.synchronize()
+
+
+def test_1080p_loops_agree_sync_pipelined_host():
+    """At the bench's size with the human-parsing network in the loop (three streams + two copy streams + the download thread):
+    the synchronous loop (step()), the pipelined loop over HBM-resident inputs and the host -> host loop give the same bytes."""
+    from video_unscreen_amd import hostio
+    from video_unscreen_amd.binseg import HumanSegAgent
+    from video_unscreen_amd.binseg.schp_net import schp_synthetic_state_dict
+    from video_unscreen_amd.pipeline import BgStepPipeline, default_config
+    from video_unscreen_amd.vmatting.net import synthetic_state_dict
+    H, W, K = 1080, 1920, 27
+    seg_agent = HumanSegAgent(model_path=None, cuda_device=0, state_dict=schp_synthetic_state_dict(0))
+    pipe = BgStepPipeline(default_config(), H, W, state_dict=synthetic_state_dict(0), seg_agent=seg_agent, seg_batch=12)
+    clip, fr = _clip(H, W, K)
+    want = []
+    for f in fr:
+        o = pipe.step(f["frame"], None, f["bg"], clip.bg_always)
+        want.append((o["alpha"].clone(), o["fg"].clone()))
+    torch.cuda.synchronize()
+    for rep in range(3):
+        got = []
+        pipe.reset()
+        pipe.run(iter([(f["frame"], None, f["bg"], clip.bg_always) for f in fr]), on_result=lambda n, o: got.append((o["alpha"].clone(), o["fg"].clone())))
+        torch.cuda.synchronize()
+        bad = [n for n in range(K) if not (torch.equal(got[n][0], want[n][0]) and torch.equal(got[n][1], want[n][1]))]
+        assert not bad, ("pipelined loop, pass %d" % rep, bad)
+    groups = [hostio.pack_host_group(f["frame"].cpu(), f["bg"].cpu(), None) for f in fr]
+    a_h, f_h = hostio.packed_outputs(K, H, W)
+    io = hostio.HostFrameIO(pipe)
+    for rep in range(3):
+        a_h.zero_(); f_h.zero_()
+        pipe.reset()
+        pipe.run(io.inputs(groups, clip.bg_always), on_result=io.collect(a_h, f_h))
+        io.drain()
+        bad = [n for n in range(K) if not (torch.equal(a_h[n], want[n][0].cpu()) and torch.equal(f_h[n], want[n][1].cpu()))]
+        assert not bad, ("host loop, pass %d" % rep, bad)
+    io.close()

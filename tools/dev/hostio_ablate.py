@@ -82,16 +82,21 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             fn()
+            for q in ios:
+                q.drain()
             torch.cuda.synchronize()
             best = min(best, time.perf_counter() - t0)
         return best
 
-    io = hostio.HostFrameIO(pipe)
+    io = hostio.HostFrameIO(pipe)                      # "hostwait": no barrier packet in either copy stream
+    io_o = hostio.HostFrameIO(pipe, down_mode="own")   # event-ordered copies (rounds 1 - 3a)
     io_p = hostio.HostFrameIO(pipe, down_mode="primed")
     io_s = hostio.HostFrameIO(pipe, down_mode="shared")
     io_x = hostio.HostFrameIO(pipe, down_mode="exclusive")
 
-    def mark_consumed():                         # frees the staging slot like collect(), downloads nothing
+    ios = (io, io_o, io_p, io_s, io_x)
+
+    def mark_consumed(io=io):                    # frees the staging slot like collect(), downloads nothing
         main = torch.cuda.current_stream(dev)
         base = io._n_in
 
@@ -112,6 +117,9 @@ def main():
         ("downloads only", lambda: pipe.run(iter(dev_frames), on_result=io.collect(alpha_h, fg_h))),
         ("uploads + downloads", lambda: pipe.run(io.inputs(host_frames, bga), on_result=io.collect(alpha_h, fg_h))),
         ("events + waits, no copies", lambda: pipe.run(nio.inputs(host_frames, bga), on_result=nio.collect())),
+        ("up + down, event-ordered", lambda: pipe.run(io_o.inputs(host_frames, bga), on_result=io_o.collect(alpha_h, fg_h))),
+        ("uploads only, event-ordered", lambda: pipe.run(io_o.inputs(host_frames, bga), on_result=mark_consumed(io_o))),
+        ("downloads only, event-ordered", lambda: pipe.run(iter(dev_frames), on_result=io_o.collect(alpha_h, fg_h))),
         ("up + down, primed", lambda: pipe.run(io_p.inputs(host_frames, bga), on_result=io_p.collect(alpha_h, fg_h))),
         ("up + down, exclusive", lambda: pipe.run(io_x.inputs(host_frames, bga), on_result=io_x.collect(alpha_h, fg_h))),
         ("up + down, one copy stream", lambda: pipe.run(io_s.inputs(host_frames, bga), on_result=io_s.collect(alpha_h, fg_h))),
@@ -121,7 +129,7 @@ def main():
     ]
     for name, fn in cases:
         t, n = timed(fn), K
-        for q in (io, io_p, io_s, io_x):
+        for q in ios:
             q.drain()
             q.done = [None] * q.depth
         print(f"{name:28s} {n / t:7.1f} frames/s  {t / n * 1e3:.3f} ms/frame", flush=True)

@@ -642,6 +642,12 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         load_b(c + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         USC_WROW(1, V1, x) USC_WROW(1, V1, y) USC_WROW(1, V1, z) USC_WROW(1, V1, w)
+        // Every load older than the four weight requests of row 0 has landed - THIS is what publishes a staged image: the image
+        // requests of this step were issued before this phase, the counter is in order, and the phase barrier that follows hands the
+        // image to the partner wave (which never waits for requests it did not issue).  The compiler emits the same literal in front
+        // of row 1's last fragment - as long as it keeps merging the paths with and without image requests the way it does today; said
+        // explicitly the hand-over does not depend on that.  (No cost: the wait is already satisfied when it is reached.)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         load_b(c + 1, 1);
         __builtin_amdgcn_s_setprio(0);
     };
@@ -655,8 +661,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     // Phase ph: the h = 0 wave runs half-phase k = ph, the h = 1 wave k = ph - 1; even k = fragment phase, odd k = MFMA phase of
     // step k >> 1.  The image of local step s is requested during phase 2s - 2 by both waves (its LDS image was last read in phase
     // 2s - 3): by the h = 0 wave when its fragment phase has read image s - 1, by the h = 1 wave at the start of its MFMA phase;
-    // it is read in phases 2s (h = 0) and 2s + 1 (h = 1), each wave waiting for its own requests in front of its own reads (the
-    // compiler places that wait) and the phase barrier in between publishing them to the partner.  Every wave of the workgroup
+    // it is read in phases 2s (h = 0) and 2s + 1 (h = 1).  Who waits for the requests: a wave can only wait for its OWN (the load
+    // counter is per wave), and the compiler places no wait in front of the fragment reads (ISA of the loop: ds_reads straight
+    // after the barrier) - so each wave makes sure its requests have landed BEFORE the barrier that precedes the partner's reads:
+    // the explicit vmcnt(4) at the end of every MFMA phase (mfma_phase: in-order counter, the image requests are older than row
+    // 0's weight requests), and for the one request the h = 1 wave issues before its first MFMA phase an explicit wait.  Every wave of the workgroup
     // runs nmax steps (the planner only splits K evenly; a wave without a unit multiplies zeros): no state of the loop is
     // modified under a condition, which is what lets the compiler keep the accumulators in place.
     auto k_loop = [&](auto pxc) {
@@ -682,7 +691,12 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         WINO_PH(2);
         frag_phase(c_begin, H1, pxc);
         WINO_PH(3);
-        if (T3) wait_vm0();                                     // (the image requested above: see the note on the transposed form's waits)
+        // The image requested above is read by the h = 0 wave right after the next barrier, and this wave has no MFMA phase in
+        // between whose weight waits would cover it (the in-order argument of mfma_phase starts with the first MFMA phase): without
+        // this wait the hand-over of the pair's SECOND image rested on its requests landing within a phase and a half - true on an
+        // idle GPU (the partner waits about as long for its own half), false now and then beside another stream's kernels: a unit
+        // then multiplied one K step of stale patch values (found in round 3: tools/dev/concurrent_conv_bisect.py).
+        wait_vm0();
         phase_barrier();
         for (int s = 1; s < nmax; s++) {
             const int c = c_begin + s;

@@ -5,7 +5,18 @@ bg_offline.py:36; cv2.imwrite of alpha and fg, :169,175).
 
 Uploads run on their own HIP stream a bounded number of frames ahead of the compute streams, downloads on a third stream
 behind them; PCIe is full duplex, so at 1080p (14.5 MB up, 8.3 MB down per frame) both directions hide behind the 3 ms of
-GPU work per frame.  Nothing here touches pixels: it is plumbing around BgStepPipeline.run()."""
+GPU work per frame.  Nothing here touches pixels: it is plumbing around BgStepPipeline.run().
+
+Who waits for whom (round 3, tools/dev/d2h_dep_probe.py): a copy costs the conv streams nothing as long as the copy stream's queue
+holds nothing but copies - 80 matting forwards with an independent 8.3 MB download each run at 1.224 ms per forward, the same as with
+no copy.  The same copy behind `stream.wait_event(compute_event)` costs 0.03 - 0.19 ms per forward: with a barrier packet in front of
+it the runtime moves the bytes with a blit KERNEL in that queue, and a blit wave on a CU keeps a one-workgroup-per-CU conv launch off
+it.  So the default mode ("hostwait") keeps barrier packets out of both copy streams: a helper thread waits for the compute event on
+the HOST and only then enqueues the download; an upload into a staging slot waits on the host for the slot's previous frame (30
+frames back).  The event-ordered form is kept as down_mode="own"."""
+import queue
+import threading
+
 import torch
 
 
@@ -80,6 +91,35 @@ def packed_outputs(K, H, W, pin=True):
     return buf[:, :n].unflatten(1, (H, W)), buf[:, fg_off:fg_off + 3 * n].unflatten(1, (H, W, 3))
 
 
+class PendingCopy:
+    """Completion of a copy that a helper thread enqueues once a compute event has fired.  Stands in for the copy's event:
+    query() / synchronize() as torch.cuda.Event, wait_on(stream) for a stream that has to run after the copy."""
+
+    def __init__(self):
+        self._issued = threading.Event()
+        self._event = None
+        self._error = None
+
+    def _set(self, event=None, error=None):
+        self._event, self._error = event, error
+        self._issued.set()
+
+    def _get(self):
+        self._issued.wait()
+        if self._error is not None:
+            raise RuntimeError("HostFrameIO: the download thread failed") from self._error
+        return self._event
+
+    def query(self):
+        return self._issued.is_set() and self._get().query()
+
+    def synchronize(self):
+        self._get().synchronize()
+
+    def wait_on(self, stream):
+        stream.wait_event(self._get())
+
+
 class HostFrameIO:
     """Ring of device staging slots + copy streams around a pipeline's run().
 
@@ -91,9 +131,11 @@ class HostFrameIO:
     alpha_host[i] / fg_host[i] are pinned CPU tensors that receive frame i's outputs.  depth must exceed the number of
     frames the pipeline holds in flight (run() looks two segmentation groups + two frames ahead)."""
 
-    def __init__(self, pipe, depth=None, down_mode="own"):
-        """down_mode: how the two device -> host copies of a frame are enqueued (tools/dev/hostio_ablate.py measures them):
-        "own" = on the download stream behind the compute event; "primed" = the same with a 64-byte host -> device copy in front of
+    def __init__(self, pipe, depth=None, down_mode="hostwait"):
+        """down_mode: how the device -> host copies of a frame are ordered behind the frame's kernels (tools/dev/hostio_ablate.py
+        measures them): "hostwait" = a helper thread waits for the compute event, then enqueues the copy on a download stream that
+        never sees a barrier packet, and an upload waits on the host for its staging slot (module docstring);
+        "own" = on the download stream behind `wait_event(compute event)`; "primed" = the same with a 64-byte host -> device copy in front of
         them; "shared" = on the upload stream (one copy stream for both directions); "exclusive" = two streams, but a download waits
         for the last upload issued and the next upload for the last download (one PCIe direction at a time)."""
         self.pipe = pipe
@@ -116,6 +158,46 @@ class HostFrameIO:
         self.down = torch.cuda.Stream(dev)
         self._n_in = 0
         self._last_down = None
+        self._jobs = None                            # "hostwait": (compute event, [(dst, src)], PendingCopy) for the download thread
+        self._thread = None
+
+    # ------------------------------------------------------------------ "hostwait": the download thread
+    def _download_loop(self):
+        torch.cuda.set_device(self.pipe.device)
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                self._jobs.task_done()
+                return
+            ev, pairs, pend = job
+            try:
+                ev.synchronize()                     # on the host: the download stream's queue holds copies only
+                with torch.cuda.stream(self.down):
+                    for dst, src in pairs:
+                        dst.copy_(src, non_blocking=True)
+                    dn = torch.cuda.Event()
+                    dn.record(self.down)
+                pend._set(dn)
+            except BaseException as e:               # handed to whoever waits on the copy
+                pend._set(error=e)
+            finally:
+                self._jobs.task_done()
+
+    def _enqueue_download(self, ev, pairs):
+        if self._thread is None or not self._thread.is_alive():
+            self._jobs = queue.Queue()
+            self._thread = threading.Thread(target=self._download_loop, name="usc-download", daemon=True)
+            self._thread.start()
+        pend = PendingCopy()
+        self._jobs.put((ev, pairs, pend))
+        return pend
+
+    def close(self):
+        """Stops the download thread (after the copies it still holds)."""
+        if self._thread is not None and self._thread.is_alive():
+            self._jobs.put(None)
+            self._thread.join()
+        self._thread = None
 
     def inputs(self, host_frames, bg_always, on_uploaded=None):
         """Generator for BgStepPipeline.run(): uploads each host frame into the next staging slot on the upload stream and
@@ -128,8 +210,11 @@ class HostFrameIO:
             self._n_in += 1
             if self.done[i] is _BUSY:
                 raise RuntimeError("HostFrameIO: depth %d is smaller than the number of frames the pipeline holds in flight" % self.depth)
-            if self.done[i] is not None:
-                self.up.wait_event(self.done[i])     # the slot's previous frame has been consumed
+            if self.done[i] is not None:             # the slot's previous frame (depth frames back) has been consumed
+                if self.down_mode == "hostwait":
+                    self.done[i].synchronize()       # on the host: no barrier packet in the upload stream's queue
+                else:
+                    self.up.wait_event(self.done[i])
             if self.down_mode == "exclusive" and self._last_down is not None:
                 self.up.wait_event(self._last_down)  # never an upload beside a download (one PCIe direction at a time)
             self.done[i] = _BUSY
@@ -161,15 +246,23 @@ class HostFrameIO:
             ev = torch.cuda.Event()
             ev.record(main)
             self.done[(base + n) % self.depth] = ev  # frames are consumed in order: the slot input n was staged in
-            down = self.up if self.down_mode == "shared" else self.down
-            down.wait_event(ev)
-            if self.down_mode == "exclusive" and getattr(self, "_last_up", None) is not None:
-                down.wait_event(self._last_up)
             if target is not None:
                 a_h, f_h, token = target(n)
             else:
                 a_h, f_h, token = alpha_host[n], fg_host[n], None
             span = _host_span([a_h, f_h], [0, out["fg"].data_ptr() - out["alpha"].data_ptr()]) if "packed" in out else None
+            if self.down_mode == "hostwait":
+                pairs = [(span, out["packed"][:span.numel()])] if span is not None else [(a_h, out["alpha"]), (f_h, out["fg"])]
+                dn = self._enqueue_download(ev, pairs)
+                self.pipe.note_output_consumed(out, dn)
+                self._last_down = dn
+                if on_downloaded is not None:
+                    on_downloaded(dn, token, n)
+                return
+            down = self.up if self.down_mode == "shared" else self.down
+            down.wait_event(ev)
+            if self.down_mode == "exclusive" and getattr(self, "_last_up", None) is not None:
+                down.wait_event(self._last_up)
             with torch.cuda.stream(down):
                 if self.down_mode == "primed":
                     self._tiny_d.copy_(self._tiny_h, non_blocking=True)
@@ -187,6 +280,8 @@ class HostFrameIO:
         return on_result
 
     def drain(self):
+        if self._jobs is not None:
+            self._jobs.join()                        # every download has been enqueued
         self.up.synchronize()
         self.down.synchronize()
 
@@ -233,4 +328,5 @@ def stream_clip(pipe, reader, writer, out_paths, bg_always, depth=None):
         uploaded[0][0].synchronize()
         reader.release(uploaded.popleft()[1])
     deferred.close()
+    io.close()
     return n

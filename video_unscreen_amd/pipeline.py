@@ -53,8 +53,10 @@ class _Slot:
         self.host = torch.empty((H, W), dtype=torch.uint8).pin_memory()
         self.ready = torch.cuda.Event()
         self.copied = torch.cuda.Event()
+        self.released = torch.cuda.Event()            # recorded behind the back half of the frame that used this slot
         self.host_done = threading.Event()            # set by the host worker that filtered this slot
         self.frame = None
+        self.mset = None                              # set of segmentation-mask buffers this frame is the last user of (run())
 
 
 class BgStepPipeline:
@@ -119,15 +121,16 @@ class BgStepPipeline:
         if seg_agent is not None and hasattr(seg_agent, "set_plan_batch"):
             seg_agent.set_plan_batch(self.seg_batch)       # step() and run() then segment a frame to the same bits
         self._seg_ring = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in range(3 * self.seg_batch)] if seg_agent is not None else []
-        # outputs live in a ring of 4 (alpha of frame t is alpha_pre of frame t + 1; a consumer on another stream - the
+        self._seg_set_done = [torch.cuda.Event() for _ in range(3)]      # the last frame of the group that used a set has left the back half
+        # outputs live in a ring of 8 (alpha of frame t is alpha_pre of frame t + 1; a consumer on another stream - the
         # download stream of hostio.HostFrameIO - may still be reading frame t - 1): no allocation inside the frame loop.  A ring
         # entry is ONE buffer [alpha (H W) | fg (H W 3)]: a consumer that wants both on the host fetches them with one copy (two
         # device -> host copies per frame cost the conv stream 0.24 ms per frame, one packed copy 0.05: tools/dev/d2h_batch_probe.py)
         from .hostio import out_layout
         fg_off, total = out_layout(H, W)                     # both parts on 16-byte boundaries
-        self._out_buf = torch.empty((4, total), dtype=torch.uint8, device=dev)
+        self._out_buf = torch.empty((8, total), dtype=torch.uint8, device=dev)
         self._out_ring = [{"alpha": self._out_buf[i, :H * W].view(H, W), "fg": self._out_buf[i, fg_off:fg_off + 3 * H * W].view(H, W, 3),
-                           "packed": self._out_buf[i], "consumed": None} for i in range(4)]
+                           "packed": self._out_buf[i], "consumed": None} for i in range(8)]
         self._out_i = 0
         self.alpha_pre = None
 
@@ -173,7 +176,11 @@ class BgStepPipeline:
         ring = self._out_ring[self._out_i % len(self._out_ring)]
         self._out_i += 1
         if ring["consumed"] is not None:                   # a reader on another stream (note_output_consumed) has finished
-            torch.cuda.current_stream(self.device).wait_event(ring["consumed"])
+            done = ring["consumed"]
+            if hasattr(done, "wait_on"):                   # hostio.PendingCopy: a copy a helper thread enqueues (blocks until it has)
+                done.wait_on(torch.cuda.current_stream(self.device))
+            else:
+                torch.cuda.current_stream(self.device).wait_event(done)
             ring["consumed"] = None
         res = nv.vmat_post(pred.view(self.in_h, self.in_w), slot.trimap, out_u8=ring["alpha"], want_float=want_float)
         alpha, alpha_f = (res if want_float else (res, None))
@@ -183,8 +190,8 @@ class BgStepPipeline:
                 "gate": slot.gate, "alphaor": slot.alphaor, "pred": pred, "seg": slot.seg, "packed": ring["packed"], "_ring": ring}
 
     def note_output_consumed(self, out, event):
-        """A consumer that reads out["alpha"] / out["fg"] on another stream hands back the event that ends its reads; the
-        ring entry is not rewritten (three frames later) before that event."""
+        """A consumer that reads out["alpha"] / out["fg"] on another stream hands back the event that ends its reads (or an
+        object with wait_on(stream), hostio.PendingCopy); the ring entry is not rewritten (three frames later) before that event."""
         out["_ring"]["consumed"] = event
 
     # ------------------------------------------------------------------ synchronous form
@@ -265,7 +272,8 @@ class BgStepPipeline:
                         state["exhausted"] = True
                 if not group:
                     return []
-                first = (state["ngroups"] % 3) * self.seg_batch
+                mset = state["ngroups"] % 3
+                first = mset * self.seg_batch
                 state["ngroups"] += 1
                 group = [tuple(g) if len(g) == 5 else tuple(g) + (None,) for g in group]
                 if any(g[4] is None for g in group):
@@ -273,11 +281,14 @@ class BgStepPipeline:
                 for g in group:
                     if g[4] is not None:
                         seg_stream.wait_event(g[4])         # frames staged on a copy stream
+                # the masks of the group three back have been read (nothing else orders this stream behind the main stream when
+                # the inputs come from a copy stream; a no-op until the set has been used once)
+                seg_stream.wait_event(self._seg_set_done[mset])
                 with torch.cuda.stream(seg_stream):
                     masks = self.seg_agent.forward_device_batch([g[0] for g in group], outs=self._seg_ring[first:first + len(group)])
                     ev = torch.cuda.Event()
                     ev.record(seg_stream)
-                return [(g[0], m, g[2], g[3], ev, g[4]) for g, m in zip(group, masks)]
+                return [(g[0], m, g[2], g[3], ev, g[4], mset if k == len(group) - 1 else None) for k, (g, m) in enumerate(zip(group, masks))]
 
             nxt = None
             while True:
@@ -289,16 +300,20 @@ class BgStepPipeline:
                         else:
                             try:
                                 g = tuple(next(it))
-                                ahead = [g[:4] + (None, g[4] if len(g) == 5 else None)]
+                                ahead = [g[:4] + (None, g[4] if len(g) == 5 else None, None)]
                             except StopIteration:
                                 state["exhausted"] = True
                         if not ahead:
                             break
-                    frame, seg, bg_i, bg_always, seg_ev, up_ev = ahead.pop(0)
+                    frame, seg, bg_i, bg_always, seg_ev, up_ev, slot_mset = ahead.pop(0)
                     if seg_ev is not None:
                         front.wait_event(seg_ev)
                     slot = self.slots[submitted % len(self.slots)]
                     slot.frame = frame
+                    slot.mset = slot_mset
+                    # the slot's buffers (gate, trimap, bg ...) are still read by the back half of the frame three back; with
+                    # staged inputs nothing else keeps the front stream behind the main stream
+                    front.wait_event(slot.released)
                     if up_ev is not None:
                         front.wait_event(up_ev)             # inputs staged on a copy stream
                     else:
@@ -323,6 +338,9 @@ class BgStepPipeline:
                 out = self._back(slot, slot.frame)
                 if on_result is not None:
                     on_result(n, out)
+                slot.released.record(main)                  # behind whatever on_result enqueued on this stream
+                if slot.mset is not None:
+                    self._seg_set_done[slot.mset].record(main)
                 n += 1
         finally:
             for th in workers:
