@@ -524,8 +524,14 @@ def main():
                 alpha_h[j].copy_(out["alpha"], non_blocking=True)
                 fg_h[j].copy_(out["fg"], non_blocking=True)
         else:
+            t_a = time.perf_counter()
             pipe.run(io.inputs(frames_h[first:first + n], bg_always), on_result=io.collect(alpha_h, fg_h))
+            t_b = time.perf_counter()
             io.drain()                                       # every download enqueued and finished (the copy thread may trail the loop)
+            if os.environ.get("USC_BENCH_DEBUG"):            # where the host spent the pass (stderr)
+                from video_unscreen_amd.hostio import PendingCopy
+                print("run_host(%d, %d): enqueue %.1f ms, drain %.1f ms; blocked so far: %.1f ms for staging slots, %.1f ms for output ring entries" % (
+                    first, n, (t_b - t_a) * 1e3, (time.perf_counter() - t_b) * 1e3, io.slot_waited * 1e3, PendingCopy.waited * 1e3), file=sys.stderr)
 
     def spin_up(seconds=1.0):
         """The clip is generated and pinned on the CPU for seconds while the GPU idles in a low power state, and W warm-up frames
@@ -548,10 +554,12 @@ def main():
         if args.no_spin_up:
             return
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < seconds:
+        passes = 0
+        while time.perf_counter() - t0 < seconds or passes < 2:           # (a 300-frame pass is longer than 0.6 s: at least two)
             pipe.reset()
             fn()
             torch.cuda.synchronize()
+            passes += 1
 
     def timed(fn_warm, fn):
         pipe.reset()

@@ -109,4 +109,12 @@ def test_1080p_loops_agree_sync_pipelined_host():
         io.drain()
         bad = [n for n in range(K) if not (torch.equal(a_h[n], want[n][0].cpu()) and torch.equal(f_h[n], want[n][1].cpu()))]
         assert not bad, ("host loop, pass %d" % rep, bad)
+    # the same loop with remove_invalid_objects on the host worker threads (bench.py's host_object_filter leg)
+    pipe.object_filter, pipe._filter_choice = "host", "host"
+    a_h.zero_(); f_h.zero_()
+    pipe.reset()
+    pipe.run(io.inputs(groups, clip.bg_always), on_result=io.collect(a_h, f_h))
+    io.drain()
+    bad = [n for n in range(K) if not (torch.equal(a_h[n], want[n][0].cpu()) and torch.equal(f_h[n], want[n][1].cpu()))]
+    assert not bad, ("host loop, host object filter", bad)
     io.close()

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--no-seg", action="store_true")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--minimal", action="store_true", help="ONE HostFrameIO, the host -> host loop first (what bench.py does)")
     args = ap.parse_args()
     import __graft_entry__ as ge
     ge.build_native()
@@ -89,6 +90,21 @@ def main():
         return best
 
     io = hostio.HostFrameIO(pipe)                      # "hostwait": no barrier packet in either copy stream
+    if args.minimal:
+        for name, fn in (("uploads + downloads (first thing in the process)", lambda: pipe.run(io.inputs(host_frames, bga), on_result=io.collect(alpha_h, fg_h))),
+                         ("device-resident", lambda: pipe.run(iter(dev_frames))),
+                         ("uploads + downloads", lambda: pipe.run(io.inputs(host_frames, bga), on_result=io.collect(alpha_h, fg_h)))):
+            for rep in range(3):
+                pipe.reset(); torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); io.drain(); torch.cuda.synchronize()
+                t = time.perf_counter() - t0
+                print(f"{name:50s} pass {rep}: {K / t:7.1f} frames/s  {t / K * 1e3:.3f} ms/frame", flush=True)
+        extra = [hostio.HostFrameIO(pipe, down_mode="own") for _ in range(4)]       # eight more streams, never used
+        name = "uploads + downloads, 8 idle streams created"
+        for rep in range(3):
+            pipe.reset(); torch.cuda.synchronize(); t0 = time.perf_counter(); pipe.run(io.inputs(host_frames, bga), on_result=io.collect(alpha_h, fg_h)); io.drain(); torch.cuda.synchronize()
+            t = time.perf_counter() - t0
+            print(f"{name:50s} pass {rep}: {K / t:7.1f} frames/s  {t / K * 1e3:.3f} ms/frame", flush=True)
+        return
     io_o = hostio.HostFrameIO(pipe, down_mode="own")   # event-ordered copies (rounds 1 - 3a)
     io_p = hostio.HostFrameIO(pipe, down_mode="primed")
     io_s = hostio.HostFrameIO(pipe, down_mode="shared")
@@ -132,7 +148,7 @@ def main():
         for q in ios:
             q.drain()
             q.done = [None] * q.depth
-        print(f"{name:28s} {n / t:7.1f} frames/s  {t / n * 1e3:.3f} ms/frame", flush=True)
+        print(f"{name:28s} {n / t:7.1f} frames/s  {t / n * 1e3:.3f} ms/frame   (blocked so far: {io.slot_waited * 1e3:.0f} ms for staging slots, {hostio.PendingCopy.waited * 1e3:.0f} ms for ring entries)", flush=True)
 
 
 if __name__ == "__main__":

@@ -12,10 +12,16 @@ holds nothing but copies - 80 matting forwards with an independent 8.3 MB downlo
 no copy.  The same copy behind `stream.wait_event(compute_event)` costs 0.03 - 0.19 ms per forward: with a barrier packet in front of
 it the runtime moves the bytes with a blit KERNEL in that queue, and a blit wave on a CU keeps a one-workgroup-per-CU conv launch off
 it.  So the default mode ("hostwait") keeps barrier packets out of both copy streams: a helper thread waits for the compute event on
-the HOST and only then enqueues the download; an upload into a staging slot waits on the host for the slot's previous frame (30
-frames back).  The event-ordered form is kept as down_mode="own"."""
+the HOST and only then enqueues the download; an upload into a staging slot waits on the host for the slot's previous frame (40
+frames back), and uploads are PACED - one per finished frame, a look-ahead of two segmentation groups staged when the run starts -
+because a burst of queued copies (12 x 50 MB when a group is pulled at 3840 x 2160) books the DMA engines, the runtime then moves
+the next copy with a kernel after all, and the download behind the burst took 8 ms instead of 0.6 (tools/dev/hostio_timeline.py).
+The event-ordered form is kept as down_mode="own".  Measured (profiles/r03/hostio_ablate*.txt): 1080p 416 frames/s host -> host
+against 419 device-resident (event-ordered: 393); 3840 x 2160 368 against 385 (event-ordered: 273)."""
+import collections
 import queue
 import threading
+import time
 
 import torch
 
@@ -117,7 +123,15 @@ class PendingCopy:
         self._get().synchronize()
 
     def wait_on(self, stream):
-        stream.wait_event(self._get())
+        if not self._issued.is_set():
+            t0 = time.perf_counter()
+            ev = self._get()
+            PendingCopy.waited += time.perf_counter() - t0       # how long loops blocked on copies not yet enqueued (diagnostics)
+        else:
+            ev = self._get()
+        stream.wait_event(ev)
+
+    waited = 0.0
 
 
 class HostFrameIO:
@@ -144,7 +158,13 @@ class HostFrameIO:
         self._tiny_d = torch.zeros(64, dtype=torch.uint8, device=pipe.device)
         dev = pipe.device
         H, W = pipe.H, pipe.W
-        self.depth = depth if depth is not None else 2 * pipe.seg_batch + 6
+        # "hostwait": `lookahead` frames are staged ahead of the frame loop (two segmentation groups + the frames between gate and
+        # matting net + slack), and a slot is rewritten `depth` frames later - by then its frame must have left the GPU, which trails
+        # the host by up to the pipeline's output ring (8): depth = lookahead + 12.  Event-ordered modes stage on demand.
+        paced = down_mode == "hostwait"
+        self.depth = depth if depth is not None else (2 * pipe.seg_batch + 16 if paced else 2 * pipe.seg_batch + 6)
+        self.lookahead = max(1, min(2 * pipe.seg_batch + 4, self.depth - 10))
+        self._feed = None
         n = H * W
         # one staging buffer per slot, [frame | bg_i | seg] (in_layout): host groups laid out the same way (pack_host_group) arrive
         # with ONE copy
@@ -154,10 +174,11 @@ class HostFrameIO:
         self.bgs = [t[self._bg_off:self._bg_off + 3 * n].view(H, W, 3) for t in self.stage]
         self.segs = [t[self._seg_off:self._seg_off + n].view(H, W) for t in self.stage]
         self.done = [None] * self.depth              # event: the frame staged in this slot has left the pipeline
-        self.up = torch.cuda.Stream(dev)
+        self.up = torch.cuda.Stream(dev)             # (normal priority: high-priority copy streams measured 4 % slower at 3840 x 2160)
         self.down = torch.cuda.Stream(dev)
         self._n_in = 0
         self._last_down = None
+        self.slot_waited = 0.0                       # seconds inputs() blocked for a staging slot (diagnostics)
         self._jobs = None                            # "hostwait": (compute event, [(dst, src)], PendingCopy) for the download thread
         self._thread = None
 
@@ -203,8 +224,21 @@ class HostFrameIO:
         """Generator for BgStepPipeline.run(): uploads each host frame into the next staging slot on the upload stream and
         yields (frame, seg, bg_i, bg_always, uploaded_event) device tensors.  host_frames yields (frame, seg | None, bg_i) or
         (frame, seg | None, bg_i, token); on_uploaded(event, token) is told when the host buffers may be reused (a FrameReader
-        slot to release)."""
-        for item in host_frames:
+        slot to release).
+
+        "hostwait" paces the uploads: `lookahead` groups go up when the run starts, after that ONE per finished frame (collect()'s
+        callback feeds the next), so the pipeline's pulls - 12 frames at once for a segmentation group - find their frames staged and
+        never put a burst of copies in front of a download (tools/dev/hostio_timeline.py: with 12 x 50 MB uploads queued at
+        3840 x 2160 a download took 8 ms instead of 0.6 and the conv kernels beside it ran at half speed - the runtime falls back to
+        copy kernels when the DMA engines are booked)."""
+        it = iter(host_frames)
+        staged = collections.deque()
+
+        def stage_one():
+            try:
+                item = next(it)
+            except StopIteration:
+                return False
             frame_h, seg_h, bg_h = item[:3]
             i = self._n_in % self.depth
             self._n_in += 1
@@ -212,7 +246,10 @@ class HostFrameIO:
                 raise RuntimeError("HostFrameIO: depth %d is smaller than the number of frames the pipeline holds in flight" % self.depth)
             if self.done[i] is not None:             # the slot's previous frame (depth frames back) has been consumed
                 if self.down_mode == "hostwait":
-                    self.done[i].synchronize()       # on the host: no barrier packet in the upload stream's queue
+                    if not self.done[i].query():
+                        t0 = time.perf_counter()
+                        self.done[i].synchronize()   # on the host: no barrier packet in the upload stream's queue
+                        self.slot_waited += time.perf_counter() - t0
                 else:
                     self.up.wait_event(self.done[i])
             if self.down_mode == "exclusive" and self._last_down is not None:
@@ -232,7 +269,22 @@ class HostFrameIO:
             self._last_up = ev
             if on_uploaded is not None:
                 on_uploaded(ev, item[3] if len(item) > 3 else None)
-            yield (self.frames[i], self.segs[i] if seg_h is not None else None, self.bgs[i], bg_always, ev)
+            staged.append((self.frames[i], self.segs[i] if seg_h is not None else None, self.bgs[i], bg_always, ev))
+            return True
+
+        if self.down_mode != "hostwait":             # event-ordered modes: a frame goes up when the pipeline asks for it
+            while stage_one():
+                yield staged.popleft()
+            return
+        self._feed = stage_one                       # collect() calls it once per finished frame
+        try:
+            for _ in range(self.lookahead):
+                if not stage_one():
+                    break
+            while staged or stage_one():             # (a consumer that never reports results just gets its frames on demand)
+                yield staged.popleft()
+        finally:
+            self._feed = None
 
     def collect(self, alpha_host=None, fg_host=None, target=None, on_downloaded=None):
         """on_result callback for run(): copies frame n's alpha and fg to alpha_host[n] / fg_host[n] - or to the pair of host
@@ -258,6 +310,8 @@ class HostFrameIO:
                 self._last_down = dn
                 if on_downloaded is not None:
                     on_downloaded(dn, token, n)
+                if self._feed is not None:
+                    self._feed()                     # one frame finished, one more goes up (inputs())
                 return
             down = self.up if self.down_mode == "shared" else self.down
             down.wait_event(ev)
