@@ -12,5 +12,9 @@ python bench.py --mode bg_online --steps 40 > $o/bench_bg_online.json 2> $o/benc
 for f in bench_driver_form bench_4k bench_4k_clip300_strong bench_green bench_bg_online; do cut -c1-150 $o/$f.json; done
 python tools/dev/pixel_times.py > $o/pixel_times_1080p.txt 2>&1; python tools/dev/pixel_times.py 2160 3840 > $o/pixel_times_4k.txt 2>&1
 python tools/dev/hostio_ablate.py > $o/hostio_ablate.txt 2>&1; tail -11 $o/hostio_ablate.txt
+python tools/dev/hostio_ablate.py --height 2160 --width 3840 --frames 120 --minimal > $o/hostio_ablate_4k.txt 2>&1; tail -4 $o/hostio_ablate_4k.txt
+python tools/dev/hostio_timeline.py > $o/hostio_timeline_4k.txt 2>&1; grep "pass:" $o/hostio_timeline_4k.txt
+python tools/dev/hostio_check.py 120 > $o/loops_agree_1080p.txt 2>&1; grep -c identical $o/loops_agree_1080p.txt
+python tools/dev/concurrent_conv_check.py default 100 > $o/concurrent_conv_check.txt 2>&1; tail -4 $o/concurrent_conv_check.txt
 python tools/dev/objects_time.py > $o/objects_time.txt 2>&1; tail -4 $o/objects_time.txt
 ROUND=r03 tools/dev/run_profiles.sh > $o/prof_log.txt 2>&1; tail -3 $o/prof_log.txt
