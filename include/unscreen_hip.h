@@ -151,6 +151,12 @@ int usc_vmat_post(const float* pred, int inH, int inW, const uint8_t* trimap, in
 int usc_get_fg_u8(const uint8_t* frame, const uint8_t* alpha, const uint8_t* bg, int paste_thr, int H, int W,
                   uint8_t* out_fg, uint8_t* out_bg, usc_stream_t stream);
 
+/* The two calls above as ONE launch, for loops that run them back to back on every frame (tools/unscreen/bg_offline.py:165-173:
+ * vmattingagent.forward(...) followed by bg[alpha == 0] = frame[alpha == 0]; get_fg(frame, alpha, bg)): alpha_u8 and out_fg receive
+ * exactly what usc_vmat_post followed by usc_get_fg_u8(paste_thr) writes (the same device code; the alpha of a pixel stays in a register). */
+int usc_vmat_post_fg(const float* pred, int inH, int inW, const uint8_t* trimap, const uint8_t* frame, const uint8_t* bg, int paste_thr,
+                     int H, int W, uint8_t* alpha_u8, float* alpha_f32, uint8_t* out_fg, usc_stream_t stream);
+
 /* unscreen/utils/fgfuncs.py:113-137 get_bg. */
 int usc_get_bg_u8(const uint8_t* alpha, const uint8_t* bg, int H, int W, uint8_t* out, usc_stream_t stream);
 

@@ -123,6 +123,28 @@ def test_vmat_post_bit_exact(nv, oracle_lib, H, W, L):
     assert np.array_equal(host(nv.vmat_post(dev(pred), dev(tri))), w8)
 
 
+@pytest.mark.parametrize("H,W,L", [(1080, 1920, 960), (2160, 3840, 960), (135, 241, 64), (33, 47, 96), (544, 960, 960), (1, 3, 64)])
+def test_vmat_post_fg_one_launch_bit_exact(nv, oracle_lib, H, W, L):
+    """The back half's fused launch (postprocess + paste + get_fg) against the oracle's two functions, and against the two kernels."""
+    in_h, in_w = oracle_lib.vmat_input_size(H, W, L)
+    rng = np.random.default_rng(51)
+    pred = ndi.gaussian_filter(rng.random((in_h, in_w)), 2).astype(np.float32)
+    pred = ((pred - pred.min()) / (pred.max() - pred.min())).astype(np.float32)
+    tri = ndi.median_filter(rng.choice(np.array([0, 128, 255], np.uint8), (H, W)), 5) if min(H, W) >= 5 else rng.choice(np.array([0, 128, 255], np.uint8), (H, W))
+    frame = rand_img(H, W, 52, smooth=False)
+    bg = rand_img(H, W, 53, smooth=False)
+    w8, wf = oracle_lib.vmat_post(pred, tri, want_float=True)
+    for paste in (1, 0, 128):
+        want_fg, _ = oracle_lib.get_fg(frame, w8, bg, paste)
+        g8, gf, gfg = nv.vmat_post_fg(dev(pred), dev(tri), dev(frame), dev(bg), paste_thr=paste, want_float=True)
+        assert np.array_equal(host(g8), w8) and np.array_equal(host(gf), wf)          # bit-exact
+        assert np.array_equal(host(gfg), want_fg), f"paste {paste}: {(host(gfg) != want_fg).sum()} bytes differ"
+        a2 = nv.vmat_post(dev(pred), dev(tri))
+        assert np.array_equal(host(nv.get_fg(dev(frame), a2, dev(bg), paste)), host(gfg))
+    g8, gf, gfg = nv.vmat_post_fg(dev(pred), dev(tri), dev(frame), dev(bg), paste_thr=1)
+    assert gf is None and np.array_equal(host(g8), w8)
+
+
 @pytest.mark.parametrize("H,W", [(1080, 1920), (2160, 3840), (270, 480), (33, 47), (1, 3), (7, 1)])
 def test_get_fg_get_bg_blend_bit_exact(nv, oracle_lib, H, W):
     frame = rand_img(H, W, 31, smooth=False)

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "usc_vmat_pre": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "usc_vmat_post": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "usc_get_fg_u8": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "usc_vmat_post_fg": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "usc_get_bg_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "usc_blend_u8": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
     "usc_count_ge_u8": (C.c_int, [_vp, C.c_size_t, C.c_int, _vp, _vp]),
@@ -319,6 +320,23 @@ def get_fg(frame, alpha, bg, paste_thr=0, out_fg=None, out_bg=None, want_bg=Fals
                                 _dev_u8(out_bg, "get_fg.out_bg", (H, W, 3)) if out_bg is not None else None, _stream()),
            "usc_get_fg_u8")
     return (out_fg, out_bg) if (want_bg or out_bg is not None) else out_fg
+
+
+def vmat_post_fg(pred, trimap_, frame, bg, paste_thr=0, out_u8=None, out_f32=None, out_fg=None, want_float=False):
+    """vmat_post followed by get_fg(paste_thr) as one launch -> (alpha u8, alpha f32 | None, fg)."""
+    H, W = trimap_.shape
+    if not (pred.is_cuda and pred.dtype == torch.float32 and pred.is_contiguous()):
+        raise NativeError("vmat_post_fg.pred: expected a contiguous float32 CUDA tensor")
+    inH, inW = pred.shape[-2], pred.shape[-1]
+    out_u8 = torch.empty((H, W), dtype=torch.uint8, device=pred.device) if out_u8 is None else out_u8
+    out_fg = torch.empty((H, W, 3), dtype=torch.uint8, device=pred.device) if out_fg is None else out_fg
+    if want_float and out_f32 is None:
+        out_f32 = torch.empty((H, W), dtype=torch.float32, device=pred.device)
+    _check(load().usc_vmat_post_fg(pred.data_ptr(), inH, inW, _dev_u8(trimap_, "vmat_post_fg.trimap"),
+                                   _dev_u8(frame, "vmat_post_fg.frame", (H, W, 3)), _dev_u8(bg, "vmat_post_fg.bg", (H, W, 3)), int(paste_thr), H, W,
+                                   _dev_u8(out_u8, "vmat_post_fg.alpha", (H, W)), out_f32.data_ptr() if out_f32 is not None else None,
+                                   _dev_u8(out_fg, "vmat_post_fg.fg", (H, W, 3)), _stream()), "usc_vmat_post_fg")
+    return out_u8, out_f32, out_fg
 
 
 def get_bg(alpha, bg, out=None):

@@ -782,6 +782,37 @@ extern "C" int usc_vmat_pre(const uint8_t* frame, const uint8_t* alpha_pre, cons
 }
 
 // Float bilinear back to full resolution + known-region clamp + *255 truncation; 4 pixels per lane.
+// (one quad of consecutive pixels i0 .. i0 + cnt - 1 -> the packed alpha bytes; shared by vmat_post_kernel and vmat_post_fg_kernel)
+__device__ __forceinline__ uint32_t vmat_post_quad(const float* __restrict__ pred, int rh, int rw, int pitch, const uint8_t* __restrict__ trimap, int W,
+                                                   double scale_y, double scale_x, int copy, uint32_t i0, int cnt, float* __restrict__ alpha_f32) {
+    uint32_t packed = 0;
+    uint32_t yy = i0 / (uint32_t)W, xx = i0 - yy * (uint32_t)W;
+    for (int k = 0; k < cnt; k++) {
+        const uint32_t i = i0 + k;
+        const int y = (int)yy, x = (int)xx;
+        if (++xx == (uint32_t)W) { xx = 0; yy++; }
+        float a;
+        if (copy) a = pred[(size_t)y * pitch + x];
+        else {
+            Tap tx = linear_tap_x(x, scale_x, rw), ty = linear_tap(y, scale_y);
+            int x0 = tx.s, x1 = min(x0 + 1, rw - 1);
+            int y0 = clampi(ty.s, 0, rh - 1), y1 = clampi(ty.s + 1, 0, rh - 1);
+            float a0 = 1.f - tx.f, a1 = tx.f, b0 = 1.f - ty.f, b1 = ty.f;
+            float r0 = pred[(size_t)y0 * pitch + x0] * a0 + pred[(size_t)y0 * pitch + x1] * a1;
+            float r1 = pred[(size_t)y1 * pitch + x0] * a0 + pred[(size_t)y1 * pitch + x1] * a1;
+            a = r0 * b0 + r1 * b1;
+        }
+        int t = trimap[i];
+        if (t == 0) a = 0.f;
+        if (t == 255) a = 1.f;
+        if (alpha_f32) alpha_f32[i] = a;
+        float s = a * 255.f;
+        int u = (int)s;                         // astype(uint8) of a value in [0, 255]: truncation
+        packed |= (uint32_t)(u & 0xff) << (8 * k);
+    }
+    return packed;
+}
+
 __global__ __launch_bounds__(256) void vmat_post_kernel(const float* __restrict__ pred, int rh, int rw, int pitch,
                                                         const uint8_t* __restrict__ trimap, int H, int W,
                                                         double scale_y, double scale_x, int copy,
@@ -790,31 +821,7 @@ __global__ __launch_bounds__(256) void vmat_post_kernel(const float* __restrict_
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += gridDim.x * blockDim.x) {
         const uint32_t i0 = q * 4;
         const int cnt = (int)min(4u, n - i0);
-        uint32_t packed = 0;
-        uint32_t yy = i0 / (uint32_t)W, xx = i0 - yy * (uint32_t)W;
-        for (int k = 0; k < cnt; k++) {
-            const uint32_t i = i0 + k;
-            const int y = (int)yy, x = (int)xx;
-            if (++xx == (uint32_t)W) { xx = 0; yy++; }
-            float a;
-            if (copy) a = pred[(size_t)y * pitch + x];
-            else {
-                Tap tx = linear_tap_x(x, scale_x, rw), ty = linear_tap(y, scale_y);
-                int x0 = tx.s, x1 = min(x0 + 1, rw - 1);
-                int y0 = clampi(ty.s, 0, rh - 1), y1 = clampi(ty.s + 1, 0, rh - 1);
-                float a0 = 1.f - tx.f, a1 = tx.f, b0 = 1.f - ty.f, b1 = ty.f;
-                float r0 = pred[(size_t)y0 * pitch + x0] * a0 + pred[(size_t)y0 * pitch + x1] * a1;
-                float r1 = pred[(size_t)y1 * pitch + x0] * a0 + pred[(size_t)y1 * pitch + x1] * a1;
-                a = r0 * b0 + r1 * b1;
-            }
-            int t = trimap[i];
-            if (t == 0) a = 0.f;
-            if (t == 255) a = 1.f;
-            if (alpha_f32) alpha_f32[i] = a;
-            float s = a * 255.f;
-            int u = (int)s;                         // astype(uint8) of a value in [0, 255]: truncation
-            packed |= (uint32_t)(u & 0xff) << (8 * k);
-        }
+        const uint32_t packed = vmat_post_quad(pred, rh, rw, pitch, trimap, W, scale_y, scale_x, copy, i0, cnt, alpha_f32);
         if (cnt == 4) *reinterpret_cast<uint32_t*>(alpha_u8 + i0) = packed;
         else for (int k = 0; k < cnt; k++) alpha_u8[i0 + k] = (packed >> (8 * k)) & 0xff;
     }
@@ -894,6 +901,61 @@ extern "C" int usc_get_fg_u8(const uint8_t* frame, const uint8_t* alpha, const u
     size_t n = (size_t)H * W;
     hipLaunchKernelGGL(get_fg_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, frame, alpha, bg, paste_thr, n, out_fg, out_bg);
     return check_launch("get_fg_kernel");
+}
+
+// vmat_post + get_fg of the frame loop's back half as ONE launch (reference vmatting/agent.py:163-173 followed by fgfuncs.py get_fg): the
+// alpha quad stays in a register between the two, one launch and one pass over alpha less per frame.  Same device code as the two kernels.
+__global__ __launch_bounds__(256) void vmat_post_fg_kernel(const float* __restrict__ pred, int rh, int rw, int pitch,
+                                                           const uint8_t* __restrict__ trimap, int H, int W, double scale_y, double scale_x, int copy,
+                                                           const uint8_t* __restrict__ frame, const uint8_t* __restrict__ bg, int paste_thr,
+                                                           uint8_t* __restrict__ alpha_u8, float* __restrict__ alpha_f32, uint8_t* __restrict__ out_fg) {
+    __shared__ int s_sdiv[256], s_hdiv[256];
+    load_hsv_tables(s_sdiv, s_hdiv);
+    __syncthreads();
+    const uint32_t n = (uint32_t)H * (uint32_t)W;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += gridDim.x * blockDim.x) {
+        const uint32_t i0 = q * 4;
+        const int cnt = (int)min(4u, n - i0);
+        const uint32_t a4 = vmat_post_quad(pred, rh, rw, pitch, trimap, W, scale_y, scale_x, copy, i0, cnt, alpha_f32);
+        if (cnt == 4) {
+            *reinterpret_cast<uint32_t*>(alpha_u8 + i0) = a4;
+            int f[12], b[12], o[12];
+            unpack12(*reinterpret_cast<const Px4*>(frame + 3 * (size_t)i0), f);
+            unpack12(*reinterpret_cast<const Px4*>(bg + 3 * (size_t)i0), b);
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                int a = (a4 >> (8 * p)) & 0xff;
+                if (a < paste_thr) { b[3 * p] = f[3 * p]; b[3 * p + 1] = f[3 * p + 1]; b[3 * p + 2] = f[3 * p + 2]; }
+                fg_pixel(f[3 * p], f[3 * p + 1], f[3 * p + 2], b[3 * p], b[3 * p + 1], b[3 * p + 2], a, s_sdiv, s_hdiv, o + 3 * p);
+            }
+            *reinterpret_cast<Px4*>(out_fg + 3 * (size_t)i0) = pack12(o);
+        } else {
+            for (int k = 0; k < cnt; k++) {
+                const size_t i = (size_t)i0 + k;
+                const int a = (a4 >> (8 * k)) & 0xff;
+                alpha_u8[i] = (uint8_t)a;
+                int o[3], b[3];
+                for (int c = 0; c < 3; c++) b[c] = a < paste_thr ? frame[3 * i + c] : bg[3 * i + c];
+                fg_pixel(frame[3 * i], frame[3 * i + 1], frame[3 * i + 2], b[0], b[1], b[2], a, s_sdiv, s_hdiv, o);
+                for (int c = 0; c < 3; c++) out_fg[3 * i + c] = (uint8_t)o[c];
+            }
+        }
+    }
+}
+
+extern "C" int usc_vmat_post_fg(const float* pred, int inH, int inW, const uint8_t* trimap, const uint8_t* frame, const uint8_t* bg, int paste_thr,
+                                int H, int W, uint8_t* alpha_u8, float* alpha_f32, uint8_t* out_fg, usc_stream_t stream) {
+    if (!pred || !trimap || !frame || !bg || !alpha_u8 || !out_fg || H <= 0 || W <= 0 || inH <= 0 || inW <= 0) return fail(USC_E_ARG, "usc_vmat_post_fg: bad argument");
+    if (too_big(H, W) || too_big(inH, inW)) return fail(USC_E_UNSUPPORTED, "usc_vmat_post_fg: image too large");
+    int rh, rw;
+    usc_inv_pad_geometry(inH, inW, H, W, &rh, &rw);
+    if (rh <= 0 || rw <= 0 || rh > inH || rw > inW) return fail(USC_E_ARG, "usc_vmat_post_fg: un-padded size %dx%d", rh, rw);
+    double scale_x = 1. / ((double)W / rw), scale_y = 1. / ((double)H / rh);
+    int copy = (rh == H && rw == W);
+    size_t quads = ((size_t)H * W + 3) / 4;
+    hipLaunchKernelGGL(vmat_post_fg_kernel, dim3(grid_for(quads, 256)), dim3(256), 0, (hipStream_t)stream, pred, rh, rw, inW, trimap,
+                       H, W, scale_y, scale_x, copy, frame, bg, paste_thr, alpha_u8, alpha_f32, out_fg);
+    return check_launch("vmat_post_fg_kernel");
 }
 
 __global__ __launch_bounds__(256) void get_bg_kernel(const uint8_t* __restrict__ alpha, const uint8_t* __restrict__ bg, size_t n,

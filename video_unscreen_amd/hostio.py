@@ -284,7 +284,8 @@ class HostFrameIO:
             while staged or stage_one():             # (a consumer that never reports results just gets its frames on demand)
                 yield staged.popleft()
         finally:
-            self._feed = None
+            if self._feed is stage_one:              # (an abandoned generator may be finalised after the next run has started)
+                self._feed = None
 
     def collect(self, alpha_host=None, fg_host=None, target=None, on_downloaded=None):
         """on_result callback for run(): copies frame n's alpha and fg to alpha_host[n] / fg_host[n] - or to the pair of host

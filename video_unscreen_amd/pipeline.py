@@ -182,9 +182,9 @@ class BgStepPipeline:
             else:
                 torch.cuda.current_stream(self.device).wait_event(done)
             ring["consumed"] = None
-        res = nv.vmat_post(pred.view(self.in_h, self.in_w), slot.trimap, out_u8=ring["alpha"], want_float=want_float)
-        alpha, alpha_f = (res if want_float else (res, None))
-        fg = nv.get_fg(frame, alpha, slot.bg, paste_thr=1, out_fg=ring["fg"])
+        # postprocess + bg[alpha == 0] = frame[alpha == 0] + get_fg (bg_offline.py:165-173) as one launch
+        alpha, alpha_f, fg = nv.vmat_post_fg(pred.view(self.in_h, self.in_w), slot.trimap, frame, slot.bg, paste_thr=1,
+                                             out_u8=ring["alpha"], out_fg=ring["fg"], want_float=want_float)
         self.alpha_pre = alpha
         return {"alpha": alpha, "alpha_f32": alpha_f, "fg": fg, "trimap": slot.trimap, "bg": slot.bg,
                 "gate": slot.gate, "alphaor": slot.alphaor, "pred": pred, "seg": slot.seg, "packed": ring["packed"], "_ring": ring}
