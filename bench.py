@@ -105,15 +105,16 @@ def kernel_table(pipe, sample, H, W):
         rows.append({"kernel": name, "us": round(t * 1e6, 2), "alg_bytes": int(nbytes),
                      "GBps": round(nbytes / t / 1e9, 1), "frac_hbm_peak": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4)})
 
-    add("bgdiff_mask (point + gate)", lambda: nv.bgdiff_mask(frame, bg_i, bg_always, seg, pipe.beta, pipe.thr,
+    add("bgdiff_mask (bgdiff_gate_kernel)", lambda: nv.bgdiff_mask(frame, bg_i, bg_always, seg, pipe.beta, pipe.thr,
                                                              out_bg=slot.bg, out_alpha=slot.gate, ws=pipe.ws_bgdiff),
         9 * N + seg_b + 3 * N + N)
     add("trimap (small + up)", lambda: nv.trimap(gate, pipe.long_side, pipe.ksize, pipe.iters, out=slot.trimap, ws=pipe.ws_trimap),
         N + n_lo)
     add("vmat_pre", lambda: nv.vmat_pre(frame, alpha, tri, pipe.in_h, pipe.in_w, layout=pipe._layout, out=pipe.x7),
         5 * N + (32 if pipe._layout == nv.NHWC8 else 28) * n_in)
-    add("vmat_post", lambda: nv.vmat_post(pred, tri, out_u8=alpha), 2 * N + 4 * n_in)
-    add("get_fg", lambda: nv.get_fg(frame, alpha, slot.bg, paste_thr=1, out_fg=out["fg"]), 10 * N)
+    # the loop's back half runs postprocess + paste + get_fg as ONE launch: pred + trimap in, frame + bg in, alpha + fg out
+    add("vmat_post_fg (postprocess + get_fg, one launch)",
+        lambda: nv.vmat_post_fg(pred, tri, frame, slot.bg, paste_thr=1, out_u8=alpha, out_fg=out["fg"]), 11 * N + 4 * n_in)
     cnt = torch.empty(1, dtype=torch.int64, device=frame.device)
     add("count_ge", lambda: nv.count_ge(alpha, 128, out=cnt), N)
     t_net = time_kernel(lambda: pipe.net(pipe.x7), iters=20, warm=3)           # the product path: planned stream launches

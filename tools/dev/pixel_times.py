@@ -43,6 +43,7 @@ t("trimap", lambda: nv.trimap(gate, pipe.long_side, pipe.ksize, pipe.iters, out=
 t("vmat_pre", lambda: nv.vmat_pre(f["frame"], alpha, tri, pipe.in_h, pipe.in_w, layout=pipe._layout, out=pipe.x7))
 t("vmat_post", lambda: nv.vmat_post(pred, tri, out_u8=alpha))
 t("get_fg", lambda: nv.get_fg(f["frame"], alpha, slot.bg, paste_thr=1, out_fg=out["fg"]))
+t("vmat_post_fg (the two as one launch)", lambda: nv.vmat_post_fg(pred, tri, f["frame"], slot.bg, paste_thr=1, out_u8=alpha, out_fg=out["fg"]))
 t("humanseg_pre", lambda: nv.humanseg_pre(f["frame"], 473, 473))
 seg_out = torch.empty((H, W), dtype=torch.uint8, device="cuda")
 t("humanseg_post", lambda: nv.humanseg_post(logits, 20, H, W, out=seg_out))

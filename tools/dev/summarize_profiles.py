@@ -11,7 +11,7 @@ import sys
 
 stats_f, fetch_f, write_f, frames, title = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
 OURS = ("conv_mfma_kernel", "conv_wino_kernel", "splitk_reduce_kernel", "head_conv_kernel", "bgdiff_gate_kernel", "seg_post_fused_kernel", "bgdiff_point_kernel", "gate_kernel", "trimap_small_kernel",
-        "trimap_up_kernel", "vmat_pre_kernel", "vmat_post_kernel", "get_fg_kernel", "seg_pre_kernel", "seg_up_kernel",
+        "trimap_up_kernel", "vmat_pre_kernel", "vmat_post_kernel", "get_fg_kernel", "vmat_post_fg_kernel", "seg_pre_kernel", "seg_up_kernel",
         "seg_warp_argmax_kernel", "upsample_ac_nhwc_kernel", "count_ge_kernel", "morph_tile_kernel", "inrange_hsv_kernel")
 
 
