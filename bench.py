@@ -649,9 +649,18 @@ def main():
             run_host(first, nchk)
             torch.cuda.synchronize()
             bad = [n for n in range(nchk) if not (torch.equal(alpha_h[n], kept[n][0].cpu()) and torch.equal(fg_h[n], kept[n][1].cpu()))]
-            result["self_check"] = {"frames": nchk, "host_loop_equals_device_loop": not bad}
-            if bad:
-                print("bench.py: the host -> host loop and the device-resident loop disagree on frames %s" % bad[:8], file=sys.stderr, flush=True)
+            # and both against the synchronous loop: every stage of a frame in order on ONE stream (pipe.step)
+            pipe.reset()
+            bad_sync = []
+            for n in range(nchk):
+                fr_, _, bg_, bga_ = frames[first + n][0], None, frames[first + n][2], frames[first + n][3]
+                o = pipe.step(fr_, frames[first + n][1] if seg_agent is None else None, bg_, bga_)
+                if not (torch.equal(o["alpha"], kept[n][0]) and torch.equal(o["fg"], kept[n][1])):
+                    bad_sync.append(n)
+            result["self_check"] = {"frames": nchk, "host_loop_equals_device_loop": not bad, "pipelined_loop_equals_synchronous_loop": not bad_sync}
+            if bad or bad_sync:
+                print("bench.py: the loops disagree - host -> host vs device-resident on frames %s, pipelined vs synchronous on frames %s"
+                      % (bad[:8], bad_sync[:8]), file=sys.stderr, flush=True)
                 sys.exit(1)
         if not args.no_kernel_table:                         # (other ranks wait at the final barrier: not inside the timed region)
             rows, t_net, t_graph = kernel_table(pipe, frames[first], H, W)
