@@ -291,7 +291,7 @@ class HostFrameIO:
         """on_result callback for run(): copies frame n's alpha and fg to alpha_host[n] / fg_host[n] - or to the pair of host
         tensors target(n) returns, with a token as third element - on the download stream and marks the frame's staging slot free;
         on_downloaded(event, token, n) is told when the copies have been enqueued (event = their completion).  The pipeline's
-        outputs live in its own ring of four, whose reuse waits for these copies."""
+        outputs live in its own ring of eight, whose reuse waits for these copies."""
         main = torch.cuda.current_stream(self.pipe.device)
         base = self._n_in                            # inputs() of this run has not started yet: slots continue from here
 
