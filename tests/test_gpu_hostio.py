@@ -75,15 +75,15 @@ def test_download_thread_failure_reaches_the_loop():
     torch.cuda.synchronize()
 
 
-def test_1080p_loops_agree_sync_pipelined_host():
-    """At the bench's size with the human-parsing network in the loop (three streams + two copy streams + the download thread):
+@pytest.mark.parametrize("H,W,K", [(1080, 1920, 27), (2160, 3840, 15)])       # BASELINE.json configs[1] and configs[3] sizes
+def test_full_size_loops_agree_sync_pipelined_host(H, W, K):
+    """At the bench's sizes with the human-parsing network in the loop (three streams + two copy streams + the download thread):
     the synchronous loop (step()), the pipelined loop over HBM-resident inputs and the host -> host loop give the same bytes."""
     from video_unscreen_amd import hostio
     from video_unscreen_amd.binseg import HumanSegAgent
     from video_unscreen_amd.binseg.schp_net import schp_synthetic_state_dict
     from video_unscreen_amd.pipeline import BgStepPipeline, default_config
     from video_unscreen_amd.vmatting.net import synthetic_state_dict
-    H, W, K = 1080, 1920, 27
     seg_agent = HumanSegAgent(model_path=None, cuda_device=0, state_dict=schp_synthetic_state_dict(0))
     pipe = BgStepPipeline(default_config(), H, W, state_dict=synthetic_state_dict(0), seg_agent=seg_agent, seg_batch=12)
     clip, fr = _clip(H, W, K)
