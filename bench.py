@@ -136,24 +136,7 @@ def cpu_model():
     return "unknown"
 
 
-def usable_cpus():
-    """CPUs this process may really use: its affinity mask, capped by the cgroup CPU quota when there is one (a GPU box hands a
-    rank a share of the host: 128 torch threads on a 16-CPU share run slower than 16)."""
-    n = len(os.sched_getaffinity(0))
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
-            else:
-                q = int(txt[0])
-                if q > 0:
-                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    return n
+from video_unscreen_amd import usable_cpus  # noqa: E402  (affinity mask capped by the cgroup quota)
 
 
 def cpu_baseline(cfg, pipe, clip_cpu_frames, bg_always, nframes, threads=None):
