@@ -415,6 +415,11 @@ def main():
     dev = torch.device("cuda", local)
     numa = bind_near_gpu(local) if world > 1 and not os.environ.get("USC_BENCH_SHARE_GPU") else "not bound (single rank)"
     if world > 1:
+        # the ranks of a node share its cores: each keeps torch's CPU pool (network set-up: folding, weight packing) to its share
+        # (bound to a NUMA node, a rank shares that node's cores with the ranks of the other GPUs on it: half of them on a two-socket host)
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        sharers = max(1, local_world // 2) if numa.startswith("node") else local_world
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_cpus() // sharers)))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
