@@ -226,7 +226,7 @@ class HostFrameIO:
         (frame, seg | None, bg_i, token); on_uploaded(event, token) is told when the host buffers may be reused (a FrameReader
         slot to release).
 
-        "hostwait" paces the uploads: `lookahead` groups go up when the run starts, after that ONE per finished frame (collect()'s
+        "hostwait" paces the uploads: `lookahead` frames go up when the run starts, after that ONE per finished frame (collect()'s
         callback feeds the next), so the pipeline's pulls - 12 frames at once for a segmentation group - find their frames staged and
         never put a burst of copies in front of a download (tools/dev/hostio_timeline.py: with 12 x 50 MB uploads queued at
         3840 x 2160 a download took 8 ms instead of 0.6 and the conv kernels beside it ran at half speed - the runtime falls back to
