@@ -118,3 +118,43 @@ def test_full_size_loops_agree_sync_pipelined_host(H, W, K):
     bad = [n for n in range(K) if not (torch.equal(a_h[n], want[n][0].cpu()) and torch.equal(f_h[n], want[n][1].cpu()))]
     assert not bad, ("host loop, host object filter", bad)
     io.close()
+
+
+def test_slow_reader_small_rings_and_a_consumer_that_never_reports():
+    """The paced upload path under awkward conditions: a reader that delivers a frame every few milliseconds (the look-ahead runs dry,
+    frames go up on demand), the smallest staging ring the loop admits, several runs through one HostFrameIO - same bytes as the
+    device-resident loop; and a loop that never hands results back runs out of staging slots with an error, not a hang."""
+    import time
+    from video_unscreen_amd import hostio
+    from video_unscreen_amd.pipeline import BgStepPipeline, default_config
+    from video_unscreen_amd.vmatting.net import synthetic_state_dict
+    H, W, K = 135, 240, 17
+    pipe = BgStepPipeline(default_config(), H, W, state_dict=synthetic_state_dict(0))
+    clip, fr = _clip(H, W, K)
+    want = []
+    pipe.run(iter([(f["frame"], f["seg"], f["bg"], clip.bg_always) for f in fr]), on_result=lambda n, o: want.append((o["alpha"].clone(), o["fg"].clone())))
+    torch.cuda.synchronize()
+    groups = [hostio.pack_host_group(f["frame"].cpu(), f["bg"].cpu(), f["seg"].cpu()) for f in fr]
+
+    def slow(gs):
+        for k, g in enumerate(gs):
+            if k % 3 == 0:
+                time.sleep(0.004)
+            yield g
+
+    a_h, f_h = hostio.packed_outputs(K, H, W)
+    io = hostio.HostFrameIO(pipe, depth=6)                       # look-ahead 1, six staging slots
+    assert io.lookahead == 1
+    for rep in range(3):
+        a_h.zero_(); f_h.zero_()
+        pipe.reset()
+        assert pipe.run(io.inputs(slow(groups), clip.bg_always), on_result=io.collect(a_h, f_h)) == K
+        io.drain()
+        for t in range(K):
+            assert torch.equal(a_h[t], want[t][0].cpu()) and torch.equal(f_h[t], want[t][1].cpu()), (rep, t)
+    io.close()
+    io2 = hostio.HostFrameIO(pipe, depth=6)
+    pipe.reset()
+    with pytest.raises(RuntimeError, match="depth 6 is smaller"):
+        pipe.run(io2.inputs(groups, clip.bg_always))            # nobody marks a staging slot free
+    torch.cuda.synchronize()
