@@ -56,10 +56,18 @@ def test_pending_copy_hands_the_helper_threads_error_to_whoever_waits():
 
 
 def test_torch_thread_pool_respects_the_cpu_share():
+    import subprocess
+    import sys
     import video_unscreen_amd as pkg
     n = pkg.usable_cpus()
     assert 1 <= n <= len(os.sched_getaffinity(0))
+    pkg.respect_cpu_share()                          # (what _native.load() does before anything is built)
     assert torch.get_num_threads() <= max(n, 1) or os.environ.get("USC_KEEP_TORCH_THREADS")
+    # importing the package must not pull torch in: the frame I/O worker processes import it too
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import sys; import video_unscreen_amd, video_unscreen_amd._io_workers; print('torch' in sys.modules)"],
+                       capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0 and r.stdout.strip() == "False", r.stdout + r.stderr
 
 
 def test_layouts_keep_every_part_16_byte_aligned():

@@ -22,19 +22,23 @@ def usable_cpus():
     return n
 
 
-def _respect_cpu_share():
+_capped = False
+
+
+def respect_cpu_share():
     """The host-side set-up of the networks (folding, weight packing, the Winograd transform of the weights in float64) runs on torch's CPU
     threads; torch sizes its pool by the HOST's cores, which on a cgroup-limited share oversubscribes it many times over.  Cap the pool at
-    what the process may use (never raise it; USC_KEEP_TORCH_THREADS=1 leaves it alone)."""
-    if os.environ.get("USC_KEEP_TORCH_THREADS"):
+    what the process may use (never raise it; USC_KEEP_TORCH_THREADS=1 leaves it alone).  Called once when the native library is loaded
+    (_native.load()) - not at package import, which the decoder / encoder worker processes of utils/frameio.py also go through and which
+    must stay free of torch."""
+    global _capped
+    if _capped or os.environ.get("USC_KEEP_TORCH_THREADS"):
         return
+    _capped = True
     try:
         import torch
         n = usable_cpus()
         if torch.get_num_threads() > n:
             torch.set_num_threads(n)
-    except Exception:      # noqa: BLE001 - a tuning step, never a reason to fail an import
+    except Exception:      # noqa: BLE001 - a tuning step, never a reason to fail
         pass
-
-
-_respect_cpu_share()

@@ -126,6 +126,8 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `make -C video_unscreen_amd/csrc`). There is no CPU fallback.")
+        from . import respect_cpu_share
+        respect_cpu_share()                      # torch's CPU pool <= the CPUs this process may use (network set-up runs on it)
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
