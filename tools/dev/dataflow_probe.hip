@@ -60,7 +60,19 @@ __global__ __launch_bounds__(THREADS) void dataflow_kernel(float* bufs, int L, i
         __syncthreads();
         if (item >= L * NB) return;
         const int l = item / NB, b = item - l * NB;
-        if (mode > 0 && mode != 3 && l > 0 && threadIdx.x == 0) {             // wait for the three producers of the previous layer (one lane, one flag after the other)
+        if (mode == 4 && l > 0 && threadIdx.x < 64) {            // wave 0 polls all flags at once, in a loop every lane iterates the same number of times
+            const int k = (int)threadIdx.x;
+            const int p = (b + NB - 1 + (k < 3 ? k : 0)) % NB;
+            bool ready = k >= 3;
+            int polls = 0;
+            for (;;) {
+                if (!ready) ready = __hip_atomic_load(&flags[(l - 1) * NB + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (__all(ready) || ++polls >= (1 << 12)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (polls >= (1 << 12) && k == 0) atomicExch(&ctl[1], 1);
+        }
+        if (mode > 0 && mode < 3 && l > 0 && threadIdx.x == 0) {             // wait for the three producers of the previous layer (one lane, one flag after the other)
             for (int k = 0; k < 3; k++) {
                 const int p = (b + NB - 1 + k) % NB;
                 int polls = 0;
@@ -110,7 +122,8 @@ int main(int argc, char** argv) {
                 else hipLaunchKernelGGL(dataflow_kernel, dim3(NB), dim3(THREADS), 0, st, bufs2, L, iters, flags, ctl, mode, 0);
             };
         };
-        const double t_tiny = timed(tiny), t_same = timed(df(3)), t_static = timed(df(2)), t_queue = timed(df(1));   // (the queue form runs last: its result is compared)
+        const double t_tiny = timed(tiny), t_same = timed(df(3)), t_static = timed(df(2)), t_par = argc > 2 ? timed(df(4)) : 0., t_queue = timed(df(1));   // (the queue form runs last: its result is compared)
+        if (argc > 2) printf("          (items from a counter, wave 0 polling its flags in parallel with a uniform loop: %.2f)\n", t_par);
         int hc[2]; CK(hipMemcpy(hc, ctl, 8, hipMemcpyDeviceToHost));
         std::vector<float> ra(tensor), rb(tensor);
         CK(hipMemcpy(ra.data(), bufs + (size_t)L * tensor, tensor * 4, hipMemcpyDeviceToHost));
