@@ -57,9 +57,10 @@ def parse():
     ap.add_argument("--no-seg", action="store_true",
                     help="stage-3 loop only (segmentation masks are inputs, as in the reference's bg_offline.py with its "
                          "stages 1-2 disabled); default: the human-parsing net runs on every frame (binseg + trimap + vmatting)")
-    ap.add_argument("--mode", default="bg_step", choices=["bg_step", "green", "bg_online"],
+    ap.add_argument("--mode", default="bg_step", choices=["bg_step", "green", "bg_online", "replace"],
                     help="bg_step (default, BASELINE.json configs[1] / [3]); green (configs[0]: SegAgent / colour filtering loop) and "
-                         "bg_online (configs[2]: STM tracking + inpainting loop) time the other frame loops the same way")
+                         "bg_online (configs[2]: STM tracking + inpainting loop) time the other frame loops the same way; replace "
+                         "(configs[4], the compositing half: tools/replace/replace.py's centroid pass + per-frame composite, host -> host)")
     ap.add_argument("--clip-frames", type=int, default=0,
                     help="strong-scaling form: ONE clip of that many frames, sharded into contiguous frame ranges over the ranks exactly as "
                          "the reference's --range runs cut it (tools/unscreen/bg_offline.py:34-35, 184-192); `steps` becomes the clip "
@@ -166,13 +167,14 @@ def cpu_baseline(cfg, pipe, clip_cpu_frames, bg_always, nframes, threads=None):
 
 
 def pmc_traffic(H, W):
-    """Fabric bytes of the conv stack per forward from the committed rocprofv3 PMC passes (profiles/r03/pmc_conv_traffic.json, else an earlier round's,
-    produced by tools/dev/run_profiles.sh + summarize_profiles.py on this workload): FETCH_SIZE x 2 (gfx950 reports half the bytes of
-    16-B/lane streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE.  Counters cannot be collected inside this process; null for any
-    other frame size or when the file is absent."""
+    """Fabric bytes of the conv stack per forward from the committed rocprofv3 PMC passes of this workload (newest round first:
+    profiles/rNN/pmc_conv_traffic.json for 1920 x 1080, profiles/rNN/pmc_conv_traffic_<W>x<H>.json for any other size; produced by
+    tools/dev/run_profiles.sh + summarize_profiles.py): FETCH_SIZE x 2 (gfx950 reports half the bytes of 16-B/lane streaming reads,
+    MI355X_MICROARCH.md) + WRITE_SIZE.  Counters cannot be collected inside this process; null when no file matches the frame size."""
     root = os.path.dirname(os.path.abspath(__file__))
-    path = next((q for q in (os.path.join(root, "profiles", r, "pmc_conv_traffic.json") for r in ("r03", "r02", "r01")) if os.path.exists(q)), None)
-    if (H, W) != (1080, 1920) or path is None:
+    name = "pmc_conv_traffic.json" if (H, W) == (1080, 1920) else f"pmc_conv_traffic_{W}x{H}.json"
+    path = next((q for q in (os.path.join(root, "profiles", r, name) for r in ("r04", "r03", "r02", "r01")) if os.path.exists(q)), None)
+    if path is None:
         return None
     z = json.load(open(path))
     return int(2 * z["fetch_raw_bytes_per_forward"] + z["write_bytes_per_forward"])
@@ -234,6 +236,137 @@ def other_mode(args, rank, world, dev):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def replace_mode(args, rank, world, dev):
+    """BASELINE.json configs[4], the loop of the reference's tools/replace/replace.py:28-82: one step = one frame through BOTH passes
+    (centroid moments of the two alpha masks; shift_fg -> rescale_fg(1.2) -> float64 blend -> side-by-side image).  Inputs start in
+    pinned host memory (target fg + alphamask, source frame + alphamask), the side-by-side image ends there (its right half is res).
+    Frames are independent: every rank takes its own contiguous range, the only exchange is the all-reduce of (sum dx, sum dy, n)."""
+    from video_unscreen_amd import _native as nv
+    from video_unscreen_amd.pipeline_replace import ReplaceHostLoop, ReplacePipeline
+    from video_unscreen_amd.synth import SyntheticClip
+    H, W, K, Wm = args.height, args.width, args.steps, args.warmup
+    n = H * W
+    tgt = SyntheticClip(H, W, K, config_id=2, device=dev)
+    src = SyntheticClip(H, W, K, config_id=3, device=dev)
+    tgt.gen.manual_seed(20260002 + 7919 * rank)
+    src.gen.manual_seed(20260003 + 7919 * rank)
+    pin = lambda t: t.cpu().pin_memory()                                                  # noqa: E731
+    masks_h, inputs_h = [], []
+    for t in range(K):
+        f, g = tgt.frame(t), src.frame(t)
+        a = (f["alpha_true"] * 255).to(torch.uint8)
+        m3 = a.unsqueeze(-1).expand(H, W, 3).contiguous()
+        fg = (f["frame"].float() * (a.float() / 255.).unsqueeze(-1)).to(torch.uint8)
+        sm3 = (g["alpha_true"] * 255).to(torch.uint8).unsqueeze(-1).expand(H, W, 3).contiguous()
+        masks_h.append((pin(m3), pin(sm3)))
+        inputs_h.append((pin(fg), pin(g["frame"])))
+    pipe = ReplacePipeline(H, W, src.bg_always, device=dev, scale=1.2, max_frames=K)
+    loop = ReplaceHostLoop(pipe, K, ring=4)
+    compare_h = torch.empty((K, H, 2 * W, 3), dtype=torch.uint8).pin_memory()
+    torch.cuda.synchronize()
+
+    def job(k):                                              # both passes over the first k frames; the mean needs every rank's sums
+        acc = torch.tensor(loop.pass1(masks_h[:k]), dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(acc)
+        dx, dy = float(acc[0] / acc[2]), float(acc[1] / acc[2])
+        loop.pass2(inputs_h[:k], pipe.shift_matrix(dx, dy), compare_h)
+        return dx, dy
+
+    for _ in range(2):
+        job(max(1, min(Wm, K)))                              # W warm-up frames (first launches, page-locked buffers touched), twice
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dx, dy = job(K)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        M = pipe.shift_matrix(dx, dy)
+        # not timed: the loop's output against the stand-alone kernel chain on HBM-resident copies of the same inputs
+        bad = []
+        for i in sorted({0, 1, K // 2, K - 1}):
+            res_c, cmp_c = pipe.compose_chain(inputs_h[i][0].to(dev), masks_h[i][0].to(dev), inputs_h[i][1].to(dev), M)
+            if not torch.equal(compare_h[i], cmp_c.cpu()):
+                bad.append(i)
+        if bad:
+            print("bench.py: the replace loop's output differs from the stand-alone kernel chain on frames %s" % bad, file=sys.stderr, flush=True)
+            sys.exit(1)
+        # the same work with everything resident in HBM (no copies): what the kernels alone sustain
+        d_in = [(inputs_h[i][0].to(dev), masks_h[i][0].to(dev), inputs_h[i][1].to(dev), masks_h[i][1].to(dev)) for i in range(min(K, 32))]
+        cmp_d = torch.empty((H, 2 * W, 3), dtype=torch.uint8, device=dev)
+
+        def resident():
+            for i, (fg, m, fr, sm) in enumerate(d_in):
+                pipe.centroid_pair(i, m, sm)
+                pipe.compose(fg, m, fr, M, compare=cmp_d, want_res=False)
+        t_res = _net_time(resident, iters=5, warm=2) / len(d_in)
+        fg, m, fr, sm = d_in[0]
+        t_k = time_kernel(lambda: pipe.compose(fg, m, fr, M, compare=cmp_d, want_res=False), iters=50)
+        t_m = time_kernel(lambda: pipe.centroid_pair(0, m, sm), iters=50)
+        t_chain = time_kernel(lambda: pipe.compose_chain(fg, m, fr, M), iters=20)
+        alg = 12 * n + 6 * n                                  # read fg, mask, bg, source frame (3 N each); write [source | res] (6 N)
+        roof = {"bound": "hbm", "kernel": "replace_compose_kernel (shift_fg + rescale_fg x2, float64 blend, side-by-side image: one launch per frame)",
+                "achieved": round(alg / t_k / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / t_k / 1e9 / HBM_PEAK_GBS, 4),
+                "traffic": None, "alg_bytes_per_launch": alg, "us_per_launch": round(t_k * 1e6, 2),
+                "stand_alone_chain_us": round(t_chain * 1e6, 2)}
+        rows = [{"kernel": "replace_compose_kernel", "us": round(t_k * 1e6, 2), "alg_bytes": alg, "GBps": round(alg / t_k / 1e9, 1)},
+                {"kernel": "gray_moments_kernel x2 (+ 2 memsets; get_center of both masks)", "us": round(t_m * 1e6, 2), "alg_bytes": 6 * n,
+                 "GBps": round(6 * n / t_m / 1e9, 1)}]
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = replace_cpu_baseline(inputs_h, masks_h, src.bg_always.cpu().numpy(), H, W)
+        print(json.dumps({
+            "metric": f"frames/sec end-to-end replace ({W}x{H})", "value": round(world * K / dt, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8 (integer fixed-point resampling, float64 blend)", "data": "synthetic",
+            "config": {"workload": f"replace (tools/replace/replace.py): centroid pass + shift_fg / rescale_fg(1.2) / blend / side-by-side, {W}x{H}, "
+                                   f"{K} frames/GPU, frame-sharded x{world}, one all-reduce of the centroid offsets",
+                       "boundary": "pinned host -> pinned host: two alpha masks, fg and source frame uploaded (12 B/px), side-by-side image downloaded (6 B/px) "
+                                   "per frame inside the timed region; the target masks stay in HBM between the two passes",
+                       "correspondence_mean": [dx, dy]},
+            "pcie_bytes_per_frame": {"up": 12 * n, "down": 6 * n},
+            "device_resident": {"value": round(1.0 / t_res, 1), "unit": "frames/s", "note": "same kernels (moments of both masks + one composite launch per frame), inputs in HBM, nothing copied"},
+            "self_check": {"frames": len({0, 1, K // 2, K - 1}), "loop_equals_stand_alone_kernel_chain": True},
+            "roofline": roof, "kernels": rows, "cpu_baseline": cpu}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def replace_cpu_baseline(inputs_h, masks_h, bg, H, W, budget_s=12.0):
+    """The reference's loop body on the CPU oracle (one thread, like the reference's own cv2 + NumPy loop): get_center of both masks,
+    shift_fg, rescale_fg, the float64 blend and the concatenation, on as many frames of the same clip as fit the time budget."""
+    import oracle
+    oracle.build()
+    M = None
+    t0 = time.time()
+    done = 0
+    for (fg, fr), (dm, sm) in zip(inputs_h, masks_h):
+        fg, fr, dm, sm = fg.numpy(), fr.numpy(), dm.numpy(), sm.numpy()
+        dc, sc = oracle.get_center(dm), oracle.get_center(oracle.resize_linear(sm, H, W))
+        if M is None:
+            M = np.float32([[1, 0, sc[0] - dc[0]], [0, 1, sc[1] - dc[1]]]).astype(np.float64)
+        res = oracle.blend(oracle.rescale_fg(oracle.warp_affine(fg, M, H, W), 1.2), oracle.rescale_fg(oracle.warp_affine(dm, M, H, W), 1.2), bg)
+        np.concatenate((oracle.resize_linear(fr, H, W), res), axis=1)
+        done += 1
+        if time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return {"value": round(done / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{done} frames {W}x{H}: both passes of replace.py on the C oracle, 1 thread, {dt:.1f} s",
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
 
 
 def _net_time(run, iters=10, warm=2):
@@ -430,6 +563,8 @@ def main():
         ge.build_native()
     if world > 1:
         dist.barrier()
+    if args.mode == "replace":
+        return replace_mode(args, rank, world, dev)
     if args.mode != "bg_step":
         return other_mode(args, rank, world, dev)
     from video_unscreen_amd import _native as nv
@@ -599,6 +734,10 @@ def main():
                        "binseg": (f"HumanSegAgent on every frame ({pipe.seg_batch} frames per network forward)" if seg_agent is not None
                                   else "masks are inputs (--no-seg)"),
                        "net_input": [pipe.in_h, pipe.in_w], "loop": "sync" if args.sync_loop else "pipelined", "convs": args.net,
+                       "parity": ("not bit-exact end to end: gate / object filter / trimap / foreground are bit-exact against the CPU chain given the same "
+                                  "inputs, alpha is within 1e-3 (float) / 1 LSB, and the segmentation mask - an argmax over float logits from two f32 "
+                                  "summation orders - differs from the CPU chain in 2 - 16 of the frame's pixels, every one an argmax tie below 1e-4 "
+                                  "(tests/test_gpu_seg.py, profiles/r03/parity_report.json); OpenCV's interior is restated by the oracle, not pinned"),
                        "object_filter": ("host worker threads (border-following C++ in libunscreen_hip.so; same masks as the device kernels)"
                                          if args.object_filter == "host" and not args.sync_loop else
                                          "device (label-based HIP kernels inside the foreground's bounding box, usc_objects.hip): no CPU stage in the loop"),
@@ -668,7 +807,8 @@ def main():
                                       "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(H, W),
                                       "alg_gflop_per_forward": round(gflop, 2), "ms_per_forward": round(t_net * 1e3, 3),
                                       "ms_per_forward_graph": round(t_graph * 1e3, 3),
-                                      "timing": "serial single-stream launches, HIP events; see profiles/r02/unet_layer_table.md"}
+                                      "timing": "serial single-stream launches, HIP events; the per-layer rocprofv3 kernel-trace table of the same launches is "
+                                                "profiles/r04/unet_layer_table.md (tools/dev/layer_table.py)"}
                 result["roofline_pixel"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
                                             "unit": "GB/s", "frac": dom["frac_hbm_peak"], "traffic": None,
                                             "alg_bytes_per_launch": dom["alg_bytes"], "us_per_launch": dom["us"]}

@@ -178,6 +178,14 @@ int usc_warp_affine_u8(const uint8_t* src, int sh, int sw, int cn, const double*
 int usc_composite_fgbg_u8(const uint8_t* fg, const uint8_t* alpha, int fh, int fw, const uint8_t* bg, int bh, int bw,
                           uint8_t* out, usc_stream_t stream);
 
+/* The per-frame body of tools/replace/replace.py:59-82 as ONE launch: res = u8(fg' * m' + bg * (1 - m')) with fg', m' =
+ * rescale_fg(shift_fg(., M), scale) (imgprocess.py:55-64, :40-52; mask_cn = 1 | 3), m' / 255 and the blend in float64 (:74-76), and
+ * compare = [adaptive_resize(src, (H, W)) | res] (:64, :82; (H, 2 W, 3)).  `bg` is the background already at (H, W) (:66 resizes it
+ * once; a same-size cv2.resize is a copy).  Either output may be NULL (compare needs src).  Bit-identical to usc_warp_affine_u8 ->
+ * usc_rescale_fg_u8 -> usc_blend_u8 (+ usc_resize_u8 of src); 21 bytes of HBM traffic per pixel instead of ~60. */
+int usc_replace_compose_u8(const uint8_t* fg, const uint8_t* mask, int mask_cn, int H, int W, const double* M2x3_host, double scale,
+                           const uint8_t* bg, const uint8_t* src, int sh, int sw, uint8_t* res, uint8_t* compare, usc_stream_t stream);
+
 /* Green-screen mode (tools/unscreen/green.py:70-126).
  * usc_cvt_color_u8: cv2.cvtColor on uint8, n pixels; code USC_CVT_* (BGR2HSV: colorfiltering/agent.py:311; HSV2BGR: :352;
  *   BGR2LAB: utils/imgprocess.py:281-283, harmonization/agent.py:63-64; BGR2GRAY: tools/unscreen/bg_offline.py:152).  BGR2LAB

@@ -210,9 +210,11 @@ static void orc_cubic_coeffs(float x, short* c)
     for (int k = 0; k < 4; k++) c[k] = orc_sat_s16(orc_round_i(f[k] * 2048.f));
 }
 
-ORC_API void orc_resize_cubic_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw)
+/* inv_x / inv_y: the fx / fy of a cv2.resize(src, None, fx=, fy=) call (cv::resize keeps the caller's factors for the coordinate
+ * map and only derives dsize from them; with a dsize it derives the factors from the two sizes), 0 = derive from the sizes. */
+static void orc_resize_cubic_scaled(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw, double inv_x, double inv_y)
 {
-    double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    double scale_x = 1. / (inv_x > 0 ? inv_x : (double)dw / sw), scale_y = 1. / (inv_y > 0 ? inv_y : (double)dh / sh);
     for (int y = 0; y < dh; y++) {
         float fy = (float)((y + 0.5) * scale_y - 0.5);
         int sy = orc_floor_i(fy);
@@ -242,13 +244,19 @@ ORC_API void orc_resize_cubic_u8(const uint8_t* src, int sh, int sw, int cn, uin
     }
 }
 
-/* unscreen/utils/imgprocess.py:40-52 rescale_fg: cv2.resize(img, None, fx=s, fy=s, INTER_CUBIC) (dsize = round(size*s)),
+ORC_API void orc_resize_cubic_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw)
+{
+    orc_resize_cubic_scaled(src, sh, sw, cn, dst, dh, dw, 0., 0.);
+}
+
+/* unscreen/utils/imgprocess.py:40-52 rescale_fg: cv2.resize(img, None, fx=s, fy=s, INTER_CUBIC) (dsize = round(size*s); the
+ * coordinate map uses 1 / s itself, which differs from old / new whenever size * s is not an integer),
  * then the centre crop back to the original size (offsets int((new - old) / 2)). */
 ORC_API void orc_rescale_fg(const uint8_t* src, int h, int w, int cn, double scale, uint8_t* dst)
 {
     int nh = orc_round_i(h * scale), nw = orc_round_i(w * scale);
     uint8_t* big = (uint8_t*)malloc((size_t)nh * nw * cn);
-    orc_resize_cubic_u8(src, h, w, cn, big, nh, nw);
+    orc_resize_cubic_scaled(src, h, w, cn, big, nh, nw, scale, scale);
     int h_off = (int)((nh - h) / 2.0), w_off = (int)((nw - w) / 2.0);
     for (int y = 0; y < h; y++)
         memcpy(dst + (size_t)y * w * cn, big + ((size_t)(y + h_off) * nw + w_off) * cn, (size_t)w * cn);

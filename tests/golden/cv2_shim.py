@@ -29,6 +29,8 @@ def _log(name, detail=""):
 def resize(src, dsize, dst=None, fx=0, fy=0, interpolation=INTER_LINEAR):
     """cv2.resize(src, dsize[, dst[, fx[, fy[, interpolation]]]]): a third POSITIONAL argument is `dst`, not the interpolation."""
     if dsize is None:
+        # (cv::resize maps coordinates with fx / fy themselves in this form; every call of the reference that reaches this branch
+        # - rescale_fg - goes through oracle.rescale_fg in the chains, which does the same)
         dsize = (int(round(src.shape[1] * fx)), int(round(src.shape[0] * fy)))
     dw, dh = int(dsize[0]), int(dsize[1])
     _log("resize", f"{src.dtype} {src.shape[:2]} -> {(dh, dw)} interp={interpolation}")

@@ -45,17 +45,29 @@ def _close(got, want, frac=1e-3):
     return d.max() <= 1 and (d > 0).mean() < frac
 
 
-def test_bg_online_pipeline_stage_by_stage(oracle_lib):
+@pytest.mark.parametrize("H,W,n,real", [(270, 480, 3, False), (1080, 1920, 2, True)])
+def test_bg_online_pipeline_stage_by_stage(oracle_lib, H, W, n, real):
+    """Every stage's device output against the oracle applied to the previous stage's device output (reference tools/unscreen/bg.py:47-104).
+    270 x 480: three frames behind a known coarse mask.  1920 x 1080 (BASELINE.json configs[2], the whole loop at its full size): the
+    agents the config names - frame 0 untracked through HumanSegAgent (SCHP on the device against the folded plan on torch-CPU: argmax
+    ties only), frame 1 tracked through the space-time memory network at long side 960 (against oracle/chains.py:stm_track) - then
+    object filter -> trimap -> matting -> get_bg -> Laplace fill -> difference gate -> object filter -> trimap -> matting -> get_fg."""
+    from oracle import chains
     from video_unscreen_amd.pipeline_bg import BgOnlinePipeline
     from video_unscreen_amd.synth import SyntheticClip
     from video_unscreen_amd.vmatting.net import MattingNet, synthetic_state_dict
-    H, W = 270, 480
     cfg = copy.deepcopy(BG_CFG)
-    clip = SyntheticClip(H, W, 3, config_id=2, device="cpu")
-    frames = [clip.frame(t) for t in range(3)]
-    pipe = BgOnlinePipeline(cfg, H, W, segagent=_FixedSeg(frames[0]["seg"].numpy()))
+    if real:
+        cfg["stm"]["input_long_side"] = 960                          # configs/bg.json
+    clip = SyntheticClip(H, W, n, config_id=2, device="cpu")
+    frames = [clip.frame(t) for t in range(n)]
+    pipe = BgOnlinePipeline(cfg, H, W, segagent=None if real else _FixedSeg(frames[0]["seg"].numpy()))
     cpu_net = MattingNet(synthetic_state_dict(0), device="cpu", dtype=torch.float32)
     in_h, in_w = oracle_lib.vmat_input_size(H, W, 960)
+    if real:
+        from video_unscreen_amd.binseg.schp_net import SchpNetTorch
+        from video_unscreen_amd.stm.net import StmNetTorch
+        schp_cpu, stm_cpu = SchpNetTorch(pipe.segagent.state_dict), StmNetTorch(pipe.stmagent.state_dict)
 
     def matting(frame, alpha_pre, tri):
         x7 = oracle_lib.vmat_pre(frame, alpha_pre, tri, in_h, in_w)
@@ -68,12 +80,19 @@ def test_bg_online_pipeline_stage_by_stage(oracle_lib):
         out = pipe.step(dev(frame))
         assert out["tracking"] == tracking
         seg = host(out["segmask"])
-        if not tracking:
+        if not tracking and not real:
             assert np.array_equal(seg, f["seg"].numpy())
+        elif not tracking:                               # HumanSegAgent: every differing pixel is an argmax tie (tests/test_gpu_seg.py)
+            x = torch.from_numpy(oracle_lib.humanseg_pre(frame))[None]
+            want = oracle_lib.humanseg_post(schp_cpu(x)[0].numpy(), H, W)
+            assert (seg != want).sum() <= 64 and 0.02 < (want > 0).mean() < 0.98
         else:                                            # the STM step itself is covered by tests/test_gpu_stm.py
             seed = np.where(alpha_pre >= 128, 255, alpha_pre).astype(np.uint8)
             again = pipe.stmagent.forward_device([dev(frames[t - 1]["frame"].numpy()), dev(frame)], dev(seed))[-1]
             assert np.array_equal(seg, host(again)) and 0.01 < (seg > 0).mean() < 0.99
+            if real:                                     # and against the CPU chain (the mask may flip where two probabilities tie)
+                want = chains.stm_track(oracle_lib, stm_cpu, frames[t - 1]["frame"].numpy(), frame, seed, 960)
+                assert (seg != want).mean() < 2e-3, float((seg != want).mean())
         want = oracle_lib.remove_invalid_objects(cfg, seg.copy())
         assert np.array_equal(host(out["alphaor1"]), want)
         tri1 = oracle_lib.trimap(want, 960, 3, 5)

@@ -203,18 +203,23 @@ class _FixedSeg:
         return dev(self.masks[min(self.calls - 1, len(self.masks) - 1)])
 
 
-def test_green_pipeline_stage_by_stage(nv, oracle_lib):
+@pytest.mark.parametrize("H,W,real", [(270, 480, False), (256, 256, True)])
+def test_green_pipeline_stage_by_stage(nv, oracle_lib, H, W, real):
     """Three frames of the green loop (train, track, track): every stage's device output is checked against the oracle
-    applied to the previous stage's device output - byte stages bit-exact, the matting alpha within 1 level."""
+    applied to the previous stage's device output - byte stages bit-exact, the matting alpha within 1 level.
+    256 x 256 = BASELINE.json configs[0] as a whole loop (reference tools/unscreen/green.py:70-138 with configs/green.json): the
+    untracked frame goes through the real SegAgent (DeepLabv3+ over 18 crops at long side 962) and is compared with the CPU chain
+    (oracle/chains.py:seg_agent; the mask may flip only where the two class scores tie)."""
     import copy
     from video_unscreen_amd.pipeline_green import GreenPipeline
     from video_unscreen_amd.vmatting.net import MattingNet, synthetic_state_dict
     from video_unscreen_amd.synth import SyntheticClip
-    H, W = 270, 480
     cfg = copy.deepcopy(GREEN_CFG)
+    if real:
+        cfg["binseg"]["input_long_side"] = 962                       # configs/green.json
     clip = SyntheticClip(H, W, 3, config_id=1, device="cpu")
     frames = [clip.frame(t) for t in range(3)]
-    pipe = GreenPipeline(cfg, H, W, segagent=_FixedSeg([frames[0]["seg"].numpy()]), cf_random_state=0)
+    pipe = GreenPipeline(cfg, H, W, segagent=None if real else _FixedSeg([frames[0]["seg"].numpy()]), cf_random_state=0)
     ref_cf = OracleColorFilter(oracle_lib, random_state=0)
     cpu_net = MattingNet(synthetic_state_dict(0), device="cpu", dtype=torch.float32)
     alpha_pre = np.zeros((H, W), np.uint8)
@@ -224,7 +229,13 @@ def test_green_pipeline_stage_by_stage(nv, oracle_lib):
         out = pipe.step(dev(frame))
         assert out["tracking"] == tracking
         seg = host(out["segmask"])
-        assert np.array_equal(seg, alpha_pre if tracking else f["seg"].numpy())
+        if real and not tracking:
+            from oracle import chains
+            from video_unscreen_amd.binseg.deeplab_net import DeepLabNetTorch
+            want_seg = chains.seg_agent(oracle_lib, frame, DeepLabNetTorch(pipe.segagent.state_dict), 962)
+            assert 0.02 < (want_seg > 0).mean() < 0.98 and (seg != want_seg).mean() < 5e-4, float((seg != want_seg).mean())
+        else:
+            assert np.array_equal(seg, alpha_pre if tracking else f["seg"].numpy())
         iters = 3 if (t % 30 == 0 or not tracking) else 0
         assert out["cf_iters"] == iters
         want_cf, want_bg = ref_cf.forward(frame.copy(), seg.copy(), iters)

@@ -1,5 +1,6 @@
 """Person replacement from already-unscreened outputs (reference tools/replace/replace.py:44-86), on the GPU:
-per frame  res = u8(fg' * m' + bg * (1 - m'))  with fg', m' = rescale_fg(shift_fg(., dx, dy), 1.2).
+per frame  res = u8(fg' * m' + bg * (1 - m'))  with fg', m' = rescale_fg(shift_fg(., dx, dy), 1.2)  -  one launch per frame
+(video_unscreen_amd/pipeline_replace.py, usc_replace_compose_u8).
 
 Same inputs as the reference (fg_%06d.jpg / alphamask_%06d.jpg of the target, frame_%06d.jpg / alphamask of the source,
 one background image); paths come from --data_root instead of being hard-coded (replace.py:95-101).  Frames are
@@ -16,21 +17,12 @@ ROOT = osp.dirname(osp.dirname(osp.dirname(osp.abspath(__file__))))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
-from video_unscreen_amd import _native as nv
 from video_unscreen_amd.dist import shard_range
+from video_unscreen_amd.pipeline_replace import ReplacePipeline
 from video_unscreen_amd.utils.fileio import read_img, save_img
-
-
-def centroid(mask_dev):
-    """get_center (reference utils/imgprocess.py:7-14, as replace.py:32,35 call it on the 3-channel mask): COLOR_RGB2GRAY, integer
-    moments on the device (usc_gray_moments_u8), int(m10 / (m00 + 1e-6)), int(m01 / (m00 + 1e-6))."""
-    _, mom = nv.gray_moments(mask_dev, rgb_order=True)
-    m00, m10, m01 = (float(v) for v in mom.tolist())
-    return int(m10 / (m00 + 1e-6)), int(m01 / (m00 + 1e-6))
 
 
 def run(args):
@@ -40,19 +32,25 @@ def run(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    numframes = len(sorted(glob(osp.join(args.tgt_data_dir, 'fg_*.jpg'))))
+    ext = args.io                                            # jpg = the reference's files; npy = raw arrays (no codec: bit-exact runs)
+    numframes = len(sorted(glob(osp.join(args.tgt_data_dir, 'fg_*.' + ext))))
     assert numframes > 0
     os.makedirs(args.dst_data_dir, exist_ok=True)
     lo, hi = shard_range(numframes, rank, world)
+    tgt = lambda name, fid: osp.join(args.tgt_data_dir, "{}_{:06d}.{}".format(name, fid, ext))       # noqa: E731
+    src = lambda name, fid: osp.join(args.src_data_dir, "{}_{:06d}.{}".format(name, fid, ext))       # noqa: E731
+    up = lambda path: torch.from_numpy(read_img(path)).to(dev)                                       # noqa: E731
 
-    if args.dx is None or args.dy is None:
-        acc = torch.zeros(3, dtype=torch.float64, device=dev)
+    first = read_img(tgt("fg", lo))
+    h, w = first.shape[:2]
+    bg_npy = osp.splitext(args.src_bg_image)[0] + ".npy"
+    bg_path = bg_npy if ext == "npy" and osp.exists(bg_npy) else args.src_bg_image
+    pipe = ReplacePipeline(h, w, torch.from_numpy(read_img(bg_path)), device=dev, scale=1.2, max_frames=max(1, hi - lo))
+
+    if args.dx is None or args.dy is None:                   # comp_dx_dy (replace.py:28-41): moments on the device, one host read
         for fid in range(lo, hi):
-            dst_mask = torch.from_numpy(read_img(osp.join(args.tgt_data_dir, "alphamask_{:06d}.jpg".format(fid)))).to(dev)
-            src_mask = torch.from_numpy(read_img(osp.join(args.src_data_dir, "alphamask_{:06d}.jpg".format(fid)))).to(dev)
-            src_mask = nv.resize(src_mask, dst_mask.shape[0], dst_mask.shape[1], 1)        # adaptive_resize (replace.py:34)
-            dc, sc = centroid(dst_mask), centroid(src_mask)
-            acc += torch.tensor([sc[0] - dc[0], sc[1] - dc[1], 1.0], dtype=torch.float64, device=dev)
+            pipe.centroid_pair(fid - lo, up(tgt("alphamask", fid)), up(src("alphamask", fid)))
+        acc = torch.tensor(pipe.offset_sums(hi - lo), dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(acc)
         dx_mean, dy_mean = float(acc[0] / acc[2]), float(acc[1] / acc[2])
@@ -60,20 +58,11 @@ def run(args):
         dx_mean, dy_mean = args.dx, args.dy
     print("Correspondence mean: ", dx_mean, dy_mean)
 
-    M = np.float32([[1, 0, dx_mean], [0, 1, dy_mean]]).astype(np.float64)
-    bg = None
+    M = pipe.shift_matrix(dx_mean, dy_mean)
     for fid in range(lo, hi):
-        dst_fg = torch.from_numpy(read_img(osp.join(args.tgt_data_dir, "fg_{:06d}.jpg".format(fid)))).to(dev)
-        dst_mask = torch.from_numpy(read_img(osp.join(args.tgt_data_dir, "alphamask_{:06d}.jpg".format(fid)))).to(dev)
-        h, w = dst_fg.shape[:2]
-        src_image = nv.resize(torch.from_numpy(read_img(osp.join(args.src_data_dir, "frame_{:06d}.jpg".format(fid)))).to(dev), h, w, 1)
-        if bg is None:
-            bg = nv.resize(torch.from_numpy(read_img(args.src_bg_image)).to(dev), h, w, 1)
-        fg_s = nv.rescale_fg(nv.warp_affine(dst_fg, M, h, w), 1.2)
-        m_s = nv.rescale_fg(nv.warp_affine(dst_mask, M, h, w), 1.2)
-        res = nv.blend(fg_s, m_s, bg)
-        save_img(res.cpu().numpy(), osp.join(args.dst_data_dir, "res_{:06d}.jpg".format(fid)))
-        save_img(torch.cat((src_image, res), 1).cpu().numpy(), osp.join(args.dst_data_dir, "compare_{:06d}.jpg".format(fid)))
+        res, cmp_img = pipe.compose(up(tgt("fg", fid)), up(tgt("alphamask", fid)), up(src("frame", fid)), M)
+        save_img(res.cpu().numpy(), osp.join(args.dst_data_dir, "res_{:06d}.{}".format(fid, ext)))
+        save_img(cmp_img.cpu().numpy(), osp.join(args.dst_data_dir, "compare_{:06d}.{}".format(fid, ext)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -84,6 +73,7 @@ if __name__ == '__main__':
     parser.add_argument('--src', type=str, default="test5")
     parser.add_argument('--tgt', type=str, default=None)
     parser.add_argument('--data_root', type=str, default=os.environ.get("UNSCREEN_REPLACE_ROOT", "../data/replace/edn"))
+    parser.add_argument('--io', type=str, default="jpg", choices=["jpg", "npy"], help='file format of inputs and outputs (npy: raw arrays, no codec)')
     parser.add_argument('--dx', type=float, default=None)
     parser.add_argument('--dy', type=float, default=None)
     args = parser.parse_args()

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "usc_count_ge_u8": (C.c_int, [_vp, C.c_size_t, C.c_int, _vp, _vp]),
     "usc_resize_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "usc_rescale_fg_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp]),
+    "usc_replace_compose_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_double, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "usc_warp_affine_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _vp, C.c_int, C.c_int, _vp]),
     "usc_composite_fgbg_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
     "usc_lab_tables_bytes": (C.c_size_t, []),
@@ -417,12 +418,12 @@ def imnormalize(img, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), to_r
     return out
 
 
-def gray_moments(img, rgb_order=False, thr=None, want_moments=True):
+def gray_moments(img, rgb_order=False, thr=None, want_moments=True, out=None):
     """Gray of a (H, W, 3) uint8 CUDA image (rgb_order: cv2.COLOR_RGB2GRAY): -> (mask | None, moments | None); mask = 255 where
     gray > thr (thr given), moments = int64 CUDA tensor (m00, m10, m01)."""
     H, W, _ = img.shape
     mask = torch.empty((H, W), dtype=torch.uint8, device=img.device) if thr is not None else None
-    mom = torch.empty(3, dtype=torch.int64, device=img.device) if want_moments else None
+    mom = (out if out is not None else torch.empty(3, dtype=torch.int64, device=img.device)) if want_moments else None      # out: 3 int64, e.g. a row of a table
     _check(load().usc_gray_moments_u8(_dev_u8(img, "gray_moments.img", (H, W, 3)), H, W, int(bool(rgb_order)), int(thr if thr is not None else 0),
                                       mask.data_ptr() if mask is not None else None, mom.data_ptr() if mom is not None else None, _stream()),
            "usc_gray_moments_u8")
@@ -495,6 +496,26 @@ def warp_affine(img, M, dh, dw, out=None):
     if rc != 0:
         raise NativeError(f"usc_warp_affine_u8 failed ({rc}): {load().usc_seg_last_error().decode()}")
     return out
+
+
+def replace_compose(fg, mask, M, bg, src=None, scale=1.2, res=None, compare=None, want_res=True):
+    """tools/replace/replace.py:59-82 per frame, one launch: (res, compare) with res = u8(fg' m' + bg (1 - m')), fg' / m' =
+    rescale_fg(shift_fg(., M), scale), compare = [resize(src) | res] (None without src).  Bit-identical to the stand-alone chain."""
+    H, W, _ = fg.shape
+    mask_cn = 3 if mask.dim() == 3 else 1
+    if res is None and want_res:
+        res = torch.empty_like(fg)
+    if compare is None and src is not None:
+        compare = torch.empty((H, 2 * W, 3), dtype=torch.uint8, device=fg.device)
+    Mc = (C.c_double * 6)(*[float(v) for v in np.asarray(M, np.float64).reshape(6)])
+    sh, sw = (src.shape[0], src.shape[1]) if src is not None else (0, 0)
+    _check(load().usc_replace_compose_u8(_dev_u8(fg, "replace.fg", (H, W, 3)), _dev_u8(mask, "replace.mask", (H, W, 3) if mask_cn == 3 else (H, W)), mask_cn, H, W,
+                                         Mc, float(scale), _dev_u8(bg, "replace.bg", (H, W, 3)),
+                                         _dev_u8(src, "replace.src", (sh, sw, 3)) if src is not None else None, sh, sw,
+                                         _dev_u8(res, "replace.res", (H, W, 3)) if res is not None else None,
+                                         _dev_u8(compare, "replace.compare", (H, 2 * W, 3)) if compare is not None else None, _stream()),
+           "usc_replace_compose_u8")
+    return res, compare
 
 
 def composite_fgbg(fg, alpha, bg, out=None):

@@ -1065,8 +1065,9 @@ __global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t* __restric
 }
 
 static int launch_resize(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw, int oh, int ow, int y_off, int x_off,
-                         int interp, hipStream_t st) {
+                         int interp, hipStream_t st, double inv_scale = 0.) {
     ResizeGeom rg = resize_geom(sh, sw, dh, dw);
+    if (inv_scale > 0) rg.scale_x = rg.scale_y = 1. / inv_scale;       // cv2.resize(src, None, fx, fy): the caller's factors map the coordinates
     const double ifx = 1. / ((double)dw / sw), ify = 1. / ((double)dh / sh);
     hipLaunchKernelGGL(resize_u8_kernel, dim3(grid_for((size_t)oh * ow, 256)), dim3(256), 0, st, src, sh, sw, cn, dst, oh, ow, y_off, x_off,
                        interp, rg.mode, rg.scale_y, rg.scale_x, ify, ifx);
@@ -1084,7 +1085,7 @@ extern "C" int usc_rescale_fg_u8(const uint8_t* src, int h, int w, int cn, doubl
     if (!src || !dst || h <= 0 || w <= 0 || (cn != 1 && cn != 3) || !(scale >= 1.0)) return fail(USC_E_ARG, "usc_rescale_fg_u8: bad argument (scale >= 1)");
     const int nh = (int)lrint(h * scale), nw = (int)lrint(w * scale);
     const int h_off = (int)((nh - h) / 2.0), w_off = (int)((nw - w) / 2.0);
-    return launch_resize(src, h, w, cn, dst, nh, nw, h, w, h_off, w_off, 2, (hipStream_t)stream);
+    return launch_resize(src, h, w, cn, dst, nh, nw, h, w, h_off, w_off, 2, (hipStream_t)stream, scale);
 }
 
 // fgfuncs.py:172-214 composite_fgbg (extend = False), the background resize fused in.
