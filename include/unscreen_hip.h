@@ -63,7 +63,9 @@ void usc_inv_pad_geometry(int h, int w, int ori_h, int ori_w, int* resized_h, in
  * usc_imnormalize_u8: imgprocess.py:135-161 imnormalize on n pixels: BGR -> RGB IN PLACE on `img` when to_rgb (as the reference
  *   does to its argument, :157), out = ((float32(img) / 255) - mean) * (1 / std), float32 operations; mean / std: host, 3 doubles.
  * usc_gray_moments_u8: imgprocess.py:7-14 get_center (rgb_order = 1: cv2.COLOR_RGB2GRAY; moments3 = m00, m10, m01 of the gray
- *   image as exact integers) and :17-30 get_mask (rgb_order = 0, mask = 255 where gray > thr); either output may be NULL. */
+ *   image as exact integers) and :17-30 get_mask (rgb_order = 0, mask = 255 where gray > thr); either output may be NULL.
+ * usc_gray_moments_pair_u8: the moments of TWO images of one size in one launch (moments6 = a's m00, m10, m01, then b's): the two
+ *   get_center calls per frame of tools/replace/replace.py:32-35 (comp_dx_dy). */
 #define USC_ELEM_U8  0
 #define USC_ELEM_F32 1
 #define USC_ELEM_F64 2
@@ -72,6 +74,8 @@ int usc_inv_pad_resize(const void* src, int h, int w, int cn, int elem, void* ds
 int usc_imnormalize_u8(uint8_t* img, size_t n, const double* mean3_host, const double* std3_host, int to_rgb, float* out, usc_stream_t stream);
 int usc_gray_moments_u8(const uint8_t* img, int H, int W, int rgb_order, int thr, uint8_t* mask, unsigned long long* moments3,
                         usc_stream_t stream);
+int usc_gray_moments_pair_u8(const uint8_t* img_a, const uint8_t* img_b, int H, int W, int rgb_order, unsigned long long* moments6,
+                             usc_stream_t stream);
 
 /* ISegAgent, no-BRS predictor (unscreen/iseg/agent.py:92-119, iseg/brs/brs_predictor.py:35-106).  The network's dense layers run
  * on usc_conv_* (video_unscreen_amd/iseg/net_hip.py); these are its pixel stages and the one non-dense layer type.

@@ -113,3 +113,54 @@ def test_replace_tool_full_size_raw_files(tmp_path, oracle_lib):
         want, want_cmp = _oracle_chain(oracle_lib, fg, m3, bg, frame, M)
         assert np.array_equal(np.load(out / f"res_{t:06d}.npy"), want), t
         assert np.array_equal(np.load(out / f"compare_{t:06d}.npy"), want_cmp), t
+
+
+@pytest.mark.parametrize("H,W", [(67, 131), (3, 1), (120, 200), (1080, 1920)])
+def test_gray_moments_pair_exact(oracle_lib, H, W):
+    """usc_gray_moments_pair_u8 (both get_center calls of a frame in one launch) == two usc_gray_moments_u8 calls == exact integer
+    moments of the oracle's RGB2GRAY image; and the centres the host loop derives equal the oracle's get_center."""
+    from video_unscreen_amd import _native as nv
+    rng = np.random.default_rng(H * W)
+    a, b = (rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(2))
+    out = torch.zeros(6, dtype=torch.int64, device="cuda")
+    nv.gray_moments_pair(dev(a), dev(b), out)
+    got = out.cpu().numpy().reshape(2, 3)
+    for k, img in enumerate((a, b)):
+        _, single = nv.gray_moments(dev(img), rgb_order=True)
+        g = oracle_lib.bgr2gray(np.ascontiguousarray(img[..., ::-1])).astype(np.int64)
+        yy, xx = np.mgrid[0:H, 0:W]
+        want = np.array([g.sum(), (g * xx).sum(), (g * yy).sum()])
+        assert np.array_equal(got[k], want) and np.array_equal(single.cpu().numpy(), want)
+        cx, cy = int(want[1] / (want[0] + 1e-6)), int(want[2] / (want[0] + 1e-6))
+        assert (cx, cy) == tuple(oracle_lib.get_center(img))
+
+
+def test_replace_host_loop_equals_tool_flow(oracle_lib):
+    """ReplaceHostLoop (pinned host -> pinned host, packed uploads, target masks kept in HBM between the passes) on 6 frames: the
+    correspondence mean and every side-by-side image equal the oracle's comp_dx_dy + per-frame chain, for packed pairs and for
+    (a, b) tuples with a source of another size."""
+    from video_unscreen_amd.pipeline_replace import ReplaceHostLoop, ReplacePipeline, pack_pair
+    H, W, n = 136, 240, 6
+    for sh, sw in ((H, W), (90, 150)):
+        frames = []
+        for t in range(n):
+            fg, m3, bg, fr = _inputs(H, W, sh, sw, 50 + t)
+            sm3 = np.roll(_inputs(sh, sw, 8, 8, 70 + t)[1], (2 * t - 3, 5 - t), (0, 1))
+            frames.append((fg, m3, fr, sm3))
+        bg = _inputs(H, W, 8, 8, 9)[2]
+        pipe = ReplacePipeline(H, W, dev(bg), max_frames=n)
+        loop = ReplaceHostLoop(pipe, n, src_hw=(sh, sw), ring=2)
+        packed = (sh, sw) == (H, W)
+        t_ = torch.from_numpy
+        masks_h = [pack_pair(t_(m3), t_(sm3)) if packed else (t_(m3).pin_memory(), t_(sm3).pin_memory()) for _, m3, _, sm3 in frames]
+        inputs_h = [pack_pair(t_(fg), t_(fr)) if packed else (t_(fg).pin_memory(), t_(fr).pin_memory()) for fg, _, fr, _ in frames]
+        sx, sy, cnt = loop.pass1(masks_h)
+        dxs = [oracle_lib.get_center(oracle_lib.resize_linear(sm3, H, W))[0] - oracle_lib.get_center(m3)[0] for _, m3, _, sm3 in frames]
+        dys = [oracle_lib.get_center(oracle_lib.resize_linear(sm3, H, W))[1] - oracle_lib.get_center(m3)[1] for _, m3, _, sm3 in frames]
+        assert (sx, sy, cnt) == (float(sum(dxs)), float(sum(dys)), float(n))
+        M = pipe.shift_matrix(sx / cnt, sy / cnt)
+        compare_h = torch.zeros((n, H, 2 * W, 3), dtype=torch.uint8).pin_memory()
+        loop.pass2(inputs_h, M, compare_h)
+        torch.cuda.synchronize()
+        for t, (fg, m3, fr, _) in enumerate(frames):
+            assert np.array_equal(compare_h[t].numpy(), _oracle_chain(oracle_lib, fg, m3, bg, fr, M)[1]), (sh, sw, t)

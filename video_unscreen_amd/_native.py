@@ -30,6 +30,7 @@ _SIGNATURES = {
     "usc_inv_pad_resize": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "usc_imnormalize_u8": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, _vp, _vp]),
     "usc_gray_moments_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "usc_gray_moments_pair_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "usc_iseg_pre": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, _vp, _vp]),
     "usc_dwconv3x3_nhwc_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "usc_iseg_post": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp]),
@@ -428,6 +429,16 @@ def gray_moments(img, rgb_order=False, thr=None, want_moments=True, out=None):
                                       mask.data_ptr() if mask is not None else None, mom.data_ptr() if mom is not None else None, _stream()),
            "usc_gray_moments_u8")
     return mask, mom
+
+
+def gray_moments_pair(img_a, img_b, out, rgb_order=True):
+    """Moments (m00, m10, m01) of the gray images of two (H, W, 3) uint8 CUDA images in one launch -> out: 6 int64 (a's, then b's)."""
+    H, W, _ = img_a.shape
+    if not (out.dtype == torch.int64 and out.is_cuda and out.is_contiguous() and out.numel() == 6):
+        raise NativeError("gray_moments_pair.out: expected 6 contiguous int64 on the device")
+    _check(load().usc_gray_moments_pair_u8(_dev_u8(img_a, "gray_moments_pair.a", (H, W, 3)), _dev_u8(img_b, "gray_moments_pair.b", (H, W, 3)), H, W,
+                                           int(bool(rgb_order)), out.data_ptr(), _stream()), "usc_gray_moments_pair_u8")
+    return out
 
 
 def score_map(H, W, center, device):

@@ -96,20 +96,38 @@ __global__ __launch_bounds__(256) void imnormalize_kernel(uint8_t* __restrict__ 
 
 // imgprocess.py:7-14 / :17-30: gray of a 3-channel image (rgb_order: the FIRST channel carries the red weight, cv2.COLOR_RGB2GRAY),
 // optional threshold (gray > thr -> 255 else 0) written to `mask`, optional spatial moments m00, m10, m01 (exact integer sums).
-__global__ __launch_bounds__(256) void gray_moments_kernel(const uint8_t* __restrict__ img, int H, int W, int rgb_order, int thr,
+// One image per blockIdx.y (img0 / img1, moments at mom + 3 * blockIdx.y): the centroid pass of the replace tool asks for the moments of two
+// masks per frame (tools/replace/replace.py:28-41).  4 pixels = 12 bytes per lane and step; per-thread sums in 64 bits, one wave
+// reduction, ONE atomic per workgroup and moment - with kMomBlocks workgroups per image (the L2 serialises same-address atomics: the
+// first version's 4096 workgroups spent 25 us on them at 1080p).
+constexpr int kMomBlocks = 256;
+__global__ __launch_bounds__(256) void gray_moments_kernel(const uint8_t* __restrict__ img0, const uint8_t* __restrict__ img1, int H, int W, int rgb_order, int thr,
                                                            uint8_t* __restrict__ mask, unsigned long long* __restrict__ mom) {
-    const uint32_t n = (uint32_t)H * (uint32_t)W;
+    const uint8_t* __restrict__ img = blockIdx.y ? img1 : img0;
+    if (mom) mom += 3 * blockIdx.y;
+    const uint32_t n = (uint32_t)H * (uint32_t)W, nq = n / 4;
     unsigned long long m00 = 0, m10 = 0, m01 = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int c0 = img[3 * (size_t)i], c1 = img[3 * (size_t)i + 1], c2 = img[3 * (size_t)i + 2];
-        const int g = rgb_order ? gray_u8(c2, c1, c0) : gray_u8(c0, c1, c2);
-        if (mask) mask[i] = g > thr ? 255 : 0;
-        if (mom) {
-            const uint32_t y = i / (uint32_t)W, x = i - y * (uint32_t)W;
-            m00 += (unsigned)g;
-            m10 += (unsigned long long)x * (unsigned)g;
-            m01 += (unsigned long long)y * (unsigned)g;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        int c[12];
+        unpack12(*reinterpret_cast<const Px4*>(img + 12 * (size_t)q), c);
+        uint32_t y = (4 * q) / (uint32_t)W, x = 4 * q - y * (uint32_t)W;
+        uint32_t s0 = 0, s1 = 0, s2 = 0, mk = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t g = (uint32_t)(rgb_order ? gray_u8(c[3 * k + 2], c[3 * k + 1], c[3 * k]) : gray_u8(c[3 * k], c[3 * k + 1], c[3 * k + 2]));
+            mk |= ((int)g > thr ? 255u : 0u) << (8 * k);
+            s0 += g; s1 += x * g; s2 += y * g;                     // < 4 * 255 * 2^15: 32 bits hold a quad's sums (too_big() bounds H W)
+            if (++x >= (uint32_t)W) { x = 0; y++; }
         }
+        if (mask) *reinterpret_cast<uint32_t*>(mask + 4 * (size_t)q) = mk;
+        m00 += s0; m10 += s1; m01 += s2;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {                // the last n % 4 pixels
+        const uint32_t i = 4 * nq + threadIdx.x, y = i / (uint32_t)W, x = i - y * (uint32_t)W;
+        const int c0 = img[3 * (size_t)i], c1 = img[3 * (size_t)i + 1], c2 = img[3 * (size_t)i + 2];
+        const uint32_t g = (uint32_t)(rgb_order ? gray_u8(c2, c1, c0) : gray_u8(c0, c1, c2));
+        if (mask) mask[i] = (int)g > thr ? 255 : 0;
+        m00 += g; m10 += (unsigned long long)x * g; m01 += (unsigned long long)y * g;
     }
     if (!mom) return;
 #pragma unroll
@@ -173,12 +191,28 @@ extern "C" int usc_imnormalize_u8(uint8_t* img, size_t n, const double* mean3_ho
     return check_launch("imnormalize_kernel");
 }
 
+static int launch_moments(const uint8_t* a, const uint8_t* b, int H, int W, int rgb_order, int thr, uint8_t* mask, unsigned long long* mom, hipStream_t st) {
+    const int images = b ? 2 : 1;
+    if (mom && hipMemsetAsync(mom, 0, 3 * images * sizeof(unsigned long long), st) != hipSuccess) return fail(USC_E_LAUNCH, "usc_gray_moments_u8: memset failed");
+    const size_t nq = ((size_t)H * W) / 4;
+    int blocks = (int)((nq + 255) / 256);
+    blocks = blocks < 1 ? 1 : (blocks > kMomBlocks ? kMomBlocks : blocks);
+    hipLaunchKernelGGL(gray_moments_kernel, dim3(blocks, images), dim3(256), 0, st, a, b, H, W, rgb_order, thr, mask, mom);
+    return check_launch("gray_moments_kernel");
+}
+
 extern "C" int usc_gray_moments_u8(const uint8_t* img, int H, int W, int rgb_order, int thr, uint8_t* mask, unsigned long long* moments3,
                                    usc_stream_t stream) {
     if (!img || H <= 0 || W <= 0 || (!mask && !moments3)) return fail(USC_E_ARG, "usc_gray_moments_u8: bad argument");
     if (too_big(H, W)) return fail(USC_E_UNSUPPORTED, "usc_gray_moments_u8: image too large");
-    hipStream_t st = (hipStream_t)stream;
-    if (moments3 && hipMemsetAsync(moments3, 0, 3 * sizeof(unsigned long long), st) != hipSuccess) return fail(USC_E_LAUNCH, "usc_gray_moments_u8: memset failed");
-    hipLaunchKernelGGL(gray_moments_kernel, dim3(grid_for((size_t)H * W, 256)), dim3(256), 0, st, img, H, W, rgb_order, thr, mask, moments3);
-    return check_launch("gray_moments_kernel");
+    if ((((uintptr_t)img | (uintptr_t)mask) & 3) != 0) return fail(USC_E_ARG, "usc_gray_moments_u8: img and mask must be 4-byte aligned");
+    return launch_moments(img, nullptr, H, W, rgb_order, thr, mask, moments3, (hipStream_t)stream);
+}
+
+extern "C" int usc_gray_moments_pair_u8(const uint8_t* img_a, const uint8_t* img_b, int H, int W, int rgb_order, unsigned long long* moments6,
+                                        usc_stream_t stream) {
+    if (!img_a || !img_b || !moments6 || H <= 0 || W <= 0) return fail(USC_E_ARG, "usc_gray_moments_pair_u8: bad argument");
+    if (too_big(H, W)) return fail(USC_E_UNSUPPORTED, "usc_gray_moments_pair_u8: image too large");
+    if ((((uintptr_t)img_a | (uintptr_t)img_b) & 3) != 0) return fail(USC_E_ARG, "usc_gray_moments_pair_u8: images must be 4-byte aligned");
+    return launch_moments(img_a, img_b, H, W, rgb_order, 0, nullptr, moments6, (hipStream_t)stream);
 }

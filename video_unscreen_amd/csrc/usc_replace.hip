@@ -47,21 +47,52 @@ __device__ __forceinline__ void warp_coord(const Affine& A, int x, int y, int& s
 constexpr int kTH = 16, kTW = 64;                 // output tile
 constexpr int kWH = kTH + 3, kWW = kTW + 3;       // largest window of shifted pixels a tile's cubic taps touch (zoom >= 1)
 
+// 8 / 2 bytes at any byte address (global memory takes unaligned accesses): the 2 x 1 neighbourhood of a 3-channel / 1-channel tap pair
+struct __attribute__((packed, aligned(1))) Raw8 { uint32_t lo, hi; };
+struct __attribute__((packed, aligned(1))) Raw2 { uint16_t v; };
+
 // One shifted pixel: cv2.warpAffine of fg (3 channels) and mask (MASK_CN channels) at (y, x) -> x = fg b | g << 8 | r << 16, y = mask likewise.
+// The two taps of a source row are 6 (2) adjacent bytes: one 8-byte (2-byte) load per row and array when both columns are inside the image.
 template <int MASK_CN>
-__device__ __forceinline__ uint2 warp_px(const uint8_t* __restrict__ fg, const uint8_t* __restrict__ mask, int H, int W, const Affine& A, int y, int x) {
+__device__ __forceinline__ uint2 warp_px(const uint8_t* __restrict__ fg, const uint8_t* __restrict__ mask, int H, int W, uint32_t nbytes, const Affine& A, int y, int x) {
     int sx, sy, fx, fy;
     warp_coord(A, x, y, sx, sy, fx, fy);
     const int w[4] = {(32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32};
     int acc[6] = {0, 0, 0, 0, 0, 0};
+    if (sx >= 0 && sx + 1 < W) {
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const int xx = sx + (t & 1), yy = sy + (t >> 1);
-        if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
-            const size_t p = (size_t)yy * W + xx;
-            acc[0] += fg[3 * p] * w[t]; acc[1] += fg[3 * p + 1] * w[t]; acc[2] += fg[3 * p + 2] * w[t];
-            if (MASK_CN == 3) { acc[3] += mask[3 * p] * w[t]; acc[4] += mask[3 * p + 1] * w[t]; acc[5] += mask[3 * p + 2] * w[t]; }
-            else acc[3] += mask[p] * w[t];
+        for (int r = 0; r < 2; r++) {
+            const int yy = sy + r;
+            if (yy < 0 || yy >= H) continue;
+            const uint32_t p = (uint32_t)yy * (uint32_t)W + (uint32_t)sx;
+            uint32_t lo, hi;
+            if (3 * p + 8 <= nbytes) { const Raw8 q = *reinterpret_cast<const Raw8*>(fg + 3 * p); lo = q.lo; hi = q.hi; }
+            else { lo = fg[3 * p] | (fg[3 * p + 1] << 8) | (fg[3 * p + 2] << 16) | ((uint32_t)fg[3 * p + 3] << 24); hi = fg[3 * p + 4] | (fg[3 * p + 5] << 8); }
+            const int w0 = w[2 * r], w1 = w[2 * r + 1];
+            acc[0] += (int)(lo & 0xff) * w0 + (int)(lo >> 24) * w1;
+            acc[1] += (int)((lo >> 8) & 0xff) * w0 + (int)(hi & 0xff) * w1;
+            acc[2] += (int)((lo >> 16) & 0xff) * w0 + (int)((hi >> 8) & 0xff) * w1;
+            if (MASK_CN == 3) {
+                if (3 * p + 8 <= nbytes) { const Raw8 q = *reinterpret_cast<const Raw8*>(mask + 3 * p); lo = q.lo; hi = q.hi; }
+                else { lo = mask[3 * p] | (mask[3 * p + 1] << 8) | (mask[3 * p + 2] << 16) | ((uint32_t)mask[3 * p + 3] << 24); hi = mask[3 * p + 4] | (mask[3 * p + 5] << 8); }
+                acc[3] += (int)(lo & 0xff) * w0 + (int)(lo >> 24) * w1;
+                acc[4] += (int)((lo >> 8) & 0xff) * w0 + (int)(hi & 0xff) * w1;
+                acc[5] += (int)((lo >> 16) & 0xff) * w0 + (int)((hi >> 8) & 0xff) * w1;
+            } else {
+                const uint32_t m2 = reinterpret_cast<const Raw2*>(mask + p)->v;
+                acc[3] += (int)(m2 & 0xff) * w0 + (int)(m2 >> 8) * w1;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int xx = sx + (t & 1), yy = sy + (t >> 1);
+            if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                const uint32_t p = (uint32_t)yy * (uint32_t)W + (uint32_t)xx;
+                acc[0] += fg[3 * p] * w[t]; acc[1] += fg[3 * p + 1] * w[t]; acc[2] += fg[3 * p + 2] * w[t];
+                if (MASK_CN == 3) { acc[3] += mask[3 * p] * w[t]; acc[4] += mask[3 * p + 1] * w[t]; acc[5] += mask[3 * p + 2] * w[t]; }
+                else acc[3] += mask[p] * w[t];
+            }
         }
     }
     int v[6];
@@ -86,23 +117,37 @@ __global__ __launch_bounds__(256) void replace_compose_kernel(const uint8_t* __r
     const int wy0 = clampi(linear_tap(ty0 + h_off, scale_y).s - 1, 0, H - 1), wy1 = clampi(linear_tap(ty1 + h_off, scale_y).s + 2, 0, H - 1);
     const int wx0 = clampi(linear_tap(tx0 + w_off, scale_x).s - 1, 0, W - 1), wx1 = clampi(linear_tap(tx1 + w_off, scale_x).s + 2, 0, W - 1);
     const int wh = wy1 - wy0 + 1, ww = wx1 - wx0 + 1;                           // <= kWH, kWW for any zoom >= 1
+    const uint32_t nbytes = 3u * (uint32_t)H * (uint32_t)W;
     s_m[threadIdx.x] = (double)threadIdx.x / 255.;
     for (int i = threadIdx.x; i < wh * ww; i += 256) {
         const int r = i / ww, c = i - r * ww;
-        s_px[r * kWW + c] = warp_px<MASK_CN>(fg, mask, H, W, A, wy0 + r, wx0 + c);
+        s_px[r * kWW + c] = warp_px<MASK_CN>(fg, mask, H, W, MASK_CN == 3 ? nbytes : nbytes / 3, A, wy0 + r, wx0 + c);
     }
     __syncthreads();
     // 4 output pixels per lane along x: 16 lanes cover a tile row
     const int y = ty0 + (int)(threadIdx.x >> 4), xq = tx0 + 4 * (int)(threadIdx.x & 15);
     if (y > ty1 || xq > tx1) return;
+    const int npx = min(4, tx1 - xq + 1);
+    const bool quad = npx == 4 && (W & 3) == 0;       // 12-byte packed accesses (rows are dword-aligned when W % 4 == 0)
+    const uint32_t p0 = (uint32_t)y * (uint32_t)W + (uint32_t)xq;
+    int bgv[12], sv[12];
+    if (quad) {                                        // issued before the taps are read: in flight during the arithmetic
+        unpack12(*reinterpret_cast<const Px4*>(bg + 3 * p0), bgv);
+        if (cmp && src_mode == RS_COPY) unpack12(*reinterpret_cast<const Px4*>(src + 3 * p0), sv);
+    } else {
+        for (int k = 0; k < 12; k++) bgv[k] = bg[3 * (p0 + min(k / 3, npx - 1)) + k % 3];
+    }
+    if (cmp && !(quad && src_mode == RS_COPY)) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) sv[k] = resize_sample_u8(src, sh, sw, 3, k % 3, y, min(xq + k / 3, tx1), 1, src_mode, src_sy, src_sx, 0., 0.);
+    }
     const Tap tyy = linear_tap(y + h_off, scale_y);
     int cy[4];
     cubic_coeffs(tyy.f, cy);
     int rows[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) rows[j] = (clampi(tyy.s - 1 + j, 0, H - 1) - wy0) * kWW;
-    int out[12], sv[12];
-    const int npx = min(4, tx1 - xq + 1);
+    int out[12];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int x = min(xq + k, tx1);
@@ -122,23 +167,22 @@ __global__ __launch_bounds__(256) void replace_compose_kernel(const uint8_t* __r
                 row[0] += (int)(p.x & 0xff) * cx[i]; row[1] += (int)((p.x >> 8) & 0xff) * cx[i]; row[2] += (int)((p.x >> 16) & 0xff) * cx[i];
                 row[3] += (int)(p.y & 0xff) * cx[i]; row[4] += (int)((p.y >> 8) & 0xff) * cx[i]; row[5] += (int)((p.y >> 16) & 0xff) * cx[i];
             }
+            // |row| <= 4 * 255 * 2331 < 2^23 and |cy| < 2^12: the 24-bit multiplier gives the exact 32-bit product (a full-rate
+            // instruction; the 32 x 32 multiply the compiler must otherwise assume runs at a quarter of the rate)
 #pragma unroll
-            for (int c = 0; c < 6; c++) acc[c] += row[c] * cy[j];
+            for (int c = 0; c < 6; c++) acc[c] += __mul24(row[c], cy[j]);
         }
         int v[6];
 #pragma unroll
         for (int c = 0; c < 6; c++) v[c] = min(max((acc[c] + (1 << 21)) >> 22, 0), 255);
-        const size_t p = (size_t)y * W + x;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const double m = s_m[v[3 + c]];
-            const double r = (double)v[c] * m + (double)bg[3 * p + c] * (1 - m);
+            const double r = (double)v[c] * m + (double)bgv[3 * k + c] * (1 - m);
             out[3 * k + c] = (int)r;
-            if (cmp) sv[3 * k + c] = resize_sample_u8(src, sh, sw, 3, c, y, x, 1, src_mode, src_sy, src_sx, 0., 0.);
         }
     }
-    const size_t p0 = (size_t)y * W + xq;
-    if (npx == 4 && (W & 3) == 0) {                   // 12-byte packed stores (rows are dword-aligned when W % 4 == 0)
+    if (quad) {
         const Px4 o = pack12(out);
         if (res) *reinterpret_cast<Px4*>(res + 3 * p0) = o;
         if (cmp) {
@@ -148,7 +192,7 @@ __global__ __launch_bounds__(256) void replace_compose_kernel(const uint8_t* __r
         }
     } else {
         for (int k = 0; k < 3 * npx; k++) {
-            if (res) res[3 * p0 + k] = (uint8_t)out[k];
+            if (res) res[3 * (size_t)p0 + k] = (uint8_t)out[k];
             if (cmp) {
                 uint8_t* row = cmp + 3 * ((size_t)y * 2 * W);
                 row[3 * (size_t)xq + k] = (uint8_t)sv[k];
@@ -166,7 +210,8 @@ extern "C" int usc_replace_compose_u8(const uint8_t* fg, const uint8_t* mask, in
     if (!fg || !mask || !bg || !M2x3_host || H <= 0 || W <= 0 || (mask_cn != 1 && mask_cn != 3) || !(scale >= 1.0) || (!res && !compare))
         return fail(USC_E_ARG, "usc_replace_compose_u8: bad argument (scale >= 1, at least one output)");
     if (compare && (!src || sh <= 0 || sw <= 0)) return fail(USC_E_ARG, "usc_replace_compose_u8: the side-by-side output needs the source frame");
-    if (too_big(H, 2 * W) || (src && too_big(sh, sw))) return fail(USC_E_UNSUPPORTED, "usc_replace_compose_u8: image too large");
+    if ((long long)H * W * 6 >= (1ll << 32) || (src && too_big(sh, sw))) return fail(USC_E_UNSUPPORTED, "usc_replace_compose_u8: image too large (32-bit byte offsets)");
+    if ((((uintptr_t)bg | (uintptr_t)res | (uintptr_t)compare | (uintptr_t)src) & 3) != 0) return fail(USC_E_ARG, "usc_replace_compose_u8: bg, src and the outputs must be 4-byte aligned");
     Affine A;
     invert_affine(M2x3_host, A.m);
     // rescale_fg (imgprocess.py:46-51): cv2.resize(fx = fy = scale, INTER_CUBIC) -> size = round(h * scale), then the centre crop

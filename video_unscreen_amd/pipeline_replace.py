@@ -29,8 +29,7 @@ class ReplacePipeline:
             if self._src_mask is None:
                 self._src_mask = torch.empty((self.H, self.W, 3), dtype=torch.uint8, device=self.device)
             src_mask = nv.resize(src_mask, self.H, self.W, 1, out=self._src_mask)
-        nv.gray_moments(dst_mask, rgb_order=True, out=self.moments[row, 0])
-        nv.gray_moments(src_mask, rgb_order=True, out=self.moments[row, 1])
+        nv.gray_moments_pair(dst_mask, src_mask, self.moments[row], rgb_order=True)
 
     def offset_sums(self, n):
         """(sum of src_cx - dst_cx, sum of src_cy - dst_cy, n) over rows 0 .. n-1: the one host read of pass 1."""
@@ -56,20 +55,32 @@ class ReplacePipeline:
         return res, (torch.cat((nv.resize(src, h, w, 1), res), 1) if src is not None else None)
 
 
+def pack_pair(a, b, pin=True):
+    """Two same-shape uint8 images as one (2, H, W, 3) host tensor (page-locked): ReplaceHostLoop moves such a pair with ONE copy
+    (a 12.4 MB transfer runs at about twice the rate of two 6.2 MB ones: tools/dev/hostio_probe.py)."""
+    t = torch.empty((2,) + tuple(a.shape), dtype=torch.uint8)
+    if pin:
+        t = t.pin_memory()
+    t[0].copy_(a)
+    t[1].copy_(b)
+    return t
+
+
 class ReplaceHostLoop:
     """The two passes over a clip whose frames start and end in page-locked host memory: uploads on one copy stream, kernels on a
     compute stream, downloads on a second copy stream, `ring` frames in flight; the target's alpha masks stay in HBM between the
     passes (they are read by both: K x 6.2 MB at 1080p), so a frame crosses PCIe as 12 bytes per pixel up (two masks, fg, source
-    frame) and 6 down (the side-by-side image, whose right half IS res - replace.py:79-82 writes both from the same array)."""
+    frame) and 6 down (the side-by-side image, whose right half IS res - replace.py:79-82 writes both from the same array).
+    Per-frame inputs are either (a, b) tuples or pack_pair(a, b) tensors (source and target of one size: one copy per pass)."""
 
     def __init__(self, pipe, nframes, src_hw=None, ring=4):
         self.pipe, self.K, self.ring = pipe, nframes, ring
         H, W, dev = pipe.H, pipe.W, pipe.device
         sh, sw = src_hw if src_hw is not None else (H, W)
         u8 = lambda *s: torch.empty(s, dtype=torch.uint8, device=dev)                      # noqa: E731
-        self.mask_bank = u8(nframes, H, W, 3)
+        self.bank = u8(nframes, 2, H, W, 3)                  # [i, 0] = the target's alphamask (both passes), [i, 1] = the source's when packed
         self.s_mask = [u8(sh, sw, 3) for _ in range(ring)]
-        self.s_fg = [u8(H, W, 3) for _ in range(ring)]
+        self.s_in = [u8(2, H, W, 3) for _ in range(ring)]    # [fg | source frame] of one size
         self.s_src = [u8(sh, sw, 3) for _ in range(ring)]
         self.s_cmp = [u8(H, 2 * W, 3) for _ in range(ring)]
         self.up, self.comp, self.down = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
@@ -87,40 +98,50 @@ class ReplaceHostLoop:
             cur.wait_stream(s)
 
     def pass1(self, masks_h):
-        """masks_h[i] = (target alphamask (H, W, 3), source alphamask (sh, sw, 3)), pinned -> (sum dx, sum dy, n)."""
+        """masks_h[i] = (target alphamask (H, W, 3), source alphamask (sh, sw, 3)) or their pack_pair -> (sum dx, sum dy, n)."""
         p, R = self.pipe, self.ring
         self._start()
-        for i, (dm, sm) in enumerate(masks_h):
+        for i, item in enumerate(masks_h):
             k = i % R
             if i >= R:
                 self.up.wait_event(self.e_used[k])
             with torch.cuda.stream(self.up):
-                self.mask_bank[i].copy_(dm, non_blocking=True)
-                self.s_mask[k].copy_(sm, non_blocking=True)
+                if torch.is_tensor(item):
+                    self.bank[i].copy_(item, non_blocking=True)
+                    sm = self.bank[i, 1]
+                else:
+                    self.bank[i, 0].copy_(item[0], non_blocking=True)
+                    sm = self.s_mask[k]
+                    sm.copy_(item[1], non_blocking=True)
                 self.e_ready[k].record(self.up)
             self.comp.wait_event(self.e_ready[k])
             with torch.cuda.stream(self.comp):
-                p.centroid_pair(i, self.mask_bank[i], self.s_mask[k])
+                p.centroid_pair(i, self.bank[i, 0], sm)
                 self.e_used[k].record(self.comp)
         self._finish()
         return p.offset_sums(len(masks_h))
 
     def pass2(self, inputs_h, M, compare_h):
-        """inputs_h[i] = (fg (H, W, 3), source frame (sh, sw, 3)), pinned; compare_h (K, H, 2 W, 3) pinned receives [source | res]."""
+        """inputs_h[i] = (fg (H, W, 3), source frame (sh, sw, 3)) or their pack_pair; compare_h (K, H, 2 W, 3) pinned receives [source | res]."""
         p, R = self.pipe, self.ring
         self._start()
-        for i, (fg, fr) in enumerate(inputs_h):
+        for i, item in enumerate(inputs_h):
             k = i % R
             if i >= R:
                 self.up.wait_event(self.e_used[k])
                 self.comp.wait_event(self.e_out[k])                     # the slot's previous composite has been copied out
             with torch.cuda.stream(self.up):
-                self.s_fg[k].copy_(fg, non_blocking=True)
-                self.s_src[k].copy_(fr, non_blocking=True)
+                if torch.is_tensor(item):
+                    self.s_in[k].copy_(item, non_blocking=True)
+                    fg, fr = self.s_in[k][0], self.s_in[k][1]
+                else:
+                    fg, fr = self.s_in[k][0], self.s_src[k]
+                    fg.copy_(item[0], non_blocking=True)
+                    fr.copy_(item[1], non_blocking=True)
                 self.e_ready[k].record(self.up)
             self.comp.wait_event(self.e_ready[k])
             with torch.cuda.stream(self.comp):
-                p.compose(self.s_fg[k], self.mask_bank[i], self.s_src[k], M, compare=self.s_cmp[k], want_res=False)
+                p.compose(fg, self.bank[i, 0], fr, M, compare=self.s_cmp[k], want_res=False)
                 self.e_used[k].record(self.comp)
             self.down.wait_event(self.e_used[k])
             with torch.cuda.stream(self.down):
