@@ -358,10 +358,12 @@ constexpr int WLIN_IMG = 576 * 4;           // floats of one LDS image of the li
 // spread over the eight waves) - instead of four: a first version with an image per phase spent 7960 cycles per K step on its
 // 14 staging requests per pair (the same dependence on the request count as between the 8 x 4 and the linear form).
 constexpr int WT3_IMG = 24 * 256;           // floats of one LDS image of the transposed form: three requests per wave (24 KB)
-constexpr int WLDS_LIN = 3 * WT3_IMG + 8 * 192 + 8 * 128;      // floats of LDS per workgroup (82 KB): the transposed form's three images + tables
+constexpr int WLDS_LIN = 3 * WT3_IMG + 8 * 320 + 8 * 128;      // floats of LDS per workgroup (86 KB): the transposed form's three images + tables (linear form without K groups: 8 x 320 request offsets + 8 x 128 fragment addresses)
 constexpr int WT3_GOFF = 3 * WT3_IMG;       // (int index) the transposed form's request offsets: 8 waves x 3 x 64, past the images
 constexpr int WT3_FA = WT3_GOFF + 8 * 192;  // (int index) the transposed form's fragment addresses: 8 waves x 2 x 64
 static_assert(WLDS_LIN >= 8 * WLIN_IMG && WLDS_LIN >= WLDS && WLDS_LIN >= WT3_FA + 8 * 128, "every form's images and tables must fit");
+constexpr int WLIN_FA = WT3_GOFF + 8 * 320;  // (int index) fragment addresses of the linear form without K groups: 8 waves x 2 x 64
+static_assert(WT3_GOFF >= 8 * WLIN_IMG && WLDS_LIN >= WLIN_FA + 8 * 128, "the linear form's request offsets (8 waves x 5 x 64) and fragment addresses sit past its images");
 constexpr int WSLAB_TAIL = 65536;      // the slab's last bytes: arrival counters of layers that split K over two workgroups
 
 struct VA { int vo, so; bool ok; };          // where a finished value goes: lane offset, scalar offset, exists
@@ -509,6 +511,16 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
 #pragma unroll
         for (int r = 0; r < 3; r++) reinterpret_cast<int*>(Ls)[WT3_GOFF + wave * 192 + r * 64 + lane] = goff[r];
     }
+    // Linear form without K groups: its epilogue (the pair exchange) keeps more values alive through the K loop than the forms with K
+    // groups do, and the compiler spilled four of the five request offsets - reloaded from scratch in front of every request, each
+    // reload followed by a wait for EVERY load in flight (round 4: found by tests/test_isa_cpu.py's rule "no scratch instruction in a
+    // loop that holds MFMAs").  They live in the table region past the images instead (free in this form: 8 waves x 5 x 64 ints), as
+    // the transposed form's do.
+    constexpr bool GOFF_LDS = LIN && !T3 && KW == 1;
+    if (GOFF_LDS) {
+#pragma unroll
+        for (int r = 0; r < NG; r++) reinterpret_cast<int*>(Ls)[WT3_GOFF + wave * 320 + r * 64 + lane] = goff[r];
+    }
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(d.in), 0, (d.batch > 1 ? d.batch : 1) * d.IH * d.IW * d.Cin * 4, 0x00020000);
     typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -547,6 +559,17 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
             return;
         }
         const int dst = img0 + ((c - c_begin) & 1) * IMGF + NG * h * 256;
+        if (GOFF_LDS) {
+            typedef __attribute__((address_space(3))) volatile int lds_vint;
+            lds_vint* const go = (lds_vint*)Ls + WT3_GOFF + wave * 320 + lane;
+            const int g0 = go[0], g1 = go[64], g2 = go[128], g3 = go[192];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst], 16, g0, c * 32, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 256], 16, g1, c * 32, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 512], 16, g2, c * 32, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 768], 16, g3, c * 32, 0, 0);
+            if (h == 0) { const int g4 = go[256]; __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 1024], 16, g4, c * 32, 0, 0); }
+            return;
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst], 16, goff[0], c * 32, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 256], 16, goff[1], c * 32, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 512], 16, goff[2], c * 32, 0, 0);
@@ -586,9 +609,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
 #pragma unroll
         for (int k = 0; k < 3; k++) fa[k] = (s0 + 2 * ((T3 ? (pary + h + k) * 3 : (h + k) * 2) * L + pp) + (lane >> 5)) * 4;
         fs2 = 2 * L * 4;
-        if (T3) {                                                   // (read back at the start of every fragment phase)
-            reinterpret_cast<int*>(Ls)[WT3_FA + wave * 128 + lane] = fa[0];
-            reinterpret_cast<int*>(Ls)[WT3_FA + wave * 128 + 64 + lane] = fs2;
+        if (T3 || GOFF_LDS) {                                       // (read back at the start of every fragment phase)
+            reinterpret_cast<int*>(Ls)[(T3 ? WT3_FA : WLIN_FA) + wave * 128 + lane] = fa[0];
+            reinterpret_cast<int*>(Ls)[(T3 ? WT3_FA : WLIN_FA) + wave * 128 + 64 + lane] = fs2;
         }
     }
     // (vector types, not float4 structs: additions of <4 x float> become two v_pk_add_f32 - half the vector instructions that
@@ -606,9 +629,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         constexpr int HH = decltype(hh)::value, PX = decltype(pxc)::value;
         const int cur = T3 ? ((c - c_begin) % 3) * IMGF : img0 + ((c - c_begin) & 1) * IMGF + (LIN ? 0 : fb);
         int t3_fa = 0, t3_fs = 0;
-        if (T3) {
+        if (T3 || GOFF_LDS) {
             typedef __attribute__((address_space(3))) volatile int lds_vint;
-            lds_vint* const fp = (lds_vint*)Ls + WT3_FA + wave * 128 + lane;
+            lds_vint* const fp = (lds_vint*)Ls + (T3 ? WT3_FA : WLIN_FA) + wave * 128 + lane;
             t3_fa = fp[0]; t3_fs = fp[64];
         }
         f32x4 Ta[4], Tb[4];
@@ -619,6 +642,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 if (T3) e[k] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&Ls[cur + t3_fa + (k * 3 + (PX + j) % 3) * t3_fs + ((PX + j) / 3) * 8], 16));
+                else if (GOFF_LDS) e[k] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&Ls[cur + t3_fa + (2 * k + (j & 1)) * t3_fs + (j >> 1) * 8], 16));   // fa[k] = fa[0] + 2 k fs2
                 else if (LIN) e[k] = *reinterpret_cast<const f32x4*>(&Ls[cur + fa[k] + (j & 1) * fs2 + (j >> 1) * 8]);
                 else e[k] = *reinterpret_cast<const f32x4*>(&Ls[cur + ((((HH + k) & 1) * 2) * WSUB + ((HH + k) >> 1) * WSUBROW) * 4 + co]);
                 if (IN_RELU) e[k] = relu4(e[k]);
