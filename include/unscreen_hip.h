@@ -460,9 +460,16 @@ const char* usc_conv_last_error(void);
 #define USC_CONV_LAUNCH_STREAM 0   /* default: the planned launches are enqueued one by one on the stream (no re-planning, ~3 us of host
                                     * time per layer; measured 1.49 ms per matting forward against 1.67 ms for the graph replay) */
 #define USC_CONV_LAUNCH_GRAPH  1   /* one hipGraphLaunch per call: least host time (one call per forward) */
+#define USC_CONV_LAUNCH_RUNS   2   /* as STREAM, but every run of consecutive same-shape Winograd layers (each reading the one before) goes
+                                    * out as ONE launch: workgroups pull (layer, block) items from a counter and wait on per-block
+                                    * arrival counters of the previous layer instead of a kernel boundary; bit-identical results */
 int  usc_conv_graph_create(const usc_conv_desc* descs, int n, void** handle);
 int  usc_conv_graph_set_mode(void* handle, int mode);
 int  usc_conv_graph_launch(void* handle, usc_stream_t stream);
+/* USC_CONV_LAUNCH_RUNS bookkeeping (blocks: reads device memory): how many runs the handle's layer list holds, how many layers they
+ * cover, and how many bounded polls of an arrival counter have ever run out (0 unless a hand-over is broken: such a launch has
+ * gone on with possibly stale inputs instead of hanging - callers that use the mode check this). */
+int  usc_conv_graph_run_info(void* handle, int* nruns, int* layers_in_runs, unsigned* poll_timeouts);
 void usc_conv_graph_destroy(void* handle);   /* the one entry of this group that blocks: waits for the device to drain (a launch
                                               * of the graph may still be queued), then destroys the graph, its execs and plans */
 

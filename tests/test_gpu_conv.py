@@ -478,3 +478,39 @@ def test_two_conv_stacks_on_two_streams_give_the_bits_of_one():
     assert sum(int(b) for b in bad) == 0, [i for i, b in enumerate(bad) if int(b)]
     assert sum(int(b) for b in mbad) == 0, [i for i, b in enumerate(mbad) if int(b)]
     net.close()
+
+
+def test_runs_mode_is_bit_identical():
+    """USC_CONV_LAUNCH_RUNS (opt-in; profiles/r04/runs_mode.md): runs of same-shape Winograd layers of the matting net as ONE launch
+    each - items from a counter, per-block arrival counters polled with a bound, write-through stores / sc1 loads across the eight
+    L2s.  Every forward must give the bits of the per-layer launches, also beside a second stream that keeps a varying share of the
+    CUs busy (uneven load is where a broken hand-over shows), every intermediate tensor included, and no poll may ever run out."""
+    import ctypes as C
+    from video_unscreen_amd import _native as nv
+    from video_unscreen_amd.vmatting.net import synthetic_state_dict
+    from video_unscreen_amd.vmatting.net_hip import HipMattingNet
+    net = HipMattingNet(synthetic_state_dict(0), 544, 960)
+    net.x8.normal_()
+    nruns, nlayers, bad_polls = C.c_int(), C.c_int(), C.c_uint()
+    assert nv.load().usc_conv_graph_run_info(net._graph, C.byref(nruns), C.byref(nlayers), C.byref(bad_polls)) == 0
+    assert nruns.value >= 3 and nlayers.value >= 8            # #3-6, #26-27, #45-46 of profiles/r03/unet_layer_table.md
+    ref = net().clone()
+    acts = [t for t in net._keep if t.dim() == 3]
+    acts_ref = [t.clone() for t in acts]
+    net.set_launch_mode("runs")
+    side = torch.cuda.Stream()
+    junk = torch.randn(2048, 2048, device="cuda")
+    bad = []
+    for i in range(60):
+        if i >= 20:
+            with torch.cuda.stream(side):
+                for _ in range(1 + i % 3):
+                    junk = (junk @ junk).clamp_(-1, 1)
+        bad.append((net() != ref).sum())
+    torch.cuda.synchronize()
+    assert sum(int(b) for b in bad) == 0, [i for i, b in enumerate(bad) if int(b)]
+    assert all(torch.equal(a, b) for a, b in zip(acts, acts_ref))
+    assert nv.load().usc_conv_graph_run_info(net._graph, None, None, C.byref(bad_polls)) == 0 and bad_polls.value == 0
+    net.set_launch_mode("stream")
+    assert torch.equal(net(), ref)
+    net.close()

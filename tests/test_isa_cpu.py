@@ -37,7 +37,7 @@ def kernels():
 def test_every_conv_kernel_is_in_the_library(kernels):
     names = [n for n in kernels if "conv_wino_kernel" in n or "conv_mfma_kernel" in n]
     wino = [n for n in names if "conv_wino_kernel" in n]
-    assert len(wino) == 14 and len(names) - len(wino) >= 20, sorted(names)       # (KW 1 | 2 | 4) x IN_RELU x (rect, linear) + transposed x IN_RELU
+    assert len(wino) == 15 and len(names) - len(wino) >= 20, sorted(names)       # (KW 1 | 2 | 4) x IN_RELU x (rect, linear) + transposed x IN_RELU + one run-mode variant
     import isa_check as ic
     for n in names:
         f = ic.facts(kernels[n])
@@ -59,11 +59,11 @@ def test_winograd_staged_image_hand_over_is_covered_by_a_wait(kernels):
     for n, ins in kernels.items():
         if "conv_wino_kernel" not in n:
             continue
-        t3 = re.search(r"<\d+, \w+, 2>", n) is not None
+        t3 = re.search(r"<\d+, \w+, 2(, \w+)?>", n) is not None
         bad = ic.handover_violations(ins, 4 if t3 else 2)
         assert not bad, (n, [(k, ins[k][1], why) for k, why in bad[:4]])
         checked += 1
-    assert checked == 14
+    assert checked == 15
 
 
 def test_hand_over_rule_flags_a_missing_wait():

@@ -87,7 +87,9 @@ def loops(ins):
 
 def facts(ins):
     lp = loops(ins)
-    mf = [(t, b) for t, b in lp if any(op.startswith("v_mfma") for _, op, _ in ins[t:b + 1])]
+    # innermost loops that hold MFMAs (a K loop; not the item loop of a run-mode kernel, which holds the whole body)
+    mf = [(t, b) for t, b in lp if any(op.startswith("v_mfma") for _, op, _ in ins[t:b + 1])
+          and not any((t2, b2) != (t, b) and t <= t2 and b2 <= b and (t2 > t or b2 < b) for t2, b2 in lp)]
     scratch_in = sum(1 for t, b in mf for _, op, _ in ins[t:b + 1] if op.startswith("scratch_"))
     return {"loops": len(lp), "mfma_loops": mf, "scratch_in_mfma_loops": scratch_in,
             "scratch_total": sum(1 for _, op, _ in ins if op.startswith("scratch_")),
@@ -168,6 +170,6 @@ if __name__ == "__main__" and "--handover" in sys.argv:
     for img in code_objects(so):
         for name, ins in disassemble(img).items():
             if "conv_wino_kernel" in name:
-                t3 = re.search(r"<\d+, \w+, 2>", name) is not None
+                t3 = re.search(r"<\d+, \w+, 2(, \w+)?>", name) is not None
                 v = handover_violations(ins, 4 if t3 else 2)
                 print(name[-60:], "lds requests", facts(ins)["lds_dma"], "violations", v[:6])

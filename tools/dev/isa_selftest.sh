@@ -46,7 +46,7 @@ for v, what in (("a", "h = 1 wave's vmcnt(0) before the second image's hand-over
     print(f"== {what}")
     for name, ins in ic.disassemble(img).items():
         if "conv_wino_kernel" in name:
-            t3 = re.search(r"<\d+, \w+, 2>", name) is not None
+            t3 = re.search(r"<\d+, \w+, 2(, \w+)?>", name) is not None
             bad = ic.handover_violations(ins, 4 if t3 else 2)
             print(f"   {name[name.index('conv_wino'):][:45]:45s} {'FLAGGED: %d request(s), first: %s' % (len(bad), bad[0][1]) if bad else 'passes'}")
 PY

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "usc_conv_last_error": (C.c_char_p, []),
     "usc_conv_graph_create": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
     "usc_conv_graph_launch": (C.c_int, [_vp, _vp]),
+    "usc_conv_graph_run_info": (C.c_int, [_vp, _vp, _vp, _vp]),
     "usc_conv_graph_set_mode": (C.c_int, [_vp, C.c_int]),
     "usc_conv_graph_destroy": (None, [_vp]),
 }

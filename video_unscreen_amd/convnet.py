@@ -129,7 +129,7 @@ class ConvGraphNet:
         """"stream" (default) or "graph": how every conv segment is enqueued (usc_conv_graph_set_mode)."""
         for kind, a, _ in self._segments:
             if kind == "conv":
-                self.nv.load().usc_conv_graph_set_mode(a, {"stream": 0, "graph": 1}[mode])
+                self.nv.load().usc_conv_graph_set_mode(a, {"stream": 0, "graph": 1, "runs": 2}[mode])
 
     def plan_gflop(self):
         """2 * M * N * K over every conv launch of the plan (GFLOP per run(), padded channels included; a Winograd layer counts its

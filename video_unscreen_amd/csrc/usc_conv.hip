@@ -332,10 +332,10 @@ static_assert(WLDS >= 4 * 2 * WIMG, "the patch images must fit");
 
 #ifdef USC_WINO_TIMING2          // per-phase stamps of the first three K steps: 16 shader-clock slots per wave
 #define WINO_STAMP(k) do { } while (0)
-#define WINO_PH(k) do { if (d.slab && lane == 0 && (k) < 16) reinterpret_cast<long long*>(d.slab)[((size_t)blockIdx.x * 8 + wave) * 16 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define WINO_PH(k) do { if (d.slab && lane == 0 && (k) < 16) reinterpret_cast<long long*>(d.slab)[((size_t)bid * 8 + wave) * 16 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 #elif defined(USC_WINO_TIMING)
 #define WINO_PH(k) do { } while (0)
-#define WINO_STAMP(k) do { if (d.slab && lane == 0) { long long* ts_ = reinterpret_cast<long long*>(d.slab) + ((size_t)blockIdx.x * 8 + wave) * 16; \
+#define WINO_STAMP(k) do { if (d.slab && lane == 0) { long long* ts_ = reinterpret_cast<long long*>(d.slab) + ((size_t)bid * 8 + wave) * 16; \
         ts_[2 * (k)] = (long long)__builtin_readcyclecounter(); ts_[2 * (k) + 1] = (long long)__builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define WINO_STAMP(k) do { } while (0)
@@ -368,13 +368,65 @@ constexpr int WSLAB_TAIL = 65536;      // the slab's last bytes: arrival counter
 
 struct VA { int vo, so; bool ok; };          // where a finished value goes: lane offset, scalar offset, exists
 
-template <int KW, bool IN_RELU, int MODE>                           // MODE 0: 8 x 4 blocks, 1: linear blocks, 2: transposed (T3, linear)
-__global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
+// ---- Run mode (RUN = true): ONE launch spans a run of consecutive layers of the same geometry and kernel variant (the matting net's
+// 64 -> 64 layers at 136 x 240, ...).  A workgroup pulls (layer, workgroup index) items in layer-major order from an atomic counter;
+// before it requests its first patch it waits until the (up to nine) blocks of the previous layer that its patch overlaps have been
+// stored - per-block arrival counters, polled with a bound (a broken hand-over becomes a counted error, never a hang).  No grid
+// barrier, and no workgroup ever waits for work that is not already owned by a running workgroup (items are handed out in order, an
+// item's producers have lower indices): the scheme cannot deadlock however many CUs other kernels hold.  Visibility across the eight
+// non-coherent L2s (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the sc1 hand-off table): every store of a layer's
+// output is a 16-byte write-through store (sc0 sc1), every storing wave waits for its stores (vmcnt(0)), a workgroup barrier, then ONE
+// lane per block x channel group adds to the block's counter (agent scope); consumers poll with sc1 loads and read the activations
+// (patches and residuals) with sc0 sc1 loads only after their own poll has matched.  Tensors are written once per launch and kernel
+// boundaries invalidate the L2s, so no stale line can sit in a consumer's L2.
+constexpr int USC_RUN_MAX = 8;
+#ifndef USC_RUN_EXP
+#define USC_RUN_EXP 0            // timing experiments of round 4 (profiles/r04/runs_mode.md; NOT correct with a bit set): 1 plain patch / residual
+#endif                           // loads, 2 plain stores, 4 no poll, 8 items by workgroup index instead of the counter, 16 no arrival counts
+struct usc_conv_run {
+    usc_conv_desc d[USC_RUN_MAX];
+    int nlayers, wgs, nblocks;      // layers of the run, workgroups per layer, blocks per layer (= arrival counters per layer)
+    unsigned* ctl;                  // [0] next item, [1] workgroups that found the queue empty, [2] launch sequence number, [3] polls that ran out
+    unsigned* flags;                // [layer][block] arrival counters, never reset: after launch q a counter shows q x channel groups
+};
+template <bool RUN> struct WinoArg { typedef usc_conv_desc type; };
+template <> struct WinoArg<true> { typedef usc_conv_run type; };
+
+template <int KW, bool IN_RELU, int MODE, bool RUN = false>         // MODE 0: 8 x 4 blocks, 1: linear blocks, 2: transposed (T3, linear)
+__global__ __launch_bounds__(512) void conv_wino_kernel(typename WinoArg<RUN>::type arg) {
     __shared__ __attribute__((aligned(16))) float Ls[WLDS_LIN];     // (a template-dependent bound makes the host pass drop the kernel's stub without a word)
+    __shared__ int s_item;
+    unsigned run_seq = 0;
+    if constexpr (RUN) run_seq = __hip_atomic_load(&arg.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (RUN) {                                             // the first item; every later one is fetched while the stores of the one before drain
+        if (threadIdx.x == 0) s_item = (USC_RUN_EXP & 8) ? (int)blockIdx.x : (int)__hip_atomic_fetch_add(&arg.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
+    int run_pass = 0;
+    do {                                                             // (one pass unless RUN)
+    int run_layer = 0, bid = (int)blockIdx.x, nwg_ = (int)gridDim.x;
+    if constexpr (RUN) {
+        const int item = __builtin_amdgcn_readfirstlane(s_item);     // (written before the barrier that ended the previous pass)
+        run_pass++;
+        if (item >= arg.nlayers * arg.wgs) {
+            // the queue is empty: the last workgroup to see that puts the queue back and advances the sequence number for the next launch
+            if (threadIdx.x == 0 && __hip_atomic_fetch_add(&arg.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+                __hip_atomic_store(&arg.ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&arg.ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&arg.ctl[2], run_seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            break;
+        }
+        run_layer = item / arg.wgs;
+        bid = item - run_layer * arg.wgs;
+        nwg_ = arg.wgs;
+    }
+    const usc_conv_desc& d = *[&]() { if constexpr (RUN) return &arg.d[run_layer]; else return &arg; }();
     constexpr bool LIN = MODE != 0, T3 = MODE == 2;
     constexpr int IMGF = T3 ? WT3_IMG : LIN ? WLIN_IMG : WIMG;      // floats per LDS image
     constexpr int NG = LIN && !T3 ? 5 : 3;                          // global -> LDS requests of a wave per image
     static_assert(!T3 || KW == 1, "the transposed form has no K groups: the four pairs are the four output phases");
+    static_assert(!RUN || (MODE == 0 && KW >= 2), "run mode: 8 x 4 blocks with K groups (the epilogue in 16-byte rounds)");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = wave >> 2, sub = wave & 3;                        // position half (rows 2h, 2h + 1) and pair of this wave
@@ -395,8 +447,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     const int nbt = T3 && TW < 11 ? min(4, 32 / TW) * TW : 32;
     const int ntile_img = TH * TW, nblk_img = T3 ? (ntile_img + nbt - 1) / nbt : LIN ? (ntile_img + 31) >> 5 : BH * BW;
     const int ntiles = nimg * nblk_img * nnb;                       // blocks x channel groups
-    const int nwg = (int)gridDim.x, xcd = (int)blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;      // XCD-aware order (see above)
-    const int wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
+    const int nwg = nwg_, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;      // XCD-aware order (see above)
+    // (run mode: items are handed out in order and the activations are read past the L2 anyway)
+    const int wid = RUN ? bid : (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     // K split across TWO workgroups (d.ksplit = 2, K groups only): neighbours in the XCD-local order take the two halves of the
     // channel range of the same units; their partial output tiles meet in the slab, the workgroup that arrives second finishes.
     const int S = d.ksplit == 2 ? 2 : 1;
@@ -570,12 +623,13 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
             if (h == 0) { const int g4 = go[256]; __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 1024], 16, g4, c * 32, 0, 0); }
             return;
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst], 16, goff[0], c * 32, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 256], 16, goff[1], c * 32, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 512], 16, goff[2], c * 32, 0, 0);
+        constexpr int AUX = RUN && !(USC_RUN_EXP & 1) ? 0x11 : 0;    // run mode: sc0 sc1 - the activations were stored by other workgroups of this launch
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst], 16, goff[0], c * 32, 0, AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 256], 16, goff[1], c * 32, 0, AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 512], 16, goff[2], c * 32, 0, AUX);
         if (LIN) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 768], 16, goff[NG - 2], c * 32, 0, 0);
-            if (h == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 1024], 16, goff[NG - 1], c * 32, 0, 0);   // 9 requests: 5 + 4
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 768], 16, goff[NG - 2], c * 32, 0, AUX);
+            if (h == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, &Ls[dst + 1024], 16, goff[NG - 1], c * 32, 0, AUX);   // 9 requests: 5 + 4
         }
     };
     auto wait_vm0 = [] { __builtin_amdgcn_s_waitcnt(0x0F70); };     // vmcnt(0): every load of this wave has landed (LDS ones too)
@@ -676,6 +730,25 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         __builtin_amdgcn_s_setprio(0);
     };
 
+    if constexpr (RUN) {
+        static_assert(!RUN || MODE == 0, "run mode: 8 x 4 blocks only (the neighbours of a block are its eight neighbours in the block grid)");
+        // wait for the blocks of the previous layer this block's patch overlaps: lane i < 9 polls neighbour (i / 3 - 1, i % 3 - 1); every
+        // lane iterates the same number of times (`__all` is the only exit: a divergent poll loop can hang - profiles/r03/dataflow_probe.md)
+        if (run_layer > 0 && !(USC_RUN_EXP & 4)) {
+            const unsigned* const fp = arg.flags + (run_layer - 1) * arg.nblocks;
+            const unsigned target = run_seq * (unsigned)(d.Cin >> 5);     // the previous layer's channel groups (its Cout = this layer's Cin)
+            const int ny = by + lane / 3 - 1, nx = bx + lane % 3 - 1;
+            bool ready = !(live && lane < 9 && ny >= 0 && ny < BH && nx >= 0 && nx < BW);
+            const unsigned* const mine = fp + (img * nblk_img + (ready ? 0 : ny * BW + nx));
+            int polls = 0;
+            for (;;) {
+                if (!ready) ready = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == target;
+                if (__all(ready) || ++polls >= (1 << 17)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (polls >= (1 << 17) && lane == 0) __hip_atomic_fetch_add(&arg.ctl[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     issue_a(c_begin);
     if (T3 && nmax > 1) issue_a(c_begin + 1);                       // (transposed form: images are requested TWO steps ahead)
     wait_vm0();
@@ -888,7 +961,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         for (int rd = 0; rd < 4; rd++)
 #pragma unroll
             for (int u = 0; u < NTK; u++) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r1_rsrc, ok4(u, rd >> 1, rd & 1) ? r1_off(u, rd >> 1, rd & 1) : INVALID, 0, 0);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r1_rsrc, ok4(u, rd >> 1, rd & 1) ? r1_off(u, rd >> 1, rd & 1) : INVALID, 0, RUN && !(USC_RUN_EXP & 1) ? 0x11 : 0);
                 r1q[rd][u] = *reinterpret_cast<const float4*>(&v);
             }
     }
@@ -897,7 +970,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
         for (int rd = 0; rd < 4; rd++)
 #pragma unroll
             for (int u = 0; u < NTK; u++) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, ok4(u, rd >> 1, rd & 1) ? (pix4(u, rd >> 1, rd & 1) * d.Cout + ch) * 4 : INVALID, 0, 0);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, ok4(u, rd >> 1, rd & 1) ? (pix4(u, rd >> 1, rd & 1) * d.Cout + ch) * 4 : INVALID, 0, RUN && !(USC_RUN_EXP & 1) ? 0x11 : 0);
                 r2q[rd][u] = *reinterpret_cast<const float4*>(&v);
             }
     }
@@ -920,7 +993,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
             // (scalar offset = the constant 0: with a register there the next instruction may overwrite the data registers of a
             // 16-byte store before it has read them - see the transposed form)
             const bool st_ok = EDGE ? ok4(u, rd >> 1, rd & 1) : (NR >= 4 || task);
-            __builtin_amdgcn_raw_buffer_store_b128(xs, out_rsrc, st_ok ? (pix4(u, rd >> 1, rd & 1) * out_ld + d.out_c0 + ch) * 4 : INVALID, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(xs, out_rsrc, st_ok ? (pix4(u, rd >> 1, rd & 1) * out_ld + d.out_c0 + ch) * 4 : INVALID, 0, RUN && !(USC_RUN_EXP & 2) ? 0x11 : 0);   // (run mode: write-through)
         };
         float vs[4][NTK][4];
         constexpr int SC = 0x11;                                  // sc0 | sc1 (two workgroups per unit, below)
@@ -1178,6 +1251,20 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(usc_conv_desc d) {
     }
     WINO_STAMP(6);
     WINO_PH(15);
+    if constexpr (RUN) {
+        // the next item is requested now: the counter's round trip (and the queue of 255 workgroups that ask at about the same time)
+        // overlaps the drain of this item's write-through stores, which has to be waited for anyway
+        unsigned nxt = 0;
+        if (threadIdx.x == 0) nxt = (USC_RUN_EXP & 8) ? (unsigned)(run_pass * (int)gridDim.x + (int)blockIdx.x) : __hip_atomic_fetch_add(&arg.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // publish this item: every wave's write-through stores have been acknowledged, then one lane per block x channel group counts
+        __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (said twice: the compiler may drop a wait it believes satisfied - MI355X_MICROARCH.md, compiler hazard)
+        if (threadIdx.x == 0) s_item = (int)nxt;
+        __syncthreads();
+        if (h == 0 && kg == 0 && lane == 0 && live && !(USC_RUN_EXP & 16))
+            __hip_atomic_fetch_add(&arg.flags[run_layer * arg.nblocks + sb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    } while (RUN);
 }
 
 // Second half of a split-K layer: sum the K slices in a fixed order (deterministic), then the fused epilogue.
@@ -1569,7 +1656,35 @@ struct ConvGraph {
     int device = -1;                       // the device the graph was created (and is launched) on
     int mode = USC_CONV_LAUNCH_STREAM;     // how usc_conv_graph_launch enqueues the layers
     void* counters = nullptr;              // arrival counters (slab tail) of the layers that split K over two workgroups, if any
+    // runs of same-shape Winograd layers that USC_CONV_LAUNCH_RUNS enqueues as ONE launch each (conv_wino_kernel<.., RUN = true>)
+    struct Run { int first, count; usc_conv_run arg; void* fn; dim3 grid; };
+    std::vector<Run> runs;
+    unsigned* run_state = nullptr;         // per run: 4 control words + count x blocks arrival counters (device memory, owned)
 };
+
+// Layers [i, i + n) can go out as one run: the same kernel variant (8 x 4 blocks, K groups, no K split over workgroups), the same
+// geometry, one image, dense outputs, each layer's input the output of the one before; residual tensors come from an earlier layer of the
+// run (their blocks are finished transitively: a block waits for the same block one layer back) or from outside it.
+static int find_run(const std::vector<LayerPlan>& pl, int i) {
+    const LayerPlan& a = pl[i];
+    if (a.fn != (void*)conv_wino_kernel<2, false, 0, false> || a.d.ksplit == 2 || (a.d.batch > 1) || a.d.dx[5] != 1) return 1;
+    int n = 1;
+    while (i + n < (int)pl.size() && n < USC_RUN_MAX) {
+        const LayerPlan& b = pl[i + n];
+        const LayerPlan& prev = pl[i + n - 1];
+        if (b.fn != a.fn || b.d.ksplit == 2 || b.d.batch > 1 || b.d.IH != a.d.IH || b.d.IW != a.d.IW || b.d.Cin != a.d.Cin || b.d.Cout != a.d.Cout ||
+            b.d.in != prev.d.out || (prev.d.out_ld && prev.d.out_ld != prev.d.Cout) || prev.d.out_c0 != 0 || a.d.Cout != a.d.Cin) break;
+        bool ok = true;
+        for (const float* r : {b.d.res1, b.d.res2}) {
+            if (!r) continue;
+            for (int k = i + n; k < (int)pl.size() && k < i + USC_RUN_MAX; k++) ok = ok && r != pl[k].d.out;     // never a tensor a later layer writes
+        }
+        if (b.d.res1 && b.d.res1_shift) ok = false;
+        if (!ok) break;
+        n++;
+    }
+    return n;
+}
 
 extern "C" int usc_conv_graph_create(const usc_conv_desc* descs, int n, void** handle) {
     if (!descs || n <= 0 || !handle) return conv_fail(USC_E_ARG, "usc_conv_graph_create: bad argument");
@@ -1582,9 +1697,47 @@ extern "C" int usc_conv_graph_create(const usc_conv_desc* descs, int n, void** h
         // arrival counters of Winograd layers split over two workgroups: zeroed here once; every launch leaves them zero (the second
         // arriver of a pair resets its counter), so no launch inherits a counter left odd and no memset sits in the launch path.
         // Handles that share a slab (the space-time memory network's parts) are created before any of them runs.
-        if (g->plans[i].wsplit && !g->counters) {
-            g->counters = wslab_counters(g->plans[i].d);
-            if (hipMemset(g->counters, 0, WSLAB_TAIL) != hipSuccess) { delete g; return conv_fail(USC_E_LAUNCH, "hipMemset (arrival counters) failed"); }
+        if (g->plans[i].wsplit) {
+            void* c = wslab_counters(g->plans[i].d);
+            bool seen = false;                               // (layers may name different slabs: every distinct tail is zeroed once)
+            for (int k = 0; k < i; k++) seen = seen || (g->plans[k].wsplit && wslab_counters(g->plans[k].d) == c);
+            if (!g->counters) g->counters = c;
+            if (!seen && hipMemset(c, 0, WSLAB_TAIL) != hipSuccess) { delete g; return conv_fail(USC_E_LAUNCH, "hipMemset (arrival counters) failed"); }
+        }
+    }
+    // runs (USC_CONV_LAUNCH_RUNS): found once, their control words and arrival counters allocated and zeroed here (sequence number 1)
+    {
+        size_t words = 0;
+        for (int i = 0; i < n;) {
+            const int cnt = find_run(g->plans, i);
+            if (cnt >= 2) {
+                ConvGraph::Run r;
+                r.first = i; r.count = cnt; r.fn = (void*)conv_wino_kernel<2, false, 0, true>;
+                memset(&r.arg, 0, sizeof(r.arg));
+                for (int k = 0; k < cnt; k++) r.arg.d[k] = g->plans[i + k].d;
+                const usc_conv_desc& d0 = r.arg.d[0];
+                const int TH = (d0.IH + 1) / 2, TW = (d0.IW + 1) / 2;
+                r.arg.nlayers = cnt; r.arg.wgs = (int)g->plans[i].grid.x; r.arg.nblocks = ((TH + 3) / 4) * ((TW + 7) / 8);
+                r.arg.ctl = reinterpret_cast<unsigned*>(words);              // offsets for now
+                words += 4 + (size_t)cnt * r.arg.nblocks;
+                g->runs.push_back(r);
+            }
+            i += cnt;
+        }
+        if (words) {
+            if (hipMalloc(&g->run_state, words * 4) != hipSuccess || hipMemset(g->run_state, 0, words * 4) != hipSuccess) {
+                delete g; return conv_fail(USC_E_LAUNCH, "hipMalloc (run state) failed");
+            }
+            int cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, g->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+            for (auto& r : g->runs) {
+                r.arg.ctl = g->run_state + (size_t)r.arg.ctl;
+                r.arg.flags = r.arg.ctl + 4;
+                const unsigned one = 1;
+                if (hipMemcpy(r.arg.ctl + 2, &one, 4, hipMemcpyHostToDevice) != hipSuccess) { delete g; return conv_fail(USC_E_LAUNCH, "hipMemcpy (run state) failed"); }
+                r.grid = dim3((unsigned)(r.arg.wgs < cus ? r.arg.wgs : cus));     // one workgroup per CU pulls items until the queue is empty
+            }
         }
     }
     if (hipGraphCreate(&g->graph, 0) != hipSuccess) { delete g; return conv_fail(USC_E_LAUNCH, "hipGraphCreate failed"); }
@@ -1626,8 +1779,18 @@ extern "C" int usc_conv_graph_launch(void* handle, usc_stream_t stream) {
     usc_debug_arm_segv_backtrace();
     ConvGraph* g = (ConvGraph*)handle;
     hipStream_t st = (hipStream_t)stream;
-    if (g->mode == USC_CONV_LAUNCH_STREAM) {                // the planned launches, one after the other on the stream
-        for (LayerPlan& p : g->plans) {
+    if (g->mode == USC_CONV_LAUNCH_STREAM || g->mode == USC_CONV_LAUNCH_RUNS) {    // the planned launches, one after the other on the stream
+        size_t next_run = 0;
+        for (int i = 0; i < (int)g->plans.size(); i++) {
+            if (g->mode == USC_CONV_LAUNCH_RUNS && next_run < g->runs.size() && g->runs[next_run].first == i) {
+                ConvGraph::Run& r = g->runs[next_run++];
+                void* rargs[] = {&r.arg};
+                hipError_t e = hipLaunchKernel(r.fn, r.grid, dim3(512), rargs, 0, st);
+                if (e != hipSuccess) return conv_fail(USC_E_LAUNCH, hipGetErrorString(e));
+                i += r.count - 1;
+                continue;
+            }
+            LayerPlan& p = g->plans[i];
             void* args[] = {&p.d};
             hipError_t e = hipLaunchKernel(p.fn, p.grid, p.block, args, 0, st);
             if (e == hipSuccess && p.reduce) e = hipLaunchKernel((void*)splitk_reduce_kernel, p.rgrid, dim3(256), args, 0, st);
@@ -1648,8 +1811,25 @@ extern "C" int usc_conv_graph_launch(void* handle, usc_stream_t stream) {
 }
 
 extern "C" int usc_conv_graph_set_mode(void* handle, int mode) {
-    if (!handle || (mode != USC_CONV_LAUNCH_STREAM && mode != USC_CONV_LAUNCH_GRAPH)) return conv_fail(USC_E_ARG, "usc_conv_graph_set_mode: bad argument");
+    if (!handle || (mode != USC_CONV_LAUNCH_STREAM && mode != USC_CONV_LAUNCH_GRAPH && mode != USC_CONV_LAUNCH_RUNS)) return conv_fail(USC_E_ARG, "usc_conv_graph_set_mode: bad argument");
     ((ConvGraph*)handle)->mode = mode;
+    return USC_OK;
+}
+
+extern "C" int usc_conv_graph_run_info(void* handle, int* nruns, int* layers_in_runs, unsigned* poll_timeouts) {
+    if (!handle) return conv_fail(USC_E_ARG, "usc_conv_graph_run_info: null handle");
+    ConvGraph* g = (ConvGraph*)handle;
+    int layers = 0;
+    unsigned bad = 0;
+    for (auto& r : g->runs) {
+        layers += r.count;
+        unsigned v = 0;
+        if (hipMemcpy(&v, r.arg.ctl + 3, 4, hipMemcpyDeviceToHost) != hipSuccess) return conv_fail(USC_E_LAUNCH, "usc_conv_graph_run_info: hipMemcpy failed");
+        bad += v;
+    }
+    if (nruns) *nruns = (int)g->runs.size();
+    if (layers_in_runs) *layers_in_runs = layers;
+    if (poll_timeouts) *poll_timeouts = bad;
     return USC_OK;
 }
 
@@ -1667,6 +1847,7 @@ extern "C" void usc_conv_graph_destroy(void* handle) {
                                            // caller releases the layers' buffers right after this call (ConvGraphNet.close())
     for (auto& se : g->execs) (void)hipGraphExecDestroy(se.second);
     if (g->graph) (void)hipGraphDestroy(g->graph);
+    if (g->run_state) (void)hipFree(g->run_state);
     if (g->device >= 0 && g->device != cur && cur >= 0) (void)hipSetDevice(cur);
     delete g;
 }

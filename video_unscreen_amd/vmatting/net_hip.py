@@ -283,8 +283,9 @@ class HipMattingNet:
     __call__ = forward
 
     def set_launch_mode(self, mode):
-        """"stream" (default: the planned launches one by one on the stream) or "graph" (one hipGraphLaunch per forward)."""
-        rc = nv.load().usc_conv_graph_set_mode(self._graph, {"stream": 0, "graph": 1}[mode])
+        """"stream" (default: the planned launches one by one on the stream), "graph" (one hipGraphLaunch per forward) or "runs" (as
+        stream, runs of same-shape Winograd layers as one launch each: USC_CONV_LAUNCH_RUNS)."""
+        rc = nv.load().usc_conv_graph_set_mode(self._graph, {"stream": 0, "graph": 1, "runs": 2}[mode])
         if rc != 0:
             raise nv.NativeError(f"usc_conv_graph_set_mode failed ({rc})")
 
