@@ -1301,49 +1301,94 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(usc_conv_desc d) {
 }
 
 // Output head: Conv2d(32 -> 1, 3x3, pad 1, bias) followed by (tanh(x) + 1) / 2  (model.py:389, 566).
-// N = 1 is no matrix product: memory-bound.  A workgroup stages an (8+2) x (32+2) pixel patch of the 32-channel
-// input in LDS with coalesced 16-byte loads (pixel pitch 36 floats -> conflict-free b128 reads), then each lane
-// owns one output pixel: 9 taps x 8 float4 reads against the 288 weights held in LDS.
-constexpr int HT_H = 8, HT_W = 32, HPITCH = 36;
-__global__ __launch_bounds__(256) void head_conv_kernel(usc_conv_desc d) {
-    __shared__ __attribute__((aligned(16))) float patch[(HT_H + 2) * (HT_W + 2) * HPITCH];
-    __shared__ __attribute__((aligned(16))) float w[9 * 32];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 9 * 32; i += 256) w[i] = d.wpk[i];
-    const int y0 = blockIdx.y * HT_H, x0 = blockIdx.x * HT_W;
-    // (10 x 34) pixels x 8 float4 each
-    for (int i = tid; i < (HT_H + 2) * (HT_W + 2) * 8; i += 256) {
-        const int px = i >> 3, q = i & 7;
-        const int py = px / (HT_W + 2), pxx = px - py * (HT_W + 2);
-        const int gy = y0 - 1 + py, gx = x0 - 1 + pxx;
-        const bool ok = gy >= 0 && gy < d.IH && gx >= 0 && gx < d.IW;
-        const int cy = min(max(gy, 0), d.IH - 1), cx = min(max(gx, 0), d.IW - 1);
-        float4 v = *reinterpret_cast<const float4*>(d.in + ((size_t)(cy * d.IW + cx) * 32 + 4 * q));
-        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(&patch[px * HPITCH + 4 * q]) = v;
-    }
-    __syncthreads();
-    const int ty = tid >> 5, tx = tid & 31;
-    const int gy = y0 + ty, gx = x0 + tx;
-    float acc = 0.f;
-#pragma unroll 1
-    for (int t = 0; t < 9; t++) {
-        const int ky = t / 3, kx = t - ky * 3;
-        const float* src = &patch[((ty + ky) * (HT_W + 2) + tx + kx) * HPITCH];
-        const float* wt = &w[t * 32];
+// N = 1 is no matrix product: the layer is bound by reading its 32-channel input once (66.8 MB at 544 x 960).  Round 4 form: one WAVE
+// per workgroup streams a strip of 32 pixels x 8 output rows: the 10 input rows (34 pixels x 128 bytes each) pass through a ring of three
+// row buffers in LDS, requested two rows ahead with global -> LDS loads (five requests of 64 x 16 bytes per row; pixel pitch 36 floats:
+// conflict-free b128 reads; padding pixels and the pad slot are out-of-range offsets = zeros).  The ring is private to the wave - the
+// only synchronisation is the wave's own `s_waitcnt vmcnt`.  Lane (pixel, channel half) forms, per INPUT row, the three partial sums
+// S_ky = sum over kx and its 16 channels (12 ds_read_b128 and 144 fused multiply-adds with the 144 weights it keeps in registers);
+// an output row is S_0(row - 1) + S_1(row) + S_2(row + 1), carried in two rolling registers, the two channel halves meet in one
+// cross-lane add.  Halo re-reads 34 / 32 x 10 / 8 = 1.33 as with the 8 x 32 tiles of rounds 1 - 3 (taller strips re-read less and were slower, below), LDS reads per output 13.5 instead of
+// 144 (the old kernel also read its weights from LDS per tap and summed in ONE dependent chain of 288 multiply + add pairs).
+// (strip height and ring depth timed on the device, tools/dev/head_ab.py, us for the 544 x 960 layer: 8 rows / ring 3: 17.4, 8 / 4: 17.8 - 18.2,
+// 12 / 4: 18.6, 16 / 4: 20.5, 4 / 4: 21.4, 8 / 6: 24.0, 32 / 4: 32.2 - two waves per SIMD matter more than the halo rows saved)
+constexpr int HS_W = 32, HS_R = 8, HS_RING = 3, HS_PITCH = 36, HS_REQ = 5, HS_ROWF = HS_REQ * 64 * 4;
+static_assert(HS_RING >= 2 && HS_RING <= 9 && (HS_W + 2) * 9 <= HS_REQ * 64, "a row's slots (34 pixels x 9 slots of 16 bytes) fit five requests");
+__global__ __launch_bounds__(64) void head_conv_kernel(usc_conv_desc d) {
+    __shared__ __attribute__((aligned(16))) float ring[HS_RING * HS_ROWF];
+    constexpr int INVALID = 0x7fff0000;
+    const int lane = threadIdx.x, px = lane & 31, half = lane >> 5;
+    const int x0 = blockIdx.x * HS_W, y0 = blockIdx.y * HS_R;
+    const int H = d.IH, W = d.IW;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.in), 0, H * W * 128, 0x00020000);
+    int goff[HS_REQ];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
-            const float4 ww = *reinterpret_cast<const float4*>(wt + 4 * q);
-            acc += v.x * ww.x;
-            acc += v.y * ww.y;
-            acc += v.z * ww.z;
-            acc += v.w * ww.w;
-        }
+    for (int r = 0; r < HS_REQ; r++) {
+        const int s = r * 64 + lane, pxs = s / 9, q = s - pxs * 9, gx = x0 - 1 + pxs;
+        goff[r] = (pxs < HS_W + 2 && q < 8 && gx >= 0 && gx < W) ? (gx * 32 + q * 4) * 4 : INVALID;
     }
-    if (gy < d.OH && gx < d.OW) {
-        acc += d.bias ? d.bias[0] : 0.f;
-        d.out[(size_t)gy * d.OW + gx] = (tanhf(acc) + 1.0f) / 2.0f;
+    auto request = [&](int rr) {                                       // input row y0 - 1 + rr -> ring slot rr & 3
+        const int y = y0 - 1 + rr;
+        const bool ok = y >= 0 && y < H;
+        const int so = ok ? y * W * 128 : 0;
+        float* const dst = ring + (rr % HS_RING) * HS_ROWF;
+#pragma unroll
+        for (int r = 0; r < HS_REQ; r++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, dst + r * 256, 16, ok ? goff[r] : INVALID, so, 0, 0);
+    };
+#pragma unroll
+    for (int rr = 0; rr < HS_RING - 1; rr++) request(rr);
+    // this lane's 9 x 16 weights (wpk is [tap][32 channels]; a tap's 16 channels of a half are 64 contiguous bytes)
+    float4 wr[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) wr[t][k] = *reinterpret_cast<const float4*>(d.wpk + t * 32 + half * 16 + 4 * k);
+    const float bias = d.bias ? d.bias[0] : 0.f;
+    float A = 0.f, B = 0.f;                                             // partial sums of output rows rr - 2 and rr - 1
+    constexpr int NROWS = HS_R + 2;
+#pragma unroll 1
+    for (int rr = 0; rr < NROWS; rr++) {
+        // (the ring slot row rr + 3 goes to was read in the pass before: its reads are complete before the request may write)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (rr + HS_RING - 1 < NROWS) request(rr + HS_RING - 1);
+        // requests are answered in order: row rr has landed when at most min(HS_RING - 1, NROWS - 1 - rr) rows' requests are outstanding
+        const int ahead = NROWS - 1 - rr;
+        if (ahead >= HS_RING - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((HS_RING - 1) * HS_REQ) : "memory");
+        else if (ahead >= 7) asm volatile("s_waitcnt vmcnt(35)" ::: "memory");      // (the tail of the strip: fewer rows outstanding)
+        else if (ahead == 6) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+        else if (ahead == 5) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+        else if (ahead == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else if (ahead == 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float* const rowp = ring + (rr % HS_RING) * HS_ROWF + half * 16;
+        float S[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};           // two chains per kernel row
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const float4*>(rowp + (px + dx) * HS_PITCH + 4 * k);
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float4 ww = wr[ky * 3 + dx][k];
+                    S[ky][k & 1] = fmaf(v[k].x, ww.x, S[ky][k & 1]);
+                    S[ky][k & 1] = fmaf(v[k].y, ww.y, S[ky][k & 1]);
+                    S[ky][k & 1] = fmaf(v[k].z, ww.z, S[ky][k & 1]);
+                    S[ky][k & 1] = fmaf(v[k].w, ww.w, S[ky][k & 1]);
+                }
+        }
+        const float done = A + (S[2][0] + S[2][1]);
+        A = B + (S[1][0] + S[1][1]);
+        B = S[0][0] + S[0][1];
+        if (rr >= 2) {                                                  // output row y0 + rr - 2 is complete: both channel halves, bias, activation
+            const float tot = done + __shfl_xor(done, 32, 64) + bias;
+            const int gy = y0 + rr - 2, gx = x0 + px;
+            if (half == 0 && gy < d.OH && gx < d.OW) d.out[(size_t)gy * d.OW + gx] = (tanhf(tot) + 1.0f) / 2.0f;
+        }
     }
 }
 
@@ -1402,7 +1447,8 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
             return conv_fail(USC_E_UNSUPPORTED, "usc_conv: the head kernel is Conv2d(32, 1, 3, padding=1)");
         if (d.in_relu) return conv_fail(USC_E_UNSUPPORTED, "usc_conv: in_relu is not offered by the head kernel");
         p.fn = (void*)head_conv_kernel;
-        p.grid = dim3((d.OW + HT_W - 1) / HT_W, (d.OH + HT_H - 1) / HT_H);
+        p.grid = dim3((d.OW + HS_W - 1) / HS_W, (d.OH + HS_R - 1) / HS_R);
+        p.block = dim3(64);                                    // one wave streams a 32-pixel x 8-row strip
         return USC_OK;
     }
     if (d.Cout % 32) return conv_fail(USC_E_UNSUPPORTED, "usc_conv: Cout must be a multiple of 32");
