@@ -2,16 +2,24 @@
 // called per colour channel from tools/unscreen/bg.py:79): inside the mask solve the discrete Laplace equation
 //     n(p) x(p) - sum_{q in N4(p), q in mask} x(q) = sum_{q in N4(p), q not in mask} I(q),     n(p) = number of in-image neighbours,
 // i.e. membrane interpolation of the surrounding pixels.  The reference assembles the sparse matrix and calls SuperLU
-// (scipy spsolve), seconds per 1080p channel.  Here the three channels are solved together in float64 by conjugate
-// gradients preconditioned with one geometric multigrid V-cycle per iteration - the matrix is the masked 5-point stencil and is
-// never stored:
+// (scipy spsolve), seconds per 1080p channel.  Here the three channels are solved together by conjugate gradients in float64,
+// preconditioned with one geometric multigrid V-cycle per iteration - the matrix is the masked 5-point stencil and is never stored:
 //   * levels: 2x2 cell aggregation (coarse cell in the mask iff any child is), piecewise-constant prolongation P, restriction
 //     P^T, coarse operator = the same masked stencil re-discretised on the coarse grid (the Galerkin operator P^T A P of an
 //     interior cell is twice that; with piecewise-constant P the unscaled stencil - an over-correction by 2 - is the better
 //     preconditioner: measured 24 iterations against 52 at 1080p), weighted-Jacobi smoothing (2 pre, 2 post, omega 0.8) -
-//     every piece symmetric, so the V-cycle is a valid CG preconditioner;
+//     every piece symmetric, so the V-cycle is a valid CG preconditioner.  (Round 4 tried, in a NumPy model of this solver,
+//     cell-centred bilinear P / P^T (28 -> 24 iterations on the bench's ragged 1080p hole), red-black Gauss-Seidel (-> 18 with two
+//     sweeps, at twice the launches per level) and Chebyshev weights for the two Jacobi sweeps (-> 25): the iteration count is set
+//     by the coarse correction on the ragged Dirichlet boundary, none of them changes it by the factor that would pay for its cost.)
 //   * ~25 iterations instead of the ~3000 plain CG needs on a 1080p silhouette (condition number ~ width^2);
 //   * dot products are reduced in a fixed order (per-block partial sums, re-summed by every consumer block): bit-reproducible.
+// Round 4: the V-cycle runs in FLOAT32 (a preconditioner only has to be a fixed symmetric linear operator; the CG vectors x, r, p, A p
+// and every dot product stay float64, so the iteration still converges to the same tolerance), and the fine levels run as TILED
+// kernels: a workgroup owns 32 x 32 cells, stages the 36 x 36 window it needs in LDS and does a whole half of the V-cycle for its
+// tile in one pass - "down": two sweeps from zero + residual + restriction, "up": coarse correction + two sweeps (+ the r.z partial
+// sums on level 0) - and the CG's direction update p = z + beta p and A p are one tiled pass too.  Four passes over level 0 per
+// iteration instead of seven, two launches per level instead of four, tiles without a masked cell are skipped by a flag.
 // The direct and the iterative solution agree to the tolerance (default: residual reduced by 1e-7, ~1e-3 grey levels), not bit
 // for bit; after the reference's astype(uint8) truncation that is +-1 level on the few pixels whose value sits next to an integer.
 #include <hip/hip_runtime.h>
@@ -26,11 +34,24 @@
 
 using namespace usc;
 
+#ifndef USC_RF_VT
+#define USC_RF_VT float
+#endif
+typedef USC_RF_VT VT;          // the V-cycle's scalar (float32; -DUSC_RF_VT=double for A/B runs of the iteration count)
+
 namespace {
 
-constexpr int kBlocks = 256, kThreads = 256;
+#ifndef USC_RF_BLOCKS
+#define USC_RF_BLOCKS 1024
+#endif
+constexpr int kBlocks = USC_RF_BLOCKS, kThreads = 256;    // (kBlocks: rows of every partial-sum array = workgroups of every reducing kernel: four per CU)
 constexpr int kMaxLevels = 12;
-constexpr double kOmega = 0.8;
+constexpr VT kOmega = (VT)0.8;             // the coarsest level's 17 sweeps
+// The two smoothing sweeps of a level use the weights of the degree-2 Chebyshev polynomial on [1/2, 2] (the high-frequency range of
+// D^-1 A for the 5-point stencil under 2 x 2 coarsening): damping 0.22 per pair instead of 0.36 for two sweeps with 0.8.  Pre-smoothing
+// applies (A, B), post-smoothing (B, A): the V-cycle stays symmetric.  NumPy model of this solver on the bench's hole: 28 -> 25 iterations.
+constexpr VT kOmegaA = (VT)1.3895, kOmegaB = (VT)0.5617;
+constexpr int TS = 32, WN = TS + 4, W1 = TS + 2;       // tile side; window with a 2-cell / 1-cell ring
 struct D3 { double v[3]; };
 
 __device__ __forceinline__ D3 block_sum(D3 a, double* s_part) {         // fixed-order reduction of 3 doubles over the block
@@ -61,6 +82,8 @@ __device__ __forceinline__ void store_partial(double* part, const D3& t) {
     if (threadIdx.x == 0) { part[3 * blockIdx.x] = t.v[0]; part[3 * blockIdx.x + 1] = t.v[1]; part[3 * blockIdx.x + 2] = t.v[2]; }
 }
 
+__device__ __forceinline__ int ncount(int y, int x, int H, int W) { return (y > 0) + (y < H - 1) + (x > 0) + (x < W - 1); }
+
 struct Nbr { int n; bool in[4]; uint32_t idx[4]; };
 __device__ __forceinline__ Nbr neighbours(int y, int x, int H, int W) {
     Nbr nb;
@@ -78,9 +101,10 @@ __device__ __forceinline__ Nbr neighbours(int y, int x, int H, int W) {
 
 // (A v)(i) / s for one masked pixel and channel block: n v_i - sum of in-mask neighbours.  All loads are issued
 // unconditionally (out-of-image neighbours alias cell 0) and de-selected afterwards, so they do not wait for the mask bytes.
-__device__ __forceinline__ void stencil3(const uint8_t* __restrict__ mask, const double* __restrict__ v, uint32_t i, const Nbr& nb, double* out3) {
+template <typename T>
+__device__ __forceinline__ void stencil3(const uint8_t* __restrict__ mask, const T* __restrict__ v, uint32_t i, const Nbr& nb, T* out3) {
     uint8_t mk[4];
-    double nv[4][3];
+    T nv[4][3];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         mk[k] = mask[nb.idx[k]];
@@ -89,9 +113,9 @@ __device__ __forceinline__ void stencil3(const uint8_t* __restrict__ mask, const
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        double a = (double)nb.n * v[3 * (size_t)i + c];
+        T a = (T)nb.n * v[3 * (size_t)i + c];
 #pragma unroll
-        for (int k = 0; k < 4; k++) a -= (nb.in[k] && mk[k]) ? nv[k][c] : 0.;
+        for (int k = 0; k < 4; k++) a -= (nb.in[k] && mk[k]) ? nv[k][c] : (T)0;
         out3[c] = a;
     }
 }
@@ -124,75 +148,91 @@ __global__ __launch_bounds__(kThreads) void rf_init_kernel(const uint8_t* __rest
     store_partial(part_rr, block_sum(acc, s_part));
 }
 
-// partial a.b over the mask
-__global__ __launch_bounds__(kThreads) void rf_dot_kernel(const uint8_t* __restrict__ mask, uint32_t n, const double* __restrict__ a,
-                                                          const double* __restrict__ b, double* __restrict__ part, const int* __restrict__ ctl) {
+// One tiled pass: p_new = z + beta p_old (beta = rz_new / rz_old; first: p_new = z) on the tile's 34 x 34 window in LDS, then
+// A p_new for the tile's own cells and the partial sums of p . A p.  p is double-buffered (a tile reads the ring of its neighbours'
+// old values).  kBlocks workgroups walk the tiles in a fixed order: the partial sums are the same on every run.
+__global__ __launch_bounds__(kThreads) void rf_pap_kernel(const uint8_t* __restrict__ mask, int H, int W, const VT* __restrict__ z,
+                                                          const double* __restrict__ p_old, double* __restrict__ p_new, double* __restrict__ Ap,
+                                                          const double* __restrict__ part_rz_old, const double* __restrict__ part_rz_new,
+                                                          const double* __restrict__ part_cross, int first, double* __restrict__ part_pap, const uint8_t* __restrict__ active, int tiles_x, int ntiles,
+                                                          const int* __restrict__ ctl) {
     if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
     __shared__ double s_part[12];
-    D3 acc = {{0., 0., 0.}};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (!mask[i]) continue;
-#pragma unroll
-        for (int c = 0; c < 3; c++) acc.v[c] += a[3 * (size_t)i + c] * b[3 * (size_t)i + c];
-    }
-    store_partial(part, block_sum(acc, s_part));
-}
-
-// p = z + beta p, beta = rz_new / rz_old (first: p = z)
-__global__ __launch_bounds__(kThreads) void rf_p_kernel(const uint8_t* __restrict__ mask, uint32_t n, const double* __restrict__ z,
-                                                        double* __restrict__ p, const double* __restrict__ part_rz_old,
-                                                        const double* __restrict__ part_rz_new, int first, const int* __restrict__ ctl) {
-    if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
-    __shared__ double s_part[12];
+    __shared__ double P[W1 * W1 * 3];
     double beta[3] = {0., 0., 0.};
     if (!first) {
-        const D3 ro = sum_partials(part_rz_old, s_part), rn = sum_partials(part_rz_new, s_part);
+        // beta = (r_k . z_k - r_k . z_{k-1}) / (r_{k-1} . z_{k-1}): the Polak-Ribiere form.  With an exactly symmetric linear preconditioner
+        // the cross term is zero; the float32 V-cycle is symmetric and linear only up to its rounding, and without the term the bench's
+        // ragged hole needed 56 iterations instead of the 46 of a float64 V-cycle.
+        const D3 ro = sum_partials(part_rz_old, s_part), rn = sum_partials(part_rz_new, s_part), cr = sum_partials(part_cross, s_part);
 #pragma unroll
-        for (int c = 0; c < 3; c++) beta[c] = ro.v[c] != 0. ? rn.v[c] / ro.v[c] : 0.;
+        for (int c = 0; c < 3; c++) beta[c] = ro.v[c] != 0. ? (rn.v[c] - cr.v[c]) / ro.v[c] : 0.;
     }
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (!mask[i]) continue;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const size_t j = 3 * (size_t)i + c;
-            p[j] = first ? z[j] : z[j] + beta[c] * p[j];
-        }
-    }
-}
-
-// Ap = A p ; partial p.Ap
-__global__ __launch_bounds__(kThreads) void rf_ap_kernel(const uint8_t* __restrict__ mask, int H, int W, const double* __restrict__ p,
-                                                         double* __restrict__ Ap, double* __restrict__ part_pap, const int* __restrict__ ctl) {
-    if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
-    __shared__ double s_part[12];
     D3 acc = {{0., 0., 0.}};
-    const uint32_t n = (uint32_t)H * (uint32_t)W;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (!mask[i]) continue;
-        const int y = (int)(i / (uint32_t)W), xq = (int)(i - (uint32_t)y * (uint32_t)W);
-        double a[3];
-        stencil3(mask, p, i, neighbours(y, xq, H, W), a);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (!active[tile]) continue;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int y0 = ty * TS - 1, x0 = tx * TS - 1;
+        __syncthreads();                                     // (the previous tile's reads of P are done)
+        {   // every load of the window is issued before the first is used (cell 0 stands in for cells outside the image)
+            constexpr int NW = (W1 * W1 + kThreads - 1) / kThreads;
+            uint32_t g[NW];
+            uint8_t mk[NW];
+            VT zv[NW][3];
+            double pv[NW][3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            Ap[3 * (size_t)i + c] = a[c];
-            acc.v[c] += p[3 * (size_t)i + c] * a[c];
+            for (int k = 0; k < NW; k++) {
+                const int i = threadIdx.x + k * kThreads, wy = i / W1, wx = i - wy * W1, y = y0 + wy, x = x0 + wx;
+                const bool in = i < W1 * W1 && y >= 0 && y < H && x >= 0 && x < W;
+                g[k] = in ? (uint32_t)y * (uint32_t)W + (uint32_t)x : 0u;
+                mk[k] = in ? mask[g[k]] : (uint8_t)0;
+            }
+#pragma unroll
+            for (int k = 0; k < NW; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) { zv[k][c] = z[3 * (size_t)g[k] + c]; pv[k][c] = first ? 0. : p_old[3 * (size_t)g[k] + c]; }
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const int i = threadIdx.x + k * kThreads;
+                if (i < W1 * W1) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) P[3 * i + c] = mk[k] ? (first ? (double)zv[k][c] : (double)zv[k][c] + beta[c] * pv[k][c]) : 0.;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < TS * TS; i += kThreads) {
+            const int cy = i / TS, cx = i - cy * TS, y = ty * TS + cy, x = tx * TS + cx;
+            if (y >= H || x >= W) continue;
+            const uint32_t g = (uint32_t)y * (uint32_t)W + (uint32_t)x;
+            if (!mask[g]) continue;
+            const int j = (cy + 1) * W1 + cx + 1;
+            const double nn = (double)ncount(y, x, H, W);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double pc = P[3 * j + c];
+                const double a = nn * pc - (P[3 * (j - W1) + c] + P[3 * (j + W1) + c] + P[3 * (j - 1) + c] + P[3 * (j + 1) + c]);
+                p_new[3 * (size_t)g + c] = pc;
+                Ap[3 * (size_t)g + c] = a;
+                acc.v[c] += pc * a;
+            }
         }
     }
     store_partial(part_pap, block_sum(acc, s_part));
 }
 
-// alpha = rz / pAp ; x += alpha p ; r -= alpha Ap ; partial r.r ; block 0 publishes r.r (and r0.r0) for the host
+// alpha = rz / pAp ; x += alpha p ; r -= alpha Ap ; partial r.r and r_new . z (z = the preconditioned residual of this iteration)
 __global__ __launch_bounds__(kThreads) void rf_xr_kernel(const uint8_t* __restrict__ mask, uint32_t n, const double* __restrict__ p,
                                                          const double* __restrict__ Ap, double* __restrict__ x, double* __restrict__ r,
-                                                         const double* __restrict__ part_rz, const double* __restrict__ part_pap,
-                                                         double* __restrict__ part_rr, const int* __restrict__ ctl) {
+                                                         const VT* __restrict__ z, const double* __restrict__ part_rz, const double* __restrict__ part_pap,
+                                                         double* __restrict__ part_rr, double* __restrict__ part_cross, const int* __restrict__ ctl) {
     if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
     __shared__ double s_part[12];
     const D3 rz = sum_partials(part_rz, s_part), pap = sum_partials(part_pap, s_part);
     double alpha[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) alpha[c] = pap.v[c] > 0. ? rz.v[c] / pap.v[c] : 0.;
-    D3 acc = {{0., 0., 0.}};
+    D3 acc = {{0., 0., 0.}}, acz = {{0., 0., 0.}};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (!mask[i]) continue;
 #pragma unroll
@@ -202,9 +242,11 @@ __global__ __launch_bounds__(kThreads) void rf_xr_kernel(const uint8_t* __restri
             const double rn = r[j] - alpha[c] * Ap[j];
             r[j] = rn;
             acc.v[c] += rn * rn;
+            acz.v[c] += rn * (double)z[j];
         }
     }
     store_partial(part_rr, block_sum(acc, s_part));
+    store_partial(part_cross, block_sum(acz, s_part));
 }
 
 // Sums r.r and decides on the device.  slot 0 (after rf_init): records r0.r0, resets the control block (done only if there is
@@ -248,7 +290,7 @@ __global__ __launch_bounds__(kThreads) void rf_out_kernel(const uint8_t* __restr
 
 // ---------------------------------------------------------------------------------------------------------------- multigrid
 namespace {
-struct Level { int H, W; double s; uint8_t* mask; double *z, *zt, *r; };
+struct Level { int H, W, tiles_x, ntiles; VT s; uint8_t *mask, *active; VT *z, *zt, *r; };
 struct LevelSet { int L, first_tail; Level lv[kMaxLevels]; };
 constexpr int kTailThreads = 1024;
 constexpr int kTailCells = 2500;           // levels with at most this many cells run inside the single-workgroup tail kernel (one CU: ~12 us per sweep of 8000 cells, measured)
@@ -269,17 +311,210 @@ __global__ __launch_bounds__(kThreads) void mg_mask_down_kernel(const uint8_t* _
     }
 }
 
+// active[tile] = 1 iff the tile's own 32 x 32 cells hold a masked cell (one workgroup per tile)
+__global__ __launch_bounds__(kThreads) void mg_active_kernel(const uint8_t* __restrict__ mask, int H, int W, uint8_t* __restrict__ active, int tiles_x) {
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    int any = 0;
+    for (int i = threadIdx.x; i < TS * TS; i += kThreads) {
+        const int y = ty * TS + i / TS, x = tx * TS + (i & (TS - 1));
+        if (y < H && x < W) any |= mask[(size_t)y * W + x] != 0;
+    }
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) active[blockIdx.x] = (uint8_t)(any != 0);
+}
+
+// "Down" half of the V-cycle for one level, tiled: z = two weighted-Jacobi sweeps from zero on r, then the restricted residual
+// r_c(I) = sum over the masked children i of I of (r - s A' z)(i).  The window of r (36 x 36, zero outside the mask) is staged once;
+// z1 = w r is pointwise, z2 needs z1 on a 1-cell ring, the residual z2 on a 1-cell ring: all from LDS.  RT = double on level 0 (the
+// CG residual), VT below.
+template <typename RT>
+__global__ __launch_bounds__(kThreads) void mg_down_kernel(const uint8_t* __restrict__ mask, int H, int W, VT s, const RT* __restrict__ r,
+                                                           VT* __restrict__ z, const uint8_t* __restrict__ mc, int Hc, int Wc,
+                                                           VT* __restrict__ rc, const uint8_t* __restrict__ active, int tiles_x, int ntiles,
+                                                           const int* __restrict__ ctl) {
+    if (ctl[0]) return;
+    __shared__ VT R[WN * WN * 3], Z1[WN * WN * 3], Z2[W1 * W1 * 3];
+    __shared__ uint8_t M[WN * WN];
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (!active[tile]) continue;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int y0 = ty * TS - 2, x0 = tx * TS - 2;
+        __syncthreads();
+        {   // every load of the window is issued before the first is used (cell 0 stands in for cells outside the image)
+            constexpr int NW = (WN * WN + kThreads - 1) / kThreads;
+            uint32_t g[NW];
+            uint8_t mk[NW];
+            int nc[NW];
+            RT rv[NW][3];
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const int i = threadIdx.x + k * kThreads, wy = i / WN, wx = i - wy * WN, y = y0 + wy, x = x0 + wx;
+                const bool in = i < WN * WN && y >= 0 && y < H && x >= 0 && x < W;
+                g[k] = in ? (uint32_t)y * (uint32_t)W + (uint32_t)x : 0u;
+                mk[k] = in ? mask[g[k]] : (uint8_t)0;
+                nc[k] = in ? ncount(y, x, H, W) : 4;
+            }
+#pragma unroll
+            for (int k = 0; k < NW; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) rv[k][c] = r[3 * (size_t)g[k] + c];
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const int i = threadIdx.x + k * kThreads;
+                if (i < WN * WN) {
+                    M[i] = (uint8_t)(mk[k] != 0);
+                    const VT w = kOmegaA / (s * (VT)nc[k]);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const VT v = mk[k] ? (VT)rv[k][c] : (VT)0;
+                        R[3 * i + c] = v;
+                        Z1[3 * i + c] = w * v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < W1 * W1; i += kThreads) {
+            const int wy = i / W1 + 1, wx = i % W1 + 1, j = wy * WN + wx, y = y0 + wy, x = x0 + wx;
+            VT o[3] = {(VT)0, (VT)0, (VT)0};
+            if (M[j]) {
+                const VT nn = (VT)ncount(y, x, H, W), w = kOmegaB / (s * nn);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const VT z1 = Z1[3 * j + c];
+                    const VT a = nn * z1 - (Z1[3 * (j - WN) + c] + Z1[3 * (j + WN) + c] + Z1[3 * (j - 1) + c] + Z1[3 * (j + 1) + c]);
+                    o[c] = z1 + w * (R[3 * j + c] - s * a);
+                }
+            }
+            Z2[3 * i] = o[0]; Z2[3 * i + 1] = o[1]; Z2[3 * i + 2] = o[2];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < TS * TS; i += kThreads) {
+            const int cy = i / TS, cx = i & (TS - 1), y = ty * TS + cy, x = tx * TS + cx;
+            if (y >= H || x >= W || !M[(cy + 2) * WN + cx + 2]) continue;
+            const size_t g = (size_t)y * W + x;
+            const int k = (cy + 1) * W1 + cx + 1;
+            z[3 * g] = Z2[3 * k]; z[3 * g + 1] = Z2[3 * k + 1]; z[3 * g + 2] = Z2[3 * k + 2];
+        }
+        {   // one coarse cell per thread: the tile's 16 x 16 parents
+            const int cy = threadIdx.x >> 4, cx = threadIdx.x & 15, Y = ty * (TS / 2) + cy, X = tx * (TS / 2) + cx;
+            if (Y < Hc && X < Wc && mc[(size_t)Y * Wc + X]) {
+                VT acc[3] = {(VT)0, (VT)0, (VT)0};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int fy = 2 * cy + (q >> 1), fx = 2 * cx + (q & 1);          // child, tile coordinates
+                    const int j = (fy + 2) * WN + fx + 2, k = (fy + 1) * W1 + fx + 1;
+                    if (!M[j]) continue;                                             // (outside the image or the mask)
+                    const VT nn = (VT)ncount(ty * TS + fy, tx * TS + fx, H, W);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const VT a = nn * Z2[3 * k + c] - (Z2[3 * (k - W1) + c] + Z2[3 * (k + W1) + c] + Z2[3 * (k - 1) + c] + Z2[3 * (k + 1) + c]);
+                        acc[c] += R[3 * j + c] - s * a;
+                    }
+                }
+                const size_t G = (size_t)Y * Wc + X;
+                rc[3 * G] = acc[0]; rc[3 * G + 1] = acc[1]; rc[3 * G + 2] = acc[2];
+            }
+        }
+    }
+}
+
+// "Up" half for one level, tiled: z' = z + z_c(parent), then two weighted-Jacobi sweeps; writes zout (another array: a tile reads
+// the ring of its neighbours' z).  DOT (level 0): also the partial sums of r . zout in float64 - kBlocks workgroups walk the tiles in
+// a fixed order.
+template <typename RT, bool DOT>
+__global__ __launch_bounds__(kThreads) void mg_up_kernel(const uint8_t* __restrict__ mask, int H, int W, VT s, const VT* __restrict__ z,
+                                                         const VT* __restrict__ zc, int Wc, const RT* __restrict__ r, VT* __restrict__ zout,
+                                                         double* __restrict__ part, const uint8_t* __restrict__ active, int tiles_x, int ntiles,
+                                                         const int* __restrict__ ctl) {
+    if (ctl[0]) return;
+    __shared__ double s_part[12];
+    __shared__ VT Zp[WN * WN * 3], R[WN * WN * 3], Zt[W1 * W1 * 3];
+    __shared__ uint8_t M[WN * WN];
+    D3 acc = {{0., 0., 0.}};
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (!active[tile]) continue;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int y0 = ty * TS - 2, x0 = tx * TS - 2;
+        __syncthreads();
+        {   // every load of the window is issued before the first is used (cell 0 stands in for cells outside the image)
+            constexpr int NW = (WN * WN + kThreads - 1) / kThreads;
+            uint32_t g[NW], G[NW];
+            uint8_t mk[NW];
+            VT zv[NW][3], cv[NW][3];
+            RT rv[NW][3];
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const int i = threadIdx.x + k * kThreads, wy = i / WN, wx = i - wy * WN, y = y0 + wy, x = x0 + wx;
+                const bool in = i < WN * WN && y >= 0 && y < H && x >= 0 && x < W;
+                g[k] = in ? (uint32_t)y * (uint32_t)W + (uint32_t)x : 0u;
+                G[k] = in ? (uint32_t)(y >> 1) * (uint32_t)Wc + (uint32_t)(x >> 1) : 0u;
+                mk[k] = in ? mask[g[k]] : (uint8_t)0;
+            }
+#pragma unroll
+            for (int k = 0; k < NW; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) { zv[k][c] = z[3 * (size_t)g[k] + c]; cv[k][c] = zc[3 * (size_t)G[k] + c]; rv[k][c] = r[3 * (size_t)g[k] + c]; }
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const int i = threadIdx.x + k * kThreads;
+                if (i < WN * WN) {
+                    M[i] = (uint8_t)(mk[k] != 0);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        Zp[3 * i + c] = mk[k] ? zv[k][c] + cv[k][c] : (VT)0;
+                        R[3 * i + c] = mk[k] ? (VT)rv[k][c] : (VT)0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < W1 * W1; i += kThreads) {
+            const int wy = i / W1 + 1, wx = i % W1 + 1, j = wy * WN + wx, y = y0 + wy, x = x0 + wx;
+            VT o[3] = {(VT)0, (VT)0, (VT)0};
+            if (M[j]) {
+                const VT nn = (VT)ncount(y, x, H, W), w = kOmegaB / (s * nn);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const VT zi = Zp[3 * j + c];
+                    const VT a = nn * zi - (Zp[3 * (j - WN) + c] + Zp[3 * (j + WN) + c] + Zp[3 * (j - 1) + c] + Zp[3 * (j + 1) + c]);
+                    o[c] = zi + w * (R[3 * j + c] - s * a);
+                }
+            }
+            Zt[3 * i] = o[0]; Zt[3 * i + 1] = o[1]; Zt[3 * i + 2] = o[2];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < TS * TS; i += kThreads) {
+            const int cy = i / TS, cx = i & (TS - 1), y = ty * TS + cy, x = tx * TS + cx;
+            const int j = (cy + 2) * WN + cx + 2, k = (cy + 1) * W1 + cx + 1;
+            if (y >= H || x >= W || !M[j]) continue;
+            const VT nn = (VT)ncount(y, x, H, W), w = kOmegaA / (s * nn);
+            const size_t g = (size_t)y * W + x;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const VT zi = Zt[3 * k + c];
+                const VT a = nn * zi - (Zt[3 * (k - W1) + c] + Zt[3 * (k + W1) + c] + Zt[3 * (k - 1) + c] + Zt[3 * (k + 1) + c]);
+                const VT zn = zi + w * (R[3 * j + c] - s * a);
+                zout[3 * g + c] = zn;
+                if (DOT) acc.v[c] += (double)r[3 * g + c] * (double)zn;
+            }
+        }
+    }
+    if (DOT) store_partial(part, block_sum(acc, s_part));
+}
+
+// ---- cell-wise forms of the same sweeps (the single-workgroup tail of the coarse levels)
 // z_out = z_in + omega / (s n) (r - s A' z_in)   (z_in == nullptr: z_in = 0).  A' is the unscaled masked stencil.
-__device__ __forceinline__ void mg_jacobi_cells(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ zin,
-                                                const double* __restrict__ r, double* __restrict__ zout, uint32_t start, uint32_t stride) {
+__device__ __forceinline__ void mg_jacobi_cells(const uint8_t* __restrict__ mask, int H, int W, VT s, const VT* __restrict__ zin,
+                                                const VT* __restrict__ r, VT* __restrict__ zout, uint32_t start, uint32_t stride, VT omega = kOmega) {
     const uint32_t n = (uint32_t)H * (uint32_t)W;
     for (uint32_t i = start; i < n; i += stride) {
         if (!mask[i]) continue;
         const int y = (int)(i / (uint32_t)W), x = (int)(i - (uint32_t)y * (uint32_t)W);
         const Nbr nb = neighbours(y, x, H, W);
-        const double w = kOmega / (s * (double)nb.n);
+        const VT w = omega / (s * (VT)nb.n);
         if (zin) {
-            double a[3];
+            VT a[3];
             stencil3(mask, zin, i, nb, a);
 #pragma unroll
             for (int c = 0; c < 3; c++) zout[3 * (size_t)i + c] = zin[3 * (size_t)i + c] + w * (r[3 * (size_t)i + c] - s * a[c]);
@@ -290,137 +525,35 @@ __device__ __forceinline__ void mg_jacobi_cells(const uint8_t* __restrict__ mask
     }
 }
 
-__global__ __launch_bounds__(kThreads) void mg_jacobi_kernel(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ zin,
-                                                             const double* __restrict__ r, double* __restrict__ zout, const int* __restrict__ ctl) {
-    if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
-    mg_jacobi_cells(mask, H, W, s, zin, r, zout, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
-}
-
-// The last sweep of a V-cycle on level 0 and the dot product r . z that follows it in the CG iteration, in one pass: launched with
-// kBlocks workgroups, every workgroup sums the cells rf_dot_kernel would have given it, in the same order (same partial sums,
-// bit for bit), one launch and one pass over r and z less per iteration.
-__global__ __launch_bounds__(kThreads) void mg_jacobi_dot_kernel(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ zin,
-                                                                 const double* __restrict__ r, double* __restrict__ zout, double* __restrict__ part,
-                                                                 const int* __restrict__ ctl) {
-    if (ctl[0]) return;
-    __shared__ double s_part[12];
-    D3 acc = {{0., 0., 0.}};
-    const uint32_t n = (uint32_t)H * (uint32_t)W;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (!mask[i]) continue;
-        const int y = (int)(i / (uint32_t)W), x = (int)(i - (uint32_t)y * (uint32_t)W);
-        const Nbr nb = neighbours(y, x, H, W);
-        const double w = kOmega / (s * (double)nb.n);
-        double a[3];
-        stencil3(mask, zin, i, nb, a);
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const double rc = r[3 * (size_t)i + c];
-            const double z = zin[3 * (size_t)i + c] + w * (rc - s * a[c]);
-            zout[3 * (size_t)i + c] = z;
-            acc.v[c] += rc * z;
-        }
-    }
-    store_partial(part, block_sum(acc, s_part));
-}
-
-// Two sweeps from zero in one pass: z1 = omega / (s n) r is pointwise, so the second sweep evaluates it on the fly for the
-// cell and its neighbours - the same operations in the same order as two mg_jacobi_cells calls, one launch less per level.
-__device__ __forceinline__ void mg_jacobi2_cells(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ r,
-                                                 double* __restrict__ zout, uint32_t start, uint32_t stride) {
+// z += z_c(parent) on the masked cells (in place: pointwise)
+__device__ __forceinline__ void mg_prolong_cells(const uint8_t* __restrict__ mask, int H, int W, VT* __restrict__ z, const VT* __restrict__ zc, int Wc,
+                                                 uint32_t start, uint32_t stride) {
     const uint32_t n = (uint32_t)H * (uint32_t)W;
     for (uint32_t i = start; i < n; i += stride) {
         if (!mask[i]) continue;
         const int y = (int)(i / (uint32_t)W), x = (int)(i - (uint32_t)y * (uint32_t)W);
-        const Nbr nb = neighbours(y, x, H, W);
-        const double w = kOmega / (s * (double)nb.n);
-        uint8_t mk[4];
-        double z1n[4][3];
-        const int dy[4] = {-1, 1, 0, 0}, dx[4] = {0, 0, -1, 1};
+        const size_t I = (size_t)(y >> 1) * Wc + (x >> 1);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            mk[k] = mask[nb.idx[k]];
-            // the neighbour's own in-image neighbour count
-            const int yy = y + dy[k], xx = x + dx[k];
-            const int nn = (yy > 0) + (yy < H - 1) + (xx > 0) + (xx < W - 1);
-            const double wn = kOmega / (s * (double)nn);
-#pragma unroll
-            for (int c = 0; c < 3; c++) z1n[k][c] = wn * r[3 * (size_t)nb.idx[k] + c];
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const double z1 = w * r[3 * (size_t)i + c];
-            double a = (double)nb.n * z1;
-#pragma unroll
-            for (int k = 0; k < 4; k++) a -= (nb.in[k] && mk[k]) ? z1n[k][c] : 0.;
-            zout[3 * (size_t)i + c] = z1 + w * (r[3 * (size_t)i + c] - s * a);
-        }
+        for (int c = 0; c < 3; c++) z[3 * (size_t)i + c] += zc[3 * I + c];
     }
-}
-
-__global__ __launch_bounds__(kThreads) void mg_jacobi2_kernel(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ r,
-                                                              double* __restrict__ zout, const int* __restrict__ ctl) {
-    if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
-    mg_jacobi2_cells(mask, H, W, s, r, zout, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
-}
-
-// Coarse correction + one sweep in one pass: z' = z + z_c(parent) is pointwise, evaluated on the fly for the cell and its
-// neighbours (same operations, same order as adding the correction in place and then sweeping).  Reads z and z_c, writes zout.
-__device__ __forceinline__ void mg_prolong_jacobi_cells(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ z,
-                                                        const double* __restrict__ zc, int Wc, const double* __restrict__ r,
-                                                        double* __restrict__ zout, uint32_t start, uint32_t stride) {
-    const uint32_t n = (uint32_t)H * (uint32_t)W;
-    for (uint32_t i = start; i < n; i += stride) {
-        if (!mask[i]) continue;
-        const int y = (int)(i / (uint32_t)W), x = (int)(i - (uint32_t)y * (uint32_t)W);
-        const Nbr nb = neighbours(y, x, H, W);
-        const double w = kOmega / (s * (double)nb.n);
-        const int dy[4] = {-1, 1, 0, 0}, dx[4] = {0, 0, -1, 1};
-        uint8_t mk[4];
-        double zn[4][3];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            mk[k] = mask[nb.idx[k]];
-            const int yy = nb.in[k] ? y + dy[k] : 0, xx = nb.in[k] ? x + dx[k] : 0;
-            const size_t I = (size_t)(yy >> 1) * Wc + (xx >> 1);
-#pragma unroll
-            for (int c = 0; c < 3; c++) zn[k][c] = z[3 * (size_t)nb.idx[k] + c] + zc[3 * I + c];
-        }
-        const size_t I0 = (size_t)(y >> 1) * Wc + (x >> 1);
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const double zi = z[3 * (size_t)i + c] + zc[3 * I0 + c];
-            double a = (double)nb.n * zi;
-#pragma unroll
-            for (int k = 0; k < 4; k++) a -= (nb.in[k] && mk[k]) ? zn[k][c] : 0.;
-            zout[3 * (size_t)i + c] = zi + w * (r[3 * (size_t)i + c] - s * a);
-        }
-    }
-}
-
-__global__ __launch_bounds__(kThreads) void mg_prolong_jacobi_kernel(const uint8_t* __restrict__ mask, int H, int W, double s, const double* __restrict__ z,
-                                                                     const double* __restrict__ zc, int Wc, const double* __restrict__ r,
-                                                                     double* __restrict__ zout, const int* __restrict__ ctl) {
-    if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
-    mg_prolong_jacobi_cells(mask, H, W, s, z, zc, Wc, r, zout, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // r_c(I) = sum over the children i of I inside the fine mask of (r_f - s_f A' z_f)(i)
-__device__ __forceinline__ void mg_restrict_cells(const uint8_t* __restrict__ mf, int Hf, int Wf, double sf, const double* __restrict__ zf,
-                                                  const double* __restrict__ rf, const uint8_t* __restrict__ mc, int Hc, int Wc,
-                                                  double* __restrict__ rc, uint32_t start, uint32_t stride) {
+__device__ __forceinline__ void mg_restrict_cells(const uint8_t* __restrict__ mf, int Hf, int Wf, VT sf, const VT* __restrict__ zf,
+                                                  const VT* __restrict__ rf, const uint8_t* __restrict__ mc, int Hc, int Wc,
+                                                  VT* __restrict__ rc, uint32_t start, uint32_t stride) {
     const uint32_t n = (uint32_t)Hc * (uint32_t)Wc;
     for (uint32_t I = start; I < n; I += stride) {
         if (!mc[I]) continue;
         const int Y = (int)(I / (uint32_t)Wc), X = (int)(I - (uint32_t)Y * (uint32_t)Wc);
-        double acc[3] = {0., 0., 0.};
+        VT acc[3] = {(VT)0, (VT)0, (VT)0};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int y = 2 * Y + (k >> 1), x = 2 * X + (k & 1);
             if (y >= Hf || x >= Wf) continue;
             const uint32_t i = (uint32_t)y * (uint32_t)Wf + (uint32_t)x;
             if (!mf[i]) continue;
-            double a[3];
+            VT a[3];
             stencil3(mf, zf, i, neighbours(y, x, Hf, Wf), a);
 #pragma unroll
             for (int c = 0; c < 3; c++) acc[c] += rf[3 * (size_t)i + c] - sf * a[c];
@@ -430,32 +563,44 @@ __device__ __forceinline__ void mg_restrict_cells(const uint8_t* __restrict__ mf
     }
 }
 
-__global__ __launch_bounds__(kThreads) void mg_restrict_kernel(const uint8_t* __restrict__ mf, int Hf, int Wf, double sf, const double* __restrict__ zf,
-                                                               const double* __restrict__ rf, const uint8_t* __restrict__ mc, int Hc, int Wc,
-                                                               double* __restrict__ rc, const int* __restrict__ ctl) {
-    if (ctl[0]) return;                                      // converged: the rest of the enqueued iterations are no-ops
-    mg_restrict_cells(mf, Hf, Wf, sf, zf, rf, mc, Hc, Wc, rc, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+// level 0 of an image so small that it is the tail's first level: the tail works on float32, the CG residual is float64
+__global__ __launch_bounds__(kThreads) void rf_cast_kernel(const double* __restrict__ r, VT* __restrict__ out, size_t n, const int* __restrict__ ctl) {
+    if (ctl[0]) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (VT)r[i];
+}
+// ... and its r . z afterwards (the tiled "up" pass of level 0 computes it on larger images)
+__global__ __launch_bounds__(kThreads) void rf_dot_kernel(const uint8_t* __restrict__ mask, uint32_t n, const double* __restrict__ a,
+                                                          const VT* __restrict__ b, double* __restrict__ part, const int* __restrict__ ctl) {
+    if (ctl[0]) return;
+    __shared__ double s_part[12];
+    D3 acc = {{0., 0., 0.}};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (!mask[i]) continue;
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc.v[c] += a[3 * (size_t)i + c] * (double)b[3 * (size_t)i + c];
+    }
+    store_partial(part, block_sum(acc, s_part));
 }
 
-// The coarse end of the V-cycle (levels first_tail .. L-1, a few thousand cells at most) inside ONE workgroup: the same
-// sweeps in the same order as the per-level kernels, separated by workgroup barriers instead of kernel boundaries
-// (every cell's arithmetic is identical, so the result does not depend on which path ran).
-// The vectors (z, zt, r) of the coarsest levels live in LDS for the duration of the kernel: the tail is a chain of ~33 tiny
-// phases separated by barriers, and a phase on global memory costs a round trip to the L2 (~2.5 us) however few cells it has.
-constexpr int kTailLdsDoubles = 6144;      // 48 KB: at 1080p the levels 17 x 30, 9 x 15 and 5 x 8 (25 of the 33 phases)
+// The coarse end of the V-cycle (levels first_tail .. L-1, a few thousand cells at most) inside ONE workgroup: sweeps separated by
+// workgroup barriers instead of kernel boundaries.  The vectors (z, zt, r) of the coarsest levels live in LDS for the duration of
+// the kernel: the tail is a chain of ~40 tiny phases separated by barriers, and a phase on global memory costs a round trip to the
+// L2 (~2.5 us) however few cells it has.  The first tail level receives its r from the "down" pass of the level above and hands its
+// z to that level's "up" pass.
+constexpr int kTailLdsFloats = 28672;      // 112 KB: at 1080p all four tail levels (34 x 60, 17 x 30, 9 x 15, 5 x 8: 24.5 k values of VT)
 __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls, const int* __restrict__ ctl) {
     if (ctl[0]) return;
-    __shared__ double s_buf[kTailLdsDoubles];
-    __shared__ int s_off[kMaxLevels];                      // first double of a level's three vectors in s_buf, -1: the level stays in global memory
+    __shared__ VT s_buf[kTailLdsFloats];
+    __shared__ int s_off[kMaxLevels];                      // first VT of a level's three vectors in s_buf, -1: the level stays in global memory
     const uint32_t t = threadIdx.x, nt = blockDim.x;
     if (t == 0) {
         int used = 0;
         bool open = true;
         for (int l = kMaxLevels - 1; l >= 0; l--) {
             s_off[l] = -1;
-            if (l >= ls.L || l <= ls.first_tail || !open) continue;      // (the first tail level receives its r from a kernel before this one)
+            if (l >= ls.L || l < ls.first_tail || !open) continue;
             const int need = 3 * 3 * ls.lv[l].H * ls.lv[l].W;
-            if (used + need > kTailLdsDoubles) { open = false; continue; }
+            if (used + need > kTailLdsFloats) { open = false; continue; }
             s_off[l] = used;
             used += need;
         }
@@ -470,6 +615,14 @@ __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls, cons
         }
         return v;
     };
+    // the first tail level receives its r from the pass before this kernel and hands its z to the pass after it: copied in and out when
+    // the level lives in LDS
+    if (s_off[ls.first_tail] >= 0) {
+        const Level g = ls.lv[ls.first_tail], v = level(ls.first_tail);
+        for (uint32_t i = t; i < (uint32_t)(g.H * g.W); i += nt)
+            if (g.mask[i]) { v.r[3 * i] = g.r[3 * i]; v.r[3 * i + 1] = g.r[3 * i + 1]; v.r[3 * i + 2] = g.r[3 * i + 2]; }
+        __syncthreads();
+    }
     for (int l = ls.first_tail; l < ls.L; l++) {
         const Level v = level(l);
         if (l == ls.L - 1) {
@@ -482,7 +635,9 @@ __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls, cons
                 __syncthreads();
             }
         } else {
-            mg_jacobi2_cells(v.mask, v.H, v.W, v.s, v.r, v.z, t, nt);
+            mg_jacobi_cells(v.mask, v.H, v.W, v.s, nullptr, v.r, v.zt, t, nt, kOmegaA);
+            __syncthreads();
+            mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, t, nt, kOmegaB);
             __syncthreads();
             const Level c = level(l + 1);
             mg_restrict_cells(v.mask, v.H, v.W, v.s, v.z, v.r, c.mask, c.H, c.W, c.r, t, nt);
@@ -491,10 +646,17 @@ __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls, cons
     }
     for (int l = ls.L - 2; l >= ls.first_tail; l--) {
         const Level v = level(l), c = level(l + 1);
-        mg_prolong_jacobi_cells(v.mask, v.H, v.W, v.s, v.z, c.z, c.W, v.r, v.zt, t, nt);
+        mg_prolong_cells(v.mask, v.H, v.W, v.z, c.z, c.W, t, nt);
         __syncthreads();
-        mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, t, nt);
+        mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.z, v.r, v.zt, t, nt, kOmegaB);
         __syncthreads();
+        mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, t, nt, kOmegaA);
+        __syncthreads();
+    }
+    if (s_off[ls.first_tail] >= 0) {
+        const Level g = ls.lv[ls.first_tail], v = level(ls.first_tail);
+        for (uint32_t i = t; i < (uint32_t)(g.H * g.W); i += nt)
+            if (g.mask[i]) { g.z[3 * i] = v.z[3 * i]; g.z[3 * i + 1] = v.z[3 * i + 1]; g.z[3 * i + 2] = v.z[3 * i + 2]; }
     }
 }
 
@@ -513,7 +675,7 @@ int level_dims(int H, int W, int* hs, int* ws) {
     return L + 1;
 }
 
-int grid_of(size_t n) {                 // element-wise multigrid kernels: one cell per thread up to 8192 workgroups
+int grid_of(size_t n) {                 // element-wise kernels: one cell per thread up to 8192 workgroups
     size_t b = (n + kThreads - 1) / kThreads;
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
@@ -532,7 +694,7 @@ struct Solver {
     int H, W, L, first_tail;
     uint32_t n;
     Level lv[kMaxLevels];
-    double *scal, *part_rr, *part_pap, *part_rz[2], *x, *p, *Ap;
+    double *scal, *part_rr, *part_pap, *part_rz[2], *part_cross, *x, *p[2], *Ap, *r;
     int* ctl;                                       // {done, iterations run, converged}: the device-side convergence state
     uint8_t* mask0;
 
@@ -547,73 +709,73 @@ struct Solver {
         part_pap = reinterpret_cast<double*>(take(psz));
         part_rz[0] = reinterpret_cast<double*>(take(psz));
         part_rz[1] = reinterpret_cast<double*>(take(psz));
+        part_cross = reinterpret_cast<double*>(take(psz));
         const size_t v0 = (size_t)H * W * 3 * sizeof(double);
         x = reinterpret_cast<double*>(take(v0));
-        p = reinterpret_cast<double*>(take(v0));
+        p[0] = reinterpret_cast<double*>(take(v0));
+        p[1] = reinterpret_cast<double*>(take(v0));
         Ap = reinterpret_cast<double*>(take(v0));
+        r = reinterpret_cast<double*>(take(v0));
         int hs[kMaxLevels], wsz[kMaxLevels];
         L = level_dims(H, W, hs, wsz);
-        const double lvl_scale = 1.;                                   // coarse operator = the unscaled re-discretised stencil (see the header)
         for (int l = 0; l < L; l++) {
-            const size_t vb = (size_t)hs[l] * wsz[l] * 3 * sizeof(double);
+            const size_t vb = (size_t)hs[l] * wsz[l] * 3 * sizeof(VT);
             lv[l].H = hs[l]; lv[l].W = wsz[l];
-            lv[l].s = l == 0 ? 1. : lvl_scale * lv[l - 1].s;
-            lv[l].z = reinterpret_cast<double*>(take(vb));
-            lv[l].zt = reinterpret_cast<double*>(take(vb));
-            lv[l].r = reinterpret_cast<double*>(take(vb));
+            lv[l].tiles_x = (wsz[l] + TS - 1) / TS;
+            lv[l].ntiles = lv[l].tiles_x * ((hs[l] + TS - 1) / TS);
+            lv[l].s = (VT)1;                                             // coarse operator = the unscaled re-discretised stencil (see the header)
+            lv[l].z = reinterpret_cast<VT*>(take(vb));
+            lv[l].zt = reinterpret_cast<VT*>(take(vb));
+            lv[l].r = reinterpret_cast<VT*>(take(vb));              // (level 0: only used when level 0 is the tail's first level)
             lv[l].mask = take((size_t)hs[l] * wsz[l]);                 // level 0: a private copy of the caller's mask
+            lv[l].active = take((size_t)lv[l].ntiles);
         }
         mask0 = lv[0].mask;
         first_tail = L - 1;
         while (first_tail > 1 && (size_t)lv[first_tail - 1].H * lv[first_tail - 1].W <= (size_t)kTailCells) first_tail--;
     }
 
-    // z_l = V-cycle(r_l): 2 pre-smoothing sweeps from zero, coarse correction, 2 post-smoothing sweeps; 17 sweeps on the last level
-    void vcycle(Launcher& q, double* part_rz_new) const {
+    static dim3 tile_grid(const Level& v) { return dim3((unsigned)(v.ntiles < 2048 ? v.ntiles : 2048)); }
+
+    // z = V-cycle(r): the result is lv[0].zt (lv[0].z when level 0 is the tail's first level), the partial sums of r . z in part_rz_new
+    const VT* vcycle(Launcher& q, double* part_rz_new) const {
         const dim3 b(kThreads);
-        const int last = first_tail < L ? first_tail : L;          // levels [0, last) run as per-level kernels
-        for (int l = 0; l < last; l++) {
-            const Level& v = lv[l];
-            const dim3 g(grid_of((size_t)v.H * v.W));
-            if (l == L - 1) {
-                q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, (const double*)nullptr, v.r, v.z, ctl);
-                for (int k = 0; k < 8; k++) {
-                    q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.z, v.r, v.zt, ctl);
-                    q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, ctl);
-                }
-            } else {
-                q.launch(mg_jacobi2_kernel, g, b, v.mask, v.H, v.W, v.s, v.r, v.z, ctl);             // two sweeps from zero
-                const Level& c = lv[l + 1];
-                q.launch(mg_restrict_kernel, dim3(grid_of((size_t)c.H * c.W)), b, v.mask, v.H, v.W, v.s, v.z, v.r, c.mask, c.H, c.W, c.r, ctl);
-            }
+        if (first_tail == 0) {                                         // an image of at most 8 x 8 cells: everything inside the tail kernel
+            q.launch(rf_cast_kernel, dim3(grid_of((size_t)n * 3)), b, r, lv[0].r, (size_t)n * 3, ctl);
         }
-        if (first_tail < L) {
-            LevelSet ls;
-            ls.L = L; ls.first_tail = first_tail;
-            for (int l = 0; l < kMaxLevels; l++) ls.lv[l] = lv[l < L ? l : L - 1];
-            q.launch(mg_tail_kernel, dim3(1), dim3(kTailThreads), ls, ctl);
+        for (int l = 0; l < first_tail; l++) {
+            const Level &v = lv[l], &c = lv[l + 1];
+            if (l == 0) q.launch(mg_down_kernel<double>, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const double*)r, v.z, c.mask, c.H, c.W, c.r, v.active, v.tiles_x, v.ntiles, ctl);
+            else q.launch(mg_down_kernel<VT>, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const VT*)v.r, v.z, c.mask, c.H, c.W, c.r, v.active, v.tiles_x, v.ntiles, ctl);
         }
-        for (int l = last - 1; l >= 0; l--) {
-            if (l == L - 1) continue;
-            const Level& v = lv[l];
-            const dim3 g(grid_of((size_t)v.H * v.W));
-            q.launch(mg_prolong_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.z, lv[l + 1].z, lv[l + 1].W, v.r, v.zt, ctl);   // correction + sweep
-            if (l == 0 && part_rz_new) q.launch(mg_jacobi_dot_kernel, dim3(kBlocks), b, v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, part_rz_new, ctl);   // + r.z
-            else q.launch(mg_jacobi_kernel, g, b, v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, ctl);
+        LevelSet ls;
+        ls.L = L; ls.first_tail = first_tail;
+        for (int l = 0; l < kMaxLevels; l++) ls.lv[l] = lv[l < L ? l : L - 1];
+        q.launch(mg_tail_kernel, dim3(1), dim3(kTailThreads), ls, ctl);
+        for (int l = first_tail - 1; l >= 0; l--) {
+            const Level &v = lv[l], &c = lv[l + 1];
+            const VT* zc = l + 1 == first_tail ? c.z : c.zt;
+            if (l == 0) q.launch(mg_up_kernel<double, true>, dim3(kBlocks), b, v.mask, v.H, v.W, v.s, (const VT*)v.z, zc, c.W, (const double*)r, v.zt, part_rz_new, v.active, v.tiles_x, v.ntiles, ctl);
+            else q.launch(mg_up_kernel<VT, false>, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const VT*)v.z, zc, c.W, (const VT*)v.r, v.zt, (double*)nullptr, v.active, v.tiles_x, v.ntiles, ctl);
         }
+        if (first_tail == 0) {
+            q.launch(rf_dot_kernel, dim3(kBlocks), b, mask0, n, (const double*)r, (const VT*)lv[0].z, part_rz_new, ctl);
+            return lv[0].z;
+        }
+        return lv[0].zt;
     }
 
-    // one preconditioned CG iteration; cur selects which of the two r.z partial arrays holds the previous value
-    void iteration(Launcher& q, int first, int& cur) const {
+    // one preconditioned CG iteration; cur selects which of the two r.z partial arrays holds the previous value, pc which p is current
+    void iteration(Launcher& q, int first, int& cur, int& pc) const {
         const dim3 b(kThreads), g(kBlocks);           // reductions always use kBlocks blocks: the partial arrays have that many rows
-        double* r = lv[0].r;
-        const bool fused = first_tail >= 1 && L >= 2;                                                // level 0 ends with a per-level sweep
-        vcycle(q, fused ? part_rz[cur ^ 1] : nullptr);                                               // z = M^-1 r (+ the partial sums of r.z)
-        if (!fused) q.launch(rf_dot_kernel, g, b, mask0, n, r, lv[0].z, part_rz[cur ^ 1], ctl);           // r.z (new)
-        q.launch(rf_p_kernel, g, b, mask0, n, lv[0].z, p, part_rz[cur], part_rz[cur ^ 1], first, ctl);
+        const VT* z = vcycle(q, part_rz[cur ^ 1]);                                                 // z = M^-1 r and the partial sums of r.z
+        const Level& v = lv[0];
+        q.launch(rf_pap_kernel, g, b, mask0, H, W, z, (const double*)p[pc], p[pc ^ 1], Ap, (const double*)part_rz[cur], (const double*)part_rz[cur ^ 1],
+                 (const double*)part_cross, first, part_pap, v.active, v.tiles_x, v.ntiles, ctl);
         cur ^= 1;
-        q.launch(rf_ap_kernel, g, b, mask0, H, W, p, Ap, part_pap, ctl);
-        q.launch(rf_xr_kernel, g, b, mask0, n, p, Ap, x, r, part_rz[cur], part_pap, part_rr, ctl);
+        pc ^= 1;
+        q.launch(rf_xr_kernel, g, b, mask0, n, (const double*)p[pc], (const double*)Ap, x, r, z, (const double*)part_rz[cur], (const double*)part_pap, part_rr,
+                 part_cross, ctl);
     }
 };
 
@@ -624,10 +786,12 @@ constexpr int kItersPerCheck = 2;         // iterations between two device-side 
 extern "C" size_t usc_regionfill_ws_bytes(int H, int W) {
     int hs[kMaxLevels], ws[kMaxLevels];
     const int L = level_dims(H, W, hs, ws);
-    size_t total = 256 + 4 * rf_align((size_t)kBlocks * 3 * sizeof(double));
-    total += 3 * rf_align((size_t)H * W * 3 * sizeof(double));                  // x, p, Ap
-    for (int l = 0; l < L; l++)
-        total += 3 * rf_align((size_t)hs[l] * ws[l] * 3 * sizeof(double)) + rf_align((size_t)hs[l] * ws[l]);   // z, zt, r, mask per level
+    size_t total = 256 + 5 * rf_align((size_t)kBlocks * 3 * sizeof(double));
+    total += 5 * rf_align((size_t)H * W * 3 * sizeof(double));                  // x, p (two), Ap, r
+    for (int l = 0; l < L; l++) {
+        const size_t tiles = (size_t)((ws[l] + TS - 1) / TS) * ((hs[l] + TS - 1) / TS);
+        total += 3 * rf_align((size_t)hs[l] * ws[l] * 3 * sizeof(VT)) + rf_align((size_t)hs[l] * ws[l]) + rf_align(tiles);   // z, zt, r, mask, tile flags per level
+    }
     return total;
 }
 
@@ -644,21 +808,24 @@ extern "C" int usc_regionfill_u8(const uint8_t* img, const uint8_t* mask, int H,
     q.st = st;
     const dim3 b(kThreads);
     const double rtol2 = rtol * rtol;
-    if (first_iter == 0) {                                      // a new solve: masks of every level, x0, r0, control block
+    if (first_iter == 0) {                                      // a new solve: masks and tile flags of every level, x0, r0, control block
         if (hipMemcpyAsync(s.mask0, mask, (size_t)H * W, hipMemcpyDeviceToDevice, st) != hipSuccess)
             return fail(USC_E_LAUNCH, "usc_regionfill_u8: mask copy failed");
         for (int l = 1; l < s.L; l++)
             q.launch(mg_mask_down_kernel, dim3(grid_of((size_t)s.lv[l].H * s.lv[l].W)), b, s.lv[l - 1].mask, s.lv[l - 1].H, s.lv[l - 1].W,
                      s.lv[l].mask, s.lv[l].H, s.lv[l].W);
-        q.launch(rf_init_kernel, dim3(kBlocks), b, img, s.mask0, H, W, s.x, s.lv[0].r, s.part_rr);
+        for (int l = 0; l < s.L && l < (s.first_tail > 0 ? s.first_tail : 1); l++)
+            q.launch(mg_active_kernel, dim3((unsigned)s.lv[l].ntiles), b, (const uint8_t*)s.lv[l].mask, s.lv[l].H, s.lv[l].W, s.lv[l].active, s.lv[l].tiles_x);
+        q.launch(rf_init_kernel, dim3(kBlocks), b, img, s.mask0, H, W, s.x, s.r, s.part_rr);
         q.launch(rf_publish_kernel, dim3(1), b, s.part_rr, s.scal, 0, s.ctl, rtol2, 0);
     }
     // Iterations [first_iter, first_iter + n_iters), a convergence test on the device after every kItersPerCheck of them; once it has
     // passed, the kernels still in the queue return at their first instruction.  No host synchronisation.
     int cur = first_iter & 1;                                   // which r.z partial array holds the previous value
+    int pc = first_iter & 1;                                    // which p buffer holds the current direction
     int since = 0;
     for (int it = first_iter; it < first_iter + n_iters; it++) {
-        s.iteration(q, it == 0 ? 1 : 0, cur);
+        s.iteration(q, it == 0 ? 1 : 0, cur, pc);
         if (++since == kItersPerCheck || it + 1 == first_iter + n_iters) {
             q.launch(rf_publish_kernel, dim3(1), b, s.part_rr, s.scal, 1, s.ctl, rtol2, since);
             since = 0;
