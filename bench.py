@@ -479,28 +479,53 @@ def mode_roofline(args, pipe, frame):
     return roof, extra
 
 
-def bind_near_gpu(local):
+def gpu_numa_node(index, sysfs="/sys"):
+    """NUMA node of GPU `index`'s PCIe root from sysfs, or None (no NUMA information, node -1, no such device)."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        dom, bus, devid = getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id
+        node = int(open(os.path.join(sysfs, "bus", "pci", "devices", f"{dom:04x}:{bus:02x}:{devid:02x}.0", "numa_node")).read())
+        return node if node >= 0 else None
+    except Exception:           # noqa: BLE001
+        return None
+
+
+def bind_near_gpu(local, local_world=1, sysfs="/sys"):
     """Multi-rank runs: keep this rank's host threads (and so its pinned staging memory, first-touched by them) on the NUMA node its
     GPU's PCIe root hangs off - uploads and downloads then do not cross the socket interconnect.  Best effort: any missing piece
-    (no NUMA information, a cpuset that excludes the node) leaves the affinity as it is.  Returns a short description."""
+    (no NUMA information, a cpuset that excludes the node) leaves the affinity as it is.  Every thread the process already has is
+    re-bound too (torch may have started its intra-op pool while importing: sched_setaffinity(0) only reaches the calling thread and
+    threads created later).  Returns (description, ranks sharing the node) - the second for sizing this rank's CPU pool: the local
+    ranks whose GPU reports the same node (NPS4 hosts have eight nodes, not two)."""
     try:
-        pr = torch.cuda.get_device_properties(local)
-        dom, bus, devid = getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id
-        sysdev = f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{devid:02x}.0"
-        node = int(open(os.path.join(sysdev, "numa_node")).read())
-        if node < 0:
-            return "no NUMA node reported"
+        node = gpu_numa_node(local, sysfs)
+        if node is None:
+            return "no NUMA node reported", max(1, local_world)
         cpus = set()
-        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+        for part in open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")).read().strip().split(","):
             a, _, b = part.partition("-")
             cpus.update(range(int(a), int(b or a) + 1))
         cpus &= os.sched_getaffinity(0)
         if not cpus:
-            return f"node {node}: outside this process's cpuset"
-        os.sched_setaffinity(0, cpus)
-        return f"node {node}: {len(cpus)} cpus"
+            return f"node {node}: outside this process's cpuset", max(1, local_world)
+        tids = [int(t) for t in os.listdir("/proc/self/task")] if os.path.isdir("/proc/self/task") else [0]
+        for tid in tids:
+            try:
+                os.sched_setaffinity(tid, cpus)
+            except OSError:         # (a thread that has just exited)
+                pass
+        sharers = sum(1 for g in range(max(1, local_world)) if gpu_numa_node(g, sysfs) == node)
+        return f"node {node}: {len(cpus)} cpus", max(1, sharers)
     except Exception as e:      # noqa: BLE001 - placement is an optimisation, never a reason to fail
-        return f"unchanged ({type(e).__name__})"
+        return f"unchanged ({type(e).__name__})", max(1, local_world)
+
+
+def strong_seg_batch(clip_frames, world):
+    """Frames per human-parsing forward of the strong-scaling form: every rank plans for the same batch - the largest range
+    (ceil(F / world)) cut into the fewest groups of <= 12 frames, evenly: a 38-frame range runs as 10 + 10 + 10 + 8, not 12 + 12 + 12 + 2
+    (a short last group rides in a full forward)."""
+    kmax = -(-clip_frames // world)
+    return -(-kmax // -(-kmax // 12))
 
 
 def launch_ranks(args):
@@ -547,12 +572,12 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    numa = bind_near_gpu(local) if world > 1 and not os.environ.get("USC_BENCH_SHARE_GPU") else "not bound (single rank)"
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    numa, sharers = (bind_near_gpu(local, local_world) if world > 1 and not os.environ.get("USC_BENCH_SHARE_GPU")
+                     else ("not bound (single rank)", local_world))
     if world > 1:
         # the ranks of a node share its cores: each keeps torch's CPU pool (network set-up: folding, weight packing) to its share
-        # (bound to a NUMA node, a rank shares that node's cores with the ranks of the other GPUs on it: half of them on a two-socket host)
-        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-        sharers = max(1, local_world // 2) if numa.startswith("node") else local_world
+        # (bound to a NUMA node, a rank shares that node's cores with the ranks whose GPUs hang off the same node)
         torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_cpus() // sharers)))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -603,10 +628,7 @@ def main():
     if args.seg_batch > 0:
         seg_batch = args.seg_batch
     elif strong:
-        # every rank plans for the same batch: the largest range (ceil(F / world)) cut into the fewest groups of <= 12 frames, evenly -
-        # a 38-frame range runs as 10 + 10 + 10 + 8, not 12 + 12 + 12 + 2 (a short last group rides in a full forward)
-        kmax = -(-F_clip // world)
-        seg_batch = -(-kmax // -(-kmax // 12))
+        seg_batch = strong_seg_batch(F_clip, world)
     else:
         seg_batch = next((b for b in (12, 8, 6, 4) if K % b == 0), 8)
     pipe = BgStepPipeline(cfg, H, W, device=dev, state_dict=sd, net_backend=args.net, seg_agent=seg_agent,

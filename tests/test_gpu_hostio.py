@@ -71,6 +71,18 @@ def test_download_thread_failure_reaches_the_loop():
         io.drain()
         for p in (io._last_down,):
             p.synchronize()
+    with pytest.raises(RuntimeError, match="download thread"):
+        io.close()                                   # the thread's first error is kept and raised again here
+    io.close()                                       # ... once
+    torch.cuda.synchronize()
+    # a clip shorter than the output ring: no later frame ever waits on the failed copies - drain() must still report them
+    # (round 3 returned the frame count with stale host outputs and no error: ADVICE round 3)
+    pipe.reset()
+    io = hostio.HostFrameIO(pipe)
+    with pytest.raises(RuntimeError, match="download thread"):
+        n = pipe.run(io.inputs(groups[:3], clip.bg_always), on_result=io.collect(bad_alpha, fg))
+        assert n == 3
+        io.drain()
     io.close()
     torch.cuda.synchronize()
 

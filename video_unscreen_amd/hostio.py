@@ -181,6 +181,7 @@ class HostFrameIO:
         self.slot_waited = 0.0                       # seconds inputs() blocked for a staging slot (diagnostics)
         self._jobs = None                            # "hostwait": (compute event, [(dst, src)], PendingCopy) for the download thread
         self._thread = None
+        self._error = None                           # the first exception of the download thread: re-raised by drain() and close()
 
     # ------------------------------------------------------------------ "hostwait": the download thread
     def _download_loop(self):
@@ -199,8 +200,10 @@ class HostFrameIO:
                     dn = torch.cuda.Event()
                     dn.record(self.down)
                 pend._set(dn)
-            except BaseException as e:               # handed to whoever waits on the copy
+            except BaseException as e:               # handed to whoever waits on the copy - and kept: nothing waits on a clip's last copies
                 pend._set(error=e)
+                if self._error is None:
+                    self._error = e
             finally:
                 self._jobs.task_done()
 
@@ -213,12 +216,18 @@ class HostFrameIO:
         self._jobs.put((ev, pairs, pend))
         return pend
 
+    def _raise_pending(self):
+        if self._error is not None:
+            err, self._error = self._error, None
+            raise RuntimeError("HostFrameIO: the download thread failed") from err
+
     def close(self):
-        """Stops the download thread (after the copies it still holds)."""
+        """Stops the download thread (after the copies it still holds); raises what it failed with, if anything."""
         if self._thread is not None and self._thread.is_alive():
             self._jobs.put(None)
             self._thread.join()
         self._thread = None
+        self._raise_pending()
 
     def inputs(self, host_frames, bg_always, on_uploaded=None):
         """Generator for BgStepPipeline.run(): uploads each host frame into the next staging slot on the upload stream and
@@ -335,10 +344,13 @@ class HostFrameIO:
         return on_result
 
     def drain(self):
+        """Every download has been enqueued and has finished.  A failure of the download thread surfaces here even when no later
+        frame waited on the failed copy (the last frames of a clip)."""
         if self._jobs is not None:
             self._jobs.join()                        # every download has been enqueued
         self.up.synchronize()
         self.down.synchronize()
+        self._raise_pending()
 
 
 def stream_clip(pipe, reader, writer, out_paths, bg_always, depth=None):
@@ -376,12 +388,21 @@ def stream_clip(pipe, reader, writer, out_paths, bg_always, depth=None):
         slot, (a, f) = writer.acquire()
         return a, f, slot
 
-    n = pipe.run(io.inputs(host_frames(), bg_always, on_uploaded=lambda ev, slot: uploaded.append((ev, slot))),
-                 on_result=io.collect(target=target, on_downloaded=lambda ev, slot, k: deferred.submit_after(ev, slot, out_paths(k))))
-    io.drain()
-    while uploaded:
-        uploaded[0][0].synchronize()
-        reader.release(uploaded.popleft()[1])
-    deferred.close()
+    try:
+        n = pipe.run(io.inputs(host_frames(), bg_always, on_uploaded=lambda ev, slot: uploaded.append((ev, slot))),
+                     on_result=io.collect(target=target, on_downloaded=lambda ev, slot, k: deferred.submit_after(ev, slot, out_paths(k))))
+        io.drain()
+        while uploaded:
+            uploaded[0][0].synchronize()
+            reader.release(uploaded.popleft()[1])
+    except BaseException:
+        # the helper threads are stopped either way; their own errors must not mask the one that is already propagating
+        for closer in (deferred.close, io.close):
+            try:
+                closer()
+            except Exception:      # noqa: BLE001
+                pass
+        raise
+    deferred.close()               # (raises if a frame could not be handed to the writer)
     io.close()
     return n

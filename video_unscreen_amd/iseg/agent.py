@@ -46,11 +46,20 @@ class ISegAgent():
         self.with_flip = with_flip
         self._nets = {}
 
+    MAX_NETS = 2          # network instances kept (one per input size): each owns its activations and a split-K slab
+
     def model_for(self, in_h, in_w):
+        """The network instance for this input size; the least recently used one is closed when a third size comes along (interactive use
+        over clips of many sizes would otherwise grow device memory without bound)."""
         key = (in_h, in_w, bool(self.with_flip))
-        if key not in self._nets:
-            self._nets[key] = HipIsegNet(self.state_dict, in_h, in_w, device=self.device, batch=2 if self.with_flip else 1)
-        return self._nets[key]
+        net = self._nets.pop(key, None)
+        if net is None:
+            while len(self._nets) >= self.MAX_NETS:
+                old_key = next(iter(self._nets))
+                self._nets.pop(old_key).close()
+            net = HipIsegNet(self.state_dict, in_h, in_w, device=self.device, batch=2 if self.with_flip else 1)
+        self._nets[key] = net                            # (re-inserted: most recently used last)
+        return net
 
     def points_nd(self, click_history, ratio, in_w=None):
         """The (2 P, 2) point table of brs_predictor.py:64-99 (get_points_nd) for the un-mirrored image: P = max(#positive,

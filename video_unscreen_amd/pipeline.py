@@ -191,7 +191,7 @@ class BgStepPipeline:
 
     def note_output_consumed(self, out, event):
         """A consumer that reads out["alpha"] / out["fg"] on another stream hands back the event that ends its reads (or an
-        object with wait_on(stream), hostio.PendingCopy); the ring entry is not rewritten (three frames later) before that event."""
+        object with wait_on(stream), hostio.PendingCopy); the ring entry is not rewritten (eight frames later) before that event."""
         out["_ring"]["consumed"] = event
 
     # ------------------------------------------------------------------ synchronous form

@@ -244,6 +244,7 @@ class DeferredSubmit:
     def __init__(self, writer):
         self.writer = writer
         self.q = queue.Queue()
+        self.error = None                      # the first exception of the helper thread (a failed copy, a dead encoder): re-raised by close()
         self.th = threading.Thread(target=self._run, daemon=True)
         self.th.start()
 
@@ -253,8 +254,13 @@ class DeferredSubmit:
             if item is None:
                 return
             event, slot, paths = item
-            event.synchronize()
-            self.writer.submit(slot, paths)
+            if self.error is not None:
+                continue                       # (keep draining the queue: close() must not block on it)
+            try:
+                event.synchronize()
+                self.writer.submit(slot, paths)
+            except BaseException as e:         # noqa: BLE001 - handed to the thread that calls close()
+                self.error = e
 
     def submit_after(self, event, slot, paths):
         self.q.put((event, slot, paths))
@@ -262,3 +268,6 @@ class DeferredSubmit:
     def close(self):
         self.q.put(None)
         self.th.join()
+        if self.error is not None:
+            err, self.error = self.error, None
+            raise RuntimeError("DeferredSubmit: handing a finished frame to the writer failed") from err
