@@ -164,3 +164,12 @@ def test_replace_host_loop_equals_tool_flow(oracle_lib):
         torch.cuda.synchronize()
         for t, (fg, m3, fr, _) in enumerate(frames):
             assert np.array_equal(compare_h[t].numpy(), _oracle_chain(oracle_lib, fg, m3, bg, fr, M)[1]), (sh, sw, t)
+        if packed:                                   # the whole clip as ONE tensor per pass: several frames per copy (6 frames, groups of 4: a ragged tail)
+            from video_unscreen_amd.pipeline_replace import pack_clip
+            loop4 = ReplaceHostLoop(ReplacePipeline(H, W, dev(bg), max_frames=n), n, ring=2, group=4)
+            again = loop4.pass1(pack_clip([(t_(m3), t_(sm3)) for _, m3, _, sm3 in frames]))
+            assert again == (sx, sy, cnt)
+            cmp4 = torch.zeros((n, H, 2 * W, 3), dtype=torch.uint8).pin_memory()
+            loop4.pass2(pack_clip([(t_(fg), t_(fr)) for fg, _, fr, _ in frames]), M, cmp4)
+            torch.cuda.synchronize()
+            assert torch.equal(cmp4, compare_h)

@@ -68,21 +68,23 @@ def pack_pair(a, b, pin=True):
 
 class ReplaceHostLoop:
     """The two passes over a clip whose frames start and end in page-locked host memory: uploads on one copy stream, kernels on a
-    compute stream, downloads on a second copy stream, `ring` frames in flight; the target's alpha masks stay in HBM between the
+    compute stream, downloads on a second copy stream, `ring` groups in flight; the target's alpha masks stay in HBM between the
     passes (they are read by both: K x 6.2 MB at 1080p), so a frame crosses PCIe as 12 bytes per pixel up (two masks, fg, source
     frame) and 6 down (the side-by-side image, whose right half IS res - replace.py:79-82 writes both from the same array).
-    Per-frame inputs are either (a, b) tuples or pack_pair(a, b) tensors (source and target of one size: one copy per pass)."""
+    Per-frame inputs are (a, b) tuples, pack_pair(a, b) tensors, or - fastest - ONE (K, 2, H, W, 3) page-locked tensor per pass
+    (`pack_clip`): then `group` frames move per copy (a 50 MB transfer runs at ~45 GB/s, a 12 MB one at ~30: tools/dev/hostio_probe.py)."""
 
-    def __init__(self, pipe, nframes, src_hw=None, ring=4):
-        self.pipe, self.K, self.ring = pipe, nframes, ring
+    def __init__(self, pipe, nframes, src_hw=None, ring=3, group=4):
+        self.pipe, self.K, self.ring, self.group = pipe, nframes, ring, max(1, group)
         H, W, dev = pipe.H, pipe.W, pipe.device
         sh, sw = src_hw if src_hw is not None else (H, W)
         u8 = lambda *s: torch.empty(s, dtype=torch.uint8, device=dev)                      # noqa: E731
+        G = self.group
         self.bank = u8(nframes, 2, H, W, 3)                  # [i, 0] = the target's alphamask (both passes), [i, 1] = the source's when packed
         self.s_mask = [u8(sh, sw, 3) for _ in range(ring)]
-        self.s_in = [u8(2, H, W, 3) for _ in range(ring)]    # [fg | source frame] of one size
+        self.s_in = [u8(G, 2, H, W, 3) for _ in range(ring)] # [fg | source frame] of one size, G frames
         self.s_src = [u8(sh, sw, 3) for _ in range(ring)]
-        self.s_cmp = [u8(H, 2 * W, 3) for _ in range(ring)]
+        self.s_cmp = [u8(G, H, 2 * W, 3) for _ in range(ring)]
         self.up, self.comp, self.down = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         mk = lambda: [torch.cuda.Event() for _ in range(ring)]                             # noqa: E731
         self.e_ready, self.e_used, self.e_out = mk(), mk(), mk()
@@ -97,54 +99,84 @@ class ReplaceHostLoop:
         for s in (self.up, self.comp, self.down):
             cur.wait_stream(s)
 
+    def _groups(self, items):
+        """(first frame, frame count, clip tensor | None): G frames of a (K, 2, H, W, 3) clip tensor at a time, else one frame per step."""
+        n = len(items)
+        if torch.is_tensor(items) and items.dim() == 5:
+            return [(g, min(self.group, n - g), items) for g in range(0, n, self.group)]
+        return [(i, 1, None) for i in range(n)]
+
     def pass1(self, masks_h):
-        """masks_h[i] = (target alphamask (H, W, 3), source alphamask (sh, sw, 3)) or their pack_pair -> (sum dx, sum dy, n)."""
+        """masks_h[i] = (target alphamask (H, W, 3), source alphamask (sh, sw, 3)) or their pack_pair; or one (K, 2, H, W, 3) clip tensor
+        -> (sum dx, sum dy, n)."""
         p, R = self.pipe, self.ring
         self._start()
-        for i, item in enumerate(masks_h):
-            k = i % R
-            if i >= R:
+        for step, (g0, cnt, clip) in enumerate(self._groups(masks_h)):
+            k = step % R
+            if step >= R:
                 self.up.wait_event(self.e_used[k])
             with torch.cuda.stream(self.up):
-                if torch.is_tensor(item):
-                    self.bank[i].copy_(item, non_blocking=True)
-                    sm = self.bank[i, 1]
+                if clip is not None:
+                    self.bank[g0:g0 + cnt].copy_(clip[g0:g0 + cnt], non_blocking=True)
+                    sm = None
+                elif torch.is_tensor(masks_h[g0]):
+                    self.bank[g0].copy_(masks_h[g0], non_blocking=True)
+                    sm = None
                 else:
-                    self.bank[i, 0].copy_(item[0], non_blocking=True)
+                    self.bank[g0, 0].copy_(masks_h[g0][0], non_blocking=True)
                     sm = self.s_mask[k]
-                    sm.copy_(item[1], non_blocking=True)
+                    sm.copy_(masks_h[g0][1], non_blocking=True)
                 self.e_ready[k].record(self.up)
             self.comp.wait_event(self.e_ready[k])
             with torch.cuda.stream(self.comp):
-                p.centroid_pair(i, self.bank[i, 0], sm)
+                for i in range(g0, g0 + cnt):
+                    p.centroid_pair(i, self.bank[i, 0], sm if sm is not None else self.bank[i, 1])
                 self.e_used[k].record(self.comp)
         self._finish()
         return p.offset_sums(len(masks_h))
 
     def pass2(self, inputs_h, M, compare_h):
-        """inputs_h[i] = (fg (H, W, 3), source frame (sh, sw, 3)) or their pack_pair; compare_h (K, H, 2 W, 3) pinned receives [source | res]."""
+        """inputs_h[i] = (fg (H, W, 3), source frame (sh, sw, 3)) or their pack_pair, or one (K, 2, H, W, 3) clip tensor; compare_h
+        (K, H, 2 W, 3) pinned receives [source | res]."""
         p, R = self.pipe, self.ring
         self._start()
-        for i, item in enumerate(inputs_h):
-            k = i % R
-            if i >= R:
+        for step, (g0, cnt, clip) in enumerate(self._groups(inputs_h)):
+            k = step % R
+            if step >= R:
                 self.up.wait_event(self.e_used[k])
-                self.comp.wait_event(self.e_out[k])                     # the slot's previous composite has been copied out
+                self.comp.wait_event(self.e_out[k])                     # the slot's previous composites have been copied out
             with torch.cuda.stream(self.up):
-                if torch.is_tensor(item):
-                    self.s_in[k].copy_(item, non_blocking=True)
-                    fg, fr = self.s_in[k][0], self.s_in[k][1]
+                if clip is not None:
+                    self.s_in[k][:cnt].copy_(clip[g0:g0 + cnt], non_blocking=True)
+                    pairs = [(self.s_in[k][j, 0], self.s_in[k][j, 1]) for j in range(cnt)]
+                elif torch.is_tensor(inputs_h[g0]):
+                    self.s_in[k][0].copy_(inputs_h[g0], non_blocking=True)
+                    pairs = [(self.s_in[k][0, 0], self.s_in[k][0, 1])]
                 else:
-                    fg, fr = self.s_in[k][0], self.s_src[k]
-                    fg.copy_(item[0], non_blocking=True)
-                    fr.copy_(item[1], non_blocking=True)
+                    fg, fr = self.s_in[k][0, 0], self.s_src[k]
+                    fg.copy_(inputs_h[g0][0], non_blocking=True)
+                    fr.copy_(inputs_h[g0][1], non_blocking=True)
+                    pairs = [(fg, fr)]
                 self.e_ready[k].record(self.up)
             self.comp.wait_event(self.e_ready[k])
             with torch.cuda.stream(self.comp):
-                p.compose(fg, self.bank[i, 0], fr, M, compare=self.s_cmp[k], want_res=False)
+                for j, (fg, fr) in enumerate(pairs):
+                    p.compose(fg, self.bank[g0 + j, 0], fr, M, compare=self.s_cmp[k][j], want_res=False)
                 self.e_used[k].record(self.comp)
             self.down.wait_event(self.e_used[k])
             with torch.cuda.stream(self.down):
-                compare_h[i].copy_(self.s_cmp[k], non_blocking=True)
+                compare_h[g0:g0 + cnt].copy_(self.s_cmp[k][:cnt], non_blocking=True)
                 self.e_out[k].record(self.down)
         self._finish()
+
+
+def pack_clip(pairs, pin=True):
+    """[(a_i, b_i)] same-shape uint8 images -> one (K, 2, H, W, 3) host tensor (page-locked): ReplaceHostLoop then moves several frames per copy."""
+    a0 = pairs[0][0]
+    t = torch.empty((len(pairs), 2) + tuple(a0.shape), dtype=torch.uint8)
+    if pin:
+        t = t.pin_memory()
+    for i, (a, b) in enumerate(pairs):
+        t[i, 0].copy_(a)
+        t[i, 1].copy_(b)
+    return t
