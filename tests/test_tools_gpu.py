@@ -89,6 +89,19 @@ def test_bench_two_ranks_rehearsal():
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_bench_replace_mode_two_ranks_rehearsal():
+    """bench.py --mode replace (BASELINE.json configs[4], the compositing half) for N = 2 on this box's one GPU over gloo: frames shard
+    over the ranks, the centroid offsets meet in one all-reduce, rank 0 prints one line whose output was checked against the stand-alone
+    kernel chain inside the run."""
+    env = dict(os.environ, USC_BENCH_BACKEND="gloo", USC_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    out = _one_line(_bench(["--gpus", "2", "--mode", "replace", "--steps", "9", "--warmup", "2", "--height", "270", "--width", "480", "--no-cpu-baseline"],
+                           env, launcher=False))
+    assert out["n_gpus"] == 2 and out["steps"] == 9 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["self_check"]["loop_equals_stand_alone_kernel_chain"] and out["roofline"]["bound"] == "hbm"
+    assert out["config"]["correspondence_mean"] != [0.0, 0.0]
+
+
 def test_bg_step_tool_raw_files_are_bit_exact(tmp_path):
     """--io npy: no codec anywhere, so the files the streaming tool writes (decoder processes -> pinned ring -> uploads -> pipelined
     loop -> downloads -> encoder processes) equal the in-process synchronous loop bit for bit."""
