@@ -412,6 +412,46 @@ def test_regionfill_matches_direct_solve(nv, oracle_lib, H, W):
     assert np.array_equal(host(nv.regionfill(dev(bg), dev(z))), bg)
 
 
+@pytest.mark.parametrize("H,W", [(5, 7), (8, 8), (9, 9), (33, 70), (2, 40), (40, 2), (97, 161)])
+def test_regionfill_small_and_ragged_sizes(nv, oracle_lib, H, W):
+    """Sizes that exercise the solver's edges: an image of at most 8 x 8 cells is ONE multigrid level handled inside the single-workgroup
+    tail (the float64 residual is cast for it), 9 x 9 is two levels, 33 x 70 / 97 x 161 leave partial 32 x 32 tiles on both axes and odd
+    coarse sizes, 2 x N / N x 2 have no interior cell at all (one-pixel-high images are outside the reference's domain: its formRightSide
+    indexes row 1).  Against the sparse direct solve, +-1 level next to
+    integers; a budget that is too small is continued (first_iter > 0) to the same bits as one long enqueue."""
+    rng = np.random.default_rng(H * 131 + W)
+    bg = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    mask = np.zeros((H, W), np.uint8)
+    mask[H // 4:max(H // 4 + 1, 3 * H // 4), W // 5:max(W // 5 + 1, 4 * W // 5)] = 255
+    if H > 6 and W > 6:
+        mask[0:2, 0:3] = 255                                   # touches a corner
+        mask[H - 1, W // 2:] = 255                             # and runs along the bottom edge
+    if mask.all():
+        mask[0, 0] = 0                                         # (at least one known pixel: the system is singular otherwise)
+    got, iters = nv.regionfill(dev(bg), dev(mask), want_iters=True)
+    got = host(got)
+    exact = np.stack([oracle_lib.regionfill(bg[..., c], mask) for c in range(3)], -1)
+    d = np.abs(got.astype(int) - exact.astype(np.uint8).astype(int))
+    assert d.max() <= 1, (iters, int(d.max()))
+    assert ((np.abs(exact - np.round(exact)) < 2e-2) | (d == 0)).all()
+    assert np.array_equal(got[mask == 0], bg[mask == 0])
+    # two iterations per call, continued until converged: the same bits as the single enqueue
+    out = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+    status = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ws = torch.empty(nv.load().usc_regionfill_ws_bytes(H, W), dtype=torch.uint8, device="cuda")
+    bgd, md = dev(bg), dev(mask)
+    it = 0
+    while True:
+        rc = nv.load().usc_regionfill_u8(bgd.data_ptr(), md.data_ptr(), H, W, out.data_ptr(), 1e-7, it, 2, status.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        it += 2
+        used, conv = status.cpu().tolist()
+        if conv or it > 400:
+            break
+    assert conv and used == iters and np.array_equal(host(out), got)
+
+
 def test_regionfill_full_size(nv, oracle_lib):
     """The inpainting at the real frame size (1920 x 1080, a silhouette-sized hole with a ragged edge): the status block reports
     convergence within the default budget logic, the image outside the hole is untouched, every filled value obeys the discrete

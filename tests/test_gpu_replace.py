@@ -39,7 +39,8 @@ def _oracle_chain(o, fg, mask, bg, src, M, scale=1.2):
     return res, np.concatenate((o.resize_linear(src, H, W), res), axis=1)
 
 
-@pytest.mark.parametrize("H,W,sh,sw", [(120, 200, 150, 240), (135, 241, 135, 241), (67, 130, 40, 77), (1080, 1920, 1080, 1920), (1080, 1920, 720, 1280)])
+@pytest.mark.parametrize("H,W,sh,sw", [(120, 200, 150, 240), (135, 241, 135, 241), (67, 130, 40, 77), (3, 5, 3, 5), (16, 64, 32, 128), (17, 65, 9, 33),
+                                      (1080, 1920, 1080, 1920), (1080, 1920, 720, 1280)])
 def test_replace_compose_one_launch_bit_exact(oracle_lib, H, W, sh, sw):
     """usc_replace_compose_u8 == warp_affine -> rescale_fg -> blend (+ resize of the source frame) == the oracle chain, for the
     reference's translation matrices (sub-pixel shifts in float32), sizes whose 1.2-fold is not an integer (the cubic resize then maps
@@ -59,7 +60,7 @@ def test_replace_compose_one_launch_bit_exact(oracle_lib, H, W, sh, sw):
         assert np.array_equal(cmp_img.cpu().numpy(), want_cmp)
         assert np.array_equal(want, oracle_lib.blend(oracle_lib.rescale_fg(oracle_lib.shift_fg(fg, dx, dy), 1.2),
                                                      oracle_lib.rescale_fg(oracle_lib.shift_fg(m3, dx, dy), 1.2), bg))
-    assert 0.02 < (want != bg).mean()                                   # the composite really changed pixels
+    assert H * W < 100 or 0.02 < (want != bg).mean()                    # the composite really changed pixels
     # one-channel mask, compare only / res only, another zoom, a general affine matrix
     m1 = np.ascontiguousarray(m3[..., 1])
     M = np.array([[0.98, 0.05, 3.25], [-0.04, 1.01, -2.5]], np.float64)
