@@ -420,6 +420,13 @@ typedef struct usc_conv_desc {
                                       residual and no affine: the Winograd F(3x3, 2x2) operands of the four phases instead,
                                       floats [4][Cin/8][16][2][Cout][4] (vmatting/net_hip.py pack_wino_t: G = [1 0; 1/2 1/2;
                                       1/2 -1/2; 0 -1], phase (py, px) = index 2 py + px). */
+    float* out2;                   /* optional second output tensor (direct, single-phase layers without residuals / affine only): output
+                                      channels [split_c, Cout) go to `out2` - a dense [pixel][Cout - split_c] tensor - with activation
+                                      `act2`, channels [0, split_c) to `out` ([pixel][split_c] unless out_ld says otherwise) with `act`.
+                                      Two convolutions that read the same input with the same geometry run as ONE launch this way (a
+                                      ResNet stage's 3x3 / stride-2 conv and its AvgPool + 1x1 shortcut: unscreen/vmatting/model.py:119-157 -
+                                      the shortcut's weights sit on four of the nine taps, zeros on the others).  NULL: one output. */
+    int split_c, act2;             /* split_c: a multiple of 32 (of 64 when Cout % 64 == 0 tiles are planned), 0 < split_c < Cout */
 } usc_conv_desc;
 
 /* Tuning hook (tools/dev/tune_convs.py): force the tile width (1 | 2 x 32 columns), the row groups per workgroup (4 | 2 | 1

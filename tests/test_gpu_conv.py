@@ -514,3 +514,38 @@ def test_runs_mode_is_bit_identical():
     net.set_launch_mode("stream")
     assert torch.equal(net(), ref)
     net.close()
+
+
+def test_stage_entry_merge_matches_separate_launches():
+    """usc_conv_desc.out2: a ResNet stage's 3x3 / stride-2 conv and its AvgPool + 1x1 shortcut as ONE two-output launch (the shortcut's
+    weights on four of the nine taps) against the two launches of rounds 1 - 3: every activation tensor both networks have in common
+    agrees to float rounding (the K partition of the merged layer differs), the prediction to 1e-6; the planner refuses the
+    combinations the kernel cannot serve (a grid K split, residual tensors, a split inside a 64-channel tile)."""
+    import ctypes as C
+    from video_unscreen_amd import _native as nv
+    from video_unscreen_amd.vmatting.net import synthetic_state_dict
+    from video_unscreen_amd.vmatting.net_hip import ConvDesc, HipMattingNet
+    sd = synthetic_state_dict(0)
+    a, b = HipMattingNet(sd, 160, 224, merge_stage_entry=False), HipMattingNet(sd, 160, 224, merge_stage_entry=True)
+    assert a.num_layers == b.num_layers + 3
+    x = torch.randn(160, 224, 8, generator=torch.Generator().manual_seed(3)).cuda()
+    x[..., 7] = 0
+    pa, pb = a(x).clone(), b(x).clone()
+    assert float((pa - pb).abs().max()) < 1e-6
+    merged = [d for d in b._descs if d.out2]
+    assert len(merged) == 3 and all(d.split_c * 2 == d.Cout and d.ntaps == 9 and d.in_stride == 2 for d in merged)
+    plans = nv.conv_plans((ConvDesc * 3)(*merged), 3)
+    assert all(p["launches"] == 1 for p in plans)                       # never the split-K reduce path
+    # the stage outputs (inputs of the next stage's merged layer) agree
+    for d_b in merged[1:]:
+        t_b = next(t for t in b._keep if t.data_ptr() == d_b.inp)
+        t_a = next(t for t in a._keep if t.shape == t_b.shape and float((t - t_b).abs().max()) < 1e-4 * float(t_b.abs().max()))
+        assert t_a is not None
+    bad = ConvDesc.from_buffer_copy(bytes(merged[0]))
+    bad.split_c = 48
+    info = nv.ConvPlanInfo()
+    assert nv.load().usc_conv_plan_query(C.byref(bad), C.byref(info)) != 0
+    bad = ConvDesc.from_buffer_copy(bytes(merged[0]))
+    bad.res1 = bad.out
+    assert nv.load().usc_conv_plan_query(C.byref(bad), C.byref(info)) != 0
+    a.close(); b.close()

@@ -213,7 +213,12 @@ __global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d
 
     // ---- epilogue: as above, through this wave's own LDS image (free now); K groups > 0 only deposit their partial tile
     float* const T = Aw;
-    const int out_ld = d.out_ld > 0 ? d.out_ld : d.Cout;
+    // two-output layers (usc_conv_desc.out2): this workgroup's channel tile lies on one side of split_c - which tensor, row pitch,
+    // channel origin and activation it uses is workgroup-uniform
+    const bool second = d.out2 != nullptr && nb0 >= d.split_c;
+    const int out_ld = second ? d.Cout - d.split_c : d.out_ld > 0 ? d.out_ld : d.out2 ? d.split_c : d.Cout;
+    const int out_c0 = second ? -d.split_c : d.out_c0;
+    const int act = second ? d.act2 : d.act;
     const int out_bytes = d.OHf * d.OWf * d.Cout * 4;
     const int erow = lane >> 3, ec4 = (lane & 7) * 4;
     int ops[4], oos[4], rps[4];
@@ -222,13 +227,13 @@ __global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d
         const int p = 32 * rg + ps * 8 + erow;
         const int opix = s_outpix[p];
         ops[ps] = opix < 0 ? INVALID : opix * d.Cout * 4;
-        oos[ps] = opix < 0 ? INVALID : (opix * out_ld + d.out_c0) * 4;
+        oos[ps] = opix < 0 ? INVALID : (opix * out_ld + out_c0) * 4;
         rps[ps] = s_res1pix[p];
     }
     const bool has_r1 = d.res1 != nullptr, has_r2 = d.res2 != nullptr, has_aff = d.scale != nullptr;
     const __amdgpu_buffer_rsrc_t out_rsrc = S > 1
         ? __builtin_amdgcn_make_buffer_rsrc(d.slab + (size_t)ks * d.OHf * d.OWf * d.Cout, 0, out_bytes, 0x00020000)
-        : __builtin_amdgcn_make_buffer_rsrc(d.out, 0, d.OHf * d.OWf * out_ld * 4, 0x00020000);
+        : __builtin_amdgcn_make_buffer_rsrc(second ? d.out2 : d.out, 0, d.OHf * d.OWf * out_ld * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(d.res1), 0, (has_r1 && S == 1) ? (d.OHf >> d.res1_shift) * (d.OWf >> d.res1_shift) * d.Cout * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -282,9 +287,9 @@ __global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 float x = v[e] + a1[e];
-                if (d.act == USC_ACT_RELU) x = fmaxf(x, 0.f);
-                else if (d.act == USC_ACT_LEAKY) x = x > 0.f ? x : x * 0.2f;
-                else if (d.act == USC_ACT_LEAKY01) x = x > 0.f ? x : x * 0.01f;
+                if (act == USC_ACT_RELU) x = fmaxf(x, 0.f);
+                else if (act == USC_ACT_LEAKY) x = x > 0.f ? x : x * 0.2f;
+                else if (act == USC_ACT_LEAKY01) x = x > 0.f ? x : x * 0.01f;
                 if (has_aff) x = x * s4[e] + h4[e];
                 v[e] = x + a2[e];
             }
@@ -1452,6 +1457,9 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
         return USC_OK;
     }
     if (d.Cout % 32) return conv_fail(USC_E_UNSUPPORTED, "usc_conv: Cout must be a multiple of 32");
+    if (d.out2 && (d.split_c <= 0 || d.split_c >= d.Cout || d.split_c % 32 || d.nphase > 1 || d.res1 || d.res2 || d.scale || d.out_c0 ||
+                   (d.out_ld && d.out_ld < d.split_c)))
+        return conv_fail(USC_E_ARG, "usc_conv: out2 needs 0 < split_c < Cout (a multiple of 32), one phase, no residual / affine tensors");
     if ((d.Cin & (d.Cin - 1)) && d.Cin % 32) return conv_fail(USC_E_UNSUPPORTED, "usc_conv: Cin must be a power of two or a multiple of 32");
     if (d.out_ld && (d.out_ld < d.Cout + d.out_c0 || d.out_c0 < 0 || d.out_ld % 4 || d.out_c0 % 4))
         return conv_fail(USC_E_ARG, "usc_conv: out_ld / out_c0 must satisfy out_c0 + Cout <= out_ld, both multiples of 4");
@@ -1504,7 +1512,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     {
         static const signed char sdy[9] = {-1, -1, -1, 0, 0, 0, 1, 1, 1}, sdx[9] = {-1, 0, 1, -1, 0, 1, -1, 0, 1};
         const int D = d.ntaps == 9 ? d.dx[5] : 0;                    // dilation: a dilated layer is D x D standard ones on the parity sub-images
-        bool std3 = d.wino && d.ntaps == 9 && nphase == 1 && d.in_stride == 1 && d.out_stride == 1 && d.Cin % 8 == 0 && D >= 1 && D <= 4 &&
+        bool std3 = d.wino && !d.out2 && d.ntaps == 9 && nphase == 1 && d.in_stride == 1 && d.out_stride == 1 && d.Cin % 8 == 0 && D >= 1 && D <= 4 &&
                     d.IH % D == 0 && d.IW % D == 0 && (D == 1 || (d.res1_shift == 0)) &&
                     d.res1_shift >= 0 && d.IW == d.OW && (long long)d.IH * nbatch == d.OH && d.OHf == d.OH && d.OWf == d.OW;
         for (int t = 0; std3 && t < 9; t++) std3 = d.dy[t] == sdy[t] * D && d.dx[t] == sdx[t] * D;
@@ -1569,6 +1577,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
     constexpr int nt2_min = kNt2Min;
     bool nt2 = (d.Cout % 64 == 0) && ((m_plan + 127) / 128 * (d.Cout / 64) * nphase >= nt2_min);
     if (g_force_nt) nt2 = g_force_nt == 2 && d.Cout % 64 == 0;
+    if (d.out2 && d.split_c % 64) nt2 = false;                   // a 64-channel tile must not straddle the two outputs
     const int nblocks = nt2 ? d.Cout / 64 : d.Cout / 32;
     const int nch = (d.ntaps * d.Cin + KC - 1) / KC;
     // Parallelism for layers with few pixels: a workgroup's RG row groups cover 128 | 64 | 32 pixels, a workgroup may hold
@@ -1589,7 +1598,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
         return rg * kw >= 4 && rg * kw <= 16;
     };
     if (g_force_s || g_force_kw || g_force_rg) {
-        S = g_force_s ? g_force_s : 1;
+        S = g_force_s && !d.out2 ? g_force_s : 1;
         KW = g_force_kw ? g_force_kw : 1;
         RG = g_force_rg ? g_force_rg : 4;
         if (S > 1 && (!d.slab || (size_t)S * plane_bytes + WSLAB_TAIL > d.slab_bytes)) S = 1;
@@ -1609,7 +1618,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
         for (int rg = 4; rg >= rg_min; rg >>= 1) {
             const long long blocks = (m_plan + 32 * rg - 1) / (32 * rg) * nblocks * nphase;
             for (int s = 1; s <= 16; s++) {
-                if (s > 1 && (!d.slab || (size_t)s * plane_bytes + WSLAB_TAIL > d.slab_bytes)) break;
+                if (s > 1 && (!d.slab || d.out2 || (size_t)s * plane_bytes + WSLAB_TAIL > d.slab_bytes)) break;      // (the reduce kernel knows one output)
                 for (int kw = 1; kw <= 16; kw *= 2) {
                     if (!exists(rg, kw)) continue;
                     if ((s > 1 && nch / (s * kw) < min_steps) || (kw > 1 && nch / (s * kw) < kw_steps)) continue;

@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ("dy", C.c_byte * 16), ("dx", C.c_byte * 16),
                 ("nphase", C.c_int), ("wphase_stride", C.c_int), ("ksplit", C.c_int), ("in_relu", C.c_int),
                 ("slab", C.c_void_p), ("slab_bytes", C.c_size_t), ("out_ld", C.c_int), ("out_c0", C.c_int),
-                ("batch", C.c_int), ("plan_batch", C.c_int), ("wino", C.c_void_p)]
+                ("batch", C.c_int), ("plan_batch", C.c_int), ("wino", C.c_void_p),
+                ("out2", C.c_void_p), ("split_c", C.c_int), ("act2", C.c_int)]
 
 
 def d_out_elems(OH, OW, out_stride, OHf, OWf, Cout):
@@ -102,7 +103,10 @@ def convt_phase_taps(w, py, px):
 
 
 class HipMattingNet:
-    def __init__(self, state_dict, in_h, in_w, device="cuda:0", use_graph=True):
+    def __init__(self, state_dict, in_h, in_w, device="cuda:0", use_graph=True, merge_stage_entry=True):
+        """merge_stage_entry: a ResNet stage's first 3x3 / stride-2 conv and its AvgPool + 1x1 shortcut as ONE two-output launch (51 instead
+        of 54 launches per forward; False: the three shortcut convs as launches of their own, as in rounds 1 - 3)."""
+        self.merge_stage_entry = merge_stage_entry
         if in_h % 32 or in_w % 32:
             raise ValueError("HipMattingNet: input size must be a multiple of 32 (vmatting/agent.py:38-42 guarantees it)")
         self.device = torch.device(device)
@@ -148,10 +152,13 @@ class HipMattingNet:
 
     def _add(self, x, out, taps, wk, bias, IH, IW, Cin, OH, OW, Cout, in_stride=1, out_stride=1, py=0, px=0,
              res1=None, res1_shift=0, act="none", scale=None, shift=None, res2=None, kind=0, OHf=None, OWf=None,
-             phases=None, wino=None, wino_t=None):
-        """phases: optional list of 4 (taps, wk) pairs (transposed conv); then `taps` / `wk` are ignored."""
+             phases=None, wino=None, wino_t=None, out2=None, split_c=0, act2="none"):
+        """phases: optional list of 4 (taps, wk) pairs (transposed conv); then `taps` / `wk` are ignored.
+        out2 / split_c / act2: output channels [split_c, Cout) go to the second tensor with their own activation (usc_conv_desc.out2)."""
         d = ConvDesc()
         d.inp, d.out = x.data_ptr(), out.data_ptr()
+        if out2 is not None:
+            d.out2, d.split_c, d.act2 = out2.data_ptr(), split_c, ACT[act2]
         if phases is not None:
             packed = [pack_k_major(w.float()) for _, w in phases]
             wp = self._dev(torch.stack(packed, 0))
@@ -227,6 +234,24 @@ class HipMattingNet:
         for blocks in p["enc"]:                                 # BasicBlock x2 per stage (model.py:119-157)
             for blk in blocks:
                 s = blk["conv1"].stride
+                if blk["down"] is not None and self.merge_stage_entry and s == 2 and blk["conv1"].w.shape[2] == 3:
+                    # Stage entry as ONE launch: the 3x3 / stride-2 conv and the shortcut (AvgPool2d(2, 2) + 1x1 conv + BN = a 2x2 /
+                    # stride-2 conv on the taps (0, 0), (0, 1), (1, 0), (1, 1) of the same nine) read the same input with the same
+                    # geometry: output channels [0, C) = conv1 with its activation -> y, [C, 2C) = the shortcut -> idt (two tensors).
+                    c1 = blk["conv1"]
+                    wd = blk["down"].w[:, :, 0, 0].t() * 0.25   # (Cin, Cout)
+                    taps, wk1 = conv_taps(c1.w, c1.pad)         # wk1: (9 Cin, C), rows tap-major
+                    ci, co = wd.shape
+                    wk2 = torch.zeros_like(wk1)
+                    for ti, tp in enumerate(taps):
+                        if tp in ((0, 0), (0, 1), (1, 0), (1, 1)):
+                            wk2[ti * ci:(ti + 1) * ci] = wd
+                    y, idt = self._buf(h // 2, w // 2, co), self._buf(h // 2, w // 2, co)
+                    self._add(t, y, taps, torch.cat([wk1, wk2], 1), torch.cat([c1.b, blk["down"].b]), h, w, ci, h // 2, w // 2, 2 * co,
+                              in_stride=2, act=c1.act, out2=idt, split_c=co, act2="none")
+                    h, w = h // s, w // s
+                    t = self._conv(blk["conv2"], y, h, w, res1=idt, act="relu")
+                    continue
                 if blk["down"] is not None:                     # AvgPool2d(2, 2) + 1x1 conv + BN as one 2x2/s2 conv
                     wd = blk["down"].w[:, :, 0, 0].t() * 0.25   # (Cin, Cout)
                     taps = [(0, 0), (0, 1), (1, 0), (1, 1)]
