@@ -333,7 +333,7 @@ def replace_mode(args, rank, world, dev):
         print(json.dumps({
             "metric": f"frames/sec end-to-end replace ({W}x{H})", "value": round(world * K / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8 (integer fixed-point resampling, float64 blend)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"replace (tools/replace/replace.py): centroid pass + shift_fg / rescale_fg(1.2) / blend / side-by-side, {W}x{H}, "
                                    f"{K} frames/GPU, frame-sharded x{world}, one all-reduce of the centroid offsets",
                        "boundary": "pinned host -> pinned host: two alpha masks (pass 1), fg and source frame (pass 2) uploaded (12 B/px), side-by-side image downloaded (6 B/px), four frames per copy, "

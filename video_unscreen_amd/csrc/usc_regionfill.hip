@@ -7,7 +7,7 @@
 //   * levels: 2x2 cell aggregation (coarse cell in the mask iff any child is), piecewise-constant prolongation P, restriction
 //     P^T, coarse operator = the same masked stencil re-discretised on the coarse grid (the Galerkin operator P^T A P of an
 //     interior cell is twice that; with piecewise-constant P the unscaled stencil - an over-correction by 2 - is the better
-//     preconditioner: measured 24 iterations against 52 at 1080p), weighted-Jacobi smoothing (2 pre, 2 post, omega 0.8) -
+//     preconditioner: measured 24 iterations against 52 at 1080p), weighted-Jacobi smoothing (2 pre, 2 post; 5 sweeps on the coarsest level) -
 //     every piece symmetric, so the V-cycle is a valid CG preconditioner.  (Round 4 tried, in a NumPy model of this solver,
 //     cell-centred bilinear P / P^T (28 -> 24 iterations on the bench's ragged 1080p hole), red-black Gauss-Seidel (-> 18 with two
 //     sweeps, at twice the launches per level) and Chebyshev weights for the two Jacobi sweeps (-> 25): the iteration count is set
@@ -46,6 +46,9 @@ namespace {
 #endif
 constexpr int kBlocks = USC_RF_BLOCKS, kThreads = 256;    // (kBlocks: rows of every partial-sum array = workgroups of every reducing kernel: four per CU)
 constexpr int kMaxLevels = 12;
+#ifndef USC_RF_COARSE_PAIRS
+#define USC_RF_COARSE_PAIRS 2          // sweeps on the coarsest level (<= 8 x 8 cells): 1 + 2 x this many.  Round 4: 17 -> 5 sweeps, the same
+#endif                                 // 52 - 54 iterations on the bench's hole, twelve barrier phases fewer in the tail kernel per iteration
 constexpr VT kOmega = (VT)0.8;             // the coarsest level's 17 sweeps
 // The two smoothing sweeps of a level use the weights of the degree-2 Chebyshev polynomial on [1/2, 2] (the high-frequency range of
 // D^-1 A for the 5-point stencil under 2 x 2 coarsening): damping 0.22 per pair instead of 0.36 for two sweeps with 0.8.  Pre-smoothing
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls, cons
         if (l == ls.L - 1) {
             mg_jacobi_cells(v.mask, v.H, v.W, v.s, nullptr, v.r, v.z, t, nt);
             __syncthreads();
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < USC_RF_COARSE_PAIRS; k++) {
                 mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.z, v.r, v.zt, t, nt);
                 __syncthreads();
                 mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, t, nt);
