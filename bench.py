@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-single-thread", action="store_true", help="skip the one-frame single-thread leg of the CPU baseline")
     ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--no-interleave", action="store_true", help="skip the opt-in `interleaved_shards` figure (two sub-ranges per matting forward)")
     ap.add_argument("--no-spin-up", action="store_true", help="skip the untimed clock spin-up in front of the warm-up frames (counter-collecting profile runs)")
     ap.add_argument("--sync-loop", action="store_true", help="use the synchronous step() instead of the pipelined run()")
     ap.add_argument("--cpu-frames", type=int, default=5)
@@ -789,6 +790,32 @@ def main():
             result["host_object_filter"] = {"value": round(K / t1, 2), "unit": "frames/s",
                                             "note": "same loop and boundary as `value` with remove_invalid_objects on two host worker threads"}
             pipe.object_filter, pipe._filter_choice = chosen_f, chosen_c
+        if world == 1 and not args.sync_loop and args.net == "hip" and K % 2 == 0 and K >= 2 * pipe.seg_batch and not args.no_interleave:
+            # Opt-in figure, never `value`: this GPU's range cut into TWO contiguous sub-ranges - independent by the reference's own --range
+            # semantics (tools/unscreen/bg_offline.py:34-35, 184-192: each starts its alpha_pre chain afresh) - whose frames share every
+            # matting forward (usc_conv_desc.batch = 2, planned as for one image: each sub-range gets the bits run() gives it on its own,
+            # tests/test_gpu_hostio.py).  It measures how much of the frame is launch granularity; the frames right after the cut differ
+            # from a run over the whole range, as they do between any two --range runs.  Inputs resident in HBM.
+            pipe2 = BgStepPipeline(cfg, H, W, device=dev, state_dict=sd, net_backend=args.net, seg_agent=seg_agent, seg_batch=pipe.seg_batch,
+                                   object_filter=args.object_filter, interleave=2)
+            half = K // 2
+            ra, rb = frames[first:first + half], frames[first + half:first + K]
+
+            def run2():
+                pipe2.reset()
+                pipe2.run_interleaved(iter(ra), iter(rb))
+            for _ in range(2):
+                run2()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run2()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter() - t0
+            result["interleaved_shards"] = {"value": round(K / t2, 2), "unit": "frames/s", "ranges": 2,
+                                            "note": "NOT the headline: two contiguous sub-ranges of this GPU's frames (independent alpha_pre chains, as two "
+                                                    "--range runs of the reference) share every matting forward; inputs in HBM; compare with `device_resident`"}
+            del pipe2
+            torch.cuda.empty_cache()
         if world == 1 and host_io and not args.sync_loop:
             # not timed: the host -> host loop must deliver the bytes of the loop over HBM-resident inputs (copy streams, the download
             # thread and the side streams may not overtake each other into buffers still in use) - two segmentation groups and a

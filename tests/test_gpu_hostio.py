@@ -170,3 +170,43 @@ def test_slow_reader_small_rings_and_a_consumer_that_never_reports():
     with pytest.raises(RuntimeError, match="depth 6 is smaller"):
         pipe.run(io2.inputs(groups, clip.bg_always))            # nobody marks a staging slot free
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("with_seg,K", [(False, 7), (True, 9)])
+def test_interleaved_ranges_equal_the_ranges_run_on_their_own(with_seg, K):
+    """BgStepPipeline(interleave=2).run_interleaved: two independent frame ranges (two sub-ranges of a shard, each its own alpha_pre chain
+    like two of the reference's --range runs: tools/unscreen/bg_offline.py:34-35, 184-192) share every matting forward - and every frame
+    of either range has the bits run() gives that range on its own (the batch-2 network is planned as for one image)."""
+    from video_unscreen_amd.pipeline import BgStepPipeline, default_config
+    from video_unscreen_amd.vmatting.net import synthetic_state_dict
+    H, W = 270, 480
+    seg_agent = None
+    if with_seg:
+        from video_unscreen_amd.binseg import HumanSegAgent
+        from video_unscreen_amd.binseg.schp_net import schp_synthetic_state_dict
+        seg_agent = HumanSegAgent(model_path=None, cuda_device=0, state_dict=schp_synthetic_state_dict(0))
+    clip, fr = _clip(H, W, 2 * K)
+    items = [(f["frame"], None if with_seg else f["seg"], f["bg"], clip.bg_always) for f in fr]
+    ranges = (items[:K], items[K:])
+    single = BgStepPipeline(default_config(), H, W, state_dict=synthetic_state_dict(0), seg_agent=seg_agent, seg_batch=4 if with_seg else 1)
+    want = []
+    for rg in ranges:
+        single.reset()
+        got = []
+        single.run(iter(rg), on_result=lambda n, o: got.append((o["alpha"].clone(), o["fg"].clone())))
+        torch.cuda.synchronize()
+        want.append(got)
+    pair = BgStepPipeline(default_config(), H, W, state_dict=synthetic_state_dict(0), seg_agent=seg_agent, seg_batch=4 if with_seg else 1, interleave=2)
+    res = {}
+    n = pair.run_interleaved(iter(ranges[0]), iter(ranges[1]), on_result=lambda lane, i, o: res.__setitem__((lane, i), (o["alpha"].clone(), o["fg"].clone())))
+    torch.cuda.synchronize()
+    assert n == 2 * K and len(res) == 2 * K
+    for lane in (0, 1):
+        for i in range(K):
+            assert torch.equal(res[(lane, i)][0], want[lane][i][0]) and torch.equal(res[(lane, i)][1], want[lane][i][1]), (lane, i)
+    # the plain loop of the same pipeline object is untouched by the second network
+    pair.reset()
+    again = []
+    pair.run(iter(ranges[0]), on_result=lambda n, o: again.append(o["alpha"].clone()))
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, w[0]) for a, w in zip(again, want[0]))

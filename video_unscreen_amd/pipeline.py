@@ -61,7 +61,7 @@ class _Slot:
 
 class BgStepPipeline:
     def __init__(self, cfg, H, W, device="cuda:0", dtype=torch.float32, state_dict=None, net_backend="hip",
-                 seg_agent=None, seg_batch=1, object_filter="auto"):
+                 seg_agent=None, seg_batch=1, object_filter="auto", interleave=1):
         """seg_agent: optional HumanSegAgent.  When given, the coarse segmentation mask of every frame is computed on
         the device (reference bg_offline.py:63 `segagent.forward(frame)`, the untracked branch of stage 1) instead of
         being read from the caller; it runs in the front half, concurrently with the previous frame's matting net.
@@ -74,6 +74,9 @@ class BgStepPipeline:
         337 frames/s all on the device against 324 with the host stage), and it leaves no CPU thread in the per-rank loop."""
         self.cfg = cfg
         self.H, self.W = H, W
+        if interleave not in (1, 2):
+            raise ValueError("interleave: 1 (one frame range) or 2 (two independent frame ranges through one matting forward)")
+        self.interleave = interleave
         self._enqueue_lock = threading.Lock()
         self.device = torch.device(device)
         nv.load()
@@ -108,6 +111,9 @@ class BgStepPipeline:
             self.net = HipMattingNet(self._sd, self.in_h, self.in_w, device=dev)
             self.x7 = self.net.x8
             self._layout = nv.NHWC8
+            # interleave = 2 (run_interleaved): two images per set of launches - planned as for one image, so each image gets the bits the
+            # single-image network gives it (usc_conv_desc.batch / plan_batch)
+            self.net2 = HipMattingNet(self._sd, self.in_h, self.in_w, device=dev, batch=2) if interleave == 2 else None
         elif net_backend == "miopen":     # the same plan through PyTorch-ROCm / MIOpen
             self.net = MattingNet(self._sd, device=dev, dtype=dtype)
             self.x7 = torch.empty((1, 7, self.in_h, self.in_w), dtype=torch.float32, device=dev,
@@ -115,7 +121,9 @@ class BgStepPipeline:
             self._layout = nv.NHWC
         else:
             raise ValueError(f"unknown net_backend {net_backend!r}")
-        self.slots = [_Slot(H, W, dev) for _ in range(3)]
+        if interleave == 2 and net_backend != "hip":
+            raise ValueError("interleave = 2 needs the HIP conv path")
+        self.slots = [_Slot(H, W, dev) for _ in range(3 * interleave)]
         self.seg_agent = seg_agent
         self.seg_batch = max(1, int(seg_batch))
         if seg_agent is not None and hasattr(seg_agent, "set_plan_batch"):
@@ -132,7 +140,7 @@ class BgStepPipeline:
         self._out_ring = [{"alpha": self._out_buf[i, :H * W].view(H, W), "fg": self._out_buf[i, fg_off:fg_off + 3 * H * W].view(H, W, 3),
                            "packed": self._out_buf[i], "consumed": None} for i in range(8)]
         self._out_i = 0
-        self.alpha_pre = None
+        self._alpha = [None, None]                            # alpha_pre of the frame range(s): index = lane (one lane unless run_interleaved)
 
     def cpu_net(self):
         """The same folded plan on the CPU in float32 (used by tests / smoke as the network's oracle)."""
@@ -140,8 +148,16 @@ class BgStepPipeline:
             self._cpu_net = MattingNet(self._sd, device="cpu", dtype=torch.float32)
         return self._cpu_net
 
+    @property
+    def alpha_pre(self):
+        return self._alpha[0]
+
+    @alpha_pre.setter
+    def alpha_pre(self, value):
+        self._alpha[0] = value
+
     def reset(self):
-        self.alpha_pre = None
+        self._alpha = [None, None]
 
     # ------------------------------------------------------------------ stages
     def _front_device(self, slot, frame, seg, bg_i, bg_always, seg_ready=False):
@@ -169,10 +185,22 @@ class BgStepPipeline:
             nv.trimap(slot.alphaor, self.long_side, self.ksize, self.iters, out=slot.trimap, ws=self.ws_trimap)
             slot.ready.record()
 
-    def _back(self, slot, frame, want_float=False):
-        alpha_pre = self.alpha_pre if self.alpha_pre is not None else slot.gate       # bg_offline.py:162-163
+    def _back(self, slot, frame, want_float=False, lane=0):
+        alpha_pre = self._alpha[lane] if self._alpha[lane] is not None else slot.gate       # bg_offline.py:162-163
         nv.vmat_pre(frame, alpha_pre, slot.trimap, self.in_h, self.in_w, layout=self._layout, out=self.x7)
         pred = self.net(self.x7)
+        return self._post(slot, frame, pred, want_float, lane)
+
+    def _back2(self, slot_a, slot_b):
+        """The back halves of one frame of each of two independent frame ranges with ONE matting forward over both (run_interleaved)."""
+        h = self.in_h
+        for lane, slot in ((0, slot_a), (1, slot_b)):
+            alpha_pre = self._alpha[lane] if self._alpha[lane] is not None else slot.gate
+            nv.vmat_pre(slot.frame, alpha_pre, slot.trimap, self.in_h, self.in_w, layout=self._layout, out=self.net2.x8[lane * h:(lane + 1) * h])
+        pred = self.net2()
+        return [self._post(slot, slot.frame, pred[lane], False, lane) for lane, slot in ((0, slot_a), (1, slot_b))]
+
+    def _post(self, slot, frame, pred, want_float, lane):
         ring = self._out_ring[self._out_i % len(self._out_ring)]
         self._out_i += 1
         if ring["consumed"] is not None:                   # a reader on another stream (note_output_consumed) has finished
@@ -185,7 +213,7 @@ class BgStepPipeline:
         # postprocess + bg[alpha == 0] = frame[alpha == 0] + get_fg (bg_offline.py:165-173) as one launch
         alpha, alpha_f, fg = nv.vmat_post_fg(pred.view(self.in_h, self.in_w), slot.trimap, frame, slot.bg, paste_thr=1,
                                              out_u8=ring["alpha"], out_fg=ring["fg"], want_float=want_float)
-        self.alpha_pre = alpha
+        self._alpha[lane] = alpha
         return {"alpha": alpha, "alpha_f32": alpha_f, "fg": fg, "trimap": slot.trimap, "bg": slot.bg,
                 "gate": slot.gate, "alphaor": slot.alphaor, "pred": pred, "seg": slot.seg, "packed": ring["packed"], "_ring": ring}
 
@@ -217,7 +245,29 @@ class BgStepPipeline:
         finally:
             self.object_filter = chosen
 
-    def _run(self, inputs, on_result):
+    def run_interleaved(self, inputs_a, inputs_b, on_result=None):
+        """Two INDEPENDENT frame ranges of equal length (two sub-ranges of this GPU's shard: each starts its own alpha_pre chain, exactly
+        like two of the reference's --range runs, tools/unscreen/bg_offline.py:34-35, 184-192) through the same pipelined loop, frame i of
+        both ranges in one matting forward (interleave = 2 at construction).  on_result(lane, i, out).  Every frame of a range gets
+        the bits BgStepPipeline.run() gives that range on its own; what is gained is launch granularity only (tools/dev/batch2_probe.py:
+        6 % of the matting forward).  Returns the number of frames processed (both ranges)."""
+        if self.interleave != 2:
+            raise ValueError("run_interleaved needs BgStepPipeline(..., interleave=2)")
+        if self.seg_agent is not None and self.seg_batch < 4:
+            raise ValueError("run_interleaved with a segmentation agent needs seg_batch >= 4 (four frames wait between gate and matting net)")
+
+        def alternate():
+            for a, b in zip(inputs_a, inputs_b):
+                yield a
+                yield b
+        chosen = self.object_filter
+        try:
+            cb = (lambda n, out: on_result(n & 1, n >> 1, out)) if on_result is not None else None
+            return self._run(alternate(), cb, lanes=2)
+        finally:
+            self.object_filter = chosen
+
+    def _run(self, inputs, on_result, lanes=1):
         main = torch.cuda.current_stream(self.device)
         # the pipeline's side streams live as long as it does: the conv graphs are instantiated once per stream they run on
         if getattr(self, "_front_stream", None) is None:
@@ -292,7 +342,7 @@ class BgStepPipeline:
 
             nxt = None
             while True:
-                while (ahead or nxt or not state["exhausted"]) and len(pending) < 2:
+                while (ahead or nxt or not state["exhausted"]) and len(pending) < 2 * lanes:
                     if not ahead:
                         if batched:
                             ahead = nxt if nxt is not None else launch_group()
@@ -329,19 +379,23 @@ class BgStepPipeline:
                     submitted += 1
                 if not pending:
                     break
-                slot = pending.pop(0)
-                if not on_device:
-                    slot.host_done.wait()
-                if err:
-                    raise err[0]
-                main.wait_event(slot.ready)
-                out = self._back(slot, slot.frame)
-                if on_result is not None:
-                    on_result(n, out)
-                slot.released.record(main)                  # behind whatever on_result enqueued on this stream
-                if slot.mset is not None:
-                    self._seg_set_done[slot.mset].record(main)
-                n += 1
+                if lanes == 2 and len(pending) < 2 and (ahead or nxt or not state["exhausted"]):
+                    continue                                # (the partner frame of the other range is still to be submitted)
+                group = [pending.pop(0) for _ in range(min(lanes, len(pending)))]
+                for slot in group:
+                    if not on_device:
+                        slot.host_done.wait()
+                    if err:
+                        raise err[0]
+                    main.wait_event(slot.ready)
+                outs = self._back2(*group) if len(group) == 2 else [self._back(group[0], group[0].frame, lane=n % lanes)]
+                for slot, out in zip(group, outs):
+                    if on_result is not None:
+                        on_result(n, out)
+                    slot.released.record(main)              # behind whatever on_result enqueued on this stream
+                    if slot.mset is not None:
+                        self._seg_set_done[slot.mset].record(main)
+                    n += 1
         finally:
             for th in workers:
                 work.put(None)

@@ -103,10 +103,15 @@ def convt_phase_taps(w, py, px):
 
 
 class HipMattingNet:
-    def __init__(self, state_dict, in_h, in_w, device="cuda:0", use_graph=True, merge_stage_entry=True):
+    def __init__(self, state_dict, in_h, in_w, device="cuda:0", use_graph=True, merge_stage_entry=True, batch=1):
         """merge_stage_entry: a ResNet stage's first 3x3 / stride-2 conv and its AvgPool + 1x1 shortcut as ONE two-output launch (51 instead
-        of 54 launches per forward; False: the three shortcut convs as launches of their own, as in rounds 1 - 3)."""
+        of 54 launches per forward; False: the three shortcut convs as launches of their own, as in rounds 1 - 3).
+        batch > 1: that many independent images per forward, stacked along y in x8 / pred (usc_conv_desc.batch, planned as for one image:
+        bit-identical per-image results).  The four-phase transposed layers and the head do not take a batch: they are launched once per
+        image.  (A measurement aid - tools/dev/batch2_probe.py: within a frame range the matting net cannot be batched, alpha_pre
+        chains the frames.)"""
         self.merge_stage_entry = merge_stage_entry
+        self.batch = max(1, int(batch))
         if in_h % 32 or in_w % 32:
             raise ValueError("HipMattingNet: input size must be a multiple of 32 (vmatting/agent.py:38-42 guarantees it)")
         self.device = torch.device(device)
@@ -146,7 +151,7 @@ class HipMattingNet:
         return t
 
     def _buf(self, h, w, c):
-        t = torch.empty((h, w, c), dtype=torch.float32, device=self.device)
+        t = torch.empty((self.batch * h, w, c), dtype=torch.float32, device=self.device)
         self._keep.append(t)
         return t
 
@@ -195,7 +200,24 @@ class HipMattingNet:
         d.res1_shift, d.act, d.ntaps, d.kind = res1_shift, ACT[act], len(taps), kind
         for i, (dy, dx) in enumerate(taps_all):
             d.dy[i], d.dx[i] = dy, dx
-        self._descs.append(d)
+        B = self.batch
+        if B == 1:
+            self._descs.append(d)
+        elif phases is None and kind == 0:                      # the kernels stack the images along y
+            d.batch, d.plan_batch = B, 1
+            d.OH, d.OHf = B * d.OH, B * d.OHf
+            self._descs.append(d)
+        else:                                                   # one launch per image, pointers moved to the image
+            ohf, owf = d.OHf, d.OWf
+            for b in range(B):
+                e = ConvDesc.from_buffer_copy(bytes(d))
+                e.inp = d.inp + b * IH * IW * Cin * 4
+                e.out = d.out + b * ohf * owf * Cout * 4
+                if res2 is not None:
+                    e.res2 = d.res2 + b * ohf * owf * Cout * 4
+                if res1 is not None:
+                    e.res1 = d.res1 + b * (ohf >> res1_shift) * (owf >> res1_shift) * Cout * 4
+                self._descs.append(e)
 
     def _conv(self, c, x, IH, IW, out=None, **kw):
         """Plain Conv2d from the folded plan (net.Conv): 3x3 s1/s2 pad 1 or 1x1."""
@@ -281,7 +303,7 @@ class HipMattingNet:
             y = self._conv(b1["conv1"], t, h, w)
             t = self._conv(b1["conv2"], y, h, w, res1=t, act="leaky", res2=skip)
         t = self._convt(p["head_up"], t, h, w, res2=fea[0])
-        self.pred = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
+        self.pred = torch.empty((self.batch, 1, H, W), dtype=torch.float32, device=self.device)
         hw = p["head"].w                                         # (1, 32, 3, 3)
         taps, wk = conv_taps(hw, 1)
         self._add(t, self.pred, taps, wk, p["head"].b, H, W, hw.shape[1], H, W, 1, kind=1)
@@ -295,7 +317,7 @@ class HipMattingNet:
         """x8: (H, W, 8) float32 NHWC (channel 7 zero) - or None when the caller wrote self.x8 directly.
         Returns self.pred, (1, 1, H, W)."""
         if x8 is not None and x8.data_ptr() != self.x8.data_ptr():
-            self.x8.copy_(x8.view(self.H, self.W, 8))
+            self.x8.copy_(x8.view(self.batch * self.H, self.W, 8))
         st = torch.cuda.current_stream().cuda_stream
         if self._graph:
             rc = nv.load().usc_conv_graph_launch(self._graph, st)
