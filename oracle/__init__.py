@@ -192,6 +192,16 @@ def resize_cubic(img, dh, dw):
     return out
 
 
+def resize_cubic_fxfy(img, fx, fy):
+    """cv2.resize(img, None, fx=fx, fy=fy, interpolation=cv2.INTER_CUBIC) on uint8: dsize = round(size * f), coordinates mapped with 1 / f."""
+    img, p = _u8(img)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    dh, dw = int(round(img.shape[0] * fy)), int(round(img.shape[1] * fx))
+    out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
+    lib().orc_resize_cubic_fxfy_u8(p, img.shape[0], img.shape[1], cn, out.ctypes.data_as(u8p), dh, dw, C.c_double(fx), C.c_double(fy))
+    return out
+
+
 def rescale_fg(img, scale_factor=1.1):
     """imgprocess.py:40-52."""
     img, p = _u8(img)

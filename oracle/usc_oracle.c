@@ -249,6 +249,13 @@ ORC_API void orc_resize_cubic_u8(const uint8_t* src, int sh, int sw, int cn, uin
     orc_resize_cubic_scaled(src, sh, sw, cn, dst, dh, dw, 0., 0.);
 }
 
+/* cv2.resize(src, None, fx=fx, fy=fy, interpolation=cv2.INTER_CUBIC): dsize = (round(sw fx), round(sh fy)) chosen by the caller, the
+ * coordinate map uses fx / fy themselves. */
+ORC_API void orc_resize_cubic_fxfy_u8(const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw, double fx, double fy)
+{
+    orc_resize_cubic_scaled(src, sh, sw, cn, dst, dh, dw, fx, fy);
+}
+
 /* unscreen/utils/imgprocess.py:40-52 rescale_fg: cv2.resize(img, None, fx=s, fy=s, INTER_CUBIC) (dsize = round(size*s); the
  * coordinate map uses 1 / s itself, which differs from old / new whenever size * s is not an integer),
  * then the centre crop back to the original size (offsets int((new - old) / 2)). */

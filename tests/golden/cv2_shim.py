@@ -28,10 +28,12 @@ def _log(name, detail=""):
 
 def resize(src, dsize, dst=None, fx=0, fy=0, interpolation=INTER_LINEAR):
     """cv2.resize(src, dsize[, dst[, fx[, fy[, interpolation]]]]): a third POSITIONAL argument is `dst`, not the interpolation."""
-    if dsize is None:
-        # (cv::resize maps coordinates with fx / fy themselves in this form; every call of the reference that reaches this branch
-        # - rescale_fg - goes through oracle.rescale_fg in the chains, which does the same)
-        dsize = (int(round(src.shape[1] * fx)), int(round(src.shape[0] * fy)))
+    if dsize is None or tuple(dsize) == (0, 0):
+        # cv::resize maps coordinates with fx / fy themselves in this form (and derives dsize from them); the one call of the reference
+        # that reaches this branch on uint8 is rescale_fg (imgprocess.py:47, INTER_CUBIC)
+        assert src.dtype == np.uint8 and interpolation == INTER_CUBIC, "resize(fx, fy): only the uint8 cubic form of rescale_fg"
+        _log("resize", f"{src.dtype} {src.shape[:2]} fx={fx} fy={fy} interp={interpolation}")
+        return oracle.resize_cubic_fxfy(np.ascontiguousarray(src), float(fx), float(fy))
     dw, dh = int(dsize[0]), int(dsize[1])
     _log("resize", f"{src.dtype} {src.shape[:2]} -> {(dh, dw)} interp={interpolation}")
     if src.dtype == np.uint8:
@@ -40,6 +42,14 @@ def resize(src, dsize, dst=None, fx=0, fy=0, interpolation=INTER_LINEAR):
     if src.dtype in (np.float32, np.float64) and interpolation == INTER_LINEAR:
         return oracle.resize_linear(np.ascontiguousarray(src), dh, dw)
     raise NotImplementedError(f"cv2_shim.resize: {src.dtype} {src.shape} interpolation {interpolation}")
+
+
+def warpAffine(src, M, dsize, dst=None, flags=INTER_LINEAR, borderMode=0, borderValue=0):
+    """cv2.warpAffine(img, M, (w, h)): INTER_LINEAR, BORDER_CONSTANT 0 - the form shift_fg uses (imgprocess.py:63); M as the caller built it
+    (float32 there), read as double by OpenCV."""
+    assert flags == INTER_LINEAR and borderMode == 0 and borderValue == 0 and src.dtype == np.uint8
+    _log("warpAffine", f"{src.shape[:2]} -> {(dsize[1], dsize[0])}")
+    return oracle.warp_affine(np.ascontiguousarray(src), np.asarray(M, np.float64), int(dsize[1]), int(dsize[0]))
 
 
 def copyMakeBorder(src, top, bottom, left, right, borderType, dst=None, value=None):

@@ -136,12 +136,13 @@ def test_gray_moments_pair_exact(oracle_lib, H, W):
         assert (cx, cy) == tuple(oracle_lib.get_center(img))
 
 
-def test_replace_host_loop_equals_tool_flow(oracle_lib):
+@pytest.mark.parametrize("H,W", [(136, 240), (61, 93)])
+def test_replace_host_loop_equals_tool_flow(oracle_lib, H, W):
     """ReplaceHostLoop (pinned host -> pinned host, packed uploads, target masks kept in HBM between the passes) on 6 frames: the
     correspondence mean and every side-by-side image equal the oracle's comp_dx_dy + per-frame chain, for packed pairs and for
     (a, b) tuples with a source of another size."""
     from video_unscreen_amd.pipeline_replace import ReplaceHostLoop, ReplacePipeline, pack_pair
-    H, W, n = 136, 240, 6
+    n = 6                                            # (61 x 93: images of a packed stack start at odd byte addresses - the kernels' byte paths)
     for sh, sw in ((H, W), (90, 150)):
         frames = []
         for t in range(n):
@@ -174,3 +175,25 @@ def test_replace_host_loop_equals_tool_flow(oracle_lib):
             loop4.pass2(pack_clip([(t_(fg), t_(fr)) for fg, _, fr, _ in frames]), M, cmp4)
             torch.cuda.synchronize()
             assert torch.equal(cmp4, compare_h)
+
+
+def test_replace_loop_matches_reference_python_golden():
+    """The device loop against tests/golden/replace_loop.npz - outputs of the reference's OWN tools/replace/replace.py (comp_dx_dy and the
+    frame loop lifted with ast, run over its own imgprocess.py on the cv2 shim: tests/golden/gen_replace.py): the correspondence mean and
+    every res / compare image bit for bit, through ReplaceHostLoop (pinned host -> pinned host) with a source of another size."""
+    from video_unscreen_amd.pipeline_replace import ReplaceHostLoop, ReplacePipeline
+    z = np.load(os.path.join(ROOT, "tests", "golden", "replace_loop.npz"))
+    n = sum(1 for k in z.files if k.startswith("res_"))
+    H, W = z["tgt_fg_0"].shape[:2]
+    sh, sw = z["src_frame_0"].shape[:2]
+    pipe = ReplacePipeline(H, W, dev(z["bg"]), max_frames=n)
+    loop = ReplaceHostLoop(pipe, n, src_hw=(sh, sw), ring=2)
+    t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory()          # noqa: E731
+    sx, sy, cnt = loop.pass1([(t_(z[f"tgt_mask_{t}"]), t_(z[f"src_mask_{t}"])) for t in range(n)])
+    assert [sx / cnt, sy / cnt] == z["dx_dy_mean"].tolist()
+    compare_h = torch.zeros((n, H, 2 * W, 3), dtype=torch.uint8).pin_memory()
+    loop.pass2([(t_(z[f"tgt_fg_{t}"]), t_(z[f"src_frame_{t}"])) for t in range(n)], pipe.shift_matrix(sx / cnt, sy / cnt), compare_h)
+    torch.cuda.synchronize()
+    for t in range(n):
+        assert np.array_equal(compare_h[t].numpy(), z[f"compare_{t}"]), t
+        assert np.array_equal(compare_h[t, :, W:].numpy(), z[f"res_{t}"]), t

@@ -159,3 +159,30 @@ def test_bg_offline_frame_loop(oracle_lib, z, gcfg):
         fg, _ = oracle_lib.get_fg(z["loop_frames"][t], z["loop_alpha"][t], want["bg"], paste_thr=1)
         assert np.array_equal(fg, z["loop_fg"][t]), t
         alpha_pre = z["loop_alpha"][t]           # both chains continue from the reference's alpha
+
+
+def test_replace_loop_oracle_chain_matches_reference_python(oracle_lib):
+    """tests/golden/replace_loop.npz = the reference's own tools/replace/replace.py (comp_dx_dy :28-41 and the frame loop :59-82, lifted
+    with ast) over its own imgprocess.py, run on the cv2 shim (gen_replace.py).  The oracle chain the GPU tests use as their checker -
+    get_center of both masks, the float32 shift matrix, shift before zoom, the float64 blend, the background resized once, the
+    concatenation - must reproduce it bit for bit: this pins the ORDER and the arguments, not OpenCV's interior."""
+    z = np.load(os.path.join(os.path.dirname(GOLD), "replace_loop.npz"))
+    n = sum(1 for k in z.files if k.startswith("res_"))
+    assert n == 3 and bytes(z["cv2_calls_reached"]).decode().split(",") == ["cvtColor", "moments", "resize", "warpAffine"]
+    H, W = z["tgt_fg_0"].shape[:2]
+    dxs, dys = [], []
+    for t in range(n):
+        dc = oracle_lib.get_center(z[f"tgt_mask_{t}"])
+        sc = oracle_lib.get_center(oracle_lib.resize_linear(z[f"src_mask_{t}"], H, W))
+        dxs.append(sc[0] - dc[0])
+        dys.append(sc[1] - dc[1])
+    dx, dy = float(np.mean(dxs)), float(np.mean(dys))
+    assert [dx, dy] == z["dx_dy_mean"].tolist()
+    bg = oracle_lib.resize_linear(z["bg"], H, W)
+    M = np.float32([[1, 0, dx], [0, 1, dy]]).astype(np.float64)
+    for t in range(n):
+        fs = oracle_lib.rescale_fg(oracle_lib.warp_affine(z[f"tgt_fg_{t}"], M, H, W), 1.2)
+        ms = oracle_lib.rescale_fg(oracle_lib.warp_affine(z[f"tgt_mask_{t}"], M, H, W), 1.2)
+        res = oracle_lib.blend(fs, ms, bg)
+        assert np.array_equal(res, z[f"res_{t}"]), t
+        assert np.array_equal(np.concatenate((oracle_lib.resize_linear(z[f"src_frame_{t}"], H, W), res), axis=1), z[f"compare_{t}"]), t

@@ -102,14 +102,18 @@ __global__ __launch_bounds__(256) void imnormalize_kernel(uint8_t* __restrict__ 
 // first version's 4096 workgroups spent 25 us on them at 1080p).
 constexpr int kMomBlocks = 256;
 __global__ __launch_bounds__(256) void gray_moments_kernel(const uint8_t* __restrict__ img0, const uint8_t* __restrict__ img1, int H, int W, int rgb_order, int thr,
-                                                           uint8_t* __restrict__ mask, unsigned long long* __restrict__ mom) {
+                                                           uint8_t* __restrict__ mask, unsigned long long* __restrict__ mom, int aligned) {
     const uint8_t* __restrict__ img = blockIdx.y ? img1 : img0;
     if (mom) mom += 3 * blockIdx.y;
     const uint32_t n = (uint32_t)H * (uint32_t)W, nq = n / 4;
     unsigned long long m00 = 0, m10 = 0, m01 = 0;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
         int c[12];
-        unpack12(*reinterpret_cast<const Px4*>(img + 12 * (size_t)q), c);
+        if (aligned) unpack12(*reinterpret_cast<const Px4*>(img + 12 * (size_t)q), c);
+        else {                                                      // (image k of a packed stack of odd-sized images: any byte address)
+#pragma unroll
+            for (int k = 0; k < 12; k++) c[k] = img[12 * (size_t)q + k];
+        }
         uint32_t y = (4 * q) / (uint32_t)W, x = 4 * q - y * (uint32_t)W;
         uint32_t s0 = 0, s1 = 0, s2 = 0, mk = 0;
 #pragma unroll
@@ -119,7 +123,10 @@ __global__ __launch_bounds__(256) void gray_moments_kernel(const uint8_t* __rest
             s0 += g; s1 += x * g; s2 += y * g;                     // < 4 * 255 * 2^15: 32 bits hold a quad's sums (too_big() bounds H W)
             if (++x >= (uint32_t)W) { x = 0; y++; }
         }
-        if (mask) *reinterpret_cast<uint32_t*>(mask + 4 * (size_t)q) = mk;
+        if (mask) {
+            if (aligned) *reinterpret_cast<uint32_t*>(mask + 4 * (size_t)q) = mk;
+            else { mask[4 * (size_t)q] = (uint8_t)mk; mask[4 * (size_t)q + 1] = (uint8_t)(mk >> 8); mask[4 * (size_t)q + 2] = (uint8_t)(mk >> 16); mask[4 * (size_t)q + 3] = (uint8_t)(mk >> 24); }
+        }
         m00 += s0; m10 += s1; m01 += s2;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {                // the last n % 4 pixels
@@ -197,7 +204,8 @@ static int launch_moments(const uint8_t* a, const uint8_t* b, int H, int W, int 
     const size_t nq = ((size_t)H * W) / 4;
     int blocks = (int)((nq + 255) / 256);
     blocks = blocks < 1 ? 1 : (blocks > kMomBlocks ? kMomBlocks : blocks);
-    hipLaunchKernelGGL(gray_moments_kernel, dim3(blocks, images), dim3(256), 0, st, a, b, H, W, rgb_order, thr, mask, mom);
+    const int aligned = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)mask) & 3) == 0;
+    hipLaunchKernelGGL(gray_moments_kernel, dim3(blocks, images), dim3(256), 0, st, a, b, H, W, rgb_order, thr, mask, mom, aligned);
     return check_launch("gray_moments_kernel");
 }
 
@@ -205,7 +213,6 @@ extern "C" int usc_gray_moments_u8(const uint8_t* img, int H, int W, int rgb_ord
                                    usc_stream_t stream) {
     if (!img || H <= 0 || W <= 0 || (!mask && !moments3)) return fail(USC_E_ARG, "usc_gray_moments_u8: bad argument");
     if (too_big(H, W)) return fail(USC_E_UNSUPPORTED, "usc_gray_moments_u8: image too large");
-    if ((((uintptr_t)img | (uintptr_t)mask) & 3) != 0) return fail(USC_E_ARG, "usc_gray_moments_u8: img and mask must be 4-byte aligned");
     return launch_moments(img, nullptr, H, W, rgb_order, thr, mask, moments3, (hipStream_t)stream);
 }
 
@@ -213,6 +220,5 @@ extern "C" int usc_gray_moments_pair_u8(const uint8_t* img_a, const uint8_t* img
                                         usc_stream_t stream) {
     if (!img_a || !img_b || !moments6 || H <= 0 || W <= 0) return fail(USC_E_ARG, "usc_gray_moments_pair_u8: bad argument");
     if (too_big(H, W)) return fail(USC_E_UNSUPPORTED, "usc_gray_moments_pair_u8: image too large");
-    if ((((uintptr_t)img_a | (uintptr_t)img_b) & 3) != 0) return fail(USC_E_ARG, "usc_gray_moments_pair_u8: images must be 4-byte aligned");
     return launch_moments(img_a, img_b, H, W, rgb_order, 0, nullptr, moments6, (hipStream_t)stream);
 }

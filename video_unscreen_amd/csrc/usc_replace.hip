@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void replace_compose_kernel(const uint8_t* __r
                                                               double scale_y, double scale_x, int h_off, int w_off,
                                                               const uint8_t* __restrict__ bg, const uint8_t* __restrict__ src, int sh, int sw,
                                                               int src_mode, double src_sy, double src_sx,
-                                                              uint8_t* __restrict__ res, uint8_t* __restrict__ cmp) {
+                                                              uint8_t* __restrict__ res, uint8_t* __restrict__ cmp, int aligned) {
     __shared__ uint2 s_px[kWH * kWW];
     __shared__ double s_m[256];
     const int tiles_x = (W + kTW - 1) / kTW;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void replace_compose_kernel(const uint8_t* __r
     const int y = ty0 + (int)(threadIdx.x >> 4), xq = tx0 + 4 * (int)(threadIdx.x & 15);
     if (y > ty1 || xq > tx1) return;
     const int npx = min(4, tx1 - xq + 1);
-    const bool quad = npx == 4 && (W & 3) == 0;       // 12-byte packed accesses (rows are dword-aligned when W % 4 == 0)
+    const bool quad = npx == 4 && (W & 3) == 0 && aligned;       // 12-byte packed accesses (dword-aligned tensors whose rows are dword-aligned: W % 4 == 0)
     const uint32_t p0 = (uint32_t)y * (uint32_t)W + (uint32_t)xq;
     int bgv[12], sv[12];
     if (quad) {                                        // issued before the taps are read: in flight during the arithmetic
@@ -211,7 +211,7 @@ extern "C" int usc_replace_compose_u8(const uint8_t* fg, const uint8_t* mask, in
         return fail(USC_E_ARG, "usc_replace_compose_u8: bad argument (scale >= 1, at least one output)");
     if (compare && (!src || sh <= 0 || sw <= 0)) return fail(USC_E_ARG, "usc_replace_compose_u8: the side-by-side output needs the source frame");
     if ((long long)H * W * 6 >= (1ll << 32) || (src && too_big(sh, sw))) return fail(USC_E_UNSUPPORTED, "usc_replace_compose_u8: image too large (32-bit byte offsets)");
-    if ((((uintptr_t)bg | (uintptr_t)res | (uintptr_t)compare | (uintptr_t)src) & 3) != 0) return fail(USC_E_ARG, "usc_replace_compose_u8: bg, src and the outputs must be 4-byte aligned");
+    const int aligned = (((uintptr_t)bg | (uintptr_t)res | (uintptr_t)compare | (uintptr_t)src) & 3) == 0;      // else byte accesses (e.g. image k of a packed stack of odd-sized images)
     Affine A;
     invert_affine(M2x3_host, A.m);
     // rescale_fg (imgprocess.py:46-51): cv2.resize(fx = fy = scale, INTER_CUBIC) -> size = round(h * scale), then the centre crop
@@ -224,9 +224,9 @@ extern "C" int usc_replace_compose_u8(const uint8_t* fg, const uint8_t* mask, in
     const int tiles = ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
     if (mask_cn == 3)
         hipLaunchKernelGGL(replace_compose_kernel<3>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, fg, mask, H, W, A, rz.scale_y, rz.scale_x, h_off, w_off,
-                           bg, src, sh, sw, rs.mode, rs.scale_y, rs.scale_x, res, compare);
+                           bg, src, sh, sw, rs.mode, rs.scale_y, rs.scale_x, res, compare, aligned);
     else
         hipLaunchKernelGGL(replace_compose_kernel<1>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, fg, mask, H, W, A, rz.scale_y, rz.scale_x, h_off, w_off,
-                           bg, src, sh, sw, rs.mode, rs.scale_y, rs.scale_x, res, compare);
+                           bg, src, sh, sw, rs.mode, rs.scale_y, rs.scale_x, res, compare, aligned);
     return check_launch("replace_compose_kernel");
 }
