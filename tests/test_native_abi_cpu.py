@@ -80,8 +80,9 @@ def test_argument_errors_are_reported(nv):
     assert lib.usc_pack_kn_f32(1, 8, 8, 1, 8, 40, 32, 2, None) == -1                                         # Kpad % 32
     assert lib.usc_box_filter_u8(1, 8, 8, 1, 17, 2, None) == -1                                              # 16-bit column sums
     assert lib.usc_stm_post(1, 4, 4, 3, 16, 16, 16, 16, 2, 3, None) == -1                                    # odd channel pitch
-    assert lib.usc_conv_desc_bytes() == 216
     import ctypes as C
+    from video_unscreen_amd.vmatting.net_hip import ConvDesc
+    assert lib.usc_conv_desc_bytes() == C.sizeof(ConvDesc) == 232                                              # the ctypes mirror and the C struct move together
     blob = (C.c_uint8 * lib.usc_lab_tables_bytes())()
     lib.usc_lab_tables_host(blob)                                                                             # host function: runs here
     gamma = np.frombuffer(blob, np.uint16, 256)
