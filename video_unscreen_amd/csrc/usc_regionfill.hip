@@ -102,27 +102,6 @@ __device__ __forceinline__ Nbr neighbours(int y, int x, int H, int W) {
     return nb;
 }
 
-// (A v)(i) / s for one masked pixel and channel block: n v_i - sum of in-mask neighbours.  All loads are issued
-// unconditionally (out-of-image neighbours alias cell 0) and de-selected afterwards, so they do not wait for the mask bytes.
-template <typename T>
-__device__ __forceinline__ void stencil3(const uint8_t* __restrict__ mask, const T* __restrict__ v, uint32_t i, const Nbr& nb, T* out3) {
-    uint8_t mk[4];
-    T nv[4][3];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        mk[k] = mask[nb.idx[k]];
-#pragma unroll
-        for (int c = 0; c < 3; c++) nv[k][c] = v[3 * (size_t)nb.idx[k] + c];
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        T a = (T)nb.n * v[3 * (size_t)i + c];
-#pragma unroll
-        for (int k = 0; k < 4; k++) a -= (nb.in[k] && mk[k]) ? nv[k][c] : (T)0;
-        out3[c] = a;
-    }
-}
-
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------- CG (level 0)
@@ -293,9 +272,11 @@ __global__ __launch_bounds__(kThreads) void rf_out_kernel(const uint8_t* __restr
 
 // ---------------------------------------------------------------------------------------------------------------- multigrid
 namespace {
-struct Level { int H, W, tiles_x, ntiles; VT s; uint8_t *mask, *active; VT *z, *zt, *r; };
-struct LevelSet { int L, first_tail; Level lv[kMaxLevels]; };
+struct Level { int H, W, tiles_x, ntiles; VT s; uint8_t *mask, *active; VT *z, *zt, *r; int off, moff, cp; };       // off / moff / cp: the tail's LDS layout (see mg_tail_levels)
+struct LevelSet { int L, first_tail, tail_floats, tail_bytes; Level lv[kMaxLevels]; };
 constexpr int kTailThreads = 1024;
+constexpr int kTailNnBytes = 4 * 1024 * 16;   // upper bound of LevelSet.tail_bytes the tail's start-up copy is written for
+constexpr int kTailLdsBytes = 124 * 1024;   // the tail levels in LDS: 37 bytes per cell of the ringed layout (1080p: 34 x 60, 17 x 30, 9 x 15, 5 x 8 = 3097 ringed cells, 112 KB)
 constexpr int kTailCells = 2500;           // levels with at most this many cells run inside the single-workgroup tail kernel (one CU: ~12 us per sweep of 8000 cells, measured)
 }  // namespace
 
@@ -330,15 +311,17 @@ __global__ __launch_bounds__(kThreads) void mg_active_kernel(const uint8_t* __re
 // r_c(I) = sum over the masked children i of I of (r - s A' z)(i).  The window of r (36 x 36, zero outside the mask) is staged once;
 // z1 = w r is pointwise, z2 needs z1 on a 1-cell ring, the residual z2 on a 1-cell ring: all from LDS.  RT = double on level 0 (the
 // CG residual), VT below.
-template <typename RT>
-__global__ __launch_bounds__(kThreads) void mg_down_kernel(const uint8_t* __restrict__ mask, int H, int W, VT s, const RT* __restrict__ r,
-                                                           VT* __restrict__ z, const uint8_t* __restrict__ mc, int Hc, int Wc,
-                                                           VT* __restrict__ rc, const uint8_t* __restrict__ active, int tiles_x, int ntiles,
-                                                           const int* __restrict__ ctl) {
-    if (ctl[0]) return;
-    __shared__ VT R[WN * WN * 3], Z1[WN * WN * 3], Z2[W1 * W1 * 3];
-    __shared__ uint8_t M[WN * WN];
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+// NT threads per workgroup; workgroup `bid` of `nbid`.
+struct TileLds { VT a[WN * WN * 3], b[WN * WN * 3], c[W1 * W1 * 3]; uint8_t m[WN * WN]; };
+template <int NT, typename RT>
+__device__ __forceinline__ void mg_down_tiles(const uint8_t* __restrict__ mask, int H, int W, VT s, const RT* __restrict__ r,
+                                              VT* __restrict__ z, const uint8_t* __restrict__ mc, int Hc, int Wc,
+                                              VT* __restrict__ rc, const uint8_t* __restrict__ active, int tiles_x, int ntiles,
+                                              int bid, int nbid, TileLds& lds) {
+    VT* const R = lds.a; VT* const Z1 = lds.b; VT* const Z2 = lds.c;
+    uint8_t* const M = lds.m;
+    constexpr int kThreads = NT;
+    for (int tile = bid; tile < ntiles; tile += nbid) {
         if (!active[tile]) continue;
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int y0 = ty * TS - 2, x0 = tx * TS - 2;
@@ -399,7 +382,7 @@ __global__ __launch_bounds__(kThreads) void mg_down_kernel(const uint8_t* __rest
             const int k = (cy + 1) * W1 + cx + 1;
             z[3 * g] = Z2[3 * k]; z[3 * g + 1] = Z2[3 * k + 1]; z[3 * g + 2] = Z2[3 * k + 2];
         }
-        {   // one coarse cell per thread: the tile's 16 x 16 parents
+        if (NT == 256 || threadIdx.x < 256) {   // one coarse cell per thread: the tile's 16 x 16 parents
             const int cy = threadIdx.x >> 4, cx = threadIdx.x & 15, Y = ty * (TS / 2) + cy, X = tx * (TS / 2) + cx;
             if (Y < Hc && X < Wc && mc[(size_t)Y * Wc + X]) {
                 VT acc[3] = {(VT)0, (VT)0, (VT)0};
@@ -422,20 +405,28 @@ __global__ __launch_bounds__(kThreads) void mg_down_kernel(const uint8_t* __rest
     }
 }
 
+template <typename RT>
+__global__ __launch_bounds__(kThreads) void mg_down_kernel(const uint8_t* __restrict__ mask, int H, int W, VT s, const RT* __restrict__ r,
+                                                           VT* __restrict__ z, const uint8_t* __restrict__ mc, int Hc, int Wc,
+                                                           VT* __restrict__ rc, const uint8_t* __restrict__ active, int tiles_x, int ntiles,
+                                                           const int* __restrict__ ctl) {
+    if (ctl[0]) return;
+    __shared__ TileLds lds;
+    mg_down_tiles<kThreads, RT>(mask, H, W, s, r, z, mc, Hc, Wc, rc, active, tiles_x, ntiles, (int)blockIdx.x, (int)gridDim.x, lds);
+}
+
 // "Up" half for one level, tiled: z' = z + z_c(parent), then two weighted-Jacobi sweeps; writes zout (another array: a tile reads
 // the ring of its neighbours' z).  DOT (level 0): also the partial sums of r . zout in float64 - kBlocks workgroups walk the tiles in
 // a fixed order.
-template <typename RT, bool DOT>
-__global__ __launch_bounds__(kThreads) void mg_up_kernel(const uint8_t* __restrict__ mask, int H, int W, VT s, const VT* __restrict__ z,
-                                                         const VT* __restrict__ zc, int Wc, const RT* __restrict__ r, VT* __restrict__ zout,
-                                                         double* __restrict__ part, const uint8_t* __restrict__ active, int tiles_x, int ntiles,
-                                                         const int* __restrict__ ctl) {
-    if (ctl[0]) return;
-    __shared__ double s_part[12];
-    __shared__ VT Zp[WN * WN * 3], R[WN * WN * 3], Zt[W1 * W1 * 3];
-    __shared__ uint8_t M[WN * WN];
+template <int NT, typename RT, bool DOT>
+__device__ __forceinline__ D3 mg_up_tiles(const uint8_t* __restrict__ mask, int H, int W, VT s, const VT* __restrict__ z,
+                                          const VT* __restrict__ zc, int Wc, const RT* __restrict__ r, VT* __restrict__ zout,
+                                          const uint8_t* __restrict__ active, int tiles_x, int ntiles, int bid, int nbid, TileLds& lds) {
+    VT* const Zp = lds.a; VT* const R = lds.b; VT* const Zt = lds.c;
+    uint8_t* const M = lds.m;
+    constexpr int kThreads = NT;
     D3 acc = {{0., 0., 0.}};
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = bid; tile < ntiles; tile += nbid) {
         if (!active[tile]) continue;
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int y0 = ty * TS - 2, x0 = tx * TS - 2;
@@ -503,67 +494,19 @@ __global__ __launch_bounds__(kThreads) void mg_up_kernel(const uint8_t* __restri
             }
         }
     }
+    return acc;
+}
+
+template <typename RT, bool DOT>
+__global__ __launch_bounds__(kThreads) void mg_up_kernel(const uint8_t* __restrict__ mask, int H, int W, VT s, const VT* __restrict__ z,
+                                                         const VT* __restrict__ zc, int Wc, const RT* __restrict__ r, VT* __restrict__ zout,
+                                                         double* __restrict__ part, const uint8_t* __restrict__ active, int tiles_x, int ntiles,
+                                                         const int* __restrict__ ctl) {
+    if (ctl[0]) return;
+    __shared__ double s_part[12];
+    __shared__ TileLds lds;
+    const D3 acc = mg_up_tiles<kThreads, RT, DOT>(mask, H, W, s, z, zc, Wc, r, zout, active, tiles_x, ntiles, (int)blockIdx.x, (int)gridDim.x, lds);
     if (DOT) store_partial(part, block_sum(acc, s_part));
-}
-
-// ---- cell-wise forms of the same sweeps (the single-workgroup tail of the coarse levels)
-// z_out = z_in + omega / (s n) (r - s A' z_in)   (z_in == nullptr: z_in = 0).  A' is the unscaled masked stencil.
-__device__ __forceinline__ void mg_jacobi_cells(const uint8_t* __restrict__ mask, int H, int W, VT s, const VT* __restrict__ zin,
-                                                const VT* __restrict__ r, VT* __restrict__ zout, uint32_t start, uint32_t stride, VT omega = kOmega) {
-    const uint32_t n = (uint32_t)H * (uint32_t)W;
-    for (uint32_t i = start; i < n; i += stride) {
-        if (!mask[i]) continue;
-        const int y = (int)(i / (uint32_t)W), x = (int)(i - (uint32_t)y * (uint32_t)W);
-        const Nbr nb = neighbours(y, x, H, W);
-        const VT w = omega / (s * (VT)nb.n);
-        if (zin) {
-            VT a[3];
-            stencil3(mask, zin, i, nb, a);
-#pragma unroll
-            for (int c = 0; c < 3; c++) zout[3 * (size_t)i + c] = zin[3 * (size_t)i + c] + w * (r[3 * (size_t)i + c] - s * a[c]);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; c++) zout[3 * (size_t)i + c] = w * r[3 * (size_t)i + c];
-        }
-    }
-}
-
-// z += z_c(parent) on the masked cells (in place: pointwise)
-__device__ __forceinline__ void mg_prolong_cells(const uint8_t* __restrict__ mask, int H, int W, VT* __restrict__ z, const VT* __restrict__ zc, int Wc,
-                                                 uint32_t start, uint32_t stride) {
-    const uint32_t n = (uint32_t)H * (uint32_t)W;
-    for (uint32_t i = start; i < n; i += stride) {
-        if (!mask[i]) continue;
-        const int y = (int)(i / (uint32_t)W), x = (int)(i - (uint32_t)y * (uint32_t)W);
-        const size_t I = (size_t)(y >> 1) * Wc + (x >> 1);
-#pragma unroll
-        for (int c = 0; c < 3; c++) z[3 * (size_t)i + c] += zc[3 * I + c];
-    }
-}
-
-// r_c(I) = sum over the children i of I inside the fine mask of (r_f - s_f A' z_f)(i)
-__device__ __forceinline__ void mg_restrict_cells(const uint8_t* __restrict__ mf, int Hf, int Wf, VT sf, const VT* __restrict__ zf,
-                                                  const VT* __restrict__ rf, const uint8_t* __restrict__ mc, int Hc, int Wc,
-                                                  VT* __restrict__ rc, uint32_t start, uint32_t stride) {
-    const uint32_t n = (uint32_t)Hc * (uint32_t)Wc;
-    for (uint32_t I = start; I < n; I += stride) {
-        if (!mc[I]) continue;
-        const int Y = (int)(I / (uint32_t)Wc), X = (int)(I - (uint32_t)Y * (uint32_t)Wc);
-        VT acc[3] = {(VT)0, (VT)0, (VT)0};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int y = 2 * Y + (k >> 1), x = 2 * X + (k & 1);
-            if (y >= Hf || x >= Wf) continue;
-            const uint32_t i = (uint32_t)y * (uint32_t)Wf + (uint32_t)x;
-            if (!mf[i]) continue;
-            VT a[3];
-            stencil3(mf, zf, i, neighbours(y, x, Hf, Wf), a);
-#pragma unroll
-            for (int c = 0; c < 3; c++) acc[c] += rf[3 * (size_t)i + c] - sf * a[c];
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++) rc[3 * (size_t)I + c] = acc[c];
-    }
 }
 
 // level 0 of an image so small that it is the tail's first level: the tail works on float32, the CG residual is float64
@@ -586,80 +529,164 @@ __global__ __launch_bounds__(kThreads) void rf_dot_kernel(const uint8_t* __restr
 }
 
 // The coarse end of the V-cycle (levels first_tail .. L-1, a few thousand cells at most) inside ONE workgroup: sweeps separated by
-// workgroup barriers instead of kernel boundaries.  The vectors (z, zt, r) of the coarsest levels live in LDS for the duration of
-// the kernel: the tail is a chain of ~40 tiny phases separated by barriers, and a phase on global memory costs a round trip to the
-// L2 (~2.5 us) however few cells it has.  The first tail level receives its r from the "down" pass of the level above and hands its
-// z to that level's "up" pass.
-constexpr int kTailLdsFloats = 28672;      // 112 KB: at 1080p all four tail levels (34 x 60, 17 x 30, 9 x 15, 5 x 8: 24.5 k values of VT)
-__global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls, const int* __restrict__ ctl) {
-    if (ctl[0]) return;
-    __shared__ VT s_buf[kTailLdsFloats];
-    __shared__ int s_off[kMaxLevels];                      // first VT of a level's three vectors in s_buf, -1: the level stays in global memory
-    const uint32_t t = threadIdx.x, nt = blockDim.x;
-    if (t == 0) {
-        int used = 0;
-        bool open = true;
-        for (int l = kMaxLevels - 1; l >= 0; l--) {
-            s_off[l] = -1;
-            if (l >= ls.L || l < ls.first_tail || !open) continue;
-            const int need = 3 * 3 * ls.lv[l].H * ls.lv[l].W;
-            if (used + need > kTailLdsFloats) { open = false; continue; }
-            s_off[l] = used;
-            used += need;
+// workgroup barriers instead of kernel boundaries - a chain of ~25 tiny phases.  Every tail level lives in LDS for the duration of
+// the cycle, in a layout made for the phases: each level with a one-cell ring around it (pitch W + 2), per cell the three channels
+// of z, zt, r and one byte nn = the cell's in-image neighbour count if it is in the mask, 0 otherwise (and on the ring).  z and zt are
+// zero wherever nn is: the masked stencil is n z - up - down - left - right with no test, a phase is one LDS round trip.  (Round 4's
+// first form addressed LDS or global memory through one generic pointer and tested the mask and the image border per neighbour:
+// 1.4 us per phase, 36 us per iteration.)  The first tail level receives its r from the "down" pass of the level above and hands
+// its z to that level's "up" pass (both in the compact global layout).
+template <int NT>
+__device__ __forceinline__ void mg_tail_levels(const LevelSet& ls, const uint8_t* __restrict__ g_nn, uint8_t* __restrict__ smem) {
+    VT* const fl = reinterpret_cast<VT*>(smem);
+    uint8_t* const nnb = smem + (size_t)ls.tail_floats * sizeof(VT);
+    const int t = (int)threadIdx.x, row0 = t >> 6, col0 = t & 63;
+    constexpr int ROWS = NT / 64;
+    {   // one round trip to global memory: the ringed nn bytes of all tail levels (built once per solve) and the first level's r are
+        // requested, LDS is zeroed (rings, cells outside the mask) while they travel, then they are put in place
+        const Level& v = ls.lv[ls.first_tail];
+        const int Wp = v.W + 2, cells = v.H * v.W;
+        constexpr int NR = (kTailCells + NT - 1) / NT;
+        VT rv[NR][3];
+        int pp[NR];
+        uint8_t nv[NR];
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int g = t + k * NT, gg = g < cells ? g : 0, y = gg / v.W, x = gg - y * v.W;
+            pp[k] = g < cells ? (y + 1) * Wp + x + 1 : -1;
+            nv[k] = g_nn[v.moff + (y + 1) * Wp + x + 1];
+#pragma unroll
+            for (int c = 0; c < 3; c++) rv[k][c] = v.r[3 * gg + c];
         }
+        const int nb16 = ls.tail_bytes / 16;                   // (<= 4 x 1024 sixteen-byte pieces: kTailLdsBytes / 37 cells)
+        uint4 mv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) mv[k] = t + k * NT < nb16 ? reinterpret_cast<const uint4*>(g_nn)[t + k * NT] : make_uint4(0u, 0u, 0u, 0u);
+        const int n4 = ls.tail_floats * (int)sizeof(VT) / 16;
+        float4* const q = reinterpret_cast<float4*>(smem);
+        for (int i = t; i < n4; i += NT) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (t + k * NT < nb16) reinterpret_cast<uint4*>(nnb)[t + k * NT] = mv[k];
+        VT* const r = fl + v.off + 6 * v.cp;
+#pragma unroll
+        for (int k = 0; k < NR; k++)
+            if (pp[k] >= 0 && nv[k]) { r[3 * pp[k]] = rv[k][0]; r[3 * pp[k] + 1] = rv[k][1]; r[3 * pp[k] + 2] = rv[k][2]; }
     }
     __syncthreads();
-    auto level = [&](int l) {
-        Level v = ls.lv[l];
-        const int o = s_off[l];
-        if (o >= 0) {
-            const int nv = 3 * v.H * v.W;
-            v.z = s_buf + o; v.zt = s_buf + o + nv; v.r = s_buf + o + 2 * nv;
-        }
-        return v;
-    };
-    // the first tail level receives its r from the pass before this kernel and hands its z to the pass after it: copied in and out when
-    // the level lives in LDS
-    if (s_off[ls.first_tail] >= 0) {
-        const Level g = ls.lv[ls.first_tail], v = level(ls.first_tail);
-        for (uint32_t i = t; i < (uint32_t)(g.H * g.W); i += nt)
-            if (g.mask[i]) { v.r[3 * i] = g.r[3 * i]; v.r[3 * i + 1] = g.r[3 * i + 1]; v.r[3 * i + 2] = g.r[3 * i + 2]; }
-        __syncthreads();
-    }
-    for (int l = ls.first_tail; l < ls.L; l++) {
-        const Level v = level(l);
-        if (l == ls.L - 1) {
-            mg_jacobi_cells(v.mask, v.H, v.W, v.s, nullptr, v.r, v.z, t, nt);
-            __syncthreads();
-            for (int k = 0; k < USC_RF_COARSE_PAIRS; k++) {
-                mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.z, v.r, v.zt, t, nt);
-                __syncthreads();
-                mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, t, nt);
-                __syncthreads();
+    // zout = zin + omega / (s n) (r - s A' zin)   (zin == nullptr: from zero)
+    auto jacobi = [&](const Level& v, const VT* __restrict__ zin, VT* __restrict__ zout, VT omega) {
+        const int Wp = v.W + 2;
+        const VT* const r = fl + v.off + 6 * v.cp;
+        const uint8_t* const nn = nnb + v.moff;
+        for (int y = row0; y < v.H; y += ROWS)
+            for (int x = col0; x < v.W; x += 64) {
+                const int p = (y + 1) * Wp + x + 1;
+                const int n = nn[p];
+                if (!n) continue;
+                const VT w = omega / (v.s * (VT)n);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    if (zin) {
+                        VT a = (VT)n * zin[3 * p + c];
+                        a -= zin[3 * (p - Wp) + c]; a -= zin[3 * (p + Wp) + c]; a -= zin[3 * (p - 1) + c]; a -= zin[3 * (p + 1) + c];
+                        zout[3 * p + c] = zin[3 * p + c] + w * (r[3 * p + c] - v.s * a);
+                    } else {
+                        zout[3 * p + c] = w * r[3 * p + c];
+                    }
+                }
             }
+        __syncthreads();
+    };
+    for (int l = ls.first_tail; l < ls.L; l++) {
+        const Level& v = ls.lv[l];
+        VT* const z = fl + v.off; VT* const zt = z + 3 * v.cp;
+        if (l == ls.L - 1) {
+            jacobi(v, nullptr, z, kOmega);
+            for (int k = 0; k < USC_RF_COARSE_PAIRS; k++) { jacobi(v, z, zt, kOmega); jacobi(v, zt, z, kOmega); }
         } else {
-            mg_jacobi_cells(v.mask, v.H, v.W, v.s, nullptr, v.r, v.zt, t, nt, kOmegaA);
-            __syncthreads();
-            mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, t, nt, kOmegaB);
-            __syncthreads();
-            const Level c = level(l + 1);
-            mg_restrict_cells(v.mask, v.H, v.W, v.s, v.z, v.r, c.mask, c.H, c.W, c.r, t, nt);
+            jacobi(v, nullptr, zt, kOmegaA);
+            jacobi(v, zt, z, kOmegaB);
+            // r_c(I) = sum over the children i of I inside the fine mask of (r_f - s_f A' z_f)(i)
+            const Level& cl = ls.lv[l + 1];
+            const int Wp = v.W + 2, Wpc = cl.W + 2;
+            const VT* const r = z + 6 * v.cp;
+            VT* const rc = fl + cl.off + 6 * cl.cp;
+            const uint8_t* const nn = nnb + v.moff;
+            const uint8_t* const nnc = nnb + cl.moff;
+            for (int Y = row0; Y < cl.H; Y += ROWS)
+                for (int X = col0; X < cl.W; X += 64) {
+                    const int P = (Y + 1) * Wpc + X + 1;
+                    if (!nnc[P]) continue;
+                    VT acc[3] = {(VT)0, (VT)0, (VT)0};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int p = (2 * Y + (k >> 1) + 1) * Wp + 2 * X + (k & 1) + 1;      // (a child outside the image sits on the ring: nn = 0)
+                        const int n = nn[p];
+                        if (!n) continue;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            VT a = (VT)n * z[3 * p + c];
+                            a -= z[3 * (p - Wp) + c]; a -= z[3 * (p + Wp) + c]; a -= z[3 * (p - 1) + c]; a -= z[3 * (p + 1) + c];
+                            acc[c] += r[3 * p + c] - v.s * a;
+                        }
+                    }
+                    rc[3 * P] = acc[0]; rc[3 * P + 1] = acc[1]; rc[3 * P + 2] = acc[2];
+                }
             __syncthreads();
         }
     }
     for (int l = ls.L - 2; l >= ls.first_tail; l--) {
-        const Level v = level(l), c = level(l + 1);
-        mg_prolong_cells(v.mask, v.H, v.W, v.z, c.z, c.W, t, nt);
+        const Level& v = ls.lv[l];
+        const Level& cl = ls.lv[l + 1];
+        VT* const z = fl + v.off; VT* const zt = z + 3 * v.cp;
+        const VT* const zc = fl + cl.off;
+        const int Wp = v.W + 2, Wpc = cl.W + 2;
+        const uint8_t* const nn = nnb + v.moff;
+        for (int y = row0; y < v.H; y += ROWS)                  // z += z_c(parent) on the masked cells
+            for (int x = col0; x < v.W; x += 64) {
+                const int p = (y + 1) * Wp + x + 1;
+                if (!nn[p]) continue;
+                const int P = ((y >> 1) + 1) * Wpc + (x >> 1) + 1;
+                z[3 * p] += zc[3 * P]; z[3 * p + 1] += zc[3 * P + 1]; z[3 * p + 2] += zc[3 * P + 2];
+            }
         __syncthreads();
-        mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.z, v.r, v.zt, t, nt, kOmegaB);
-        __syncthreads();
-        mg_jacobi_cells(v.mask, v.H, v.W, v.s, v.zt, v.r, v.z, t, nt, kOmegaA);
-        __syncthreads();
+        jacobi(v, z, zt, kOmegaB);
+        jacobi(v, zt, z, kOmegaA);
     }
-    if (s_off[ls.first_tail] >= 0) {
-        const Level g = ls.lv[ls.first_tail], v = level(ls.first_tail);
-        for (uint32_t i = t; i < (uint32_t)(g.H * g.W); i += nt)
-            if (g.mask[i]) { g.z[3 * i] = v.z[3 * i]; g.z[3 * i + 1] = v.z[3 * i + 1]; g.z[3 * i + 2] = v.z[3 * i + 2]; }
+    {
+        const Level& v = ls.lv[ls.first_tail];
+        const VT* const z = fl + v.off;
+        const uint8_t* const nn = nnb + v.moff;
+        const int Wp = v.W + 2;
+        for (int y = row0; y < v.H; y += ROWS)
+            for (int x = col0; x < v.W; x += 64) {
+                const int g = y * v.W + x, p = (y + 1) * Wp + x + 1;
+                if (!nn[p]) continue;
+                v.z[3 * g] = z[3 * p]; v.z[3 * g + 1] = z[3 * p + 1]; v.z[3 * g + 2] = z[3 * p + 2];
+            }
+    }
+}
+
+__global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls, const uint8_t* __restrict__ g_nn, const int* __restrict__ ctl) {
+    if (ctl[0]) return;
+    __shared__ __align__(16) uint8_t smem[kTailLdsBytes];
+    mg_tail_levels<kTailThreads>(ls, g_nn, smem);
+}
+
+// Once per solve: the tail levels' nn bytes (in-image neighbour count of a masked cell, 0 elsewhere and on the ring) in the layout
+// mg_tail_levels keeps them in - it copies them in 16-byte pieces at the start of every V-cycle.
+__global__ __launch_bounds__(kTailThreads) void mg_tail_nn_kernel(LevelSet ls, uint8_t* __restrict__ g_nn) {
+    const int t = (int)threadIdx.x;
+    for (int i = t; i < ls.tail_bytes; i += kTailThreads) g_nn[i] = 0;
+    __syncthreads();
+    for (int l = ls.first_tail; l < ls.L; l++) {
+        const Level& v = ls.lv[l];
+        for (int g = t; g < v.H * v.W; g += kTailThreads) {
+            const int y = g / v.W, x = g - y * v.W;
+            if (v.mask[g]) g_nn[v.moff + (y + 1) * (v.W + 2) + x + 1] = (uint8_t)ncount(y, x, v.H, v.W);
+        }
     }
 }
 
@@ -694,12 +721,12 @@ struct Launcher {
 };
 
 struct Solver {
-    int H, W, L, first_tail;
+    int H, W, L, first_tail, tail_floats, tail_bytes;
     uint32_t n;
     Level lv[kMaxLevels];
     double *scal, *part_rr, *part_pap, *part_rz[2], *part_cross, *x, *p[2], *Ap, *r;
     int* ctl;                                       // {done, iterations run, converged}: the device-side convergence state
-    uint8_t* mask0;
+    uint8_t *mask0, *tail_nn;                       // tail_nn: the tail levels' ringed nn bytes (mg_tail_nn_kernel)
 
     void carve(void* ws, int H_, int W_) {
         H = H_; W = W_; n = (uint32_t)H * (uint32_t)W;
@@ -734,8 +761,33 @@ struct Solver {
             lv[l].active = take((size_t)lv[l].ntiles);
         }
         mask0 = lv[0].mask;
+        tail_nn = take(kTailNnBytes);
+        // the tail: the coarsest levels as far as their ringed LDS layout (9 values of VT + 1 byte per cell) fits
+        auto ringed = [&](int l) { return (size_t)(lv[l].H + 2) * (lv[l].W + 2); };
+        auto lds_need = [&](int l) { return ringed(l) * 9 * sizeof(VT) + ((ringed(l) + 15) & ~(size_t)15); };
         first_tail = L - 1;
-        while (first_tail > 1 && (size_t)lv[first_tail - 1].H * lv[first_tail - 1].W <= (size_t)kTailCells) first_tail--;
+        size_t used = lds_need(first_tail);
+        while (first_tail > 1 && (size_t)lv[first_tail - 1].H * lv[first_tail - 1].W <= (size_t)kTailCells && used + lds_need(first_tail - 1) <= (size_t)kTailLdsBytes) {
+            first_tail--;
+            used += lds_need(first_tail);
+        }
+        int fo = 0, mo = 0;
+        for (int l = 0; l < L; l++) {
+            lv[l].off = lv[l].moff = lv[l].cp = 0;
+            if (l < first_tail) continue;
+            lv[l].cp = (int)ringed(l);
+            lv[l].off = fo; fo += 9 * lv[l].cp;
+            lv[l].moff = mo; mo += (lv[l].cp + 15) & ~15;
+        }
+        tail_floats = (fo + 3) & ~3;
+        tail_bytes = mo;
+    }
+
+    LevelSet level_set() const {
+        LevelSet ls;
+        ls.L = L; ls.first_tail = first_tail; ls.tail_floats = tail_floats; ls.tail_bytes = tail_bytes;
+        for (int l = 0; l < kMaxLevels; l++) ls.lv[l] = lv[l < L ? l : L - 1];
+        return ls;
     }
 
     static dim3 tile_grid(const Level& v) { return dim3((unsigned)(v.ntiles < 2048 ? v.ntiles : 2048)); }
@@ -746,20 +798,25 @@ struct Solver {
         if (first_tail == 0) {                                         // an image of at most 8 x 8 cells: everything inside the tail kernel
             q.launch(rf_cast_kernel, dim3(grid_of((size_t)n * 3)), b, r, lv[0].r, (size_t)n * 3, ctl);
         }
-        for (int l = 0; l < first_tail; l++) {
-            const Level &v = lv[l], &c = lv[l + 1];
-            if (l == 0) q.launch(mg_down_kernel<double>, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const double*)r, v.z, c.mask, c.H, c.W, c.r, v.active, v.tiles_x, v.ntiles, ctl);
-            else q.launch(mg_down_kernel<VT>, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const VT*)v.r, v.z, c.mask, c.H, c.W, c.r, v.active, v.tiles_x, v.ntiles, ctl);
+        const LevelSet ls = level_set();
+        if (first_tail > 0) {
+            const Level &v = lv[0], &c = lv[1];
+            q.launch(mg_down_kernel<double>, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const double*)r, v.z, c.mask, c.H, c.W, c.r, v.active, v.tiles_x, v.ntiles, ctl);
         }
-        LevelSet ls;
-        ls.L = L; ls.first_tail = first_tail;
-        for (int l = 0; l < kMaxLevels; l++) ls.lv[l] = lv[l < L ? l : L - 1];
-        q.launch(mg_tail_kernel, dim3(1), dim3(kTailThreads), ls, ctl);
-        for (int l = first_tail - 1; l >= 0; l--) {
+        for (int l = 1; l < first_tail; l++) {
+            const Level &v = lv[l], &c = lv[l + 1];
+            q.launch(mg_down_kernel<VT>, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const VT*)v.r, v.z, c.mask, c.H, c.W, c.r, v.active, v.tiles_x, v.ntiles, ctl);
+        }
+        q.launch(mg_tail_kernel, dim3(1), dim3(kTailThreads), ls, (const uint8_t*)tail_nn, ctl);
+        for (int l = first_tail - 1; l >= 1; l--) {
             const Level &v = lv[l], &c = lv[l + 1];
             const VT* zc = l + 1 == first_tail ? c.z : c.zt;
-            if (l == 0) q.launch(mg_up_kernel<double, true>, dim3(kBlocks), b, v.mask, v.H, v.W, v.s, (const VT*)v.z, zc, c.W, (const double*)r, v.zt, part_rz_new, v.active, v.tiles_x, v.ntiles, ctl);
-            else q.launch(mg_up_kernel<VT, false>, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const VT*)v.z, zc, c.W, (const VT*)v.r, v.zt, (double*)nullptr, v.active, v.tiles_x, v.ntiles, ctl);
+            q.launch(mg_up_kernel<VT, false>, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const VT*)v.z, zc, c.W, (const VT*)v.r, v.zt, (double*)nullptr, v.active, v.tiles_x, v.ntiles, ctl);
+        }
+        if (first_tail > 0) {
+            const Level &v = lv[0], &c = lv[1];
+            const VT* zc = 1 == first_tail ? c.z : c.zt;
+            q.launch(mg_up_kernel<double, true>, dim3(kBlocks), b, v.mask, v.H, v.W, v.s, (const VT*)v.z, zc, c.W, (const double*)r, v.zt, part_rz_new, v.active, v.tiles_x, v.ntiles, ctl);
         }
         if (first_tail == 0) {
             q.launch(rf_dot_kernel, dim3(kBlocks), b, mask0, n, (const double*)r, (const VT*)lv[0].z, part_rz_new, ctl);
@@ -790,6 +847,7 @@ extern "C" size_t usc_regionfill_ws_bytes(int H, int W) {
     int hs[kMaxLevels], ws[kMaxLevels];
     const int L = level_dims(H, W, hs, ws);
     size_t total = 256 + 5 * rf_align((size_t)kBlocks * 3 * sizeof(double));
+    total += rf_align(kTailNnBytes);
     total += 5 * rf_align((size_t)H * W * 3 * sizeof(double));                  // x, p (two), Ap, r
     for (int l = 0; l < L; l++) {
         const size_t tiles = (size_t)((ws[l] + TS - 1) / TS) * ((hs[l] + TS - 1) / TS);
@@ -819,6 +877,7 @@ extern "C" int usc_regionfill_u8(const uint8_t* img, const uint8_t* mask, int H,
                      s.lv[l].mask, s.lv[l].H, s.lv[l].W);
         for (int l = 0; l < s.L && l < (s.first_tail > 0 ? s.first_tail : 1); l++)
             q.launch(mg_active_kernel, dim3((unsigned)s.lv[l].ntiles), b, (const uint8_t*)s.lv[l].mask, s.lv[l].H, s.lv[l].W, s.lv[l].active, s.lv[l].tiles_x);
+        q.launch(mg_tail_nn_kernel, dim3(1), dim3(kTailThreads), s.level_set(), s.tail_nn);
         q.launch(rf_init_kernel, dim3(kBlocks), b, img, s.mask0, H, W, s.x, s.r, s.part_rr);
         q.launch(rf_publish_kernel, dim3(1), b, s.part_rr, s.scal, 0, s.ctl, rtol2, 0);
     }
