@@ -23,6 +23,7 @@
 // The direct and the iterative solution agree to the tolerance (default: residual reduced by 1e-7, ~1e-3 grey levels), not bit
 // for bit; after the reference's astype(uint8) truncation that is +-1 level on the few pixels whose value sits next to an integer.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
@@ -272,28 +273,13 @@ __global__ __launch_bounds__(kThreads) void rf_out_kernel(const uint8_t* __restr
 
 // ---------------------------------------------------------------------------------------------------------------- multigrid
 namespace {
-struct Level { int H, W, tiles_x, ntiles; VT s; uint8_t *mask, *active; VT *z, *zt, *r; int off, moff, cp; };       // off / moff / cp: the tail's LDS layout (see mg_tail_levels)
-struct LevelSet { int L, first_tail, tail_floats, tail_bytes; Level lv[kMaxLevels]; };
+struct Level { int H, W, tiles_x, ntiles; VT s; uint8_t *mask, *active; VT *z, *zt, *r, *d; float4* w; int off, moff, cp; };   // d / w: the level's operator (levels >= 1, mg_galerkin_kernel); off / moff / cp: the tail's LDS layout (mg_tail_levels)
+struct LevelSet { int L, first_tail, tail_floats, tail_cells; Level lv[kMaxLevels]; };
 constexpr int kTailThreads = 1024;
-constexpr int kTailNnBytes = 4 * 1024 * 16;   // upper bound of LevelSet.tail_bytes the tail's start-up copy is written for
-constexpr int kTailLdsBytes = 124 * 1024;   // the tail levels in LDS: 37 bytes per cell of the ringed layout (1080p: 34 x 60, 17 x 30, 9 x 15, 5 x 8 = 3097 ringed cells, 112 KB)
+constexpr int kTailLdsBytes = 156 * 1024;   // the tail levels in LDS: 48 bytes per cell of the ringed layout (1080p: 34 x 60, 17 x 30, 9 x 15, 5 x 8 = 3097 ringed cells, 146 KB)
+constexpr int kTailDwBytes = 4 * 1024 * 16;   // upper bound of the packed d / w image (12 bytes per ringed tail cell) the tail's start-up copy is written for
 constexpr int kTailCells = 2500;           // levels with at most this many cells run inside the single-workgroup tail kernel (one CU: ~12 us per sweep of 8000 cells, measured)
 }  // namespace
-
-__global__ __launch_bounds__(kThreads) void mg_mask_down_kernel(const uint8_t* __restrict__ mf, int Hf, int Wf, uint8_t* __restrict__ mc,
-                                                                int Hc, int Wc) {
-    const uint32_t n = (uint32_t)Hc * (uint32_t)Wc;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int Y = (int)(i / (uint32_t)Wc), X = (int)(i - (uint32_t)Y * (uint32_t)Wc);
-        int any = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int y = 2 * Y + (k >> 1), x = 2 * X + (k & 1);
-            if (y < Hf && x < Wf) any |= mf[(size_t)y * Wf + x] != 0;
-        }
-        mc[i] = (uint8_t)any;
-    }
-}
 
 // active[tile] = 1 iff the tile's own 32 x 32 cells hold a masked cell (one workgroup per tile)
 __global__ __launch_bounds__(kThreads) void mg_active_kernel(const uint8_t* __restrict__ mask, int H, int W, uint8_t* __restrict__ active, int tiles_x) {
@@ -308,16 +294,19 @@ __global__ __launch_bounds__(kThreads) void mg_active_kernel(const uint8_t* __re
 }
 
 // "Down" half of the V-cycle for one level, tiled: z = two weighted-Jacobi sweeps from zero on r, then the restricted residual
-// r_c(I) = sum over the masked children i of I of (r - s A' z)(i).  The window of r (36 x 36, zero outside the mask) is staged once;
+// r_c(I) = sum over the masked children i of I of (r - s A z)(i).  The window of r (36 x 36, zero outside the mask) is staged once;
 // z1 = w r is pointwise, z2 needs z1 on a 1-cell ring, the residual z2 on a 1-cell ring: all from LDS.  RT = double on level 0 (the
-// CG residual), VT below.
+// CG residual), VT below.  GAL = false (level 0): A is the masked 5-point stencil, n z - the in-mask neighbours.  GAL = true (the coarse
+// levels): A is the level's Galerkin operator - per cell a diagonal dg and four edge weights wg (up, down, left, right; zero towards
+// cells outside the mask, dg = 0 outside the mask), staged beside the window.
 // NT threads per workgroup; workgroup `bid` of `nbid`.
 struct TileLds { VT a[WN * WN * 3], b[WN * WN * 3], c[W1 * W1 * 3]; uint8_t m[WN * WN]; };
-template <int NT, typename RT>
+struct GalLds { VT d[WN * WN]; float4 w[W1 * W1]; };
+template <int NT, typename RT, bool GAL>
 __device__ __forceinline__ void mg_down_tiles(const uint8_t* __restrict__ mask, int H, int W, VT s, const RT* __restrict__ r,
                                               VT* __restrict__ z, const uint8_t* __restrict__ mc, int Hc, int Wc,
                                               VT* __restrict__ rc, const uint8_t* __restrict__ active, int tiles_x, int ntiles,
-                                              int bid, int nbid, TileLds& lds) {
+                                              int bid, int nbid, TileLds& lds, const VT* __restrict__ dg, const float4* __restrict__ wg, GalLds* gal) {
     VT* const R = lds.a; VT* const Z1 = lds.b; VT* const Z2 = lds.c;
     uint8_t* const M = lds.m;
     constexpr int kThreads = NT;
@@ -332,13 +321,21 @@ __device__ __forceinline__ void mg_down_tiles(const uint8_t* __restrict__ mask, 
             uint8_t mk[NW];
             int nc[NW];
             RT rv[NW][3];
+            VT dv[NW];
+            float4 wv[NW];
 #pragma unroll
             for (int k = 0; k < NW; k++) {
                 const int i = threadIdx.x + k * kThreads, wy = i / WN, wx = i - wy * WN, y = y0 + wy, x = x0 + wx;
                 const bool in = i < WN * WN && y >= 0 && y < H && x >= 0 && x < W;
                 g[k] = in ? (uint32_t)y * (uint32_t)W + (uint32_t)x : 0u;
-                mk[k] = in ? mask[g[k]] : (uint8_t)0;
-                nc[k] = in ? ncount(y, x, H, W) : 4;
+                if (GAL) {
+                    dv[k] = dg[g[k]];
+                    wv[k] = wg[g[k]];
+                    if (!in) dv[k] = (VT)0;
+                } else {
+                    mk[k] = in ? mask[g[k]] : (uint8_t)0;
+                    nc[k] = in ? ncount(y, x, H, W) : 4;
+                }
             }
 #pragma unroll
             for (int k = 0; k < NW; k++)
@@ -348,13 +345,19 @@ __device__ __forceinline__ void mg_down_tiles(const uint8_t* __restrict__ mask, 
             for (int k = 0; k < NW; k++) {
                 const int i = threadIdx.x + k * kThreads;
                 if (i < WN * WN) {
-                    M[i] = (uint8_t)(mk[k] != 0);
-                    const VT w = kOmegaA / (s * (VT)nc[k]);
+                    const bool in_mask = GAL ? dv[k] > (VT)0 : mk[k] != 0;
+                    M[i] = (uint8_t)in_mask;
+                    const VT w = kOmegaA / (s * (GAL ? (in_mask ? dv[k] : (VT)1) : (VT)nc[k]));
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        const VT v = mk[k] ? (VT)rv[k][c] : (VT)0;
+                        const VT v = in_mask ? (VT)rv[k][c] : (VT)0;
                         R[3 * i + c] = v;
                         Z1[3 * i + c] = w * v;
+                    }
+                    if (GAL) {
+                        gal->d[i] = dv[k];
+                        const int wy = i / WN, wx = i - wy * WN;
+                        if (wy >= 1 && wy <= W1 && wx >= 1 && wx <= W1) gal->w[(wy - 1) * W1 + wx - 1] = wv[k];
                     }
                 }
             }
@@ -364,11 +367,19 @@ __device__ __forceinline__ void mg_down_tiles(const uint8_t* __restrict__ mask, 
             const int wy = i / W1 + 1, wx = i % W1 + 1, j = wy * WN + wx, y = y0 + wy, x = x0 + wx;
             VT o[3] = {(VT)0, (VT)0, (VT)0};
             if (M[j]) {
-                const VT nn = (VT)ncount(y, x, H, W), w = kOmegaB / (s * nn);
+                const VT nn = GAL ? gal->d[j] : (VT)ncount(y, x, H, W), w = kOmegaB / (s * nn);
+                float4 e = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (GAL) e = gal->w[i];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     const VT z1 = Z1[3 * j + c];
-                    const VT a = nn * z1 - (Z1[3 * (j - WN) + c] + Z1[3 * (j + WN) + c] + Z1[3 * (j - 1) + c] + Z1[3 * (j + 1) + c]);
+                    VT a;
+                    if (GAL) {
+                        a = nn * z1;
+                        a -= e.x * Z1[3 * (j - WN) + c]; a -= e.y * Z1[3 * (j + WN) + c]; a -= e.z * Z1[3 * (j - 1) + c]; a -= e.w * Z1[3 * (j + 1) + c];
+                    } else {
+                        a = nn * z1 - (Z1[3 * (j - WN) + c] + Z1[3 * (j + WN) + c] + Z1[3 * (j - 1) + c] + Z1[3 * (j + 1) + c]);
+                    }
                     o[c] = z1 + w * (R[3 * j + c] - s * a);
                 }
             }
@@ -391,10 +402,18 @@ __device__ __forceinline__ void mg_down_tiles(const uint8_t* __restrict__ mask, 
                     const int fy = 2 * cy + (q >> 1), fx = 2 * cx + (q & 1);          // child, tile coordinates
                     const int j = (fy + 2) * WN + fx + 2, k = (fy + 1) * W1 + fx + 1;
                     if (!M[j]) continue;                                             // (outside the image or the mask)
-                    const VT nn = (VT)ncount(ty * TS + fy, tx * TS + fx, H, W);
+                    const VT nn = GAL ? gal->d[j] : (VT)ncount(ty * TS + fy, tx * TS + fx, H, W);
+                    float4 e = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (GAL) e = gal->w[k];
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        const VT a = nn * Z2[3 * k + c] - (Z2[3 * (k - W1) + c] + Z2[3 * (k + W1) + c] + Z2[3 * (k - 1) + c] + Z2[3 * (k + 1) + c]);
+                        VT a;
+                        if (GAL) {
+                            a = nn * Z2[3 * k + c];
+                            a -= e.x * Z2[3 * (k - W1) + c]; a -= e.y * Z2[3 * (k + W1) + c]; a -= e.z * Z2[3 * (k - 1) + c]; a -= e.w * Z2[3 * (k + 1) + c];
+                        } else {
+                            a = nn * Z2[3 * k + c] - (Z2[3 * (k - W1) + c] + Z2[3 * (k + W1) + c] + Z2[3 * (k - 1) + c] + Z2[3 * (k + 1) + c]);
+                        }
                         acc[c] += R[3 * j + c] - s * a;
                     }
                 }
@@ -405,23 +424,34 @@ __device__ __forceinline__ void mg_down_tiles(const uint8_t* __restrict__ mask, 
     }
 }
 
-template <typename RT>
-__global__ __launch_bounds__(kThreads) void mg_down_kernel(const uint8_t* __restrict__ mask, int H, int W, VT s, const RT* __restrict__ r,
-                                                           VT* __restrict__ z, const uint8_t* __restrict__ mc, int Hc, int Wc,
-                                                           VT* __restrict__ rc, const uint8_t* __restrict__ active, int tiles_x, int ntiles,
-                                                           const int* __restrict__ ctl) {
+// level 0
+__global__ __launch_bounds__(kThreads) void mg_down0_kernel(const uint8_t* __restrict__ mask, int H, int W, VT s, const double* __restrict__ r,
+                                                            VT* __restrict__ z, const uint8_t* __restrict__ mc, int Hc, int Wc,
+                                                            VT* __restrict__ rc, const uint8_t* __restrict__ active, int tiles_x, int ntiles,
+                                                            const int* __restrict__ ctl) {
     if (ctl[0]) return;
     __shared__ TileLds lds;
-    mg_down_tiles<kThreads, RT>(mask, H, W, s, r, z, mc, Hc, Wc, rc, active, tiles_x, ntiles, (int)blockIdx.x, (int)gridDim.x, lds);
+    mg_down_tiles<kThreads, double, false>(mask, H, W, s, r, z, mc, Hc, Wc, rc, active, tiles_x, ntiles, (int)blockIdx.x, (int)gridDim.x, lds, nullptr, nullptr, nullptr);
+}
+// levels >= 1
+__global__ __launch_bounds__(kThreads) void mg_down_kernel(const uint8_t* __restrict__ mask, int H, int W, VT s, const VT* __restrict__ r,
+                                                           VT* __restrict__ z, const uint8_t* __restrict__ mc, int Hc, int Wc,
+                                                           VT* __restrict__ rc, const uint8_t* __restrict__ active, int tiles_x, int ntiles,
+                                                           const VT* __restrict__ dg, const float4* __restrict__ wg, const int* __restrict__ ctl) {
+    if (ctl[0]) return;
+    __shared__ TileLds lds;
+    __shared__ GalLds gal;
+    mg_down_tiles<kThreads, VT, true>(mask, H, W, s, r, z, mc, Hc, Wc, rc, active, tiles_x, ntiles, (int)blockIdx.x, (int)gridDim.x, lds, dg, wg, &gal);
 }
 
 // "Up" half for one level, tiled: z' = z + z_c(parent), then two weighted-Jacobi sweeps; writes zout (another array: a tile reads
 // the ring of its neighbours' z).  DOT (level 0): also the partial sums of r . zout in float64 - kBlocks workgroups walk the tiles in
-// a fixed order.
-template <int NT, typename RT, bool DOT>
+// a fixed order.  GAL as in mg_down_tiles.
+template <int NT, typename RT, bool DOT, bool GAL>
 __device__ __forceinline__ D3 mg_up_tiles(const uint8_t* __restrict__ mask, int H, int W, VT s, const VT* __restrict__ z,
                                           const VT* __restrict__ zc, int Wc, const RT* __restrict__ r, VT* __restrict__ zout,
-                                          const uint8_t* __restrict__ active, int tiles_x, int ntiles, int bid, int nbid, TileLds& lds) {
+                                          const uint8_t* __restrict__ active, int tiles_x, int ntiles, int bid, int nbid, TileLds& lds,
+                                          const VT* __restrict__ dg, const float4* __restrict__ wg, GalLds* gal) {
     VT* const Zp = lds.a; VT* const R = lds.b; VT* const Zt = lds.c;
     uint8_t* const M = lds.m;
     constexpr int kThreads = NT;
@@ -437,13 +467,21 @@ __device__ __forceinline__ D3 mg_up_tiles(const uint8_t* __restrict__ mask, int 
             uint8_t mk[NW];
             VT zv[NW][3], cv[NW][3];
             RT rv[NW][3];
+            VT dv[NW];
+            float4 wv[NW];
 #pragma unroll
             for (int k = 0; k < NW; k++) {
                 const int i = threadIdx.x + k * kThreads, wy = i / WN, wx = i - wy * WN, y = y0 + wy, x = x0 + wx;
                 const bool in = i < WN * WN && y >= 0 && y < H && x >= 0 && x < W;
                 g[k] = in ? (uint32_t)y * (uint32_t)W + (uint32_t)x : 0u;
                 G[k] = in ? (uint32_t)(y >> 1) * (uint32_t)Wc + (uint32_t)(x >> 1) : 0u;
-                mk[k] = in ? mask[g[k]] : (uint8_t)0;
+                if (GAL) {
+                    dv[k] = dg[g[k]];
+                    wv[k] = wg[g[k]];
+                    if (!in) dv[k] = (VT)0;
+                } else {
+                    mk[k] = in ? mask[g[k]] : (uint8_t)0;
+                }
             }
 #pragma unroll
             for (int k = 0; k < NW; k++)
@@ -453,11 +491,17 @@ __device__ __forceinline__ D3 mg_up_tiles(const uint8_t* __restrict__ mask, int 
             for (int k = 0; k < NW; k++) {
                 const int i = threadIdx.x + k * kThreads;
                 if (i < WN * WN) {
-                    M[i] = (uint8_t)(mk[k] != 0);
+                    const bool in_mask = GAL ? dv[k] > (VT)0 : mk[k] != 0;
+                    M[i] = (uint8_t)in_mask;
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        Zp[3 * i + c] = mk[k] ? zv[k][c] + cv[k][c] : (VT)0;
-                        R[3 * i + c] = mk[k] ? (VT)rv[k][c] : (VT)0;
+                        Zp[3 * i + c] = in_mask ? zv[k][c] + cv[k][c] : (VT)0;
+                        R[3 * i + c] = in_mask ? (VT)rv[k][c] : (VT)0;
+                    }
+                    if (GAL) {
+                        gal->d[i] = dv[k];
+                        const int wy = i / WN, wx = i - wy * WN;
+                        if (wy >= 1 && wy <= W1 && wx >= 1 && wx <= W1) gal->w[(wy - 1) * W1 + wx - 1] = wv[k];
                     }
                 }
             }
@@ -467,11 +511,19 @@ __device__ __forceinline__ D3 mg_up_tiles(const uint8_t* __restrict__ mask, int 
             const int wy = i / W1 + 1, wx = i % W1 + 1, j = wy * WN + wx, y = y0 + wy, x = x0 + wx;
             VT o[3] = {(VT)0, (VT)0, (VT)0};
             if (M[j]) {
-                const VT nn = (VT)ncount(y, x, H, W), w = kOmegaB / (s * nn);
+                const VT nn = GAL ? gal->d[j] : (VT)ncount(y, x, H, W), w = kOmegaB / (s * nn);
+                float4 e = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (GAL) e = gal->w[i];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     const VT zi = Zp[3 * j + c];
-                    const VT a = nn * zi - (Zp[3 * (j - WN) + c] + Zp[3 * (j + WN) + c] + Zp[3 * (j - 1) + c] + Zp[3 * (j + 1) + c]);
+                    VT a;
+                    if (GAL) {
+                        a = nn * zi;
+                        a -= e.x * Zp[3 * (j - WN) + c]; a -= e.y * Zp[3 * (j + WN) + c]; a -= e.z * Zp[3 * (j - 1) + c]; a -= e.w * Zp[3 * (j + 1) + c];
+                    } else {
+                        a = nn * zi - (Zp[3 * (j - WN) + c] + Zp[3 * (j + WN) + c] + Zp[3 * (j - 1) + c] + Zp[3 * (j + 1) + c]);
+                    }
                     o[c] = zi + w * (R[3 * j + c] - s * a);
                 }
             }
@@ -482,12 +534,20 @@ __device__ __forceinline__ D3 mg_up_tiles(const uint8_t* __restrict__ mask, int 
             const int cy = i / TS, cx = i & (TS - 1), y = ty * TS + cy, x = tx * TS + cx;
             const int j = (cy + 2) * WN + cx + 2, k = (cy + 1) * W1 + cx + 1;
             if (y >= H || x >= W || !M[j]) continue;
-            const VT nn = (VT)ncount(y, x, H, W), w = kOmegaA / (s * nn);
+            const VT nn = GAL ? gal->d[j] : (VT)ncount(y, x, H, W), w = kOmegaA / (s * nn);
+            float4 e = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (GAL) e = gal->w[k];
             const size_t g = (size_t)y * W + x;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const VT zi = Zt[3 * k + c];
-                const VT a = nn * zi - (Zt[3 * (k - W1) + c] + Zt[3 * (k + W1) + c] + Zt[3 * (k - 1) + c] + Zt[3 * (k + 1) + c]);
+                VT a;
+                if (GAL) {
+                    a = nn * zi;
+                    a -= e.x * Zt[3 * (k - W1) + c]; a -= e.y * Zt[3 * (k + W1) + c]; a -= e.z * Zt[3 * (k - 1) + c]; a -= e.w * Zt[3 * (k + 1) + c];
+                } else {
+                    a = nn * zi - (Zt[3 * (k - W1) + c] + Zt[3 * (k + W1) + c] + Zt[3 * (k - 1) + c] + Zt[3 * (k + 1) + c]);
+                }
                 const VT zn = zi + w * (R[3 * j + c] - s * a);
                 zout[3 * g + c] = zn;
                 if (DOT) acc.v[c] += (double)r[3 * g + c] * (double)zn;
@@ -497,16 +557,27 @@ __device__ __forceinline__ D3 mg_up_tiles(const uint8_t* __restrict__ mask, int 
     return acc;
 }
 
-template <typename RT, bool DOT>
-__global__ __launch_bounds__(kThreads) void mg_up_kernel(const uint8_t* __restrict__ mask, int H, int W, VT s, const VT* __restrict__ z,
-                                                         const VT* __restrict__ zc, int Wc, const RT* __restrict__ r, VT* __restrict__ zout,
-                                                         double* __restrict__ part, const uint8_t* __restrict__ active, int tiles_x, int ntiles,
-                                                         const int* __restrict__ ctl) {
+// level 0 (with the partial sums of r . z)
+__global__ __launch_bounds__(kThreads) void mg_up0_kernel(const uint8_t* __restrict__ mask, int H, int W, VT s, const VT* __restrict__ z,
+                                                          const VT* __restrict__ zc, int Wc, const double* __restrict__ r, VT* __restrict__ zout,
+                                                          double* __restrict__ part, const uint8_t* __restrict__ active, int tiles_x, int ntiles,
+                                                          const int* __restrict__ ctl) {
     if (ctl[0]) return;
     __shared__ double s_part[12];
     __shared__ TileLds lds;
-    const D3 acc = mg_up_tiles<kThreads, RT, DOT>(mask, H, W, s, z, zc, Wc, r, zout, active, tiles_x, ntiles, (int)blockIdx.x, (int)gridDim.x, lds);
-    if (DOT) store_partial(part, block_sum(acc, s_part));
+    const D3 acc = mg_up_tiles<kThreads, double, true, false>(mask, H, W, s, z, zc, Wc, r, zout, active, tiles_x, ntiles, (int)blockIdx.x, (int)gridDim.x, lds,
+                                                              nullptr, nullptr, nullptr);
+    store_partial(part, block_sum(acc, s_part));
+}
+// levels >= 1
+__global__ __launch_bounds__(kThreads) void mg_up_kernel(const uint8_t* __restrict__ mask, int H, int W, VT s, const VT* __restrict__ z,
+                                                         const VT* __restrict__ zc, int Wc, const VT* __restrict__ r, VT* __restrict__ zout,
+                                                         const uint8_t* __restrict__ active, int tiles_x, int ntiles,
+                                                         const VT* __restrict__ dg, const float4* __restrict__ wg, const int* __restrict__ ctl) {
+    if (ctl[0]) return;
+    __shared__ TileLds lds;
+    __shared__ GalLds gal;
+    mg_up_tiles<kThreads, VT, false, true>(mask, H, W, s, z, zc, Wc, r, zout, active, tiles_x, ntiles, (int)blockIdx.x, (int)gridDim.x, lds, dg, wg, &gal);
 }
 
 // level 0 of an image so small that it is the tail's first level: the tail works on float32, the CG residual is float64
@@ -531,70 +602,77 @@ __global__ __launch_bounds__(kThreads) void rf_dot_kernel(const uint8_t* __restr
 // The coarse end of the V-cycle (levels first_tail .. L-1, a few thousand cells at most) inside ONE workgroup: sweeps separated by
 // workgroup barriers instead of kernel boundaries - a chain of ~25 tiny phases.  Every tail level lives in LDS for the duration of
 // the cycle, in a layout made for the phases: each level with a one-cell ring around it (pitch W + 2), per cell the three channels
-// of z, zt, r and one byte nn = the cell's in-image neighbour count if it is in the mask, 0 otherwise (and on the ring).  z and zt are
-// zero wherever nn is: the masked stencil is n z - up - down - left - right with no test, a phase is one LDS round trip.  (Round 4's
-// first form addressed LDS or global memory through one generic pointer and tested the mask and the image border per neighbour:
-// 1.4 us per phase, 36 us per iteration.)  The first tail level receives its r from the "down" pass of the level above and hands
-// its z to that level's "up" pass (both in the compact global layout).
+// of z, zt, r, the operator's diagonal d (float; 0 outside the mask and on the ring) and its four edge weights (half precision:
+// multiples of 2^-level, exact).  z and zt are zero wherever d is: the stencil is d z - sum w_k z_k with no test, a phase is one LDS
+// round trip.  (Round 4's first form addressed LDS or global memory through one generic pointer and tested the mask and the image
+// border per neighbour: 1.4 us per phase, 36 us per iteration.)  d and w of all tail levels come as one packed image (mg_tail_pack_kernel,
+// once per solve), copied in 16-byte pieces in the same round trip as the first level's r, which the "down" pass of the level above
+// wrote; the first level's z goes back to that level's "up" pass (both in the compact global layout).
+struct H4 { __half2 a, b; };                 // up, down | left, right
 template <int NT>
-__device__ __forceinline__ void mg_tail_levels(const LevelSet& ls, const uint8_t* __restrict__ g_nn, uint8_t* __restrict__ smem) {
+__device__ __forceinline__ void mg_tail_levels(const LevelSet& ls, const uint8_t* __restrict__ g_dw, uint8_t* __restrict__ smem) {
     VT* const fl = reinterpret_cast<VT*>(smem);
-    uint8_t* const nnb = smem + (size_t)ls.tail_floats * sizeof(VT);
+    float* const dd = reinterpret_cast<float*>(smem + (size_t)ls.tail_floats * sizeof(VT));
+    H4* const ww = reinterpret_cast<H4*>(dd + ls.tail_cells);
     const int t = (int)threadIdx.x, row0 = t >> 6, col0 = t & 63;
     constexpr int ROWS = NT / 64;
-    {   // one round trip to global memory: the ringed nn bytes of all tail levels (built once per solve) and the first level's r are
-        // requested, LDS is zeroed (rings, cells outside the mask) while they travel, then they are put in place
+    {   // one round trip to global memory: the packed d / w image and the first level's r are requested, the vectors are zeroed (rings,
+        // cells outside the mask) while they travel, then everything is put in place
         const Level& v = ls.lv[ls.first_tail];
         const int Wp = v.W + 2, cells = v.H * v.W;
         constexpr int NR = (kTailCells + NT - 1) / NT;
         VT rv[NR][3];
         int pp[NR];
-        uint8_t nv[NR];
+        float dv[NR];
 #pragma unroll
         for (int k = 0; k < NR; k++) {
             const int g = t + k * NT, gg = g < cells ? g : 0, y = gg / v.W, x = gg - y * v.W;
             pp[k] = g < cells ? (y + 1) * Wp + x + 1 : -1;
-            nv[k] = g_nn[v.moff + (y + 1) * Wp + x + 1];
+            dv[k] = reinterpret_cast<const float*>(g_dw)[v.moff + (y + 1) * Wp + x + 1];
 #pragma unroll
             for (int c = 0; c < 3; c++) rv[k][c] = v.r[3 * gg + c];
         }
-        const int nb16 = ls.tail_bytes / 16;                   // (<= 4 x 1024 sixteen-byte pieces: kTailLdsBytes / 37 cells)
+        const int nb16 = ls.tail_cells * 12 / 16;               // (<= 4 x 1024 sixteen-byte pieces: see kTailDwBytes)
         uint4 mv[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) mv[k] = t + k * NT < nb16 ? reinterpret_cast<const uint4*>(g_nn)[t + k * NT] : make_uint4(0u, 0u, 0u, 0u);
+        for (int k = 0; k < 4; k++) mv[k] = t + k * NT < nb16 ? reinterpret_cast<const uint4*>(g_dw)[t + k * NT] : make_uint4(0u, 0u, 0u, 0u);
         const int n4 = ls.tail_floats * (int)sizeof(VT) / 16;
         float4* const q = reinterpret_cast<float4*>(smem);
         for (int i = t; i < n4; i += NT) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (t + k * NT < nb16) reinterpret_cast<uint4*>(nnb)[t + k * NT] = mv[k];
+            if (t + k * NT < nb16) reinterpret_cast<uint4*>(dd)[t + k * NT] = mv[k];
         VT* const r = fl + v.off + 6 * v.cp;
 #pragma unroll
         for (int k = 0; k < NR; k++)
-            if (pp[k] >= 0 && nv[k]) { r[3 * pp[k]] = rv[k][0]; r[3 * pp[k] + 1] = rv[k][1]; r[3 * pp[k] + 2] = rv[k][2]; }
+            if (pp[k] >= 0 && dv[k] > 0.f) { r[3 * pp[k]] = rv[k][0]; r[3 * pp[k] + 1] = rv[k][1]; r[3 * pp[k] + 2] = rv[k][2]; }
     }
     __syncthreads();
-    // zout = zin + omega / (s n) (r - s A' zin)   (zin == nullptr: from zero)
+    // (A v)(p) for channel c
+    auto stencil = [&](const VT* __restrict__ v, int p, int Wp, VT d, const H4& e, int c) {
+        VT a = d * v[3 * p + c];
+        a -= __low2float(e.a) * v[3 * (p - Wp) + c]; a -= __high2float(e.a) * v[3 * (p + Wp) + c];
+        a -= __low2float(e.b) * v[3 * (p - 1) + c]; a -= __high2float(e.b) * v[3 * (p + 1) + c];
+        return a;
+    };
+    // zout = zin + omega / (s d) (r - s A zin)   (zin == nullptr: from zero)
     auto jacobi = [&](const Level& v, const VT* __restrict__ zin, VT* __restrict__ zout, VT omega) {
         const int Wp = v.W + 2;
         const VT* const r = fl + v.off + 6 * v.cp;
-        const uint8_t* const nn = nnb + v.moff;
         for (int y = row0; y < v.H; y += ROWS)
             for (int x = col0; x < v.W; x += 64) {
                 const int p = (y + 1) * Wp + x + 1;
-                const int n = nn[p];
-                if (!n) continue;
-                const VT w = omega / (v.s * (VT)n);
+                const VT d = dd[v.moff + p];
+                if (!(d > (VT)0)) continue;
+                const VT w = omega / (v.s * d);
+                if (zin) {
+                    const H4 e = ww[v.moff + p];
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    if (zin) {
-                        VT a = (VT)n * zin[3 * p + c];
-                        a -= zin[3 * (p - Wp) + c]; a -= zin[3 * (p + Wp) + c]; a -= zin[3 * (p - 1) + c]; a -= zin[3 * (p + 1) + c];
-                        zout[3 * p + c] = zin[3 * p + c] + w * (r[3 * p + c] - v.s * a);
-                    } else {
-                        zout[3 * p + c] = w * r[3 * p + c];
-                    }
+                    for (int c = 0; c < 3; c++) zout[3 * p + c] = zin[3 * p + c] + w * (r[3 * p + c] - v.s * stencil(zin, p, Wp, d, e, c));
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) zout[3 * p + c] = w * r[3 * p + c];
                 }
             }
         __syncthreads();
@@ -608,29 +686,24 @@ __device__ __forceinline__ void mg_tail_levels(const LevelSet& ls, const uint8_t
         } else {
             jacobi(v, nullptr, zt, kOmegaA);
             jacobi(v, zt, z, kOmegaB);
-            // r_c(I) = sum over the children i of I inside the fine mask of (r_f - s_f A' z_f)(i)
+            // r_c(I) = sum over the children i of I inside the fine mask of (r_f - s_f A z_f)(i)
             const Level& cl = ls.lv[l + 1];
             const int Wp = v.W + 2, Wpc = cl.W + 2;
             const VT* const r = z + 6 * v.cp;
             VT* const rc = fl + cl.off + 6 * cl.cp;
-            const uint8_t* const nn = nnb + v.moff;
-            const uint8_t* const nnc = nnb + cl.moff;
             for (int Y = row0; Y < cl.H; Y += ROWS)
                 for (int X = col0; X < cl.W; X += 64) {
                     const int P = (Y + 1) * Wpc + X + 1;
-                    if (!nnc[P]) continue;
+                    if (!(dd[cl.moff + P] > (VT)0)) continue;
                     VT acc[3] = {(VT)0, (VT)0, (VT)0};
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const int p = (2 * Y + (k >> 1) + 1) * Wp + 2 * X + (k & 1) + 1;      // (a child outside the image sits on the ring: nn = 0)
-                        const int n = nn[p];
-                        if (!n) continue;
+                        const int p = (2 * Y + (k >> 1) + 1) * Wp + 2 * X + (k & 1) + 1;      // (a child outside the image sits on the ring: d = 0)
+                        const VT d = dd[v.moff + p];
+                        if (!(d > (VT)0)) continue;
+                        const H4 e = ww[v.moff + p];
 #pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            VT a = (VT)n * z[3 * p + c];
-                            a -= z[3 * (p - Wp) + c]; a -= z[3 * (p + Wp) + c]; a -= z[3 * (p - 1) + c]; a -= z[3 * (p + 1) + c];
-                            acc[c] += r[3 * p + c] - v.s * a;
-                        }
+                        for (int c = 0; c < 3; c++) acc[c] += r[3 * p + c] - v.s * stencil(z, p, Wp, d, e, c);
                     }
                     rc[3 * P] = acc[0]; rc[3 * P + 1] = acc[1]; rc[3 * P + 2] = acc[2];
                 }
@@ -643,11 +716,10 @@ __device__ __forceinline__ void mg_tail_levels(const LevelSet& ls, const uint8_t
         VT* const z = fl + v.off; VT* const zt = z + 3 * v.cp;
         const VT* const zc = fl + cl.off;
         const int Wp = v.W + 2, Wpc = cl.W + 2;
-        const uint8_t* const nn = nnb + v.moff;
         for (int y = row0; y < v.H; y += ROWS)                  // z += z_c(parent) on the masked cells
             for (int x = col0; x < v.W; x += 64) {
                 const int p = (y + 1) * Wp + x + 1;
-                if (!nn[p]) continue;
+                if (!(dd[v.moff + p] > (VT)0)) continue;
                 const int P = ((y >> 1) + 1) * Wpc + (x >> 1) + 1;
                 z[3 * p] += zc[3 * P]; z[3 * p + 1] += zc[3 * P + 1]; z[3 * p + 2] += zc[3 * P + 2];
             }
@@ -658,34 +730,99 @@ __device__ __forceinline__ void mg_tail_levels(const LevelSet& ls, const uint8_t
     {
         const Level& v = ls.lv[ls.first_tail];
         const VT* const z = fl + v.off;
-        const uint8_t* const nn = nnb + v.moff;
         const int Wp = v.W + 2;
         for (int y = row0; y < v.H; y += ROWS)
             for (int x = col0; x < v.W; x += 64) {
                 const int g = y * v.W + x, p = (y + 1) * Wp + x + 1;
-                if (!nn[p]) continue;
+                if (!(dd[v.moff + p] > (VT)0)) continue;
                 v.z[3 * g] = z[3 * p]; v.z[3 * g + 1] = z[3 * p + 1]; v.z[3 * g + 2] = z[3 * p + 2];
             }
     }
 }
 
-__global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls, const uint8_t* __restrict__ g_nn, const int* __restrict__ ctl) {
+__global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(LevelSet ls, const uint8_t* __restrict__ g_dw, const int* __restrict__ ctl) {
     if (ctl[0]) return;
     __shared__ __align__(16) uint8_t smem[kTailLdsBytes];
-    mg_tail_levels<kTailThreads>(ls, g_nn, smem);
+    mg_tail_levels<kTailThreads>(ls, g_dw, smem);
 }
 
-// Once per solve: the tail levels' nn bytes (in-image neighbour count of a masked cell, 0 elsewhere and on the ring) in the layout
-// mg_tail_levels keeps them in - it copies them in 16-byte pieces at the start of every V-cycle.
-__global__ __launch_bounds__(kTailThreads) void mg_tail_nn_kernel(LevelSet ls, uint8_t* __restrict__ g_nn) {
+// Once per solve: the Galerkin operator of a coarse level from the level above it.  With piecewise-constant prolongation over 2 x 2
+// aggregates, P^T A P of aggregate I has the diagonal sum_{i in I} d_i - (the edge weights between children of I) and, towards the
+// neighbouring aggregate J, the sum of the children's edge weights that cross from I to J.  The coarse operator is HALF of that: the
+// over-correction by two that piecewise-constant P needs (see the header; an interior cell gets 4 / 1 1 1 1 on every level).  A coarse
+// cell that is only partly inside the mask - the ragged Dirichlet boundary of a real silhouette - gets exactly the diagonal and the
+// couplings its children have, where re-discretising the stencil on the coarse mask pretends the whole cell is inside: NumPy model
+// (tools/dev/rf_model.py) on the bench's hole 44 -> 24 iterations, the kernels 52 -> see DESIGN.md section 3b.  All values are sums of
+// multiples of 2^-level: exact in float32, the same on every run.  FINE0: the fine level is level 0 (d = in-image neighbour count,
+// w = 1 towards neighbours in the mask).
+template <bool FINE0>
+__global__ __launch_bounds__(kThreads) void mg_galerkin_kernel(const uint8_t* __restrict__ mf, const VT* __restrict__ df, const float4* __restrict__ wf,
+                                                               int Hf, int Wf, uint8_t* __restrict__ mc, VT* __restrict__ dc, float4* __restrict__ wc,
+                                                               int Hc, int Wc) {
+    const uint32_t n = (uint32_t)Hc * (uint32_t)Wc;
+    for (uint32_t I = blockIdx.x * blockDim.x + threadIdx.x; I < n; I += gridDim.x * blockDim.x) {
+        const int Y = (int)(I / (uint32_t)Wc), X = (int)(I - (uint32_t)Y * (uint32_t)Wc);
+        int any = 0;
+        VT dsum = 0, internal = 0, up = 0, dn = 0, lf = 0, rt = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = 2 * Y + (k >> 1), x = 2 * X + (k & 1);
+            if (y >= Hf || x >= Wf) continue;
+            const size_t i = (size_t)y * Wf + x;
+            if (!mf[i]) continue;
+            any = 1;
+            VT d;
+            float4 e;
+            if (FINE0) {
+                d = (VT)ncount(y, x, Hf, Wf);
+                e.x = (y > 0 && mf[i - Wf]) ? 1.f : 0.f;
+                e.y = (y < Hf - 1 && mf[i + Wf]) ? 1.f : 0.f;
+                e.z = (x > 0 && mf[i - 1]) ? 1.f : 0.f;
+                e.w = (x < Wf - 1 && mf[i + 1]) ? 1.f : 0.f;
+            } else {
+                d = df[i];
+                e = wf[i];
+            }
+            dsum += d;
+            if ((k >> 1) == 0) { up += e.x; internal += e.y; } else { dn += e.y; internal += e.x; }
+            if ((k & 1) == 0) { lf += e.z; internal += e.w; } else { rt += e.w; internal += e.z; }
+        }
+        mc[I] = (uint8_t)any;
+        dc[I] = any ? (dsum - internal) * (VT)0.5 : (VT)0;
+        wc[I] = make_float4(up * 0.5f, dn * 0.5f, lf * 0.5f, rt * 0.5f);
+    }
+}
+
+// Once per solve: d (float) and w (four halves) of the tail levels in the ringed layout mg_tail_levels keeps them in - [d of all tail
+// cells][w of all tail cells], a level's cells from its moff.
+__global__ __launch_bounds__(kTailThreads) void mg_tail_pack_kernel(LevelSet ls, uint8_t* __restrict__ g_dw) {
     const int t = (int)threadIdx.x;
-    for (int i = t; i < ls.tail_bytes; i += kTailThreads) g_nn[i] = 0;
+    float* const dd = reinterpret_cast<float*>(g_dw);
+    H4* const ww = reinterpret_cast<H4*>(dd + ls.tail_cells);
+    for (int i = t; i < ls.tail_cells * 3; i += kTailThreads) reinterpret_cast<uint32_t*>(g_dw)[i] = 0u;
     __syncthreads();
     for (int l = ls.first_tail; l < ls.L; l++) {
         const Level& v = ls.lv[l];
         for (int g = t; g < v.H * v.W; g += kTailThreads) {
-            const int y = g / v.W, x = g - y * v.W;
-            if (v.mask[g]) g_nn[v.moff + (y + 1) * (v.W + 2) + x + 1] = (uint8_t)ncount(y, x, v.H, v.W);
+            if (!v.mask[g]) continue;
+            const int y = g / v.W, x = g - y * v.W, p = v.moff + (y + 1) * (v.W + 2) + x + 1;
+            float d;
+            float4 e;
+            if (l == 0) {                                      // (an image of at most 8 x 8 cells: level 0 is the tail)
+                d = (float)ncount(y, x, v.H, v.W);
+                e.x = (y > 0 && v.mask[g - v.W]) ? 1.f : 0.f;
+                e.y = (y < v.H - 1 && v.mask[g + v.W]) ? 1.f : 0.f;
+                e.z = (x > 0 && v.mask[g - 1]) ? 1.f : 0.f;
+                e.w = (x < v.W - 1 && v.mask[g + 1]) ? 1.f : 0.f;
+            } else {
+                d = v.d[g];
+                e = v.w[g];
+            }
+            dd[p] = d;
+            H4 h;
+            h.a = __floats2half2_rn(e.x, e.y);
+            h.b = __floats2half2_rn(e.z, e.w);
+            ww[p] = h;
         }
     }
 }
@@ -721,12 +858,12 @@ struct Launcher {
 };
 
 struct Solver {
-    int H, W, L, first_tail, tail_floats, tail_bytes;
+    int H, W, L, first_tail, tail_floats, tail_cells;
     uint32_t n;
     Level lv[kMaxLevels];
     double *scal, *part_rr, *part_pap, *part_rz[2], *part_cross, *x, *p[2], *Ap, *r;
     int* ctl;                                       // {done, iterations run, converged}: the device-side convergence state
-    uint8_t *mask0, *tail_nn;                       // tail_nn: the tail levels' ringed nn bytes (mg_tail_nn_kernel)
+    uint8_t *mask0, *tail_dw;                       // tail_dw: the tail levels' operators in the tail's LDS layout (mg_tail_pack_kernel)
 
     void carve(void* ws, int H_, int W_) {
         H = H_; W = W_; n = (uint32_t)H * (uint32_t)W;
@@ -758,13 +895,15 @@ struct Solver {
             lv[l].zt = reinterpret_cast<VT*>(take(vb));
             lv[l].r = reinterpret_cast<VT*>(take(vb));              // (level 0: only used when level 0 is the tail's first level)
             lv[l].mask = take((size_t)hs[l] * wsz[l]);                 // level 0: a private copy of the caller's mask
+            lv[l].d = l > 0 ? reinterpret_cast<VT*>(take((size_t)hs[l] * wsz[l] * sizeof(VT))) : nullptr;
+            lv[l].w = l > 0 ? reinterpret_cast<float4*>(take((size_t)hs[l] * wsz[l] * sizeof(float4))) : nullptr;
             lv[l].active = take((size_t)lv[l].ntiles);
         }
         mask0 = lv[0].mask;
-        tail_nn = take(kTailNnBytes);
-        // the tail: the coarsest levels as far as their ringed LDS layout (9 values of VT + 1 byte per cell) fits
-        auto ringed = [&](int l) { return (size_t)(lv[l].H + 2) * (lv[l].W + 2); };
-        auto lds_need = [&](int l) { return ringed(l) * 9 * sizeof(VT) + ((ringed(l) + 15) & ~(size_t)15); };
+        tail_dw = take(kTailDwBytes);
+        // the tail: the coarsest levels as far as their ringed LDS layout (9 values of VT + d + four half-precision weights per cell) fits
+        auto ringed = [&](int l) { return ((size_t)(lv[l].H + 2) * (lv[l].W + 2) + 15) & ~(size_t)15; };
+        auto lds_need = [&](int l) { return ringed(l) * (9 * sizeof(VT) + 12); };
         first_tail = L - 1;
         size_t used = lds_need(first_tail);
         while (first_tail > 1 && (size_t)lv[first_tail - 1].H * lv[first_tail - 1].W <= (size_t)kTailCells && used + lds_need(first_tail - 1) <= (size_t)kTailLdsBytes) {
@@ -777,15 +916,15 @@ struct Solver {
             if (l < first_tail) continue;
             lv[l].cp = (int)ringed(l);
             lv[l].off = fo; fo += 9 * lv[l].cp;
-            lv[l].moff = mo; mo += (lv[l].cp + 15) & ~15;
+            lv[l].moff = mo; mo += lv[l].cp;
         }
-        tail_floats = (fo + 3) & ~3;
-        tail_bytes = mo;
+        tail_floats = fo;
+        tail_cells = mo;
     }
 
     LevelSet level_set() const {
         LevelSet ls;
-        ls.L = L; ls.first_tail = first_tail; ls.tail_floats = tail_floats; ls.tail_bytes = tail_bytes;
+        ls.L = L; ls.first_tail = first_tail; ls.tail_floats = tail_floats; ls.tail_cells = tail_cells;
         for (int l = 0; l < kMaxLevels; l++) ls.lv[l] = lv[l < L ? l : L - 1];
         return ls;
     }
@@ -801,22 +940,24 @@ struct Solver {
         const LevelSet ls = level_set();
         if (first_tail > 0) {
             const Level &v = lv[0], &c = lv[1];
-            q.launch(mg_down_kernel<double>, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const double*)r, v.z, c.mask, c.H, c.W, c.r, v.active, v.tiles_x, v.ntiles, ctl);
+            q.launch(mg_down0_kernel, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const double*)r, v.z, c.mask, c.H, c.W, c.r, v.active, v.tiles_x, v.ntiles, ctl);
         }
         for (int l = 1; l < first_tail; l++) {
             const Level &v = lv[l], &c = lv[l + 1];
-            q.launch(mg_down_kernel<VT>, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const VT*)v.r, v.z, c.mask, c.H, c.W, c.r, v.active, v.tiles_x, v.ntiles, ctl);
+            q.launch(mg_down_kernel, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const VT*)v.r, v.z, c.mask, c.H, c.W, c.r, v.active, v.tiles_x, v.ntiles,
+                     (const VT*)v.d, (const float4*)v.w, ctl);
         }
-        q.launch(mg_tail_kernel, dim3(1), dim3(kTailThreads), ls, (const uint8_t*)tail_nn, ctl);
+        q.launch(mg_tail_kernel, dim3(1), dim3(kTailThreads), ls, (const uint8_t*)tail_dw, ctl);
         for (int l = first_tail - 1; l >= 1; l--) {
             const Level &v = lv[l], &c = lv[l + 1];
             const VT* zc = l + 1 == first_tail ? c.z : c.zt;
-            q.launch(mg_up_kernel<VT, false>, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const VT*)v.z, zc, c.W, (const VT*)v.r, v.zt, (double*)nullptr, v.active, v.tiles_x, v.ntiles, ctl);
+            q.launch(mg_up_kernel, tile_grid(v), b, v.mask, v.H, v.W, v.s, (const VT*)v.z, zc, c.W, (const VT*)v.r, v.zt, v.active, v.tiles_x, v.ntiles,
+                     (const VT*)v.d, (const float4*)v.w, ctl);
         }
         if (first_tail > 0) {
             const Level &v = lv[0], &c = lv[1];
             const VT* zc = 1 == first_tail ? c.z : c.zt;
-            q.launch(mg_up_kernel<double, true>, dim3(kBlocks), b, v.mask, v.H, v.W, v.s, (const VT*)v.z, zc, c.W, (const double*)r, v.zt, part_rz_new, v.active, v.tiles_x, v.ntiles, ctl);
+            q.launch(mg_up0_kernel, dim3(kBlocks), b, v.mask, v.H, v.W, v.s, (const VT*)v.z, zc, c.W, (const double*)r, v.zt, part_rz_new, v.active, v.tiles_x, v.ntiles, ctl);
         }
         if (first_tail == 0) {
             q.launch(rf_dot_kernel, dim3(kBlocks), b, mask0, n, (const double*)r, (const VT*)lv[0].z, part_rz_new, ctl);
@@ -847,11 +988,12 @@ extern "C" size_t usc_regionfill_ws_bytes(int H, int W) {
     int hs[kMaxLevels], ws[kMaxLevels];
     const int L = level_dims(H, W, hs, ws);
     size_t total = 256 + 5 * rf_align((size_t)kBlocks * 3 * sizeof(double));
-    total += rf_align(kTailNnBytes);
+    total += rf_align(kTailDwBytes);
     total += 5 * rf_align((size_t)H * W * 3 * sizeof(double));                  // x, p (two), Ap, r
     for (int l = 0; l < L; l++) {
         const size_t tiles = (size_t)((ws[l] + TS - 1) / TS) * ((hs[l] + TS - 1) / TS);
         total += 3 * rf_align((size_t)hs[l] * ws[l] * 3 * sizeof(VT)) + rf_align((size_t)hs[l] * ws[l]) + rf_align(tiles);   // z, zt, r, mask, tile flags per level
+        if (l > 0) total += rf_align((size_t)hs[l] * ws[l] * sizeof(VT)) + rf_align((size_t)hs[l] * ws[l] * sizeof(float4));       // the level's operator: d, w
     }
     return total;
 }
@@ -872,12 +1014,15 @@ extern "C" int usc_regionfill_u8(const uint8_t* img, const uint8_t* mask, int H,
     if (first_iter == 0) {                                      // a new solve: masks and tile flags of every level, x0, r0, control block
         if (hipMemcpyAsync(s.mask0, mask, (size_t)H * W, hipMemcpyDeviceToDevice, st) != hipSuccess)
             return fail(USC_E_LAUNCH, "usc_regionfill_u8: mask copy failed");
-        for (int l = 1; l < s.L; l++)
-            q.launch(mg_mask_down_kernel, dim3(grid_of((size_t)s.lv[l].H * s.lv[l].W)), b, s.lv[l - 1].mask, s.lv[l - 1].H, s.lv[l - 1].W,
-                     s.lv[l].mask, s.lv[l].H, s.lv[l].W);
+        for (int l = 1; l < s.L; l++) {                          // masks and operators of the coarse levels
+            const Level &f = s.lv[l - 1], &c = s.lv[l];
+            const dim3 g(grid_of((size_t)c.H * c.W));
+            if (l == 1) q.launch(mg_galerkin_kernel<true>, g, b, (const uint8_t*)f.mask, (const VT*)nullptr, (const float4*)nullptr, f.H, f.W, c.mask, c.d, c.w, c.H, c.W);
+            else q.launch(mg_galerkin_kernel<false>, g, b, (const uint8_t*)f.mask, (const VT*)f.d, (const float4*)f.w, f.H, f.W, c.mask, c.d, c.w, c.H, c.W);
+        }
         for (int l = 0; l < s.L && l < (s.first_tail > 0 ? s.first_tail : 1); l++)
             q.launch(mg_active_kernel, dim3((unsigned)s.lv[l].ntiles), b, (const uint8_t*)s.lv[l].mask, s.lv[l].H, s.lv[l].W, s.lv[l].active, s.lv[l].tiles_x);
-        q.launch(mg_tail_nn_kernel, dim3(1), dim3(kTailThreads), s.level_set(), s.tail_nn);
+        q.launch(mg_tail_pack_kernel, dim3(1), dim3(kTailThreads), s.level_set(), s.tail_dw);
         q.launch(rf_init_kernel, dim3(kBlocks), b, img, s.mask0, H, W, s.x, s.r, s.part_rr);
         q.launch(rf_publish_kernel, dim3(1), b, s.part_rr, s.scal, 0, s.ctl, rtol2, 0);
     }
