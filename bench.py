@@ -466,10 +466,10 @@ def mode_roofline(args, pipe, frame):
         roof = {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_wino_kernel (space-time memory network: memorize + query trunk + memory read + decoder)",
                 "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                 "alg_gflop_per_forward": round(gf, 1), "ms_per_forward": round(t * 1e3, 3)}
-    # the Laplace fill of the frame's own hole: bytes = iterations x unknowns x 116 B - per unknown and preconditioned CG iteration the four
+    # the Laplace fill of the frame's own hole: bytes = iterations x unknowns x 130 B - per unknown and preconditioned CG iteration the four
     # level-0 passes move 12 ("down": r f64 in, z f32 out) + 17 ("up": z, r, a quarter of z_c in, z out) + 28 (p = z + beta p, A p) + 52
-    # (x, r update + the two dot products) bytes, the float32 coarser levels a third of 22 more (round 3's float64 / seven-pass form: 195);
-    # time = HIP events around one converged solve
+    # (x, r update + the two dot products) bytes, the float32 coarser levels a third of 22 + 40 more (their two passes also read the level's
+    # operator: a diagonal and four edge weights per cell) (round 3's float64 / seven-pass form: 195); time = HIP events around one converged solve
     from video_unscreen_amd import _native as nv
     out = pipe.step(frame)
     if "bg_holes" in out and "hole" in out:
@@ -477,8 +477,8 @@ def mode_roofline(args, pipe, frame):
         _, iters = nv.regionfill(bg, hole, want_iters=True)
         t = _net_time(lambda: nv.regionfill(bg, hole), iters=3, warm=1)
         unknowns = 3 * int((hole > 0).sum().item())
-        nbytes = iters * unknowns * 116
-        extra["roofline_fill"] = {"bound": "hbm", "kernel": "usc_regionfill.hip (CG in float64, tiled float32 multigrid V-cycle as preconditioner; 13 dependent launches per iteration: latency-bound)", "achieved": round(nbytes / t / 1e9, 1),
+        nbytes = iters * unknowns * 130
+        extra["roofline_fill"] = {"bound": "hbm", "kernel": "usc_regionfill.hip (CG in float64, tiled float32 multigrid V-cycle with Galerkin coarse operators as preconditioner; 13 dependent launches per iteration: latency-bound)", "achieved": round(nbytes / t / 1e9, 1),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                                   "iterations": iters, "unknowns": unknowns, "ms_per_solve": round(t * 1e3, 3)}
     return roof, extra

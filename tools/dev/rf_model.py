@@ -44,7 +44,7 @@ def pad2(a):
     return np.pad(a, ((0, H & 1), (0, W & 1)))
 
 
-def coarsen(lv, mode):
+def coarsen(lv, mode, scale=0.5):
     mask = pad2(lv.mask)
     Hc, Wc = mask.shape[0] // 2, mask.shape[1] // 2
     mc = mask.reshape(Hc, 2, Wc, 2).any(axis=(1, 3))
@@ -55,8 +55,8 @@ def coarsen(lv, mode):
     D, Wt = blk(d), [blk(x) for x in w]
     # internal edges of an aggregate: up-edges of its lower children, down-edges of its upper children, left of the right, right of the left
     internal = Wt[0][:, 1].sum(-1) + Wt[1][:, 0].sum(-1) + Wt[2][:, :, :, 1].sum(1) + Wt[3][:, :, :, 0].sum(1)
-    dc = (D.sum(axis=(1, 3)) - internal) / 2
-    wc = [Wt[0][:, 0].sum(-1) / 2, Wt[1][:, 1].sum(-1) / 2, Wt[2][:, :, :, 0].sum(1) / 2, Wt[3][:, :, :, 1].sum(1) / 2]
+    dc = (D.sum(axis=(1, 3)) - internal) * scale
+    wc = [Wt[0][:, 0].sum(-1) * scale, Wt[1][:, 1].sum(-1) * scale, Wt[2][:, :, :, 0].sum(1) * scale, Wt[3][:, :, :, 1].sum(1) * scale]
     return Level(mc, np.where(mc, dc, 0.0), [np.where(mc, x, 0.0) for x in wc])
 
 
@@ -96,10 +96,10 @@ def vcycle(levels, l, r, sweeps=1):
     return z
 
 
-def solve(img, mask, coarse="rediscretised", rtol=1e-7, sweeps=1, max_iters=400):
+def solve(img, mask, coarse="rediscretised", rtol=1e-7, sweeps=1, max_iters=400, scale=0.5):
     levels = [level0(mask)]
     while levels[-1].mask.shape[0] > 8 or levels[-1].mask.shape[1] > 8:
-        levels.append(coarsen(levels[-1], coarse))
+        levels.append(coarsen(levels[-1], coarse, scale))
     A = levels[0]
     x = np.where(mask, img, 0.0)
     known = np.where(mask, 0.0, img)

@@ -5,14 +5,17 @@
 // (scipy spsolve), seconds per 1080p channel.  Here the three channels are solved together by conjugate gradients in float64,
 // preconditioned with one geometric multigrid V-cycle per iteration - the matrix is the masked 5-point stencil and is never stored:
 //   * levels: 2x2 cell aggregation (coarse cell in the mask iff any child is), piecewise-constant prolongation P, restriction
-//     P^T, coarse operator = the same masked stencil re-discretised on the coarse grid (the Galerkin operator P^T A P of an
-//     interior cell is twice that; with piecewise-constant P the unscaled stencil - an over-correction by 2 - is the better
-//     preconditioner: measured 24 iterations against 52 at 1080p), weighted-Jacobi smoothing (2 pre, 2 post; 5 sweeps on the coarsest level) -
-//     every piece symmetric, so the V-cycle is a valid CG preconditioner.  (Round 4 tried, in a NumPy model of this solver,
-//     cell-centred bilinear P / P^T (28 -> 24 iterations on the bench's ragged 1080p hole), red-black Gauss-Seidel (-> 18 with two
-//     sweeps, at twice the launches per level) and Chebyshev weights for the two Jacobi sweeps (-> 25): the iteration count is set
-//     by the coarse correction on the ragged Dirichlet boundary, none of them changes it by the factor that would pay for its cost.)
-//   * ~25 iterations instead of the ~3000 plain CG needs on a 1080p silhouette (condition number ~ width^2);
+//     P^T, coarse operator = HALF the Galerkin operator P^T A P of the level above (mg_galerkin_kernel: per cell a diagonal and four
+//     edge weights summed from the children's; an interior cell gets the 5-point stencil 4 / 1 1 1 1 again - the over-correction by 2
+//     that piecewise-constant P needs), weighted-Jacobi smoothing (2 pre, 2 post; 5 sweeps on the coarsest level) - every piece
+//     symmetric, so the V-cycle is a valid CG preconditioner.  Rounds 1 - 4 re-discretised the masked stencil on the coarse mask
+//     instead, which treats a coarse cell that is partly outside the mask as if it were inside: on a real silhouette's ragged
+//     Dirichlet boundary that coarse correction is wrong where it matters, and the iteration count doubled (52 against 24 on the
+//     bench's hole; tools/dev/rf_model.py, the NumPy model of this solver that priced the change: 44 -> 24.  The same model had said
+//     before that cell-centred bilinear P, red-black Gauss-Seidel or Chebyshev weights do NOT pay: 28 -> 24 / 18 / 25; and a second
+//     pair of sweeps each way from level 2 on - built as tiled kernels with a 4-cell ring, 24 -> 20 iterations - costs per cycle
+//     what it saves: 5.30 against 5.43 ms per solve, not kept).
+//   * 18 - 24 iterations instead of the ~3000 plain CG needs on a 1080p silhouette (condition number ~ width^2);
 //   * dot products are reduced in a fixed order (per-block partial sums, re-summed by every consumer block): bit-reproducible.
 // Round 4: the V-cycle runs in FLOAT32 (a preconditioner only has to be a fixed symmetric linear operator; the CG vectors x, r, p, A p
 // and every dot product stay float64, so the iteration still converges to the same tolerance), and the fine levels run as TILED
