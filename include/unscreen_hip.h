@@ -251,6 +251,10 @@ int usc_adaptive_avgpool_nhwc_f32(const float* src, int H, int W, int ld, int c0
 /* The same for `batch` images stacked along y in src ((batch*H, W, ld)) -> dst (batch*s, s, C); per image bit-identical. */
 int usc_adaptive_avgpool_nhwc_batch_f32(const float* src, int H, int W, int ld, int c0, int C, float* dst, int s, int batch,
                                         usc_stream_t stream);
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of `batch` images stacked along y: src (batch*H, W, C) float32 NHWC -> dst
+ * (batch*OH, OW, C), OH = (H - 1) / 2 + 1 (the ResNet stems: binseg/human_parse.py:210, binseg/deeplab/backbone/resnet.py:185,
+ * stm/model.py:46,58,73,83, iseg/brs/models/resnetv1b.py:191).  C % 4 == 0, 16-byte aligned tensors. */
+int usc_maxpool3x3s2_nhwc_f32(const float* src, int H, int W, int C, float* dst, int batch, usc_stream_t stream);
 size_t usc_segagent_post_ws_bytes(int th, int tw);
 int usc_segagent_post(const float* logits, int ncrops, int lh, int lw, int cbuf, const int* locs_host, int crop_h, int crop_w,
                       int th, int tw, int H, int W, uint8_t* out, double* score_out, void* ws, size_t ws_bytes,

@@ -66,6 +66,21 @@ def test_im2col_and_upsample_nc(nv, oracle_lib):
     assert np.abs(want - t.numpy()).max() < 1e-5                                              # and it is torch's formula
 
 
+@pytest.mark.parametrize("B,H,W,C", [(1, 237, 237, 128), (3, 45, 61, 64), (2, 8, 9, 4), (1, 1, 1, 8), (12, 237, 237, 128)])
+def test_maxpool3x3s2_matches_torch(nv, B, H, W, C):
+    """The ResNet stems' MaxPool2d(3, 2, 1) (usc_maxpool3x3s2_nhwc_f32) against torch's on the same values: max is exact, so bit for bit;
+    images stacked along y must not see each other's rows."""
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, H, W, C, generator=g)
+    want = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+    OH, OW = want.shape[1:3]
+    got = torch.full((B * OH, OW, C), 7.0, device="cuda")
+    nv.maxpool3x3s2(x.view(B * H, W, C).cuda(), got, batch=B)
+    assert torch.equal(got.cpu().view(B, OH, OW, C), want)
+    with pytest.raises(nv.NativeError):
+        nv.maxpool3x3s2(x.view(B * H, W, C).cuda(), torch.empty((B * OH + 1, OW, C), device="cuda"), batch=B)
+
+
 @pytest.mark.parametrize("H,W,L", [(1080, 1920, 962), (256, 256, 962), (300, 200, 600)])
 def test_segagent_post_bit_exact(nv, oracle_lib, H, W, L):
     """Random smooth logits for every crop: merged mask and float64 scores identical to the oracle's."""

@@ -105,6 +105,7 @@ _SIGNATURES = {
     "usc_upsample_ac_nhwc_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "usc_upsample_ac_nhwc_batch_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "usc_adaptive_avgpool_nhwc_batch_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp]),
+    "usc_maxpool3x3s2_nhwc_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "usc_seg_last_error": (C.c_char_p, []),
     "usc_conv_desc_bytes": (C.c_size_t, []),
     "usc_conv_plan_query": (C.c_int, [_vp, _vp]),
@@ -679,6 +680,16 @@ def upsample_nc(src, dst, c0=0):
     dh, dw, ld = dst.shape
     _check(load().usc_upsample_nc_nhwc_f32(src.data_ptr(), sh, sw, Cc, dst.data_ptr(), dh, dw, ld, int(c0), _stream()),
            "usc_upsample_nc_nhwc_f32")
+    return dst
+
+
+def maxpool3x3s2(src, dst, batch=1):
+    """nn.MaxPool2d(3, 2, 1) of src (batch*H, W, C) f32 NHWC -> dst (batch*OH, OW, C), OH = (H - 1) // 2 + 1 (the ResNet stems)."""
+    BH, W, Cn = src.shape
+    H = BH // batch
+    if BH % batch or tuple(dst.shape) != (batch * ((H - 1) // 2 + 1), (W - 1) // 2 + 1, Cn) or not (src.is_contiguous() and dst.is_contiguous()):
+        raise NativeError("maxpool3x3s2: dst must be the contiguous (batch*OH, OW, C) tensor of a contiguous (batch*H, W, C) src")
+    _check(load().usc_maxpool3x3s2_nhwc_f32(src.data_ptr(), H, W, Cn, dst.data_ptr(), int(batch), _stream()), "usc_maxpool3x3s2_nhwc_f32")
     return dst
 
 

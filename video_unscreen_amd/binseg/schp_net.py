@@ -236,7 +236,7 @@ class HipSchpNet(ConvGraphNet):
         ph, pw = _out_size(h, 3, 2, 1, 1), _out_size(w, 3, 2, 1, 1)
         pooled = self._buf(ph, pw, 128)
         src = t
-        self._glue(lambda: self.nchw(pooled).copy_(F.max_pool2d(self.nchw(src), 3, 2, 1)))
+        self._glue(lambda: self.nv.maxpool3x3s2(src, pooled, batch=self.batch))
         t, h, w = pooled, ph, pw
         feats = []
         nv = self.nv

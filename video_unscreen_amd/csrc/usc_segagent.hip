@@ -263,6 +263,51 @@ extern "C" int usc_adaptive_avgpool_nhwc_f32(const float* src, int H, int W, int
 }
 
 // --------------------------------------------------------------------------------------------
+// nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC f32 - the ResNet stems of the four segmentation / tracking networks
+// (binseg/human_parse.py:210, binseg/deeplab/backbone/resnet.py:185, stm/model.py:46,58,73,83 (torchvision's resnet.maxpool), iseg/brs/models/resnetv1b.py:191).  One
+// lane = one output pixel x 4 channels: nine 16-byte loads (taps outside the image are skipped: the padding is -inf), one 16-byte
+// store; consecutive lanes = consecutive channel groups of a pixel, so every load is a contiguous run.  HBM-bound: the input is read
+// once (2.25 taps per input element come from L2), e.g. 12 x 237 x 237 x 128 floats of the human-parsing net: 345 MB in, 87 MB out.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float4* __restrict__ src, int H, int W, int C4, float4* __restrict__ dst,
+                                                           int OH, int OW, int batch) {
+    const size_t total = (size_t)batch * OH * OW * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t p = i / C4;
+        const int ox = (int)(p % OW);
+        p /= OW;
+        const int oy = (int)(p % OH), img = (int)(p / OH);
+        const float4* __restrict__ base = src + (size_t)img * H * W * C4 + c;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+            const int y = 2 * oy - 1 + dy;
+            if (y < 0 || y >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                const int x = 2 * ox - 1 + dx;
+                if (x < 0 || x >= W) continue;
+                const float4 v = base[((size_t)y * W + x) * C4];
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        dst[i] = m;
+    }
+}
+
+extern "C" int usc_maxpool3x3s2_nhwc_f32(const float* src, int H, int W, int C, float* dst, int batch, usc_stream_t stream) {
+    if (!src || !dst || H <= 0 || W <= 0 || C <= 0 || (C & 3) || batch < 1 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15))
+        return fail(USC_E_ARG, "usc_maxpool3x3s2_nhwc_f32: bad argument (C % 4, 16-byte aligned tensors)");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;                 // floor((H + 2 - 3) / 2) + 1
+    const size_t total = (size_t)batch * OH * OW * (C / 4);
+    const size_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(src), H, W, C / 4, reinterpret_cast<float4*>(dst), OH, OW, batch);
+    return check_launch("maxpool3x3s2_kernel");
+}
+
+// --------------------------------------------------------------------------------------------
 // post (agent.py:200-237, 143-174; utils/imgprocess.py:100-132)
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void segagent_merge_kernel(const float* __restrict__ logits, CropTable ct, int lh, int lw, int cbuf,

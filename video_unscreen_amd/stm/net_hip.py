@@ -60,7 +60,7 @@ class HipStmNet:
         ph, pw = _out_size(h, 3, 2, 1, 1), _out_size(w, 3, 2, 1, 1)
         pooled = net._buf(ph, pw, 64)
         src = t
-        net._glue(lambda: net.nchw(pooled).copy_(F.max_pool2d(net.nchw(src), 3, 2, 1)))
+        net._glue(lambda: net.nv.maxpool3x3s2(src, pooled, batch=net.batch))
         t, h, w = pooled, ph, pw
         feats = []
         for blocks in layers:
