@@ -475,7 +475,7 @@ def mode_roofline(args, pipe, frame):
     if "bg_holes" in out and "hole" in out:
         bg, hole = out["bg_holes"], out["hole"]
         _, iters = nv.regionfill(bg, hole, want_iters=True)
-        t = _net_time(lambda: nv.regionfill(bg, hole), iters=3, warm=1)
+        t = _net_time(lambda: nv.regionfill(bg, hole, budget=iters + (iters & 1)), iters=3, warm=1)     # (the default budget of 48 would time 13 no-op launches per unused iteration too)
         unknowns = 3 * int((hole > 0).sum().item())
         nbytes = iters * unknowns * 130
         extra["roofline_fill"] = {"bound": "hbm", "kernel": "usc_regionfill.hip (CG in float64, tiled float32 multigrid V-cycle with Galerkin coarse operators as preconditioner; 13 dependent launches per iteration: latency-bound)", "achieved": round(nbytes / t / 1e9, 1),

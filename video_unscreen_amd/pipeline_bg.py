@@ -51,9 +51,9 @@ class BgOnlinePipeline:
         count + a margin; 48 to start with), the convergence test runs on the device, and the 8-byte status is read at the
         step's next natural synchronisation point (exist_foreground) - if a budget ever turns out too small the solve is
         continued there, before anything downstream has been consumed."""
-        # (every iteration past convergence is 24 launches that return at their first instruction, ~60 us: the margin is kept small;
+        # (every iteration past convergence is 13 launches that return at their first instruction, ~30 us: the margin is kept small;
         # the iteration count of consecutive frames barely moves, and a short budget only costs one continuation below)
-        budget = 48 if self.fill_iters <= 0 else min(400, self.fill_iters + max(6, self.fill_iters // 6))
+        budget = 48 if self.fill_iters <= 0 else min(400, self.fill_iters + max(4, self.fill_iters // 6))
         bgimg = nv.regionfill(bg, hole, rtol=self.fill_rtol, ws=self._ws_fill, budget=budget, sync=False, status=self._fill_status)
         self._fill_pending = (bg, hole, bgimg, budget)
         return bgimg
