@@ -253,7 +253,7 @@ def replace_mode(args, rank, world, dev):
     src = SyntheticClip(H, W, K, config_id=3, device=dev, n_objects=1)   # (another silhouette: the mean centroid offset is not zero)
     tgt.gen.manual_seed(20260002 + 7919 * rank)
     src.gen.manual_seed(20260003 + 7919 * rank)
-    # one page-locked (K, 2, H, W, 3) tensor per pass: the loop moves four frames per copy
+    # one page-locked (K, 2, H, W, 3) tensor per pass: the loop moves eight frames per copy
     masks_h = torch.empty((K, 2, H, W, 3), dtype=torch.uint8).pin_memory()
     inputs_h = torch.empty((K, 2, H, W, 3), dtype=torch.uint8).pin_memory()
     for t in range(K):
@@ -267,7 +267,7 @@ def replace_mode(args, rank, world, dev):
         inputs_h[t, 0].copy_(fg)
         inputs_h[t, 1].copy_(g["frame"])
     pipe = ReplacePipeline(H, W, src.bg_always, device=dev, scale=1.2, max_frames=K)
-    loop = ReplaceHostLoop(pipe, K, ring=3, group=4)
+    loop = ReplaceHostLoop(pipe, K, ring=3, group=8)           # eight frames (100 MB) per copy: tools/dev/replace_group_probe.py - 2065 frames/s against 1042 at four
     compare_h = torch.empty((K, H, 2 * W, 3), dtype=torch.uint8).pin_memory()
     torch.cuda.synchronize()
 
@@ -337,7 +337,7 @@ def replace_mode(args, rank, world, dev):
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"replace (tools/replace/replace.py): centroid pass + shift_fg / rescale_fg(1.2) / blend / side-by-side, {W}x{H}, "
                                    f"{K} frames/GPU, frame-sharded x{world}, one all-reduce of the centroid offsets",
-                       "boundary": "pinned host -> pinned host: two alpha masks (pass 1), fg and source frame (pass 2) uploaded (12 B/px), side-by-side image downloaded (6 B/px), four frames per copy, "
+                       "boundary": "pinned host -> pinned host: two alpha masks (pass 1), fg and source frame (pass 2) uploaded (12 B/px), side-by-side image downloaded (6 B/px), eight frames per copy, "
                                    "per frame inside the timed region; the target masks stay in HBM between the two passes",
                        "correspondence_mean": [dx, dy]},
             "pcie_bytes_per_frame": {"up": 12 * n, "down": 6 * n},

@@ -72,9 +72,10 @@ class ReplaceHostLoop:
     passes (they are read by both: K x 6.2 MB at 1080p), so a frame crosses PCIe as 12 bytes per pixel up (two masks, fg, source
     frame) and 6 down (the side-by-side image, whose right half IS res - replace.py:79-82 writes both from the same array).
     Per-frame inputs are (a, b) tuples, pack_pair(a, b) tensors, or - fastest - ONE (K, 2, H, W, 3) page-locked tensor per pass
-    (`pack_clip`): then `group` frames move per copy (a 50 MB transfer runs at ~45 GB/s, a 12 MB one at ~30: tools/dev/hostio_probe.py)."""
+    (`pack_clip`): then `group` frames move per copy (tools/dev/replace_group_probe.py, both passes at 1080p: 1213 / 1238 / 1042 / 2065 / 2043
+    frames/s at 1 / 2 / 4 / 8 / 12 frames per copy - from 100 MB on the uploads run at 51 GB/s and the downloads beside them)."""
 
-    def __init__(self, pipe, nframes, src_hw=None, ring=3, group=4):
+    def __init__(self, pipe, nframes, src_hw=None, ring=3, group=8):
         self.pipe, self.K, self.ring, self.group = pipe, nframes, ring, max(1, group)
         H, W, dev = pipe.H, pipe.W, pipe.device
         sh, sw = src_hw if src_hw is not None else (H, W)
