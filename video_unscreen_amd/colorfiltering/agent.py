@@ -16,10 +16,71 @@ from .. import _native as nv
 from ..utils._dev import to_dev, to_host
 
 
+class _FitPool:
+    """Six processes that run GaussianMixture.fit (video_unscreen_amd/_fit_worker.py); started at the first training frame."""
+
+    def __init__(self, n):
+        import multiprocessing as mp
+        from .._fit_worker import fit_worker
+        from ..utils.frameio import _light_children
+        ctx = mp.get_context("spawn")                         # no fork: the parent holds a HIP context
+        self.conns, self.procs = [], []
+        limits = {}
+        try:                                                  # the thread counts sklearn's OpenMP / BLAS code sees in THIS process (torch has set them)
+            import sklearn.cluster                            # noqa: F401
+            from threadpoolctl import threadpool_info
+            for info in threadpool_info():
+                api = info.get("user_api")
+                if api in ("openmp", "blas"):
+                    limits[api] = min(limits.get(api, 1 << 30), int(info["num_threads"]))
+        except Exception:                                     # noqa: BLE001 - without threadpoolctl the workers keep their defaults
+            limits = {}
+        with _light_children():
+            for _ in range(n):
+                a, b = ctx.Pipe()
+                p = ctx.Process(target=fit_worker, args=(b, limits), daemon=True)
+                p.start()
+                b.close()
+                self.conns.append(a)
+                self.procs.append(p)
+
+    def fit(self, jobs):
+        """jobs: [(mixture, packed samples, stride)] -> the fitted mixtures, in order (job i on worker i % n)."""
+        n = len(self.conns)
+        out = [None] * len(jobs)
+        for base in range(0, len(jobs), n):
+            chunk = jobs[base:base + n]
+            for i, job in enumerate(chunk):
+                self.conns[i].send(job)
+            for i in range(len(chunk)):
+                if not self.conns[i].poll(120.0):
+                    raise RuntimeError("ColorFilteringAgent: an EM worker process did not answer within 120 s (alive: %s)" % self.procs[i].is_alive())
+                gmm, err = self.conns[i].recv()
+                if err:
+                    raise RuntimeError("ColorFilteringAgent: GaussianMixture.fit failed in a worker: " + err)
+                out[base + i] = gmm
+        return out
+
+    def close(self):
+        for c in self.conns:
+            try:
+                c.send(None)
+                c.close()
+            except Exception:                                 # noqa: BLE001
+                pass
+        for p in self.procs:
+            p.join(timeout=2)
+            if p.is_alive():
+                p.terminate()
+        self.conns, self.procs = [], []
+
+
 class ColorFilteringAgent():
 
     def __init__(self, input_long_side=960, bg_ncomp=(3, 5, 5), fg_ncomp=(10, 10, 10), max_num_samples=10000,
-                 color_prior_winsize=30, use_opencv_gmm=False, random_state=None):
+                 color_prior_winsize=30, use_opencv_gmm=False, random_state=None, fit_workers=6):
+        """fit_workers (not in the reference): processes the six independent EM fits of a training round run in (0: in this
+        interpreter, one after the other, as the reference).  Same results either way."""
         assert isinstance(input_long_side, int)
         assert len(bg_ncomp) == 3 and len(fg_ncomp) == 3
         assert isinstance(max_num_samples, int) and max_num_samples > 2
@@ -33,6 +94,8 @@ class ColorFilteringAgent():
         self.color_prior_winsize = color_prior_winsize
         self.use_opencv_gmm = use_opencv_gmm
         self.random_state = random_state          # None = unseeded, as the reference (agent.py:101-110)
+        self.fit_workers = int(fit_workers)
+        self._pool = None
         self._luts = None
         self._ws = None
         self._cnt2 = None
@@ -70,12 +133,48 @@ class ColorFilteringAgent():
         half = color_prior_winsize // 2
         return (hue.astype(np.int64) > peak - half) & (hue.astype(np.int64) < peak + half)
 
+    def _samples(self, img_hsv, mask):
+        return [self._subsample(img_hsv[:, :, i][mask].astype(np.float64))[..., np.newaxis] for i in range(3)]
+
     def _fit(self, gmms, img_hsv, mask):
-        for i in range(3):
-            samples = self._subsample(img_hsv[:, :, i][mask].astype(np.float64))
-            gmms[i].fit(samples[..., np.newaxis])
+        for i, samples in enumerate(self._samples(img_hsv, mask)):
+            gmms[i].fit(samples)
         self._is_trained = True
         self._luts = None
+
+    def _fg_mask(self, mask, mask_by_prior):
+        keep = mask & ~mask_by_prior
+        return keep if keep.sum() > max(self.fg_ncomp) * 5 else mask
+
+    def fit_both(self, img_hsv, bg_mask, bg_prior, fg_mask, fg_prior):
+        """fit_bg_gmms(img_hsv, bg_mask, bg_prior) then fit_fg_gmms(img_hsv, fg_mask, fg_prior) - the six fits are independent of each
+        other, so with fit_workers > 0 they run side by side in the worker processes (the fitted objects replace bg_gmms / fg_gmms)."""
+        if self.fit_workers <= 0:
+            self.fit_bg_gmms(img_hsv, bg_mask, bg_prior)
+            self.fit_fg_gmms(img_hsv, fg_mask, fg_prior)
+            return
+        if self._pool is None:
+            self._pool = _FitPool(self.fit_workers)
+        def job(gmm, view):                                   # (mixture, samples packed, stride in elements of the parent's view)
+            return gmm, np.ascontiguousarray(view[:, 0]), max(1, view.strides[0] // view.itemsize)
+        jobs = [job(g, v) for g, v in zip(self.bg_gmms, self._samples(img_hsv, bg_mask & bg_prior))] + \
+            [job(g, v) for g, v in zip(self.fg_gmms, self._samples(img_hsv, self._fg_mask(fg_mask, fg_prior)))]
+        # the slowest first (ten components against three / five): with fewer workers than jobs the long ones do not queue behind short ones
+        fitted = self._pool.fit(jobs[3:] + jobs[:3])
+        self.fg_gmms, self.bg_gmms = list(fitted[:3]), list(fitted[3:])
+        self._is_trained = True
+        self._luts = None
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.close()
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                     # noqa: BLE001
+            pass
 
     def fit_bg_gmms(self, img_hsv, mask, mask_by_prior=None):
         """Screen model from (coarse background) & (hue prior) (agent.py:151-176)."""
@@ -87,10 +186,7 @@ class ColorFilteringAgent():
         """Foreground model; screen-hued pixels are dropped when enough others remain (agent.py:178-199)."""
         if mask_by_prior is None:
             mask_by_prior = self.get_color_prior(img_hsv, ~mask, self.color_prior_winsize // 5)
-        keep = mask & ~mask_by_prior
-        if keep.sum() > max(self.fg_ncomp) * 5:
-            mask = keep
-        self._fit(self.fg_gmms, img_hsv, mask)
+        self._fit(self.fg_gmms, img_hsv, self._fg_mask(mask, mask_by_prior))
 
     # ------------------------------------------------------------------ device: inference
     def get_prob_by_gmm(self, samples, gmm):
@@ -156,8 +252,7 @@ class ColorFilteringAgent():
                 mask_host = to_host(mask)
                 bg_prior = self.get_color_prior(hsv_host, mask_host < 128, self.color_prior_winsize)
                 fg_prior = self.get_color_prior(hsv_host, mask_host < 128, self.color_prior_winsize // 5)
-                self.fit_bg_gmms(hsv_host, mask_host < 128, bg_prior)
-                self.fit_fg_gmms(hsv_host, mask_host > 128, fg_prior)
+                self.fit_both(hsv_host, mask_host < 128, bg_prior, mask_host > 128, fg_prior)
                 alpha, confidence = self.get_alpha_by_gmm_device(img_hsv, want_confidence)
                 alpha = self.postprocess_device(alpha, mask)
                 mask = (alpha > 128).to(torch.uint8) * 255
