@@ -212,3 +212,61 @@ def test_replace_tool_end_to_end(tmp_path, oracle_lib):
         assert got.shape == want.shape and np.abs(got.astype(int) - want.astype(int)).mean() < 1.5      # the output JPEG is lossy
         cmp_img = read_img(str(out / f"compare_{t:06d}.jpg"))
         assert cmp_img.shape == (H, 2 * W, 3)
+
+
+def _tool_dataset(tmp_path, H, W, n, config_id):
+    from video_unscreen_amd.synth import SyntheticClip
+    from video_unscreen_amd.utils.fileio import save_img
+    root = tmp_path / "data"
+    src = root / "src_img" / "1"
+    src.mkdir(parents=True)
+    clip = SyntheticClip(H, W, n, config_id=config_id, device="cpu")
+    for t in range(n):
+        save_img(clip.frame(t)["frame"].numpy(), str(src / f"frame_{t:06d}.jpg"))
+    return root, src
+
+
+def _synthetic_cfg(tmp_path, name, keys):
+    cfg = json.load(open(os.path.join(ROOT, "configs", name)))
+    for k in keys:
+        cfg[k]["model_path"] = "synthetic"
+    path = tmp_path / name
+    path.write_text(json.dumps(cfg))
+    return cfg, str(path)
+
+
+@pytest.mark.parametrize("tool,cfg_name,keys,config_id,out_dir", [("green.py", "green.json", ("binseg", "vmatting"), 1, "test_img"),
+                                                                 ("bg.py", "bg.json", ("binseg", "vmatting", "stm"), 2, "test_bg_img")])
+def test_green_and_bg_tools_write_what_the_pipeline_gives(tmp_path, tool, cfg_name, keys, config_id, out_dir):
+    """tools/unscreen/green.py and bg.py (reference tools/unscreen/green.py:70-138, bg.py:47-104) on a small dataset on disk: every JPEG the
+    tool writes - through the encoder processes (utils/frameio.py: AsyncSaver) - is byte for byte the file save_img() writes from the
+    tensors the same pipeline returns in this process on the same decoded frames."""
+    import torch
+    from video_unscreen_amd.utils.fileio import read_img, save_img
+    H, W, n = 136, 240, 5
+    root, src = _tool_dataset(tmp_path, H, W, n, config_id)
+    cfg, cfg_path = _synthetic_cfg(tmp_path, cfg_name, keys)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "unscreen", tool), "--cfg", cfg_path, "--data_root", str(root), "--io_workers", "3"] +
+                       (["--cf_seed", "0"] if tool == "green.py" else []),
+                       capture_output=True, text=True, cwd=ROOT, timeout=900, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    if tool == "green.py":
+        from video_unscreen_amd.pipeline_green import GreenPipeline
+        pipe, names = GreenPipeline(cfg, H, W, device="cuda:0", cf_random_state=0), (("fg", "fg"), ("alphamask", "alpha"), ("bg", "bg"))
+    else:
+        from video_unscreen_amd.pipeline_bg import BgOnlinePipeline
+        pipe, names = BgOnlinePipeline(cfg, H, W, device="cuda:0"), (("segmask", "segmask"), ("bg", "bgimg"), ("alphamask", "alpha"), ("fg", "fg"))
+    dst = root / out_dir / "1"
+    written = 0
+    for t in range(n):
+        out = pipe.step(torch.from_numpy(read_img(str(src / f"frame_{t:06d}.jpg"))).cuda())
+        for fname, key in names:
+            path = dst / f"{fname}_{t:06d}.jpg"
+            if key not in out:
+                assert not path.exists()
+                continue
+            ref = tmp_path / "ref.jpg"
+            save_img(out[key].cpu().numpy(), str(ref))
+            assert path.read_bytes() == ref.read_bytes(), (tool, fname, t)
+            written += 1
+    assert written >= 3 * n

@@ -23,7 +23,8 @@ import torch.distributed as dist
 
 from video_unscreen_amd.dist import shard_range
 from video_unscreen_amd.pipeline_bg import BgOnlinePipeline
-from video_unscreen_amd.utils.fileio import parallel_read_img, save_img
+from video_unscreen_amd.utils.fileio import parallel_read_img
+from video_unscreen_amd.utils.frameio import AsyncSaver
 
 
 def main(cfg):
@@ -52,17 +53,22 @@ def main(cfg):
     print('Agent built in {:.2f}s'.format(time.time() - st))
     st = time.time()
     tracked = 0
-    for i in range(numframes):
-        out = pipe.step(torch.from_numpy(frame_list[i]).to(dev))
-        tracked += int(out["tracking"])
-        fid = first + lo + i
-        save_img(out["segmask"].cpu().numpy(), osp.join(dst_img_dir, 'segmask_{:06d}.jpg'.format(fid)))
-        if "bgimg" in out:
-            save_img(out["bgimg"].cpu().numpy(), osp.join(dst_img_dir, 'bg_{:06d}.jpg'.format(fid)))
-            save_img(out["alpha"].cpu().numpy(), osp.join(dst_img_dir, 'alphamask_{:06d}.jpg'.format(fid)))
-            save_img(out["fg"].cpu().numpy(), osp.join(dst_img_dir, 'fg_{:06d}.jpg'.format(fid)))
-    torch.cuda.synchronize()
-    print('{} frames ({} tracked) in {:.2f}s on rank {}'.format(numframes, tracked, time.time() - st, rank))
+    # the JPEGs of a frame are encoded by worker processes while the loop goes on (utils/frameio.py: AsyncSaver)
+    saver = AsyncSaver([(h, w), (h, w, 3), (h, w), (h, w, 3)], workers=int(cfg["data"].get("io_workers", 8)))
+    try:
+        for i in range(numframes):
+            out = pipe.step(torch.from_numpy(frame_list[i]).to(dev))
+            tracked += int(out["tracking"])
+            fid = first + lo + i
+            name = lambda kind: osp.join(dst_img_dir, '{}_{:06d}.jpg'.format(kind, fid))      # noqa: E731
+            if "bgimg" in out:
+                saver.save((out["segmask"], out["bgimg"], out["alpha"], out["fg"]), (name('segmask'), name('bg'), name('alphamask'), name('fg')))
+            else:
+                saver.save((out["segmask"], None, None, None), (name('segmask'), None, None, None))
+        torch.cuda.synchronize()
+    finally:
+        saver.close()
+    print('{} frames ({} tracked), files written, in {:.2f}s on rank {}'.format(numframes, tracked, time.time() - st, rank))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -74,6 +80,7 @@ if __name__ == '__main__':
     parser.add_argument('-vid', '--video_id', type=str, default="1")
     parser.add_argument('--range', type=str, default=None, help="eg. 400-700")
     parser.add_argument('--data_root', type=str, default=os.environ.get("UNSCREEN_DATA_ROOT", "./data/greenmat"))
+    parser.add_argument('--io_workers', type=int, default=8, help='JPEG encoder processes (not in the reference)')
     args = parser.parse_args()
     cfg = json.load(open(args.cfg))
     cfg["data"] = {"range": [int(i) for i in args.range.split('-')] if args.range else None,
@@ -81,5 +88,5 @@ if __name__ == '__main__':
                    "src_img_dir": osp.join(args.data_root, 'src_img', args.video_id),
                    "src_img_tmpl": '*.jpg',
                    "dst_img_dir": osp.join(args.data_root, 'test_bg_img', args.video_id),
-                   "dst_vid_dir": osp.join(args.data_root, 'video')}
+                   "dst_vid_dir": osp.join(args.data_root, 'video'), "io_workers": args.io_workers}
     main(cfg)

@@ -24,7 +24,8 @@ import torch.distributed as dist
 
 from video_unscreen_amd.dist import shard_range
 from video_unscreen_amd.pipeline_green import GreenPipeline
-from video_unscreen_amd.utils.fileio import parallel_read_img, save_img, save_video
+from video_unscreen_amd.utils.fileio import parallel_read_img, save_video
+from video_unscreen_amd.utils.frameio import AsyncSaver
 
 
 def print_statistic(runtime, tracking_count, numframes):
@@ -59,19 +60,26 @@ def main(cfg):
     print('{} frames. Reading Data Done! {:.2f}s'.format(numframes, time.time() - st))
 
     st = time.time()
-    pipe = GreenPipeline(cfg, h, w, device=dev)
+    pipe = GreenPipeline(cfg, h, w, device=dev, cf_random_state=cfg["data"].get("cf_seed"))
     print(f'Building Agents Done! {time.time() - st:.2f}s')
 
     runtime = {'frame': 0.0}
-    for i in range(numframes):
-        st = time.time()
-        out = pipe.step(torch.from_numpy(frame_list[i]).to(dev))
-        torch.cuda.synchronize()
-        runtime['frame'] += time.time() - st
-        fid = first + lo + i
-        save_img(out["fg"].cpu().numpy(), osp.join(dst_img_dir, 'fg_{:06d}.jpg'.format(fid)))
-        save_img(out["alpha"].cpu().numpy(), osp.join(dst_img_dir, 'alphamask_{:06d}.jpg'.format(fid)))
-        save_img(out["bg"].cpu().numpy(), osp.join(dst_img_dir, 'bg_{:06d}.jpg'.format(fid)))
+    t_loop = time.time()
+    # the three JPEGs of a frame are encoded by worker processes while the loop goes on (utils/frameio.py: AsyncSaver)
+    saver = AsyncSaver([(h, w, 3), (h, w), (h, w, 3)], workers=int(cfg["data"].get("io_workers", 8)))
+    try:
+        for i in range(numframes):
+            st = time.time()
+            out = pipe.step(torch.from_numpy(frame_list[i]).to(dev))
+            torch.cuda.synchronize()
+            runtime['frame'] += time.time() - st
+            fid = first + lo + i
+            saver.save((out["fg"], out["alpha"], out["bg"]),
+                       (osp.join(dst_img_dir, 'fg_{:06d}.jpg'.format(fid)), osp.join(dst_img_dir, 'alphamask_{:06d}.jpg'.format(fid)),
+                        osp.join(dst_img_dir, 'bg_{:06d}.jpg'.format(fid))))
+    finally:
+        saver.close()
+    print('{} frames, files written, in {:.2f}s on rank {}'.format(numframes, time.time() - t_loop, rank))
     print_statistic(runtime, pipe.tracking_count, numframes)
     if world > 1:
         dist.barrier()
@@ -88,6 +96,8 @@ if __name__ == '__main__':
     parser.add_argument('-vid', '--video_id', type=str, default="1")
     parser.add_argument('--range', type=str, default=None, help="eg. 400-700")
     parser.add_argument('--data_root', type=str, default=os.environ.get("UNSCREEN_DATA_ROOT", "./data/greenmat"))
+    parser.add_argument('--io_workers', type=int, default=8, help='JPEG encoder processes (not in the reference)')
+    parser.add_argument('--cf_seed', type=int, default=None, help='seed of the colour filter\'s EM fits (not in the reference, whose fits are unseeded)')
     args = parser.parse_args()
     cfg = json.load(open(args.cfg))
     cfg["data"] = {"range": [int(i) for i in args.range.split('-')] if args.range else None,
@@ -95,5 +105,5 @@ if __name__ == '__main__':
                    "src_img_dir": osp.join(args.data_root, 'src_img', args.video_id),
                    "src_img_tmpl": '*.jpg',
                    "dst_img_dir": osp.join(args.data_root, 'test_img', args.video_id),
-                   "dst_vid_dir": osp.join(args.data_root, 'video')}
+                   "dst_vid_dir": osp.join(args.data_root, 'video'), "io_workers": args.io_workers, "cf_seed": args.cf_seed}
     main(cfg)

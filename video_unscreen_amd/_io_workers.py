@@ -61,6 +61,8 @@ def encode_worker(shm_name, nbytes, slot_bytes, shapes, tasks, done):
             try:
                 offs, _ = part_offsets(shapes)
                 for p, shp, o in zip(paths, shapes, offs):
+                    if p is None:                                          # (this array of the slot is not written for this frame)
+                        continue
                     n = int(np.prod(shp))
                     off = slot * slot_bytes + o
                     save_img(ring[off:off + n].reshape(shp), p)

@@ -271,3 +271,32 @@ class DeferredSubmit:
         if self.error is not None:
             err, self.error = self.error, None
             raise RuntimeError("DeferredSubmit: handing a finished frame to the writer failed") from err
+
+
+class AsyncSaver:
+    """What the green / bg tools do with a finished frame, off the frame loop.  The reference writes three or four JPEGs per frame with
+    cv2.imwrite on the main thread (tools/unscreen/green.py:119-131, tools/unscreen/bg.py:93-103: ~25 ms of encoding per 1080p frame, ten
+    times the GPU's share of the frame); here save() copies the frame's device tensors into a free slot of a FrameWriter ring on the
+    CURRENT stream (page-locked: the copies are asynchronous and ordered behind the kernels that produce the tensors, ahead of the next
+    frame's), and a helper thread hands the slot to the encoder processes once the copies have landed.  The files are the ones
+    save_img() writes from the same arrays.  paths[i] = None: array i is not written for this frame."""
+
+    def __init__(self, shapes, workers=8, depth=12):
+        self.writer = FrameWriter(shapes, workers=workers, depth=depth)
+        self.deferred = DeferredSubmit(self.writer)
+
+    def save(self, tensors, paths):
+        slot, views = self.writer.acquire()                    # (blocks only when every slot is still being encoded)
+        for v, t, p in zip(views, tensors, paths):
+            if p is not None:
+                v.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.deferred.submit_after(ev, slot, tuple(paths))
+
+    def close(self):
+        """Waits for every file; re-raises the first failure of a copy or an encoder."""
+        try:
+            self.deferred.close()
+        finally:
+            self.writer.close()
