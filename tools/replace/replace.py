@@ -22,7 +22,8 @@ import torch.distributed as dist
 
 from video_unscreen_amd.dist import shard_range
 from video_unscreen_amd.pipeline_replace import ReplacePipeline
-from video_unscreen_amd.utils.fileio import read_img, save_img
+from video_unscreen_amd.utils.fileio import read_img
+from video_unscreen_amd.utils.frameio import AsyncLoader, AsyncSaver
 
 
 def run(args):
@@ -39,7 +40,6 @@ def run(args):
     lo, hi = shard_range(numframes, rank, world)
     tgt = lambda name, fid: osp.join(args.tgt_data_dir, "{}_{:06d}.{}".format(name, fid, ext))       # noqa: E731
     src = lambda name, fid: osp.join(args.src_data_dir, "{}_{:06d}.{}".format(name, fid, ext))       # noqa: E731
-    up = lambda path: torch.from_numpy(read_img(path)).to(dev)                                       # noqa: E731
 
     first = read_img(tgt("fg", lo))
     h, w = first.shape[:2]
@@ -47,9 +47,15 @@ def run(args):
     bg_path = bg_npy if ext == "npy" and osp.exists(bg_npy) else args.src_bg_image
     pipe = ReplacePipeline(h, w, torch.from_numpy(read_img(bg_path)), device=dev, scale=1.2, max_frames=max(1, hi - lo))
 
+    # Files are decoded by worker processes into a page-locked ring and go up asynchronously (AsyncLoader), the two output images of a frame
+    # are encoded by worker processes (AsyncSaver): the loop's own thread only enqueues (the reference: cv2.imread x 5 and cv2.imwrite x 2
+    # per frame on it, ~60 ms of codec work against 0.03 ms of kernel).
+    sh, sw = read_img(src("frame", lo)).shape[:2]
+    workers = args.io_workers
     if args.dx is None or args.dy is None:                   # comp_dx_dy (replace.py:28-41): moments on the device, one host read
-        for fid in range(lo, hi):
-            pipe.centroid_pair(fid - lo, up(tgt("alphamask", fid)), up(src("alphamask", fid)))
+        groups = [(tgt("alphamask", fid), src("alphamask", fid)) for fid in range(lo, hi)]
+        for i, (dst_mask, src_mask) in enumerate(AsyncLoader(groups, [(h, w, 3), (sh, sw, 3)], dev, workers=workers)):
+            pipe.centroid_pair(i, dst_mask, src_mask)
         acc = torch.tensor(pipe.offset_sums(hi - lo), dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(acc)
@@ -59,10 +65,15 @@ def run(args):
     print("Correspondence mean: ", dx_mean, dy_mean)
 
     M = pipe.shift_matrix(dx_mean, dy_mean)
-    for fid in range(lo, hi):
-        res, cmp_img = pipe.compose(up(tgt("fg", fid)), up(tgt("alphamask", fid)), up(src("frame", fid)), M)
-        save_img(res.cpu().numpy(), osp.join(args.dst_data_dir, "res_{:06d}.{}".format(fid, ext)))
-        save_img(cmp_img.cpu().numpy(), osp.join(args.dst_data_dir, "compare_{:06d}.{}".format(fid, ext)))
+    groups = [(tgt("fg", fid), tgt("alphamask", fid), src("frame", fid)) for fid in range(lo, hi)]
+    saver = AsyncSaver([(h, w, 3), (h, 2 * w, 3)], workers=workers)
+    try:
+        for i, (fg, mask, frame) in enumerate(AsyncLoader(groups, [(h, w, 3), (h, w, 3), (sh, sw, 3)], dev, workers=workers)):
+            res, cmp_img = pipe.compose(fg, mask, frame, M)
+            saver.save((res, cmp_img), (osp.join(args.dst_data_dir, "res_{:06d}.{}".format(lo + i, ext)),
+                                        osp.join(args.dst_data_dir, "compare_{:06d}.{}".format(lo + i, ext))))
+    finally:
+        saver.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -74,6 +85,7 @@ if __name__ == '__main__':
     parser.add_argument('--tgt', type=str, default=None)
     parser.add_argument('--data_root', type=str, default=os.environ.get("UNSCREEN_REPLACE_ROOT", "../data/replace/edn"))
     parser.add_argument('--io', type=str, default="jpg", choices=["jpg", "npy"], help='file format of inputs and outputs (npy: raw arrays, no codec)')
+    parser.add_argument('--io_workers', type=int, default=8, help='decoder / encoder processes (not in the reference)')
     parser.add_argument('--dx', type=float, default=None)
     parser.add_argument('--dy', type=float, default=None)
     args = parser.parse_args()

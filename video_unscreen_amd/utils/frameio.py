@@ -300,3 +300,42 @@ class AsyncSaver:
             self.deferred.close()
         finally:
             self.writer.close()
+
+
+class AsyncLoader:
+    """for tensors in AsyncLoader(groups, shapes, device): the files of each group as DEVICE tensors, in order.  Decoder processes fill the
+    slots of a page-locked ring (FrameReader), each slot goes up with asynchronous copies on the current stream and is handed back to the
+    decoders once its copies have landed - the reference reads every file with cv2.imread on the loop's own thread
+    (tools/replace/replace.py:32-35, 61-64).  At most `depth` groups are decoded ahead."""
+
+    def __init__(self, groups, shapes, device, workers=8, depth=16):
+        self.device = torch.device(device)
+        self.pending = []                                      # (event after a slot's uploads, slot), oldest first
+        self.reader = FrameReader(groups, shapes, workers=workers, depth=depth, wait_release=self._wait_oldest)
+
+    def _reap(self):
+        while self.pending and self.pending[0][0].query():
+            self.reader.release(self.pending.pop(0)[1])
+
+    def _wait_oldest(self):
+        ev, slot = self.pending.pop(0)
+        ev.synchronize()
+        self.reader.release(slot)
+
+    def __iter__(self):
+        try:
+            for slot, views in self.reader:
+                devs = [torch.empty(v.shape, dtype=v.dtype, device=self.device).copy_(v, non_blocking=True) for v in views]
+                ev = torch.cuda.Event()
+                ev.record()
+                self.pending.append((ev, slot))
+                self._reap()
+                yield devs
+        finally:
+            self.close()
+
+    def close(self):
+        if self.reader is not None:
+            torch.cuda.synchronize(self.device)                # (no copy may still read the ring when it is unmapped)
+            self.reader.close()
+            self.reader = None
