@@ -36,7 +36,7 @@ from video_unscreen_amd.pipeline import BgStepPipeline
 from video_unscreen_amd.pipeline_bg import BgOnlinePipeline
 from video_unscreen_amd.hostio import stream_clip
 from video_unscreen_amd.utils.fileio import parallel_read_img, read_img, save_img, save_video
-from video_unscreen_amd.utils.frameio import FrameReader, FrameWriter
+from video_unscreen_amd.utils.frameio import AsyncSaver, FrameReader, FrameWriter
 
 
 def main(cfg):
@@ -79,18 +79,21 @@ def main(cfg):
                                  segagent=HumanSegAgent(**dict(cfg["binseg"], cuda_device=idx, state_dict=w1["schp"])),
                                  stmagent=STMAgent(**dict(cfg["stm"], cuda_device=idx, state_dict=w1["stm"])),
                                  vmatagent=VMattingAgent(**dict(cfg["vmatting"], cuda_device=idx, state_dict=w1["vmatting"])))
-        for i, f in enumerate(frames):
-            fid = first + lo + i
-            fd = torch.from_numpy(f).to(dev)
-            out = pipe1.step(fd, passes=1)
-            seg = out["segmask"].cpu().numpy()
-            # without a foreground the reference appends no background and its stage 3 then refuses the unequal lists
-            # (bg_offline.py:68-71,140); here such a frame is its own background
-            bgimg = out["bgimg"].cpu().numpy() if "bgimg" in out else f
-            masks.append(seg[..., None].repeat(3, 2))
-            bgs.append(bgimg)
-            save_img(seg, osp.join(dst_img_dir, 'segmask_{:06d}.{}'.format(fid, ext)))
-            save_img(bgimg, osp.join(dst_img_dir, 'bg_{:06d}.{}'.format(fid, ext)))
+        saver = AsyncSaver([(h, w), (h, w, 3)], workers=int(cfg["data"].get("io_workers", 6)))     # the two files of a frame are encoded off this thread
+        try:
+            for i, f in enumerate(frames):
+                fid = first + lo + i
+                fd = torch.from_numpy(f).to(dev)
+                out = pipe1.step(fd, passes=1)
+                # without a foreground the reference appends no background and its stage 3 then refuses the unequal lists
+                # (bg_offline.py:68-71,140); here such a frame is its own background
+                bg_dev = out["bgimg"] if "bgimg" in out else fd
+                saver.save((out["segmask"], bg_dev), (osp.join(dst_img_dir, 'segmask_{:06d}.{}'.format(fid, ext)),
+                                                     osp.join(dst_img_dir, 'bg_{:06d}.{}'.format(fid, ext))))
+                masks.append(out["segmask"].cpu().numpy()[..., None].repeat(3, 2))
+                bgs.append(bg_dev.cpu().numpy())
+        finally:
+            saver.close()
         del pipe1
         print('stage 1: {} frames in {:.2f}s on rank {}'.format(len(frames), time.time() - st, rank))
 
