@@ -73,7 +73,8 @@ class ReplaceHostLoop:
     frame) and 6 down (the side-by-side image, whose right half IS res - replace.py:79-82 writes both from the same array).
     Per-frame inputs are (a, b) tuples, pack_pair(a, b) tensors, or - fastest - ONE (K, 2, H, W, 3) page-locked tensor per pass
     (`pack_clip`): then `group` frames move per copy (tools/dev/replace_group_probe.py, both passes at 1080p: 1213 / 1238 / 1042 / 2065 / 2043
-    frames/s at 1 / 2 / 4 / 8 / 12 frames per copy - from 100 MB on the uploads run at 51 GB/s and the downloads beside them)."""
+    frames/s at 1 / 2 / 4 / 8 / 12 frames per copy - from eight frames per group on the uploads run at 51 GB/s with the downloads beside them; the copies themselves are
+    as fast at any size (tools/dev/h2d_streams_probe.py): what a larger group buys is fewer event hand-overs per frame for the three-slot ring to hide)."""
 
     def __init__(self, pipe, nframes, src_hw=None, ring=3, group=8):
         self.pipe, self.K, self.ring, self.group = pipe, nframes, ring, max(1, group)
