@@ -484,3 +484,27 @@ def test_regionfill_full_size(nv, oracle_lib):
     exact = oracle_lib.regionfill(bg[..., 1], mask)
     d = np.abs(got[..., 1].astype(int) - exact.astype(np.uint8).astype(int))
     assert d.max() <= 1 and ((np.abs(exact - np.round(exact)) < 2e-2) | (d == 0)).all()
+
+
+@pytest.mark.parametrize("H,W", [(2160, 3840), (1083, 1925)])
+def test_regionfill_at_3840x2160_and_an_odd_size_satisfies_its_equation(nv, H, W):
+    """BASELINE.json's largest frame (and a size no level of which is even): the oracle's sparse direct solve takes minutes there, so the
+    size-independent property instead - the truncated solution satisfies the discrete Laplace equation of region_fill.py:26-63 up to the
+    truncation (five values, each cut by less than one level: |4 x - sum of neighbours| < 4 at every interior hole pixel), the image
+    outside the hole is untouched, and the solve converges in the iteration count the Galerkin coarse operators give (about 20)."""
+    from video_unscreen_amd.synth import SyntheticClip
+    f = SyntheticClip(H, W, 1, config_id=2, device="cuda").frame(0)
+    alpha = (f["alpha_true"] * 255).to(torch.uint8)
+    bg = nv.get_bg(alpha, f["frame"])
+    hole = nv.morph((alpha > 128).to(torch.uint8) * 255, 3, 2, nv.DILATE)
+    out, iters = nv.regionfill(bg, hole, want_iters=True)
+    assert 4 <= iters <= 60, iters
+    m = hole > 0
+    assert torch.equal(out[~m], bg[~m])
+    x = out.double()
+    p = torch.nn.functional.pad(x.permute(2, 0, 1)[None], (1, 1, 1, 1), mode="replicate")[0].permute(1, 2, 0)
+    lap = 4 * x - (p[:-2, 1:-1] + p[2:, 1:-1] + p[1:-1, :-2] + p[1:-1, 2:])
+    inner = m.clone()
+    inner[0, :] = inner[-1, :] = False
+    inner[:, 0] = inner[:, -1] = False
+    assert float(lap[inner].abs().max()) < 4 and float(lap[inner].abs().mean()) < 0.5
