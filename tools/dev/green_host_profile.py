@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT)
 import torch
 from video_unscreen_amd.pipeline_green import GreenPipeline
 from video_unscreen_amd.synth import SyntheticClip
-H, W, K, Wm = 1080, 1920, 40, 10
+H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1080, 1920)
+K, Wm = 40, 10
 cfg = json.load(open(os.path.join(ROOT, "configs", "green.json")))
 for k in ("binseg", "vmatting"):
     cfg[k]["model_path"] = "synthetic"
