@@ -479,7 +479,9 @@ int  usc_conv_graph_set_mode(void* handle, int mode);
 int  usc_conv_graph_launch(void* handle, usc_stream_t stream);
 /* USC_CONV_LAUNCH_RUNS bookkeeping (blocks: reads device memory): how many runs the handle's layer list holds, how many layers they
  * cover, and how many bounded polls of an arrival counter have ever run out (0 unless a hand-over is broken: such a launch has
- * gone on with possibly stale inputs instead of hanging - callers that use the mode check this). */
+ * gone on with possibly stale inputs instead of hanging - callers that use the mode check this: HipMattingNet.forward() does after every
+ * forward and raises).  The queue, sequence words and arrival counters of the mode belong to the HANDLE: at most one launch of a handle may
+ * be in flight at a time in this mode (launches of one handle on one stream are ordered and therefore fine; two streams are not). */
 int  usc_conv_graph_run_info(void* handle, int* nruns, int* layers_in_runs, unsigned* poll_timeouts);
 void usc_conv_graph_destroy(void* handle);   /* the one entry of this group that blocks: waits for the device to drain (a launch
                                               * of the graph may still be queued), then destroys the graph, its execs and plans */

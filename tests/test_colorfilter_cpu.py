@@ -36,3 +36,31 @@ def test_fit_workers_give_the_in_process_fits():
     finally:
         b.close()
     assert b._pool is None
+
+
+def test_fit_pool_starts_afresh_after_a_failed_round():
+    """a round in which one worker fails (or times out) left the other workers' replies in their pipes - a caller that
+    caught the error and fitted again received the PREVIOUS round's mixtures.  The pool is recreated before the error is raised."""
+    import pytest
+    from sklearn import mixture
+    from video_unscreen_amd.colorfiltering.agent import _FitPool
+    rng = np.random.RandomState(5)
+    mk = lambda: mixture.GaussianMixture(n_components=2, covariance_type='spherical', warm_start=True, random_state=0)   # noqa: E731
+    a = np.concatenate([rng.normal(10, 1, 400), rng.normal(50, 2, 400)])
+    b = np.concatenate([rng.normal(100, 1, 400), rng.normal(200, 2, 400)])
+    pool = _FitPool(2)
+    try:
+        old = list(pool.procs)
+        with pytest.raises(RuntimeError, match="failed in a worker"):
+            pool.fit([(mk(), np.zeros(1), 1), (mk(), a, 1)])              # job 0 fails (one sample, two components); job 1's reply is still in its pipe
+        assert len(pool.procs) == 2 and not any(p in old for p in pool.procs)
+        got = pool.fit([(mk(), b, 1), (mk(), b, 1)])                      # used to return job 1 of the failed round for worker 1
+        want = mk().fit(b[..., np.newaxis])
+        for g in got:
+            assert np.array_equal(g.means_, want.means_)
+        with pytest.raises(RuntimeError, match="did not answer"):
+            pool.fit([(mk(), np.tile(rng.normal(0, 1, 200000), 1), 1)], timeout=0.0)
+        got = pool.fit([(mk(), b, 1)])
+        assert np.array_equal(got[0].means_, want.means_)
+    finally:
+        pool.close()

@@ -138,3 +138,90 @@ def test_ring_slots_share_the_staging_layout(tmp_path):
         assert (offs[1], offs[2], total) == in_layout(H, W)
         offs, total = part_offsets([(H, W), (H, W, 3)])
         assert (offs[1], total) == out_layout(H, W)
+
+
+class _Ev:
+    def __init__(self, fail=False, gate=None):
+        self.fail, self.gate = fail, gate
+
+    def synchronize(self):
+        if self.gate is not None:
+            self.gate.wait()
+        if self.fail:
+            raise RuntimeError("hipErrorLaunchFailure")
+
+
+def test_failed_hand_over_raises_in_the_loop_instead_of_hanging(tmp_path):
+    """after a failure in DeferredSubmit's helper thread the later slots were neither written nor returned, the loop
+    then blocked for ever in FrameWriter.acquire() (close(), the only place the error surfaced, was never reached).  Now the slots come
+    back, and the next submit_after() / acquire() on the loop's thread raises the helper's error."""
+    import threading
+    import pytest
+    from video_unscreen_amd.utils.frameio import DeferredSubmit
+    H, W, depth = 6, 8, 3
+    wr = FrameWriter([(H, W)], workers=1, depth=depth, pin=False)
+    d = DeferredSubmit(wr)
+    gate = threading.Event()
+    # the loop runs ahead of the "GPU": every slot acquired, all of them waiting in the helper thread, nothing with the encoders yet
+    for i in range(depth):
+        slot, (a,) = wr.acquire()
+        a.zero_()
+        d.submit_after(_Ev(fail=(i == 0), gate=gate), slot, (str(tmp_path / f"a_{i}.npy"),))
+    threading.Timer(0.3, gate.set).start()
+    with pytest.raises(RuntimeError, match="handing a finished frame to the writer failed") as ei:
+        wr.acquire()                                   # used to block for ever
+    assert "hipErrorLaunchFailure" in str(ei.value.__cause__)
+    with pytest.raises(RuntimeError, match="handing a finished frame"):
+        d.submit_after(_Ev(), 0, ("x",))
+    with pytest.raises(RuntimeError, match="handing a finished frame"):
+        d.close()
+    assert not list(tmp_path.iterdir())                # nothing is written after the failure
+    wr.close()                                         # every slot came back: close() does not wait for anything
+    assert sorted(wr.free) == list(range(depth))
+
+
+def test_writer_acquire_is_bounded(tmp_path):
+    """Slots that were acquired and never handed on, or encoders that died, make acquire() raise instead of waiting for ever."""
+    import pytest
+    wr = FrameWriter([(4, 4)], workers=1, depth=2, pin=False)
+    wr.acquire(), wr.acquire()
+    with pytest.raises(RuntimeError, match="none is being written"):
+        wr.acquire()
+    wr.give_back(0)
+    slot, _ = wr.acquire()
+    assert slot == 0
+    wr.submit(slot, (str(tmp_path / "nonexistent_dir" / "a.npy"),))       # the encoder reports the failure ...
+    with pytest.raises(RuntimeError, match="FrameWriter"):
+        for _ in range(3):
+            wr.acquire()                                                   # ... and the next acquire raises it
+    wr.errors.clear()
+    slot, _ = wr.acquire()                                                 # (the failed slot came back; slot 1 is still held)
+    wr.procs[0].terminate()
+    wr.procs[0].join()
+    wr.submit(slot, (str(tmp_path / "b.npy"),))
+    with pytest.raises(RuntimeError, match="died"):
+        wr.acquire()
+    wr.inflight = 0
+    wr.errors.clear()
+    wr.close()
+
+
+def test_async_saver_save_raises_after_a_failed_copy():
+    """AsyncSaver.save() checks the helper thread's error before it asks for a slot (CPU stand-in: the class is built by hand around a
+    CPU writer; the real save() copies on the current HIP stream)."""
+    import pytest
+    from video_unscreen_amd.utils.frameio import AsyncSaver, DeferredSubmit
+    sv = AsyncSaver.__new__(AsyncSaver)
+    sv.writer = FrameWriter([(4, 4)], workers=1, depth=2, pin=False)
+    sv.deferred = DeferredSubmit(sv.writer)
+    slot, _ = sv.writer.acquire()
+    sv.deferred.submit_after(_Ev(fail=True), slot, ("a",))
+    sv.deferred.th.join(timeout=0.5)
+    import time
+    t0 = time.time()
+    while sv.deferred.error is None and time.time() - t0 < 5:
+        time.sleep(0.01)
+    with pytest.raises(RuntimeError, match="handing a finished frame"):
+        sv.save([None], [None])
+    with pytest.raises(RuntimeError):
+        sv.close()

@@ -270,3 +270,43 @@ def test_green_and_bg_tools_write_what_the_pipeline_gives(tmp_path, tool, cfg_na
             assert path.read_bytes() == ref.read_bytes(), (tool, fname, t)
             written += 1
     assert written >= 3 * n
+
+
+def test_replace_tool_more_ranks_than_frames(tmp_path):
+    """a rank whose frame range is empty (WORLD_SIZE > number of frames) used to die on a missing file before the
+    collectives, leaving the other ranks in all_reduce until the time-out.  Three ranks (sharing this box's GPU, gloo) over two frames of
+    raw files write exactly the files of the one-rank run and print the same correspondence mean."""
+    from video_unscreen_amd.synth import SyntheticClip
+    H, W, n = 96, 160, 2
+    root = tmp_path / "replace"
+    src, tgt, bgd = root / "unscreen_img" / "test7", root / "unscreenbg_img" / "out7", root / "unscreen_img" / "bg"
+    for d in (src, tgt, bgd):
+        d.mkdir(parents=True)
+    clip = SyntheticClip(H, W, n, config_id=2, device="cpu")
+    clip2 = SyntheticClip(H, W, n, config_id=3, device="cpu", n_objects=1)
+    np.save(str(bgd / "test5_case.npy"), clip2.bg_always.numpy())
+    from video_unscreen_amd.utils.fileio import save_img
+    save_img(clip2.bg_always.numpy(), str(bgd / "test5_case.jpg"))
+    for t in range(n):
+        f, g = clip.frame(t), clip2.frame(t)
+        a = (f["alpha_true"].numpy() * 255).astype(np.uint8)
+        np.save(str(tgt / f"fg_{t:06d}.npy"), (f["frame"].numpy() * (a[..., None] / 255.)).astype(np.uint8))
+        np.save(str(tgt / f"alphamask_{t:06d}.npy"), np.stack([a] * 3, -1))
+        np.save(str(src / f"frame_{t:06d}.npy"), g["frame"].numpy())
+        np.save(str(src / f"alphamask_{t:06d}.npy"), np.stack([(g["alpha_true"].numpy() * 255).astype(np.uint8)] * 3, -1))
+    tool = [os.path.join(ROOT, "tools", "replace", "replace.py"), "--src", "test7", "--data_root", str(root), "--io", "npy", "--io_workers", "2"]
+    out = root / "merge_test_img" / "test7_out7"
+    r1 = subprocess.run([sys.executable] + tool, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    want = {p.name: np.load(str(p)) for p in sorted(out.iterdir())}
+    assert len(want) == 2 * n
+    for p in out.iterdir():
+        p.unlink()
+    env = dict(os.environ, USC_BENCH_BACKEND="gloo", USC_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r3 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                         "--master-port", "29631"] + tool, capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert r3.returncode == 0, r3.stdout[-3000:] + r3.stderr[-3000:]
+    mean = lambda r: sorted({ln for ln in r.stdout.splitlines() if ln.startswith("Correspondence mean")})      # noqa: E731
+    assert mean(r3) == mean(r1) and len(mean(r1)) == 1
+    got = {p.name: np.load(str(p)) for p in sorted(out.iterdir())}
+    assert got.keys() == want.keys() and all(np.array_equal(got[k], want[k]) for k in want)

@@ -28,11 +28,19 @@ from video_unscreen_amd.utils.frameio import AsyncLoader, AsyncSaver
 
 def run(args):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # (rehearsal knobs, as in bench.py: ranks may share a device and talk over gloo - tests/test_tools_gpu.py on a one-GPU box)
+    backend = os.environ.get("USC_BENCH_BACKEND", "nccl")
+    if os.environ.get("USC_BENCH_SHARE_GPU"):
+        local = local % torch.cuda.device_count()
+    dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     ext = args.io                                            # jpg = the reference's files; npy = raw arrays (no codec: bit-exact runs)
     numframes = len(sorted(glob(osp.join(args.tgt_data_dir, 'fg_*.' + ext))))
     assert numframes > 0
@@ -41,8 +49,9 @@ def run(args):
     tgt = lambda name, fid: osp.join(args.tgt_data_dir, "{}_{:06d}.{}".format(name, fid, ext))       # noqa: E731
     src = lambda name, fid: osp.join(args.src_data_dir, "{}_{:06d}.{}".format(name, fid, ext))       # noqa: E731
 
-    first = read_img(tgt("fg", lo))
-    h, w = first.shape[:2]
+    # Sizes come from frame 0 on every rank (not from the rank's own first frame: a rank whose range is empty - more ranks than frames -
+    # has none, and must still reach the collectives below).  Every frame of a clip has its first frame's size (fixed ring slots).
+    h, w = read_img(tgt("fg", 0)).shape[:2]
     bg_npy = osp.splitext(args.src_bg_image)[0] + ".npy"
     bg_path = bg_npy if ext == "npy" and osp.exists(bg_npy) else args.src_bg_image
     pipe = ReplacePipeline(h, w, torch.from_numpy(read_img(bg_path)), device=dev, scale=1.2, max_frames=max(1, hi - lo))
@@ -50,12 +59,13 @@ def run(args):
     # Files are decoded by worker processes into a page-locked ring and go up asynchronously (AsyncLoader), the two output images of a frame
     # are encoded by worker processes (AsyncSaver): the loop's own thread only enqueues (the reference: cv2.imread x 5 and cv2.imwrite x 2
     # per frame on it, ~60 ms of codec work against 0.03 ms of kernel).
-    sh, sw = read_img(src("frame", lo)).shape[:2]
+    sh, sw = read_img(src("frame", 0)).shape[:2]
     workers = args.io_workers
     if args.dx is None or args.dy is None:                   # comp_dx_dy (replace.py:28-41): moments on the device, one host read
         groups = [(tgt("alphamask", fid), src("alphamask", fid)) for fid in range(lo, hi)]
-        for i, (dst_mask, src_mask) in enumerate(AsyncLoader(groups, [(h, w, 3), (sh, sw, 3)], dev, workers=workers)):
-            pipe.centroid_pair(i, dst_mask, src_mask)
+        if groups:                                           # (an empty range contributes (0, 0, 0) to the all-reduce)
+            for i, (dst_mask, src_mask) in enumerate(AsyncLoader(groups, [(h, w, 3), (sh, sw, 3)], dev, workers=workers)):
+                pipe.centroid_pair(i, dst_mask, src_mask)
         acc = torch.tensor(pipe.offset_sums(hi - lo), dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(acc)
@@ -66,9 +76,9 @@ def run(args):
 
     M = pipe.shift_matrix(dx_mean, dy_mean)
     groups = [(tgt("fg", fid), tgt("alphamask", fid), src("frame", fid)) for fid in range(lo, hi)]
-    saver = AsyncSaver([(h, w, 3), (h, 2 * w, 3)], workers=workers)
+    saver = AsyncSaver([(h, w, 3), (h, 2 * w, 3)], workers=workers if groups else 1)
     try:
-        for i, (fg, mask, frame) in enumerate(AsyncLoader(groups, [(h, w, 3), (h, w, 3), (sh, sw, 3)], dev, workers=workers)):
+        for i, (fg, mask, frame) in enumerate(AsyncLoader(groups, [(h, w, 3), (h, w, 3), (sh, sw, 3)], dev, workers=workers) if groups else ()):
             res, cmp_img = pipe.compose(fg, mask, frame, M)
             saver.save((res, cmp_img), (osp.join(args.dst_data_dir, "res_{:06d}.{}".format(lo + i, ext)),
                                         osp.join(args.dst_data_dir, "compare_{:06d}.{}".format(lo + i, ext))))

@@ -20,11 +20,15 @@ class _FitPool:
     """Six processes that run GaussianMixture.fit (video_unscreen_amd/_fit_worker.py); started at the first training frame."""
 
     def __init__(self, n):
+        self.n = n
+        self.conns, self.procs = [], []
+        self._start()
+
+    def _start(self):
         import multiprocessing as mp
         from .._fit_worker import fit_worker
         from ..utils.frameio import _light_children
         ctx = mp.get_context("spawn")                         # no fork: the parent holds a HIP context
-        self.conns, self.procs = [], []
         limits = {}
         try:                                                  # the thread counts sklearn's OpenMP / BLAS code sees in THIS process (torch has set them)
             import sklearn.cluster                            # noqa: F401
@@ -36,7 +40,7 @@ class _FitPool:
         except Exception:                                     # noqa: BLE001 - without threadpoolctl the workers keep their defaults
             limits = {}
         with _light_children():
-            for _ in range(n):
+            for _ in range(self.n):
                 a, b = ctx.Pipe()
                 p = ctx.Process(target=fit_worker, args=(b, limits), daemon=True)
                 p.start()
@@ -44,7 +48,18 @@ class _FitPool:
                 self.conns.append(a)
                 self.procs.append(p)
 
-    def fit(self, jobs):
+    def _fail(self, msg):
+        """An answer is missing or an error came back: the other workers of the round may still hold (or be about to send) THIS round's
+        replies, which a caller that catches the error and fits again would read as the next round's.  The pool is torn down (pipes
+        closed, processes ended) and started afresh before the error is raised, so no stale reply survives."""
+        for p in self.procs:
+            if p.is_alive():
+                p.terminate()
+        self.close()
+        self._start()
+        raise RuntimeError(msg)
+
+    def fit(self, jobs, timeout=120.0):
         """jobs: [(mixture, packed samples, stride)] -> the fitted mixtures, in order (job i on worker i % n)."""
         n = len(self.conns)
         out = [None] * len(jobs)
@@ -53,11 +68,14 @@ class _FitPool:
             for i, job in enumerate(chunk):
                 self.conns[i].send(job)
             for i in range(len(chunk)):
-                if not self.conns[i].poll(120.0):
-                    raise RuntimeError("ColorFilteringAgent: an EM worker process did not answer within 120 s (alive: %s)" % self.procs[i].is_alive())
-                gmm, err = self.conns[i].recv()
+                if not self.conns[i].poll(timeout):
+                    self._fail("ColorFilteringAgent: an EM worker process did not answer within %g s (alive: %s)" % (timeout, self.procs[i].is_alive()))
+                try:
+                    gmm, err = self.conns[i].recv()
+                except (EOFError, OSError) as e:
+                    self._fail("ColorFilteringAgent: an EM worker process went away (%r)" % (e,))
                 if err:
-                    raise RuntimeError("ColorFilteringAgent: GaussianMixture.fit failed in a worker: " + err)
+                    self._fail("ColorFilteringAgent: GaussianMixture.fit failed in a worker: " + err)
                 out[base + i] = gmm
         return out
 

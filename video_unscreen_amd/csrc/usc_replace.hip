@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void replace_compose_kernel(const uint8_t* __r
     s_m[threadIdx.x] = (double)threadIdx.x / 255.;
     for (int i = threadIdx.x; i < wh * ww; i += 256) {
         const int r = i / ww, c = i - r * ww;
-        s_px[r * kWW + c] = warp_px<MASK_CN>(fg, mask, H, W, MASK_CN == 3 ? nbytes : nbytes / 3, A, wy0 + r, wx0 + c);
+        s_px[r * kWW + c] = warp_px<MASK_CN>(fg, mask, H, W, nbytes, A, wy0 + r, wx0 + c);     // nbytes bounds the 8-byte loads of the 3-channel arrays (a 1-channel mask is read two bytes at a time: sx + 1 < W keeps them inside)
     }
     __syncthreads();
     // 4 output pixels per lane along x: 16 lanes cover a tile row

@@ -186,11 +186,13 @@ class FrameWriter:
         self.free = list(range(depth))
         self.inflight = 0
         self.errors = []
-        self._lock = threading.Lock()                     # submit() may come from DeferredSubmit's thread
+        self.check = None                                 # optional callable that raises a pending failure of whoever feeds submit()
+        self.pending = None                               # optional callable: slots that someone (DeferredSubmit) still holds and will hand over
+        self._lock = threading.Lock()                     # submit() / give_back() may come from DeferredSubmit's thread
 
-    def _reap(self, block):
+    def _reap(self, block, timeout=None):
         try:
-            slot, err = self.done.get(block=block)
+            slot, err = self.done.get(block=block, timeout=timeout)
         except queue.Empty:
             return False
         with self._lock:
@@ -201,14 +203,36 @@ class FrameWriter:
         return True
 
     def acquire(self):
+        """A free slot.  Blocks while every slot is being encoded - but never for ever: the wait is cut into 2 s pieces, and between them
+        an encoder's error, a dead encoder process, a failure `check` reports (DeferredSubmit: a copy that failed before its slot reached
+        the encoders) or "no slot is with the encoders at all" (slots acquired and never submitted or given back) raise."""
         while self._reap(False):
             pass
         while not self.free:
-            self._reap(True)
-        if self.errors:
-            raise RuntimeError("FrameWriter: " + self.errors[0])
+            self._raise_errors()
+            if self.inflight == 0 and (self.pending is None or self.pending() == 0) and self.done.empty():
+                raise RuntimeError("FrameWriter: all %d slots are acquired and none is being written - submit() or give_back() a slot "
+                                   "before asking for the next" % self.ring.depth)
+            if not self._reap(True, timeout=2.0):
+                dead = [p.pid for p in self.procs if not p.is_alive()]
+                if dead:
+                    raise RuntimeError("FrameWriter: encoder process(es) %s died with %d slot(s) outstanding" % (dead, self.inflight))
+        self._raise_errors()
         slot = self.free.pop()
         return slot, self.ring.views(slot)
+
+    def _raise_errors(self):
+        if self.check is not None:
+            self.check()
+        if self.errors:
+            raise RuntimeError("FrameWriter: " + self.errors[0])
+
+    def give_back(self, slot, err=None):
+        """A slot that was acquired but will not be written (its copy failed, or an earlier failure stopped the hand-over): it comes back
+        through the encoders' reply queue (thread-safe, and the one place acquire() waits on), with `err` recorded like an encoder's."""
+        with self._lock:
+            self.inflight += 1
+        self.done.put((slot, err))
 
     def submit(self, slot, paths):
         with self._lock:
@@ -239,14 +263,29 @@ class FrameWriter:
 
 class DeferredSubmit:
     """Hands a writer slot to the encoders once the GPU copies into it have finished, without blocking the frame loop: a helper
-    thread waits on the copy's event."""
+    thread waits on the copy's event.  After the first failure (a failed copy, a submit() that raises) nothing more is written, every
+    later slot goes straight back to the writer (`give_back`), and the error is raised by the NEXT submit_after() / writer.acquire() on
+    the loop's thread - not only by close(), which a loop blocked in acquire() would never reach."""
 
     def __init__(self, writer):
         self.writer = writer
         self.q = queue.Queue()
-        self.error = None                      # the first exception of the helper thread (a failed copy, a dead encoder): re-raised by close()
+        self.error = None                      # the first exception of the helper thread (a failed copy, a dead encoder)
+        self.outstanding = 0                   # slots handed to submit_after() that the helper thread has not passed on yet
+        self._count = threading.Lock()
+        if hasattr(writer, "check"):
+            writer.check = self.raise_pending
+            writer.pending = lambda: self.outstanding
         self.th = threading.Thread(target=self._run, daemon=True)
         self.th.start()
+
+    def _give_back(self, slot, err):
+        give_back = getattr(self.writer, "give_back", None)
+        if give_back is not None:
+            try:
+                give_back(slot, err)
+            except Exception:                  # noqa: BLE001 - the first error is the one that is reported
+                pass
 
     def _run(self):
         while True:
@@ -255,19 +294,32 @@ class DeferredSubmit:
                 return
             event, slot, paths = item
             if self.error is not None:
-                continue                       # (keep draining the queue: close() must not block on it)
-            try:
-                event.synchronize()
-                self.writer.submit(slot, paths)
-            except BaseException as e:         # noqa: BLE001 - handed to the thread that calls close()
-                self.error = e
+                self._give_back(slot, None)    # (keep draining the queue: close() must not block on it)
+            else:
+                try:
+                    event.synchronize()
+                    self.writer.submit(slot, paths)
+                except BaseException as e:     # noqa: BLE001 - handed to the loop's thread
+                    self.error = e
+                    self._give_back(slot, None)
+            with self._count:
+                self.outstanding -= 1
+
+    def raise_pending(self):
+        if self.error is not None:
+            raise RuntimeError("DeferredSubmit: handing a finished frame to the writer failed") from self.error
 
     def submit_after(self, event, slot, paths):
+        self.raise_pending()
+        with self._count:
+            self.outstanding += 1
         self.q.put((event, slot, paths))
 
     def close(self):
         self.q.put(None)
         self.th.join()
+        if hasattr(self.writer, "check"):
+            self.writer.check = self.writer.pending = None
         if self.error is not None:
             err, self.error = self.error, None
             raise RuntimeError("DeferredSubmit: handing a finished frame to the writer failed") from err
@@ -286,7 +338,8 @@ class AsyncSaver:
         self.deferred = DeferredSubmit(self.writer)
 
     def save(self, tensors, paths):
-        slot, views = self.writer.acquire()                    # (blocks only when every slot is still being encoded)
+        self.deferred.raise_pending()                          # a frame that could not be handed over fails the NEXT save, not only close()
+        slot, views = self.writer.acquire()                    # (blocks only when every slot is still being encoded; bounded, see acquire)
         for v, t, p in zip(views, tensors, paths):
             if p is not None:
                 v.copy_(t, non_blocking=True)

@@ -325,9 +325,27 @@ class HipMattingNet:
             rc = nv.load().usc_conv_sequence_f32(self._arr, len(self._descs), st)
         if rc != 0:
             raise nv.NativeError(f"conv launch failed ({rc}): {nv.load().usc_conv_last_error().decode()}")
+        if getattr(self, "_launch_mode", "stream") == "runs" and self.check_runs:
+            self.raise_on_broken_handover()
         return self.pred
 
     __call__ = forward
+
+    check_runs = True          # "runs" mode only: every forward is followed by a (blocking) look at the hand-over counters
+
+    def raise_on_broken_handover(self):
+        """"runs" mode: a workgroup whose bounded poll of a producer's arrival counter ran out has gone on with possibly stale activations
+        (it must not hang the GPU) and counted that in the handle - a prediction computed that way must not be used.  Blocks (reads device
+        memory), which is why the mode's forward() is synchronous unless check_runs is switched off by a caller that checks itself."""
+        import ctypes as C
+        bad = C.c_uint(0)
+        rc = nv.load().usc_conv_graph_run_info(self._graph, None, None, C.byref(bad))
+        if rc != 0:
+            raise nv.NativeError(f"usc_conv_graph_run_info failed ({rc}): {nv.load().usc_conv_last_error().decode()}")
+        if bad.value:
+            raise nv.NativeError(f"USC_CONV_LAUNCH_RUNS: {bad.value} arrival-counter poll(s) of this network have run out - a layer hand-over "
+                                 f"inside a multi-layer launch is broken and the prediction may be built on stale activations; use "
+                                 f"set_launch_mode('stream')")
 
     def set_launch_mode(self, mode):
         """"stream" (default: the planned launches one by one on the stream), "graph" (one hipGraphLaunch per forward) or "runs" (as
@@ -335,6 +353,7 @@ class HipMattingNet:
         rc = nv.load().usc_conv_graph_set_mode(self._graph, {"stream": 0, "graph": 1, "runs": 2}[mode])
         if rc != 0:
             raise nv.NativeError(f"usc_conv_graph_set_mode failed ({rc})")
+        self._launch_mode = mode     # ("runs": ONE launch of this network in flight at a time - queue and arrival counters belong to the handle)
 
     def forward_serial(self):
         """The same layers launched one after the other on the current stream (no graph, no branch overlap): what the per-layer
