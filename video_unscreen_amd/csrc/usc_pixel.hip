@@ -207,7 +207,7 @@ extern "C" int usc_morph_u8(const uint8_t* src, uint8_t* dst, int H, int W, int 
 // value reaches 255.  One uint32 holds 32 horizontal pixels (bit i <-> x0 + i), a workgroup owns a tile of
 // kBitH rows x kBitWW words plus halo rows and one halo word (32 px) per side, and one SE pass is a handful of
 // shifts / ORs per word instead of k*k byte compares per pixel.
-constexpr int kBitH = 16, kBitWW = 4, kBitEWW = kBitWW + 2, kBitThreads = 256;
+constexpr int kBitH = 16, kBitWW = 4, kBitEWW = kBitWW + 2, kBitThreads = 1024;     // 16 waves: the ~80 64-pixel chunks of a tile's byte loads go out in ONE round (round 5; 4 waves needed four round trips)
 
 struct BitSE {                // per SE row: contiguous run [lo, hi] of dx (lo > hi: empty row)
     int nrows, anchor, top, bottom;
