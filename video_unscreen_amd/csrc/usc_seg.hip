@@ -128,25 +128,31 @@ __device__ __forceinline__ float up_ac_value(const float* __restrict__ logits, i
 // When the box does not fit the LDS budget (frames smaller than the network input are magnified) the taps are evaluated on the fly.
 constexpr int kSpTileH = 16, kSpGroups = 16, kSpCap = 320;
 
-template <int C>
+// R: row groups per workgroup (tile = 16 R rows x 64 pixels).  The staging pass (the box's cells x C bilinear evaluations from the
+// logits, a chain of dependent global loads) is what a workgroup waits for; on a frame much larger than the network input the box
+// of a 16 x 64 tile is a handful of cells, so taller tiles share it between R times the pixels (round 5: 3840 x 2160, R = 4).
+template <int C, int R>
 __global__ __launch_bounds__(256) void seg_post_fused_kernel(const float* __restrict__ logits, int Cbuf, int lh, int lw, int in_h, int in_w,
                                                              float rh, float rw, Affine A, uint8_t* __restrict__ out, int H, int W) {
     __shared__ __attribute__((aligned(16))) float s_up[kSpCap * C];
     __shared__ int s_box[4];
     const int t = threadIdx.x;
-    const int y = blockIdx.y * kSpTileH + (t >> 4), x0 = blockIdx.x * (kSpGroups * 4) + (t & 15) * 4;
+    const int yb = blockIdx.y * (kSpTileH * R) + (t >> 4), x0 = blockIdx.x * (kSpGroups * 4) + (t & 15) * 4;
     if (t < 4) s_box[t] = (t & 1) ? -0x7fffffff : 0x7fffffff;
     __syncthreads();
-    int sx[4], sy[4], fx[4], fy[4];
     int bx0 = 0x7fffffff, bx1 = -0x7fffffff, by0 = 0x7fffffff, by1 = -0x7fffffff;
-    const int cnt = (y < H && x0 < W) ? min(4, W - x0) : 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        sx[k] = sy[k] = fx[k] = fy[k] = 0;
-        if (k < cnt) {
-            warp_coord(A, x0 + k, y, sx[k], sy[k], fx[k], fy[k]);
-            bx0 = min(bx0, min(max(sx[k], 0), in_w - 1)); bx1 = max(bx1, min(max(sx[k] + 1, 0), in_w - 1));
-            by0 = min(by0, min(max(sy[k], 0), in_h - 1)); by1 = max(by1, min(max(sy[k] + 1, 0), in_h - 1));
+    for (int r = 0; r < R; r++) {
+        const int y = yb + r * kSpTileH;
+        const int cnt = (y < H && x0 < W) ? min(4, W - x0) : 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k < cnt) {
+                int sx, sy, fx, fy;
+                warp_coord(A, x0 + k, y, sx, sy, fx, fy);
+                bx0 = min(bx0, min(max(sx, 0), in_w - 1)); bx1 = max(bx1, min(max(sx + 1, 0), in_w - 1));
+                by0 = min(by0, min(max(sy, 0), in_h - 1)); by1 = max(by1, min(max(sy + 1, 0), in_h - 1));
+            }
         }
     }
 #pragma unroll
@@ -168,60 +174,67 @@ __global__ __launch_bounds__(256) void seg_post_fused_kernel(const float* __rest
         }
     }
     __syncthreads();
-    if (cnt == 0) return;
-    uint32_t packed = 0;
+#pragma unroll 1
+    for (int r = 0; r < R; r++) {
+        const int y = yb + r * kSpTileH;
+        const int cnt = (y < H && x0 < W) ? min(4, W - x0) : 0;
+        if (cnt == 0) continue;
+        uint32_t packed = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (k >= cnt) continue;
-        const float ax = fx[k] * (1.f / 32), ay = fy[k] * (1.f / 32);
-        const float wx0 = 1.f - ax, wx1 = ax, wy0 = 1.f - ay, wy1 = ay;
-        const float w0 = wy0 * wx0, w1 = wy0 * wx1, w2 = wy1 * wx0, w3 = wy1 * wx1;
-        const bool in0 = sx[k] >= 0 && sx[k] < in_w, in1 = sx[k] + 1 >= 0 && sx[k] + 1 < in_w;
-        const bool jn0 = sy[k] >= 0 && sy[k] < in_h, jn1 = sy[k] + 1 >= 0 && sy[k] + 1 < in_h;
-        const int cx0 = min(max(sx[k], 0), in_w - 1), cx1 = min(max(sx[k] + 1, 0), in_w - 1);
-        const int cy0 = min(max(sy[k], 0), in_h - 1), cy1 = min(max(sy[k] + 1, 0), in_h - 1);
-        const bool m00 = in0 && jn0, m01 = in1 && jn0, m10 = in0 && jn1, m11 = in1 && jn1;
-        float best = 0.f;
-        int besti = 0;
-        if (staged) {
-            const float4* p00 = reinterpret_cast<const float4*>(s_up + ((cy0 - by0) * bw + (cx0 - bx0)) * C);
-            const float4* p01 = reinterpret_cast<const float4*>(s_up + ((cy0 - by0) * bw + (cx1 - bx0)) * C);
-            const float4* p10 = reinterpret_cast<const float4*>(s_up + ((cy1 - by0) * bw + (cx0 - bx0)) * C);
-            const float4* p11 = reinterpret_cast<const float4*>(s_up + ((cy1 - by0) * bw + (cx1 - bx0)) * C);
+        for (int k = 0; k < 4; k++) {
+            if (k >= cnt) continue;
+            int sxk, syk, fxk, fyk;
+            warp_coord(A, x0 + k, y, sxk, syk, fxk, fyk);
+            const float ax = fxk * (1.f / 32), ay = fyk * (1.f / 32);
+            const float wx0 = 1.f - ax, wx1 = ax, wy0 = 1.f - ay, wy1 = ay;
+            const float w0 = wy0 * wx0, w1 = wy0 * wx1, w2 = wy1 * wx0, w3 = wy1 * wx1;
+            const bool in0 = sxk >= 0 && sxk < in_w, in1 = sxk + 1 >= 0 && sxk + 1 < in_w;
+            const bool jn0 = syk >= 0 && syk < in_h, jn1 = syk + 1 >= 0 && syk + 1 < in_h;
+            const int cx0 = min(max(sxk, 0), in_w - 1), cx1 = min(max(sxk + 1, 0), in_w - 1);
+            const int cy0 = min(max(syk, 0), in_h - 1), cy1 = min(max(syk + 1, 0), in_h - 1);
+            const bool m00 = in0 && jn0, m01 = in1 && jn0, m10 = in0 && jn1, m11 = in1 && jn1;
+            float best = 0.f;
+            int besti = 0;
+            if (staged) {
+                const float4* p00 = reinterpret_cast<const float4*>(s_up + ((cy0 - by0) * bw + (cx0 - bx0)) * C);
+                const float4* p01 = reinterpret_cast<const float4*>(s_up + ((cy0 - by0) * bw + (cx1 - bx0)) * C);
+                const float4* p10 = reinterpret_cast<const float4*>(s_up + ((cy1 - by0) * bw + (cx0 - bx0)) * C);
+                const float4* p11 = reinterpret_cast<const float4*>(s_up + ((cy1 - by0) * bw + (cx1 - bx0)) * C);
 #pragma unroll
-            for (int c4 = 0; c4 < C / 4; c4++) {
-                const float4 a = p00[c4], b = p01[c4], c = p10[c4], d = p11[c4];
-                const float va[4] = {a.x, a.y, a.z, a.w}, vb[4] = {b.x, b.y, b.z, b.w}, vc[4] = {c.x, c.y, c.z, c.w}, vd[4] = {d.x, d.y, d.z, d.w};
+                for (int c4 = 0; c4 < C / 4; c4++) {
+                    const float4 a = p00[c4], b = p01[c4], c = p10[c4], d = p11[c4];
+                    const float va[4] = {a.x, a.y, a.z, a.w}, vb[4] = {b.x, b.y, b.z, b.w}, vc[4] = {c.x, c.y, c.z, c.w}, vd[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    // out-of-image taps read the border value 0 (select, not multiply: -0 / NaN safe)
-                    const float t0 = m00 ? va[e] : 0.f, t1 = m01 ? vb[e] : 0.f, t2 = m10 ? vc[e] : 0.f, t3 = m11 ? vd[e] : 0.f;
-                    float r = t0 * w0;
-                    r = r + t1 * w1;
-                    r = r + t2 * w2;
-                    r = r + t3 * w3;
-                    const int ci = c4 * 4 + e;
-                    if (ci == 0 || r > best) { best = r; besti = ci; }       // np.argmax: the first maximum wins
+                    for (int e = 0; e < 4; e++) {
+                        // out-of-image taps read the border value 0 (select, not multiply: -0 / NaN safe)
+                        const float t0 = m00 ? va[e] : 0.f, t1 = m01 ? vb[e] : 0.f, t2 = m10 ? vc[e] : 0.f, t3 = m11 ? vd[e] : 0.f;
+                        float rr = t0 * w0;
+                        rr = rr + t1 * w1;
+                        rr = rr + t2 * w2;
+                        rr = rr + t3 * w3;
+                        const int ci = c4 * 4 + e;
+                        if (ci == 0 || rr > best) { best = rr; besti = ci; }       // np.argmax: the first maximum wins
+                    }
+                }
+            } else {
+                for (int ci = 0; ci < C; ci++) {
+                    const float t0 = m00 ? up_ac_value(logits, Cbuf, lh, lw, ci, cy0, cx0, rh, rw) : 0.f;
+                    const float t1 = m01 ? up_ac_value(logits, Cbuf, lh, lw, ci, cy0, cx1, rh, rw) : 0.f;
+                    const float t2 = m10 ? up_ac_value(logits, Cbuf, lh, lw, ci, cy1, cx0, rh, rw) : 0.f;
+                    const float t3 = m11 ? up_ac_value(logits, Cbuf, lh, lw, ci, cy1, cx1, rh, rw) : 0.f;
+                    float rr = t0 * w0;
+                    rr = rr + t1 * w1;
+                    rr = rr + t2 * w2;
+                    rr = rr + t3 * w3;
+                    if (ci == 0 || rr > best) { best = rr; besti = ci; }
                 }
             }
-        } else {
-            for (int ci = 0; ci < C; ci++) {
-                const float t0 = m00 ? up_ac_value(logits, Cbuf, lh, lw, ci, cy0, cx0, rh, rw) : 0.f;
-                const float t1 = m01 ? up_ac_value(logits, Cbuf, lh, lw, ci, cy0, cx1, rh, rw) : 0.f;
-                const float t2 = m10 ? up_ac_value(logits, Cbuf, lh, lw, ci, cy1, cx0, rh, rw) : 0.f;
-                const float t3 = m11 ? up_ac_value(logits, Cbuf, lh, lw, ci, cy1, cx1, rh, rw) : 0.f;
-                float r = t0 * w0;
-                r = r + t1 * w1;
-                r = r + t2 * w2;
-                r = r + t3 * w3;
-                if (ci == 0 || r > best) { best = r; besti = ci; }
-            }
+            packed |= (uint32_t)(besti > 0 ? 255 : 0) << (8 * k);
         }
-        packed |= (uint32_t)(besti > 0 ? 255 : 0) << (8 * k);
+        const size_t i0 = (size_t)y * W + x0;
+        if (cnt == 4 && (i0 & 3) == 0) *reinterpret_cast<uint32_t*>(out + i0) = packed;
+        else for (int k = 0; k < cnt; k++) out[i0 + k] = (packed >> (8 * k)) & 0xff;
     }
-    const size_t i0 = (size_t)y * W + x0;
-    if (cnt == 4 && (i0 & 3) == 0) *reinterpret_cast<uint32_t*>(out + i0) = packed;
-    else for (int k = 0; k < cnt; k++) out[i0 + k] = (packed >> (8 * k)) & 0xff;
 }
 
 // F.interpolate(mode='bilinear', align_corners=True) on NHWC float32, 4 channels per lane, written into channels
@@ -377,8 +390,17 @@ extern "C" int usc_humanseg_post(const float* logits, int C, int Cbuf, int lh, i
     Affine A;
     usc_humanseg_affine(W, H, in_w, in_h, 1, M);
     invert_affine(M, A.m);
-    const dim3 grid((W + kSpGroups * 4 - 1) / (kSpGroups * 4), (H + kSpTileH - 1) / kSpTileH);
-    hipLaunchKernelGGL(seg_post_fused_kernel<20>, grid, dim3(256), 0, (hipStream_t)stream, logits, Cbuf, lh, lw, in_h, in_w, rh, rw, A, out, H, W);
+    // rows per workgroup: as tall as the box of network-input cells under a 16 R x 64 tile still fits the LDS budget with a margin
+    // (A.m[0], A.m[4]: input cells per frame pixel; a tile that overflows anyway evaluates its taps on the fly, so this is a speed choice only)
+    int R = 1;
+    for (int cand = 4; cand > 1; cand >>= 1) {
+        const double tw = kSpGroups * 4, th = kSpTileH * cand;          // box of the inverse-warped tile: |A| applied to its extent
+        if ((tw * fabs(A.m[0]) + th * fabs(A.m[1]) + 3) * (tw * fabs(A.m[3]) + th * fabs(A.m[4]) + 3) <= 0.8 * kSpCap) { R = cand; break; }
+    }
+    const dim3 grid((W + kSpGroups * 4 - 1) / (kSpGroups * 4), (H + kSpTileH * R - 1) / (kSpTileH * R));
+    if (R == 4) hipLaunchKernelGGL((seg_post_fused_kernel<20, 4>), grid, dim3(256), 0, (hipStream_t)stream, logits, Cbuf, lh, lw, in_h, in_w, rh, rw, A, out, H, W);
+    else if (R == 2) hipLaunchKernelGGL((seg_post_fused_kernel<20, 2>), grid, dim3(256), 0, (hipStream_t)stream, logits, Cbuf, lh, lw, in_h, in_w, rh, rw, A, out, H, W);
+    else hipLaunchKernelGGL((seg_post_fused_kernel<20, 1>), grid, dim3(256), 0, (hipStream_t)stream, logits, Cbuf, lh, lw, in_h, in_w, rh, rw, A, out, H, W);
     return hipGetLastError() == hipSuccess ? USC_OK : seg_fail(USC_E_LAUNCH, "seg_post_fused_kernel launch failed");
 }
 
