@@ -43,6 +43,15 @@ namespace {
 constexpr int KC = 32;         // K slice per step
 constexpr int APITCH = 36;     // floats per A row in LDS (32 + 4 pad: b128 reads hit 64 distinct banks)
 
+#ifdef USC_MFMA_TIMING           // dev instrumentation (tools/dev/mfma_phases.py): per wave 8 slots of {shader clock, 100 MHz real time} + its hardware id
+#define MFMA_STAMP(k) do { if (d.slab && d.ksplit == 1 && lane == 0) { long long* ts_ = reinterpret_cast<long long*>(d.slab) + \
+        (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * (RG * KW) + wave) * 16; \
+        ts_[2 * (k)] = (long long)__builtin_readcyclecounter(); ts_[2 * (k) + 1] = (long long)__builtin_amdgcn_s_memrealtime(); \
+        if ((k) == 0) ts_[15] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); } } while (0)
+#else
+#define MFMA_STAMP(k) do { } while (0)
+#endif
+
 // NT: 32-column tiles per wave (1 | 2).  RG: row groups = waves side by side on 32 pixels each (4 | 2 | 1: a workgroup owns
 // 128 | 64 | 32 pixels).  KW: K groups (RG x KW waves in all, <= 16).  IN_RELU: the layer computes conv(relu(x)).
 template <int NT, int RG, int KW, bool IN_RELU>
@@ -53,6 +62,14 @@ __global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d
     __shared__ int s_outpix[BM], s_res1pix[BM], s_vbase[BM], s_vmask[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifndef USC_MFMA_NO_PRIO
+    // A wave that starts while older waves of its SIMD are inside their K loops is the youngest in the issue arbiter's order: its few
+    // hundred scalar / vector instructions of table building waited behind their MFMA streams (tools/dev/mfma_phases.py: 9300 cycles on
+    // average for the prologue of the parsing net's 1024 -> 256 layers, more than the 8192 MFMA cycles of the whole wave).  Prologue and
+    // epilogue therefore run at a raised priority, the K loop at the default.
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    MFMA_STAMP(0);
     const int rg = wave % RG, kg = wave / RG;                    // row group (32 pixels) and K group of this wave
     const int M = d.OH * d.OW;
     const int nblk = d.Cout / (32 * NT);
@@ -132,6 +149,7 @@ __global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d
         s_vmask[tid] = (int)mk;
     }
     __syncthreads();
+    MFMA_STAMP(1);
 
     // ---- staging assignment: lane -> (4 of this wave's rows, 8 apart; one float4 of the 32-wide K slice)
     const int q = lane & 7;
@@ -204,12 +222,20 @@ __global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d
     load_a(c_begin, ra0);
     load_a(c_begin + 1, ra1);
     stage(ra0);
+    MFMA_STAMP(2);
+#ifndef USC_MFMA_NO_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     int c = c_begin;
     for (; c + 1 < c_end; c += 2) {
         step(c, ra1, ra0);
         step(c + 1, ra0, ra1);
     }
     if (c < c_end) step(c, ra1, ra0);          // odd count: the trailing requests are out of range (zeros, no traffic)
+    MFMA_STAMP(3);
+#ifndef USC_MFMA_NO_PRIO
+    __builtin_amdgcn_s_setprio(2);
+#endif
 
     // ---- epilogue: as above, through this wave's own LDS image (free now); K groups > 0 only deposit their partial tile
     float* const T = Aw;
@@ -297,6 +323,7 @@ __global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d
             __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), out_rsrc, oos[ps] + nb4, 0, 0);
         }
     }
+    MFMA_STAMP(4);
 }
 
 
