@@ -175,7 +175,7 @@ def pmc_traffic(H, W):
     MI355X_MICROARCH.md) + WRITE_SIZE.  Counters cannot be collected inside this process; null when no file matches the frame size."""
     root = os.path.dirname(os.path.abspath(__file__))
     name = "pmc_conv_traffic.json" if (H, W) == (1080, 1920) else f"pmc_conv_traffic_{W}x{H}.json"
-    path = next((q for q in (os.path.join(root, "profiles", r, name) for r in ("r04", "r03", "r02", "r01")) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(root, "profiles", r, name) for r in ("r05", "r04", "r03", "r02", "r01")) if os.path.exists(q)), None)
     if path is None:
         return None
     z = json.load(open(path))
@@ -773,7 +773,7 @@ def main():
                        "parity": ("not bit-exact end to end: gate / object filter / trimap / foreground are bit-exact against the CPU chain given the same "
                                   "inputs, alpha is within 1e-3 (float) / 1 LSB, and the segmentation mask - an argmax over float logits from two f32 "
                                   "summation orders - differs from the CPU chain in 2 - 16 of the frame's pixels, every one an argmax tie below 1e-4 "
-                                  "(tests/test_gpu_seg.py, profiles/r03/parity_report.json); OpenCV's interior is restated by the oracle, not pinned"),
+                                  "(tests/test_gpu_seg.py, profiles/r05/parity_report.json); OpenCV's interior is restated by the oracle, not pinned"),
                        "object_filter": ("host worker threads (border-following C++ in libunscreen_hip.so; same masks as the device kernels)"
                                          if args.object_filter == "host" and not args.sync_loop else
                                          "device (label-based HIP kernels inside the foreground's bounding box, usc_objects.hip): no CPU stage in the loop"),
@@ -870,7 +870,7 @@ def main():
                                       "alg_gflop_per_forward": round(gflop, 2), "ms_per_forward": round(t_net * 1e3, 3),
                                       "ms_per_forward_graph": round(t_graph * 1e3, 3),
                                       "timing": "serial single-stream launches, HIP events; the per-layer rocprofv3 kernel-trace table of the same launches is "
-                                                "profiles/r04/unet_layer_table.md (tools/dev/layer_table.py)"}
+                                                "profiles/r05/unet_layer_table.md (tools/dev/layer_table.py)"}
                 result["roofline_pixel"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
                                             "unit": "GB/s", "frac": dom["frac_hbm_peak"], "traffic": None,
                                             "alg_bytes_per_launch": dom["alg_bytes"], "us_per_launch": dom["us"]}
