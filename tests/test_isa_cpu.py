@@ -41,7 +41,7 @@ def test_every_conv_kernel_is_in_the_library(kernels):
     import isa_check as ic
     for n in names:
         f = ic.facts(kernels[n])
-        assert f["mfma"] >= 48 and f["mfma_loops"], n                            # f32 MFMA kernels with a K loop
+        assert f["mfma"] >= 16 and f["mfma_loops"], n                            # f32 MFMA kernels with a K loop (16 NT MFMAs per step in the direct kernel)
     for n in wino:
         assert ic.facts(kernels[n])["lds_dma"] >= 12, n                          # global -> LDS staging without registers
 
@@ -66,6 +66,23 @@ def test_winograd_staged_image_hand_over_is_covered_by_a_wait(kernels):
     assert checked == 15
 
 
+def test_direct_kernel_staged_chunk_is_covered_before_its_fragment_reads(kernels):
+    """conv_mfma_kernel (round 5): the A operand goes global -> LDS without registers, one K step ahead, into the wave's OWN image, and
+    the fragment reads are inline assembly the compiler does not order against the requests: every `buffer_load ... lds` must be covered by
+    an `s_waitcnt vmcnt(N)` (N <= the vector-memory instructions issued after it) before the next `ds_read_b128` of the issuing wave."""
+    import isa_check as ic
+    checked = 0
+    for n, ins in kernels.items():
+        if "conv_mfma_kernel" not in n:
+            continue
+        f = ic.facts(ins)
+        assert f["lds_dma"] >= 8, (n, f["lds_dma"])                 # four requests in the prologue, four per K step
+        bad = ic.handover_violations(ins, 1, stop_at=("ds_read_b128",))
+        assert not bad, (n, [(k, ins[k][1], why) for k, why in bad[:4]])
+        checked += 1
+    assert checked >= 20
+
+
 def test_hand_over_rule_flags_a_missing_wait():
     """The rule itself on a hand-written instruction stream: request, barrier, barrier without a covering wait -> flagged; with
     `s_waitcnt vmcnt(0)` before the second barrier, or vmcnt(4) behind four newer loads -> clean."""
@@ -76,6 +93,8 @@ def test_hand_over_rule_flags_a_missing_wait():
         return [(4 * k, op, a) for k, (op, a) in enumerate(body)]
 
     assert ic.handover_violations(stream([("s_barrier", ""), ("ds_read_b128", "v[2:5], v6")]), 2)
+    assert ic.handover_violations(stream([("ds_read_b128", "v[2:5], v6"), ("s_waitcnt", "vmcnt(0)")]), 2, stop_at=("ds_read_b128",))      # read before the wait
+    assert not ic.handover_violations(stream([("s_waitcnt", "vmcnt(0)"), ("ds_read_b128", "v[2:5], v6")]), 2, stop_at=("ds_read_b128",))
     assert not ic.handover_violations(stream([("s_barrier", ""), ("s_waitcnt", "vmcnt(0)")]), 2)
     four = [("buffer_load_dwordx4", "v[8:11], v7, s[8:11], 0 offen")] * 4
     assert not ic.handover_violations(stream(four + [("s_waitcnt", "vmcnt(4)")]), 2)

@@ -117,13 +117,14 @@ def _vmcnt(args):
     return int(m.group(1)) if m else None
 
 
-def handover_violations(ins, max_barriers):
+def handover_violations(ins, max_barriers, stop_at=()):
     """A wave can only wait for its OWN global -> LDS requests (the load counter is per wave), and the partner wave reads the staged
     image after a workgroup barrier without any wait of its own.  So every `buffer_load ... lds` must be followed - on the path the
     issuing wave runs - by an `s_waitcnt vmcnt(N)` that covers it (N <= the number of vector-memory instructions issued after the
     request: the counter is in order) BEFORE the wave passes `max_barriers` s_barriers.  The walk follows the layout: straight on,
     an unconditional forward branch is taken, a backward branch whose target lies at or before the request closes the loop once
-    (the walk continues at the target), other conditional branches fall through.  -> [(index of the request, what happened)]"""
+    (the walk continues at the target), other conditional branches fall through.  stop_at: mnemonic prefixes that must not be reached
+    before the covering wait either (the direct conv kernel reads its OWN image: `ds_read_b128`).  -> [(index of the request, what happened)]"""
     lp = {b: t for t, b in loops(ins)}
     addr_idx = {a: k for k, (a, _, _) in enumerate(ins)}
     bad = []
@@ -144,6 +145,9 @@ def handover_violations(ins, max_barriers):
                 if barriers >= max_barriers:
                     ok = False
                     break
+            elif stop_at and o.startswith(stop_at):
+                ok = False
+                break
             elif o.startswith(VMEM):
                 newer += 1
             elif o == "s_endpgm":

@@ -4,7 +4,7 @@ import os, re, subprocess, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from isa_check import code_objects, LLVM, ROOT
 
-so = os.path.join(ROOT, "video_unscreen_amd", "libunscreen_hip.so")
+so = os.environ.get("USC_LIB", os.path.join(ROOT, "video_unscreen_amd", "libunscreen_hip.so"))
 pats = sys.argv[1:]
 rows = []
 for img in code_objects(so):

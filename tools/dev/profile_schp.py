@@ -3,6 +3,7 @@ import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from video_unscreen_amd import _native as nv
+if os.environ.get('USC_LIB'): nv.LIB_PATH = os.path.abspath(os.environ['USC_LIB'])      # (A/B runs against another build of the library)
 from video_unscreen_amd.binseg.schp_net import HipSchpNet, schp_synthetic_state_dict
 from video_unscreen_amd.vmatting.net_hip import ConvDesc
 B = int(os.environ.get('B', '1'))

@@ -55,7 +55,7 @@ constexpr int APITCH = 36;     // floats per A row in LDS (32 + 4 pad: b128 read
 // NT: 32-column tiles per wave (1 | 2).  RG: row groups = waves side by side on 32 pixels each (4 | 2 | 1: a workgroup owns
 // 128 | 64 | 32 pixels).  KW: K groups (RG x KW waves in all, <= 16).  IN_RELU: the layer computes conv(relu(x)).
 template <int NT, int RG, int KW, bool IN_RELU>
-__global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d) {
+__global__ __launch_bounds__(64 * RG * KW) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 5 : 4))) void conv_mfma_kernel(usc_conv_desc d) {
     constexpr int BM = 32 * RG;                                  // output pixels per workgroup
     __shared__ __attribute__((aligned(16))) float As[RG * KW][32 * APITCH];
     __shared__ int s_toff[16];
@@ -152,7 +152,6 @@ __global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d
     MFMA_STAMP(1);
 
     // ---- staging assignment: lane -> (4 of this wave's rows, 8 apart; one float4 of the 32-wide K slice)
-    const int q = lane & 7;
     const bool cin_pow2 = (d.Cin & (d.Cin - 1)) == 0;
     const int log2cin = 31 - __builtin_clz(d.Cin);
     int vbase[4];
@@ -166,72 +165,77 @@ __global__ __launch_bounds__(64 * RG * KW) void conv_mfma_kernel(usc_conv_desc d
         const_cast<float*>(d.in), 0, (d.batch > 1 ? d.batch : 1) * d.IH * d.IW * d.Cin * 4, 0x00020000);
     float* const Aw = As[wave];
 
-    float4 ra0[4], ra1[4];
-    auto load_a = [&](int c, float4 (&ra)[4]) {
+    // A goes global -> LDS without passing through registers (buffer_load ... lds, 16 bytes per lane, lane l of request j lands at byte
+    // 1024 j + 16 l of the wave's image): request j holds rows 8 j .. 8 j + 7, lane (r, p) of it fetches k-quad p ^ r of row 8 j + r, so
+    // that a fragment read (32 rows x one k-quad) finds its 16-byte pieces in eight distinct columns of the 128-byte rows - conflict-free
+    // without a padded pitch.  One image, requested one K step ahead (the fragments of step c are in registers before the requests of
+    // step c + 1 overwrite it).  Rounds 1 - 4 staged A through registers (global -> two register sets -> ds_write_b128, two steps ahead):
+    // 32 VGPRs more, four waves per SIMD (three at NT = 2) instead of five (four) - profiles/r05/mfma_phases.md, mfma_dma.md.
+    const int qsw = (lane & 7) ^ ((lane >> 3) & 7);
+    __attribute__((address_space(3))) float* const Al = (__attribute__((address_space(3))) float*)Aw;
+    auto dma_a = [&](int c) {
+        // (always four requests, also for the chunk past the last one, whose offsets are out of range and only write zeros: under a
+        // condition the compiler loses count of the loads in flight and waits for more than the weight fragment it needs)
         const bool live = c < c_end;
-        const int k0 = c * KC + 4 * q;
+        const int k0 = c * KC + 4 * qsw;
         const int tap = cin_pow2 ? (k0 >> log2cin) : (c * KC) / d.Cin;
         const int koff = s_toff[tap & 15] + ((k0 - tap * d.Cin) << 2);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const bool ok = live && ((vmask[j] >> tap) & 1u);
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? vbase[j] + koff : 0x7ffffff0, 0, 0);
-            ra[j] = *reinterpret_cast<const float4*>(&v);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, Al + 256 * j, 16, ok ? vbase[j] + koff : 0x7ffffff0, 0, 0, 0);
         }
     };
-    auto stage = [&](const float4 (&ra)[4]) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float4 a = ra[j];
-            if (IN_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-            *reinterpret_cast<float4*>(&Aw[((lane >> 3) + 8 * j) * APITCH + 4 * q]) = a;
-        }
-    };
-
     f32x16 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
 
-    const int arow = (lane & 31) * APITCH + 4 * (lane >> 5);
-    // One K step: the staged chunk's fragments -> registers; request chunk + 2 of A; per MFMA group multiply and then
-    // re-request that group's weight fragments for chunk + 1 into the registers just consumed (a rolling window: one
-    // register set, almost a full step of latency cover); late in the run put A chunk + 1 (requested one step ago) into
-    // the LDS image the fragments have left.
-    auto step = [&](int c, float4 (&ra_next)[4], float4 (&ra_far)[4]) {
-        float4 a[4];
+    // Fragment reads are inline assembly with their own waits: the compiler cannot tell the image's LDS addresses from the requests'
+    // destinations and would put `s_waitcnt vmcnt(0)` - a wait for the weight fragments requested a moment ago - in front of every
+    // fragment read it can see.  The load counter is in order and every vector-memory instruction of the loop is known to the compiler's
+    // own count (requests and weight loads are builtins), so its waits for the weight fragments stay exact; what the image needs is
+    // written out here: the 4 NT weight loads of a step are the only loads younger than that step's requests.
+    const int lds_img = (int)(unsigned)(unsigned long long)((__attribute__((address_space(3))) float*)Aw);
+    const int asw = lane & 7, ah = lane >> 5;
+    int fa[4];
 #pragma unroll
-        for (int g = 0; g < 4; g++) a[g] = *reinterpret_cast<const float4*>(&Aw[arow + g * 8]);
-        load_a(c + 2, ra_far);
+    for (int g = 0; g < 4; g++) fa[g] = lds_img + ((lane & 31) * 32 + (((2 * g + ah) ^ asw) << 2)) * 4;
+    f32x4 a0, a1, a2, a3;
+    auto read_frags = [&](auto vm) {                      // vm: loads that may still be in flight behind the image's requests
+        asm volatile("s_waitcnt vmcnt(%8)\n\tds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3) : "v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fa[3]), "n"(decltype(vm)::value) : "memory");
+        if (IN_RELU) {
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            if (g == 3) stage(ra_next);
-#pragma unroll
-            for (int j = 0; j < NT; j++) {
-                const float4 b = bf[g * NT + j];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, b.x, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, b.y, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, b.z, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, b.w, acc[j], 0, 0, 0);
-            }
-            load_b(c + 1, g);
+            for (int e = 0; e < 4; e++) { a0[e] = fmaxf(a0[e], 0.f); a1[e] = fmaxf(a1[e], 0.f); a2[e] = fmaxf(a2[e], 0.f); a3[e] = fmaxf(a3[e], 0.f); }
         }
     };
-
-    load_a(c_begin, ra0);
-    load_a(c_begin + 1, ra1);
-    stage(ra0);
+    auto mfma_group = [&](const f32x4& a, int g) {
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const float4 b = bf[g * NT + j];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b.x, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b.y, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b.z, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b.w, acc[j], 0, 0, 0);
+        }
+    };
+    dma_a(c_begin);
+    read_frags(std::integral_constant<int, 0>());           // (the first chunk: nothing behind it may be left in flight)
     MFMA_STAMP(2);
 #ifndef USC_MFMA_NO_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
-    int c = c_begin;
-    for (; c + 1 < c_end; c += 2) {
-        step(c, ra1, ra0);
-        step(c + 1, ra0, ra1);
+    for (int c = c_begin; c < c_end; c++) {
+        dma_a(c + 1);                                           // the fragments of chunk c are in registers: the image is free
+        __builtin_amdgcn_sched_barrier(0);                      // (the scheduler otherwise sinks the requests and the weight loads to the end of the step)
+        mfma_group(a0, 0); load_b(c + 1, 0); __builtin_amdgcn_sched_barrier(0);
+        mfma_group(a1, 1); load_b(c + 1, 1); __builtin_amdgcn_sched_barrier(0);
+        mfma_group(a2, 2); load_b(c + 1, 2); __builtin_amdgcn_sched_barrier(0);
+        mfma_group(a3, 3); load_b(c + 1, 3); __builtin_amdgcn_sched_barrier(0);
+        read_frags(std::integral_constant<int, 4 * NT>());      // (after the last step: zeros, unused; the epilogue's own LDS accesses are the compiler's to order)
     }
-    if (c < c_end) step(c, ra1, ra0);          // odd count: the trailing requests are out of range (zeros, no traffic)
     MFMA_STAMP(3);
 #ifndef USC_MFMA_NO_PRIO
     __builtin_amdgcn_s_setprio(2);
