@@ -61,7 +61,7 @@ def time_layer(d, reps=12):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-table, log = {}, []
+table, log, counts = {}, [], {}
 for name, net, descs in nets():
     seen = 0
     for d in descs:
@@ -70,6 +70,7 @@ for name, net, descs in nets():
         nb = max(d.batch, 1)
         nphase = max(d.nphase, 1)
         key = (d.OH * d.OW // nb * max(d.plan_batch, 1), d.Cin, d.Cout, d.ntaps, d.in_stride, nphase)
+        counts[(name, key)] = counts.get((name, key), 0) + 1
         if key in table:
             continue
         seen += 1
@@ -98,11 +99,16 @@ for name, net, descs in nets():
             table[key] = best[1:]
         else:
             table[key] = None
-        log.append({"net": name, "key": key, "planner_us": round(base, 2), "best_us": round(best[0], 2), "best": best[1:], "all": rows})
+        plan = nv.conv_plans((ConvDesc * 1)(d), 1)[0]
+        log.append({"net": name, "key": key, "planner_us": round(base, 2), "best_us": round(best[0], 2), "best": best[1:], "all": rows,
+                    "planner_plan": plan["plan"], "two_outputs": bool(d.out2), "has_slab": bool(d.slab), "slab_bytes": int(d.slab_bytes),
+                    "plane_bytes": int(d.OHf * d.OWf * d.Cout * 4)})
         print(f"{name:20s} {key} planner {base:7.1f} us  best {best[0]:7.1f} us  nt/RG/S/KW={best[1:]}", flush=True)
     print(f"{name}: {seen} new shapes", flush=True)
     del net
     torch.cuda.empty_cache()
 
+for r in log:
+    r["count"] = counts.get((r["net"], tuple(r["key"])), 1)
 json.dump(log, open(os.path.join(out_dir, "tune_log.json"), "w"))
 print("planner total %.1f us, tuned total %.1f us" % (sum(r["planner_us"] for r in log), sum(min(r["planner_us"], r["best_us"]) for r in log)))

@@ -1453,6 +1453,10 @@ extern "C" void usc_conv_force_winograd(int mode) { g_force_wino = mode; }
 static thread_local int g_force_t3 = -1, g_force_lin = -1, g_force_ws = 0;
 extern "C" void usc_conv_force_winograd_form(int t3, int lin, int split) { g_force_t3 = t3; g_force_lin = lin; g_force_ws = split; }
 // cost-model constants of the direct kernel's planner (microseconds; fitted on the device with tools/dev/tune_convs.py)
+// (round 5: the LDS-DMA kernel admits 5 / 4 waves per SIMD; the constants and the model's 4 / 3 slots were kept - tools/dev/tune_convs.py times every
+// admissible plan of every layer shape, tools/dev/plan_model_fit.py replays this model on that table: a re-fit is worth 1.3 % of the direct layers on paper
+// (16.06 -> 15.85 ms over all networks; best plan per shape 15.52) and measured as a wash on the two networks of the headline loop (matting -5.6 us, parsing
+// +6.4 us per frame); plans - and with them every summation order - are those of rounds 2 - 4)
 static constexpr int kNt2Min = 512, kMinSteps = 9, kKwSteps = 4, kRgMin = 1;
 static constexpr double kTStep = 0.43, kTLone = 1.5, kTFixed = 3.0, kTReduce = 8.0;
 
@@ -1644,7 +1648,7 @@ static int plan_layer(const usc_conv_desc& d, LayerPlan& p) {
         //   exceed the CU's wave slots; a grid split adds the reduce launch and the slab round trip.
         constexpr double t_step = kTStep, t_lone = kTLone, t_fixed = kTFixed, t_reduce = kTReduce;
         const double plane_mb = (double)m_plan * d.Cout * 4e-6 * nphase;
-        const double slots = nt2 ? 3. : 4.;                          // waves per SIMD the register file admits
+        const double slots = nt2 ? 3. : 4.;                          // waves per SIMD the model counts with (see the note at the constants)
         double best = 1e30;
         for (int rg = 4; rg >= rg_min; rg >>= 1) {
             const long long blocks = (m_plan + 32 * rg - 1) / (32 * rg) * nblocks * nphase;
