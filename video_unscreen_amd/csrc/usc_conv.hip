@@ -241,7 +241,11 @@ __global__ __launch_bounds__(64 * RG * KW) __attribute__((amdgpu_waves_per_eu(NT
     __builtin_amdgcn_s_setprio(2);
 #endif
 
-    // ---- epilogue: as above, through this wave's own LDS image (free now); K groups > 0 only deposit their partial tile
+    // ---- epilogue: as above, through this wave's own LDS image (free now).  With K groups every wave deposits its partial tile and then
+    // FINISHES a share of the tile (round 5; rounds 1 - 4 left the whole sum and the fused epilogue to K group 0 - sixteen partial tiles read
+    // and added by one wave while fifteen waited): the tile's four passes of eight rows are dealt out to the KW waves of a row group - KW = 2:
+    // two passes each, 4: one, 8: half a pass (four rows), 16: a quarter (two rows; the other lanes' offsets are out of range: their loads
+    // return zeros, their stores are dropped).  The partial sums are added in the same slice order ((p0 + p1) + p2) + ... : same bits.
     float* const T = Aw;
     // two-output layers (usc_conv_desc.out2): this workgroup's channel tile lies on one side of split_c - which tensor, row pitch,
     // channel origin and activation it uses is workgroup-uniform
@@ -251,14 +255,17 @@ __global__ __launch_bounds__(64 * RG * KW) __attribute__((amdgpu_waves_per_eu(NT
     const int act = second ? d.act2 : d.act;
     const int out_bytes = d.OHf * d.OWf * d.Cout * 4;
     const int erow = lane >> 3, ec4 = (lane & 7) * 4;
-    int ops[4], oos[4], rps[4];
+    constexpr int NP = KW >= 4 ? 1 : 4 / KW;                     // passes this wave finishes
+    const int ps0 = KW == 1 ? 0 : KW == 2 ? 2 * kg : KW == 4 ? kg : KW == 8 ? (kg >> 1) : (kg >> 2);
+    const bool row_on = KW <= 4 ? true : KW == 8 ? ((erow >> 2) == (kg & 1)) : ((erow >> 1) == (kg & 3));
+    int ops[NP], oos[NP], rps[NP];
 #pragma unroll
-    for (int ps = 0; ps < 4; ps++) {
-        const int p = 32 * rg + ps * 8 + erow;
-        const int opix = s_outpix[p];
-        ops[ps] = opix < 0 ? INVALID : opix * d.Cout * 4;
-        oos[ps] = opix < 0 ? INVALID : (opix * out_ld + out_c0) * 4;
-        rps[ps] = s_res1pix[p];
+    for (int i = 0; i < NP; i++) {
+        const int p = 32 * rg + (ps0 + i) * 8 + erow;
+        const int opix = row_on ? s_outpix[p] : -1;
+        ops[i] = opix < 0 ? INVALID : opix * d.Cout * 4;
+        oos[i] = opix < 0 ? INVALID : (opix * out_ld + out_c0) * 4;
+        rps[i] = row_on ? s_res1pix[p] : INVALID;
     }
     const bool has_r1 = d.res1 != nullptr, has_r2 = d.res2 != nullptr, has_aff = d.scale != nullptr;
     const __amdgpu_buffer_rsrc_t out_rsrc = S > 1
@@ -272,45 +279,43 @@ __global__ __launch_bounds__(64 * RG * KW) __attribute__((amdgpu_waves_per_eu(NT
     for (int j = 0; j < NT; j++) {
         const int n = nb0 + j * 32 + ec4;
         const int nb4 = n * 4;
-        // residuals of all four passes are requested before the accumulators go through LDS (one wait, hidden behind the
+        // residuals of the wave's passes are requested before the accumulators go through LDS (one wait, hidden behind the
         // transposition); a zero-sized descriptor (no residual, split layer) turns them into zeros without touching memory
-        u32x4 r1v[4], r2v[4];
-        if (kg == 0) {
+        u32x4 r1v[NP], r2v[NP];
 #pragma unroll
-            for (int ps = 0; ps < 4; ps++) {
-                r1v[ps] = __builtin_amdgcn_raw_buffer_load_b128(r1_rsrc, rps[ps] + nb4, 0, 0);
-                r2v[ps] = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, ops[ps] + nb4, 0, 0);
-            }
+        for (int i = 0; i < NP; i++) {
+            r1v[i] = __builtin_amdgcn_raw_buffer_load_b128(r1_rsrc, rps[i] + nb4, 0, 0);
+            r2v[i] = __builtin_amdgcn_raw_buffer_load_b128(r2_rsrc, ops[i] + nb4, 0, 0);
         }
-        if (KW > 1 && j > 0) __syncthreads();                     // the previous tile has been read by K group 0
+        if (KW > 1 && j > 0) __syncthreads();                     // the previous tile's partial sums have been read by every wave
 #pragma unroll
         for (int r = 0; r < 16; r++) T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * APITCH + (lane & 31)] = acc[j][r];
         if (KW > 1) __syncthreads();
-        if (kg != 0) continue;
-        float4 tv[4];
+        float4 tv[NP];
 #pragma unroll
-        for (int ps = 0; ps < 4; ps++) {
-            float4 t = *reinterpret_cast<const float4*>(&T[(ps * 8 + erow) * APITCH + ec4]);
+        for (int i = 0; i < NP; i++) {
+            const int o = ((ps0 + i) * 8 + erow) * APITCH + ec4;
+            float4 t = *reinterpret_cast<const float4*>(&As[rg][o]);
 #pragma unroll
             for (int k = 1; k < KW; k++) {                        // slice order: ((p0 + p1) + p2) + p3
-                const float4 u = *reinterpret_cast<const float4*>(&As[RG * k + rg][(ps * 8 + erow) * APITCH + ec4]);
+                const float4 u = *reinterpret_cast<const float4*>(&As[RG * k + rg][o]);
                 t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
             }
-            tv[ps] = t;
+            tv[i] = t;
         }
         if (S > 1) {
 #pragma unroll
-            for (int ps = 0; ps < 4; ps++)
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&tv[ps]), out_rsrc, ops[ps] + nb4, 0, 0);
+            for (int i = 0; i < NP; i++)
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&tv[i]), out_rsrc, ops[i] + nb4, 0, 0);
             continue;
         }
         float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bias;
         if (d.bias) bias = *reinterpret_cast<const float4*>(d.bias + n);
         if (has_aff) { sc = *reinterpret_cast<const float4*>(d.scale + n); sh = *reinterpret_cast<const float4*>(d.shift + n); }
 #pragma unroll
-        for (int ps = 0; ps < 4; ps++) {
-            const float4 t = tv[ps];
-            const float4 r1 = *reinterpret_cast<const float4*>(&r1v[ps]), r2 = *reinterpret_cast<const float4*>(&r2v[ps]);
+        for (int i = 0; i < NP; i++) {
+            const float4 t = tv[i];
+            const float4 r1 = *reinterpret_cast<const float4*>(&r1v[i]), r2 = *reinterpret_cast<const float4*>(&r2v[i]);
             float v[4] = {t.x + bias.x, t.y + bias.y, t.z + bias.z, t.w + bias.w};
             const float a1[4] = {r1.x, r1.y, r1.z, r1.w}, a2[4] = {r2.x, r2.y, r2.z, r2.w};
             const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(64 * RG * KW) __attribute__((amdgpu_waves_per_eu(NT
                 v[e] = x + a2[e];
             }
             const float4 o = make_float4(v[0], v[1], v[2], v[3]);
-            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), out_rsrc, oos[ps] + nb4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), out_rsrc, oos[i] + nb4, 0, 0);
         }
     }
     MFMA_STAMP(4);
