@@ -144,6 +144,7 @@ def test_overall_background_allreduce_world2():
 
 
 def _all_nets_worker(rank, world, port, q):
+    torch.set_num_threads(max(1, len(os.sched_getaffinity(0)) // world))      # (two ranks on one box: each its share of the cores)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
