@@ -7,15 +7,16 @@
 //     avg-pool + 1x1, and the four 2x2 output phases of ConvTranspose2d(k4, s2, p1) are the same code;
 //   * a workgroup owns 128 output pixels x (32 | 64) channels; each of its waves owns 32 of those pixels.  A wave only ever
 //     multiplies ITS OWN 32 pixel rows, so LDS is a layout transposer for A (coalesced 128-byte pixel rows -> the MFMA's
-//     one-row-per-lane operand), not a sharing medium: every wave stages its rows in a private 4.6 KB LDS image (LDS
-//     executes one wave's instructions in order: no barrier between its ds_write and ds_read) and reads its weight
+//     one-row-per-lane operand), not a sharing medium: every wave has a private 4.6 KB LDS image, which its A chunk reaches
+//     straight from global memory (buffer_load ... lds, 16 bytes per lane, swizzled so that fragment reads are conflict-free; one K
+//     step ahead: round 5 - rounds 1 - 4 went through two register sets), and reads its weight
 //     fragments straight from global memory - the packed layout [k/4][n][4] IS the B-operand layout, a fragment load is two
 //     contiguous 512-byte runs that all waves of the layer share through L1 / L2.  No __syncthreads in the K loop: waves
-//     drift freely, 4 (3 for the 64-column tile) per SIMD;
+//     drift freely, 5 (4 for the 64-column tile) per SIMD;
 //   * K parallelism for the many layers with only one or two tiles per CU: a workgroup may hold KW groups of 4 waves that
 //     split the K range of the same tile (partial sums meet in LDS, added in slice order), and / or the grid splits K into
 //     S slices whose partial sums go through a slab and splitk_reduce_kernel;
-//   * A is padded in LDS (36-float row pitch) so every ds_read_b128 / ds_write_b128 of a fragment is conflict-free;
+//   * the epilogue's transposition through the same image uses a 36-float row pitch (conflict-free b128 accesses);
 //   * the epilogue fuses bias, residual (optionally from a half-resolution tensor = nearest x2 upsample),
 //     ReLU / LeakyReLU, a per-channel affine (the shortcut branches' BN-after-ReLU), a second residual and a channel
 //     slice of a wider output tensor (concat buffers), so no elementwise pass ever touches HBM again.
